@@ -1,0 +1,34 @@
+/* oracle/synth_reads.c -- TEST INFRASTRUCTURE.
+ * Deterministic synthetic read generator: base j of read i is
+ * "ACGT"[splitmix64_output(seed, i*L+j+1) >> 62], one read per line.
+ *   usage: synth_reads <n_reads> <read_len> [seed=42] [first_read=0]  > reads.txt
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+static inline uint64_t sm64(uint64_t seed, uint64_t k)
+{
+	uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return z ^ (z >> 31);
+}
+
+int main(int argc, char **argv)
+{
+	if (argc < 3) { fprintf(stderr, "usage: %s n_reads read_len [seed] [first_read]\n", argv[0]); return 1; }
+	uint64_t n = strtoull(argv[1], 0, 10), L = strtoull(argv[2], 0, 10);
+	uint64_t seed = argc > 3 ? strtoull(argv[3], 0, 10) : 42;
+	uint64_t first = argc > 4 ? strtoull(argv[4], 0, 10) : 0;
+	char *line = (char*)malloc(L + 2);
+	static char obuf[1 << 20];
+	setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
+	for (uint64_t i = first; i < first + n; ++i) {
+		for (uint64_t j = 0; j < L; ++j) line[j] = "ACGT"[sm64(seed, i * L + j) >> 62];
+		line[L] = '\n';
+		fwrite(line, 1, L + 1, stdout);
+	}
+	free(line);
+	return 0;
+}
