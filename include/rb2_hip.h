@@ -1,0 +1,110 @@
+/* rb2_hip.h -- C ABI of the MI355X (gfx950) multi-string BWT insertion engine.
+ *
+ * This is the drop-in boundary for ropebwt2's hot path.  The host side stays plain C; every
+ * symbol below is `extern "C"`, takes plain pointers and sizes, and is what the `mrope` layer
+ * (include/mrope.h, our replacement for /root/reference/mrope.h) binds to:
+ *
+ *   reference interface replaced                         entry point here
+ *   ---------------------------------------------------  -----------------------------------------
+ *   mr_insert_multi()            mrope.c:258-345         rb2_hip_insert_multi[_dev]()
+ *     mr_insert_multi_aux()      mrope.c:184-233           (k_prep / k_merge / k_advance kernels)
+ *     rope_insert_run()          rope.c:114-148            (k_merge: rank + positional insert)
+ *     rope_rank2a()              rope.c:179-194            (k_prep: interval sizes)
+ *     rle_insert_cached/rank2a   rle.c:10-89, 134-191      (k_merge: run-length leaf decode/encode)
+ *   rope_t.c[6] marginal counts  rope.h:19, mrope.h:86   rb2_hip_get_counts()
+ *   mr_itr_first/next_block      mrope.c:111-130         rb2_hip_rope_bytes() + rb2_hip_download_rope()
+ *   mr_restore / rope_restore    mrope.c:145, rope.c:308 rb2_hip_load_ropes()
+ *
+ * Run-length byte streams crossing this boundary use ropebwt2's "43+3" codec (rle.h:39-75), so
+ * the host can splice them straight into rope leaves.  The device itself only ever emits the
+ * 1-byte form (run length < 16), which is a valid subset of that codec.
+ *
+ * Error convention: like the reference (mrope.c has none), functions do not return error codes
+ * for programming errors; any HIP failure or a missing GPU prints a message to stderr and
+ * abort()s -- there is no CPU fallback behind this ABI.
+ */
+#ifndef RB2_HIP_H_
+#define RB2_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rb2_hip_s rb2_hip_t;
+
+/* sorting orders, same values as MR_SO_IO / MR_SO_RLO / MR_SO_RCLO (mrope.h:6-8) */
+#define RB2_SO_IO   0
+#define RB2_SO_RLO  1
+#define RB2_SO_RCLO 2
+
+/* number of visible HIP devices (0 when there is no GPU; never aborts) */
+int rb2_hip_device_count(void);
+
+/* create an empty six-rope BWT on `device` (mr_init, mrope.c:14-25).  abort()s without a GPU. */
+rb2_hip_t *rb2_hip_create(int device, int sorting_order);
+void rb2_hip_destroy(rb2_hip_t *h);
+int  rb2_hip_sorting_order(const rb2_hip_t *h);
+
+/* mr_insert_multi (mrope.c:258): insert all strings of `s` (concatenated, each REVERSED and
+ * 0-terminated, nt6 codes 0..5, s[len-1]==0).  `s` is a host buffer, borrowed for the call. */
+void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s);
+
+/* same, but `s_dev` already resides in this device's HBM (no PCIe transfer in the call) */
+void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev);
+
+/* c[b*6+a] = number of symbol a in rope b == mr->r[b]->c[a] (rope.h:19) */
+void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36]);
+
+/* rope b as a run-length byte stream (43+3 codec, 1-byte runs only).  rb2_hip_rope_bytes gives
+ * the exact size; download copies it to host memory `dst` and returns the byte count. */
+int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b);
+int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst);
+
+/* replace all six ropes by the symbols described by six 43+3 run-length streams (any run
+ * width; rle[b] may be NULL when n_bytes[b]==0).  Used to seed the device from an .fmr file /
+ * host ropes (mr_restore, mrope.c:145-160; rope_restore, rope.c:308-318). */
+void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6]);
+
+/* rank of all six symbols in [0,x) of rope b, computed on the device (rope_rank1a, rope.h:45) */
+void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
+
+/* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */
+
+/* allocate / free raw device memory */
+void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes);
+void  rb2_hip_dev_free(rb2_hip_t *h, void *p);
+
+/* fill dst_dev (n_reads*(read_len+1) bytes) with synthetic reads first_read..first_read+n_reads
+ * of the SURVEY.md 8c generator (splitmix64 counter stream), already nt6-encoded, reversed and
+ * 0-terminated -- i.e. exactly what main.c:177-237 would put in the batch buffer for `-R`.
+ * strand: 0 = forward strand only; 1 = forward followed by reverse complement (buffer doubles). */
+void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads,
+                         int read_len, uint64_t seed, int strand);
+
+void rb2_hip_sync(rb2_hip_t *h);
+
+/* per-kernel timing, measured with hipEvents on the engine's own stream when enabled */
+#define RB2_K_SYM      0
+#define RB2_K_TSCAN    1
+#define RB2_K_PREP     2
+#define RB2_K_PART     3
+#define RB2_K_MERGE    4
+#define RB2_K_META     5
+#define RB2_K_ADVANCE  6
+#define RB2_K_INIT     7
+#define RB2_K_COUNT    8
+void rb2_hip_profile(rb2_hip_t *h, int enable);
+/* launches[k], ms[k] (summed), units[k] (strings processed, summed) since the last reset */
+void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[RB2_K_COUNT],
+                         int64_t units[RB2_K_COUNT], int reset);
+const char *rb2_hip_kernel_name(int k);
+
+/* device layout constants: symbols per leaf, leaves per merge tile, strings per string tile */
+void rb2_hip_layout(int *leaf_syms, int *tile_leaves, int *string_tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,185 @@
+// rb2_device.h -- device data layout + wave/block primitives for the gfx950 BWT insertion engine.
+//
+// Layout in HBM (all sizes are compile-time constants below):
+//
+//   leaf          LEAF symbols of one rope, stored as <= LEAF one-byte runs of ropebwt2's 43+3 codec
+//                 (byte = len<<3 | sym, 1 <= len <= 15; reference format: rle.h:53-57).  Every
+//                 leaf of a rope holds exactly LEAF symbols except the last, so "which leaf holds
+//                 position p" is p / LEAF -- no B+ tree descent (the reference walks rpnode_t
+//                 buckets, rope.c:119-134).  Slot stride is LEAF bytes.
+//   LeafMeta      16 B per leaf: per-symbol counts of the preceding leaves of the same superblock
+//                 (u16 x 6) + number of bytes used.
+//   superblock    SB consecutive leaves; Cnt6 (6 x u64) exclusive prefix of symbol counts over
+//                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf scan  (rope_rank2a,
+//                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
+//   pool          two sides (ping-pong); each round the merge kernel streams side -> side^1.
+//   strings       SoA per-string state (reference triple64_t, mrope.c:174-178): L, U (interval in
+//                 the reference's own coordinates), ID, W (next 16 symbols, 4 bit each).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rb2 {
+
+constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
+constexpr int TL     = 4;             // leaves per merge tile
+constexpr int MT     = LEAF * TL;     // output symbols per merge block (4096)
+constexpr int SB     = 32;            // leaves per superblock
+constexpr int STILE  = 512;           // strings per string tile
+constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
+constexpr int ZBLOCK = 16384;         // bytes per block when locating sentinels
+
+struct LeafMeta { uint16_t c[6]; uint16_t nbytes; uint16_t pad; };
+struct Cnt6 { uint64_t v[6]; };
+
+struct RopeDesc {
+	uint64_t n;         // symbols
+	uint64_t leaf0;     // first leaf (multiple of SB)
+	uint64_t nleaves;   // ceil(n / LEAF)
+	uint64_t sb0;       // leaf0 / SB
+	uint64_t cnt[6];    // marginal counts (rope_t.c, rope.h:19)
+};
+
+struct SegDesc {        // where the strings of bucket b live in the current SoA arrays
+	uint64_t start[6], cnt[6];
+	uint32_t tile0[8];  // first string tile of each segment; [6] = total
+};
+
+struct Ctl {
+	RopeDesc rope[2][6];
+	SegDesc  seg[2];
+	uint64_t mt0[8];        // first merge tile per rope this round; [6] = total
+	uint64_t ac[6][6];      // ac[b][a] = #a in ropes < b after this round (mrope.c:332-336)
+	uint64_t dest[6][6];    // where members of bucket b inserting a go in the next arrays
+	uint64_t count[6][6];   // count[b][a] = members of bucket b inserting a this round
+	uint64_t nsb_total;     // superblocks in use on the new side
+	uint64_t n_strings;     // strings in this batch
+	uint64_t max_len;       // longest string (without sentinel)
+	uint64_t n0;            // strings already in the index (#'$' in the BWT, mrope.c:279)
+	uint64_t len;           // batch bytes
+};
+
+struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
+
+struct TileRec {            // per string tile, written by k_sym
+	uint32_t hist[6];
+	uint32_t lhpre[6];      // symbol counts in the tile before its last group head
+	uint32_t fhpre[6];      // ... before its first group head
+	int32_t  lh, fh;        // in-tile index of last / first head, -1 when the tile has none
+};
+
+struct TileScan {           // per string tile (+1), written by the tile scan
+	uint32_t pre[6];        // exclusive prefix of hist over ALL tiles (subtract the segment's first)
+	int32_t  lht;           // last tile before this one that contains a head (-1 if none)
+	int32_t  nht;           // first tile after this one that contains a head (INT_MAX if none)
+};
+
+struct ChunkPart { uint32_t sum[6]; int32_t mx, mn; };
+
+// ---------------------------------------------------------------------------------------------
+// wave / block primitives (wave = 64 lanes on gfx950)
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T> __device__ __forceinline__ T wave_incl_add(T v)
+{
+	const int l = lane_id();
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { T t = __shfl_up(v, d); if (l >= d) v += t; }
+	return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v)
+{
+	const int l = lane_id();
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (l >= d) v = max(v, t); }
+	return v;
+}
+__device__ __forceinline__ int wave_incl_min_down(int v)     // suffix minimum
+{
+	const int l = lane_id();
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { int t = __shfl_down(v, d); if (l + d < 64) v = min(v, t); }
+	return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+	return v;
+}
+
+// exclusive prefix sum over the block; s_w needs blockDim/64 (+0) entries; *total gets the block sum
+template <typename T> __device__ __forceinline__ T block_excl_add(T v, T *s_w, T *total)
+{
+	const int l = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
+	T inc = wave_incl_add(v);
+	if (l == 63) s_w[w] = inc;
+	__syncthreads();
+	T off = 0, tot = 0;
+	for (int i = 0; i < nw; ++i) { T x = s_w[i]; if (i < w) off += x; tot += x; }
+	__syncthreads();
+	if (total) *total = tot;
+	return off + inc - v;
+}
+__device__ __forceinline__ int block_excl_max(int v, int *s_w, int ident)    // max over earlier threads
+{
+	const int l = lane_id(), w = wave_id();
+	int inc = wave_incl_max(v);
+	if (l == 63) s_w[w] = inc;
+	__syncthreads();
+	int off = ident;
+	for (int i = 0; i < w; ++i) off = max(off, s_w[i]);
+	__syncthreads();
+	int prev = __shfl_up(inc, 1);
+	return l == 0 ? off : max(off, prev);
+}
+__device__ __forceinline__ int block_excl_min_down(int v, int *s_w, int ident)   // min over later threads
+{
+	const int l = lane_id(), w = wave_id(), nw = blockDim.x >> 6;
+	int inc = wave_incl_min_down(v);
+	if (l == 0) s_w[w] = inc;
+	__syncthreads();
+	int off = ident;
+	for (int i = w + 1; i < nw; ++i) off = min(off, s_w[i]);
+	__syncthreads();
+	int nxt = __shfl_down(inc, 1);
+	return l == 63 ? off : min(off, nxt);
+}
+
+__device__ __forceinline__ uint64_t lt_mask(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }   // bits < lane
+
+// insertion order of the symbols inside one suffix-array interval (mrope.c:206-224):
+// RLO / input order: $ A C G T N;  RCLO: $ T G C A N
+__device__ __forceinline__ int sym_ord(int a, int is_comp) { return (is_comp && a >= 1 && a <= 4) ? 5 - a : a; }
+
+// counts of all six symbols in [0,p) of a rope on pool side `pv` (rope_rank1a, rope.h:45):
+// superblock prefix + leaf-relative prefix + sequential decode of one leaf (rle.c:147-158)
+__device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
+{
+	if (p >= rp.n) {
+#pragma unroll
+		for (int s = 0; s < 6; ++s) out[s] = rp.cnt[s];
+		return;
+	}
+	const uint64_t lf = p / LEAF, gl = rp.leaf0 + lf;
+	const uint32_t off = (uint32_t)(p % LEAF);
+	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
+	const LeafMeta m = pv.meta[gl];
+#pragma unroll
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s];
+	const uint8_t *q = pv.data + gl * (uint64_t)LEAF;
+	uint32_t acc = 0;
+	while (acc < off) {
+		const uint32_t byte = *q++;
+		const uint32_t len = byte >> 3, s = byte & 7;
+		const uint32_t take = min(len, off - acc);
+#pragma unroll
+		for (int t = 0; t < 6; ++t) out[t] += (s == (uint32_t)t) ? take : 0u;
+		acc += len;
+	}
+}
+
+} // namespace rb2

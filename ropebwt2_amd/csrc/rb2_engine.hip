@@ -1,0 +1,451 @@
+// rb2_engine.hip -- host orchestration + C ABI (include/rb2_hip.h) of the gfx950 BCR engine.
+//
+// Replaces the body of mr_insert_multi (/root/reference/mrope.c:258-345).  One process drives
+// one GPU; everything is enqueued on a private HIP stream and the host synchronises twice per
+// batch (string count, end of batch).  No CPU fallback: a missing device aborts.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <climits>
+#include <vector>
+#include <algorithm>
+#include "rb2_hip.h"
+#include "rb2_kernels.h"
+
+using namespace rb2;
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
+	fprintf(stderr, "[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); abort(); } } while (0)
+
+namespace {
+
+template <typename T> struct DevBuf {
+	T *p = nullptr; size_t cap = 0;
+	void ensure(size_t n, bool keep = false, hipStream_t st = 0) {
+		if (n <= cap) return;
+		size_t ncap = std::max(n, cap + cap / 2);
+		T *q = nullptr;
+		HIPCHK(hipMalloc((void**)&q, ncap * sizeof(T)));
+		if (keep && p && cap) { HIPCHK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
+		if (p) HIPCHK(hipFree(p));
+		p = q; cap = ncap;
+	}
+	void release() { if (p) HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+};
+
+struct Pool {
+	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta; DevBuf<Cnt6> sbcum;
+	uint64_t cap_leaves = 0;
+	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
+		if (leaves <= cap_leaves) return;
+		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
+		nl = (nl + SB - 1) / SB * SB;
+		data.ensure(nl * LEAF, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st);
+		cap_leaves = nl;
+	}
+	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p}; }
+	void release() { data.release(); meta.release(); sbcum.release(); cap_leaves = 0; }
+};
+
+struct ProfRec { int k; hipEvent_t a, b; int64_t units; };
+
+} // namespace
+
+struct rb2_hip_s {
+	int dev = 0, so = 0;
+	hipStream_t st = 0;
+	Pool pool[2];
+	int side = 0;                       // pool side holding the current BWT
+	Ctl *ctl = nullptr;                 // device
+	RopeDesc h_rope[6];                 // host mirror of ctl->rope[side]
+	// per-string state
+	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, RK, zblk;
+	DevBuf<uint32_t> ID[2], SLOT, PA, PGA, TQ;
+	DevBuf<uint8_t> A, INS_A, sbuf;
+	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<ChunkPart> cpart;
+	DevBuf<Cnt6> sbtot, sbpart;
+	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
+	// profiling
+	int prof = 0;
+	std::vector<ProfRec> recs;
+	std::vector<hipEvent_t> evpool;
+	int64_t p_launch[RB2_K_COUNT]; double p_ms[RB2_K_COUNT]; int64_t p_units[RB2_K_COUNT];
+	int debug = 0;
+};
+
+namespace {
+
+uint64_t total_leaves_needed(const uint64_t n[6])
+{
+	uint64_t t = 0;
+	for (int b = 0; b < 6; ++b) t += ((n[b] + LEAF - 1) / LEAF + SB - 1) / SB * SB;
+	return t;
+}
+
+hipEvent_t get_event(rb2_hip_t *h)
+{
+	if (!h->evpool.empty()) { hipEvent_t e = h->evpool.back(); h->evpool.pop_back(); return e; }
+	hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e;
+}
+
+struct Scope {          // times everything enqueued between construction and destruction
+	rb2_hip_t *h; int k; ProfRec r;
+	Scope(rb2_hip_t *h_, int k_, int64_t units) : h(h_), k(k_) {
+		if (!h->prof) return;
+		r.k = k; r.units = units; r.a = get_event(h); r.b = get_event(h);
+		HIPCHK(hipEventRecord(r.a, h->st));
+	}
+	~Scope() {
+		if (h->debug) { hipError_t e = hipStreamSynchronize(h->st); if (e != hipSuccess) { fprintf(stderr, "[rb2_hip] kernel group %s failed: %s\n", rb2_hip_kernel_name(k), hipGetErrorString(e)); abort(); } }
+		if (!h->prof) return;
+		HIPCHK(hipEventRecord(r.b, h->st));
+		h->recs.push_back(r);
+	}
+};
+
+void drain_profile(rb2_hip_t *h)
+{
+	for (auto &r : h->recs) {
+		float ms = 0;
+		HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+		h->p_launch[r.k] += 1; h->p_ms[r.k] += ms; h->p_units[r.k] += r.units;
+		h->evpool.push_back(r.a); h->evpool.push_back(r.b);
+	}
+	h->recs.clear();
+}
+
+inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
+void build_directory(rb2_hip_t *h, int sd, uint64_t nsb_ub)
+{
+	if (nsb_ub == 0) return;
+	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
+	if (nchunk > SCHUNK) { fprintf(stderr, "[rb2_hip] index too large for one device (%llu superblocks)\n", (unsigned long long)nsb_ub); abort(); }
+	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
+	PoolView pv = h->pool[sd].view();
+	hipLaunchKernelGGL(k_meta_sb, dim3((unsigned)nsb_ub), dim3(64), 0, h->st, h->ctl, sd, pv, h->sbtot.p);
+	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
+	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
+	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);
+}
+
+void fetch_ropes(rb2_hip_t *h)
+{
+	HIPCHK(hipMemcpyAsync(h->h_rope, &h->ctl->rope[h->side][0], sizeof(RopeDesc) * 6, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
+{
+	const uint64_t len = (uint64_t)len64;
+	hipStream_t st = h->st;
+	const int is_srt = h->so != RB2_SO_IO, is_comp = h->so == RB2_SO_RCLO;
+
+	// ---- split into strings (mrope.c:269-277): count sentinels, prefix, starts
+	const unsigned nzb = cdiv(len, ZBLOCK);
+	uint64_t m = 0;
+	{
+		Scope sc(h, RB2_K_INIT, 0);
+		h->zblk.ensure(nzb + 1);
+		hipLaunchKernelGGL(k_count_zeros, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p);
+		std::vector<uint64_t> hb(nzb + 1);
+		HIPCHK(hipMemcpyAsync(hb.data(), h->zblk.p, nzb * 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		for (unsigned i = 0; i < nzb; ++i) { uint64_t c = hb[i]; hb[i] = m; m += c; }   // 8 B per 16 KiB of input: host prefix
+		hb[nzb] = m;
+		HIPCHK(hipMemcpyAsync(h->zblk.p, hb.data(), (nzb + 1) * 8, hipMemcpyHostToDevice, st));
+		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { fprintf(stderr, "[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); abort(); }
+		h->START.ensure(m + 1);
+		const uint64_t zero = 0;
+		HIPCHK(hipMemcpyAsync(h->START.p, &zero, 8, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
+		HIPCHK(hipStreamSynchronize(st));      // hb / zero are stack/heap temporaries
+	}
+	// ---- capacities
+	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RK.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
+	h->A.ensure(m); h->INS_A.ensure(m);
+	const unsigned nst_ub = cdiv(m, STILE) + 6;                 // string tiles, upper bound for every round
+	const unsigned nsc = cdiv(nst_ub, SCHUNK);
+	if (nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
+	h->trec.ensure(nst_ub + 1); h->tsc.ensure(nst_ub + 2); h->cpart.ensure(nsc + 1);
+	uint64_t n_tot = 0, nn[6];
+	for (int b = 0; b < 6; ++b) n_tot += h->h_rope[b].n;
+	const uint64_t leaves_ub = (n_tot + len) / LEAF + 6 * (SB + 1);
+	h->pool[h->side].ensure(leaves_ub, true, st);
+	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
+	(void)nn;
+	const uint64_t mt_ub = (n_tot + len) / MT + 6 + 1;
+	h->TQ.ensure(mt_ub + 8);
+	const uint64_t nsb_ub = leaves_ub / SB + 1;
+
+	// ---- initial state (mrope.c:279-284)
+	{
+		Scope sc(h, RB2_K_INIT, 0);
+		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len);
+		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
+				h->L[0].p, h->U[0].p, h->ID[0].p, h->W[0].p);
+	}
+	uint64_t max_len = 0;
+	HIPCHK(hipMemcpyAsync(&max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+
+	// ---- one round per string position, last symbol first (mrope.c:285, 299-342)
+	int cur = 0;                                               // string array side
+	for (uint64_t r = 0; r <= max_len; ++r) {
+		const int sd = h->side;
+		PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
+		const uint64_t n_new_ub = n_tot + std::min<uint64_t>(len, (r + 1) * m);
+		const unsigned nmt = cdiv(n_new_ub, MT) + 6;
+		const int64_t units = (int64_t)m;                      // upper bound: strings still active this round
+		{ Scope sc(h, RB2_K_SYM, units);
+		  hipLaunchKernelGGL(k_sym, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+		{ Scope sc(h, RB2_K_TSCAN, units);
+		  hipLaunchKernelGGL(k_tscan1, dim3(nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
+		  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
+		  hipLaunchKernelGGL(k_tscan3, dim3(nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
+		  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->tsc.p); }
+		{ Scope sc(h, RB2_K_PREP, units);
+		  hipLaunchKernelGGL(k_prep, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+				h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
+		{ Scope sc(h, RB2_K_PART, units);
+		  hipLaunchKernelGGL(k_part, dim3(cdiv(nmt + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
+		{ Scope sc(h, RB2_K_MERGE, units);
+		  hipLaunchKernelGGL(k_merge, dim3(nmt), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RK.p, h->TQ.p); }
+		{ Scope sc(h, RB2_K_META, units);
+		  build_directory(h, sd ^ 1, std::min<uint64_t>(nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
+		{ Scope sc(h, RB2_K_ADVANCE, units);
+		  hipLaunchKernelGGL(k_advance, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, s, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
+				h->PGA.p, h->SIZE.p, h->RK.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p); }
+		h->side ^= 1; cur ^= 1;
+	}
+	HIPCHK(hipGetLastError());
+	fetch_ropes(h);
+	drain_profile(h);
+}
+
+} // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+
+extern "C" {
+
+int rb2_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+rb2_hip_t *rb2_hip_create(int device, int sorting_order)
+{
+	int n = rb2_hip_device_count();
+	if (n <= 0 || device < 0 || device >= n) {
+		fprintf(stderr, "[rb2_hip] no usable HIP device (requested %d, visible %d); this engine has no CPU fallback\n", device, n);
+		abort();
+	}
+	if (sorting_order < 0 || sorting_order > 2) { fprintf(stderr, "[rb2_hip] bad sorting order %d\n", sorting_order); abort(); }   // mrope.c:18
+	HIPCHK(hipSetDevice(device));
+	rb2_hip_t *h = new rb2_hip_s();
+	h->dev = device; h->so = sorting_order;
+	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
+	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
+	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
+	HIPCHK(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->st));
+	HIPCHK(hipMalloc((void**)&h->d_tmp, 64));
+	memset(h->h_rope, 0, sizeof(h->h_rope));
+	memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units));
+	h->pool[0].ensure(SB * 8, false, h->st); h->pool[1].ensure(SB * 8, false, h->st);
+	HIPCHK(hipStreamSynchronize(h->st));
+	return h;
+}
+
+void rb2_hip_destroy(rb2_hip_t *h)
+{
+	if (!h) return;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipStreamSynchronize(h->st));
+	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RK.release(); h->zblk.release();
+	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->TQ.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
+	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
+	for (auto e : h->evpool) hipEventDestroy(e);
+	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp));
+	HIPCHK(hipStreamDestroy(h->st));
+	delete h;
+}
+
+int rb2_hip_sorting_order(const rb2_hip_t *h) { return h->so; }
+
+void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (len <= 0) { fprintf(stderr, "[rb2_hip] insert_multi: len must be > 0\n"); abort(); }   // mrope.c:268
+	if (((uintptr_t)s_dev & 15) != 0) {              // kernels use 16-byte loads
+		h->sbuf.ensure((size_t)len + 64);
+		HIPCHK(hipMemcpyAsync(h->sbuf.p, s_dev, (size_t)len, hipMemcpyDeviceToDevice, h->st));
+		s_dev = h->sbuf.p;
+	}
+	insert_dev(h, len, s_dev);
+}
+
+void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
+	h->sbuf.ensure((size_t)len + 64);
+	HIPCHK(hipMemcpyAsync(h->sbuf.p, s, (size_t)len, hipMemcpyHostToDevice, h->st));
+	insert_dev(h, len, h->sbuf.p);
+}
+
+void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
+{
+	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) c[b * 6 + a] = (int64_t)h->h_rope[b].cnt[a];
+}
+
+static void fetch_meta(rb2_hip_t *h, int b, std::vector<LeafMeta> &m)
+{
+	const RopeDesc &r = h->h_rope[b];
+	m.resize(r.nleaves);
+	if (r.nleaves) {
+		HIPCHK(hipMemcpyAsync(m.data(), h->pool[h->side].meta.p + r.leaf0, r.nleaves * sizeof(LeafMeta), hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+	}
+}
+
+int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	std::vector<LeafMeta> m;
+	fetch_meta(h, b, m);
+	int64_t t = 0;
+	for (auto &x : m) t += x.nbytes;
+	return t;
+}
+
+int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	std::vector<LeafMeta> m;
+	fetch_meta(h, b, m);
+	const RopeDesc &r = h->h_rope[b];
+	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB)
+	std::vector<uint8_t> stage(std::min<uint64_t>(CH, std::max<uint64_t>(r.nleaves, 1)) * LEAF);
+	int64_t k = 0;
+	for (uint64_t l0 = 0; l0 < r.nleaves; l0 += CH) {
+		const uint64_t nl = std::min<uint64_t>(CH, r.nleaves - l0);
+		HIPCHK(hipMemcpyAsync(stage.data(), h->pool[h->side].data.p + (r.leaf0 + l0) * LEAF, nl * LEAF, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		for (uint64_t i = 0; i < nl; ++i) { memcpy(dst + k, stage.data() + i * LEAF, m[l0 + i].nbytes); k += m[l0 + i].nbytes; }
+	}
+	return k;
+}
+
+void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	// decode the 43+3 streams (rle.h:39-51) and re-chunk into LEAF-symbol leaves of 1-byte runs
+	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
+	RopeDesc rp[6];
+	uint64_t leaf = 0;
+	for (int b = 0; b < 6; ++b) {
+		RopeDesc &r = rp[b];
+		memset(&r, 0, sizeof(r));
+		r.leaf0 = leaf; r.sb0 = leaf / SB;
+		data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
+		LeafMeta cur; memset(&cur, 0, sizeof(cur));
+		uint32_t fill = 0;                            // symbols in the open leaf
+		uint8_t *slot = nullptr;
+		auto open_leaf = [&]() { data.resize(data.size() + LEAF); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAF; memset(&cur, 0, sizeof(cur)); fill = 0; };
+		auto close_leaf = [&]() { meta.back() = cur; ++r.nleaves; slot = nullptr; };
+		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
+		while (p && p < end) {
+			int c = *p & 7; int64_t l;
+			if ((*p & 0x80) == 0) { l = *p++ >> 3; }
+			else if ((*p >> 5) == 6) { l = ((int64_t)(*p & 0x18) << 3) | (p[1] & 0x3f); p += 2; }
+			else { int nb = (*p & 0x10) ? 8 : 4; l = (*p >> 3) & 1; for (int i = 1; i < nb; ++i) l = (l << 6) | (p[i] & 0x3f); p += nb; }
+			if (c > 5) { fprintf(stderr, "[rb2_hip] load_ropes: bad symbol %d\n", c); abort(); }
+			r.n += l; r.cnt[c] += l;
+			while (l > 0) {
+				if (!slot) open_leaf();
+				const int64_t take = std::min<int64_t>(std::min<int64_t>(l, 15), LEAF - fill);
+				slot[cur.nbytes++] = (uint8_t)(take << 3 | c);
+				cur.c[c] += (uint16_t)take; fill += (uint32_t)take; l -= take;
+				if (fill == LEAF) close_leaf();
+			}
+		}
+		if (slot) close_leaf();
+		leaf += (r.nleaves + SB - 1) / SB * SB;
+	}
+	data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
+	const int sd = h->side;
+	h->pool[sd].ensure(leaf + SB, false, h->st);
+	if (leaf) {
+		HIPCHK(hipMemcpyAsync(h->pool[sd].data.p, data.data(), data.size(), hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipMemcpyAsync(h->pool[sd].meta.p, meta.data(), meta.size() * sizeof(LeafMeta), hipMemcpyHostToDevice, h->st));
+	}
+	HIPCHK(hipMemcpyAsync(&h->ctl->rope[sd][0], rp, sizeof(rp), hipMemcpyHostToDevice, h->st));
+	const uint64_t nsb = leaf / SB;
+	HIPCHK(hipMemcpyAsync(&h->ctl->nsb_total, &nsb, 8, hipMemcpyHostToDevice, h->st));
+	build_directory(h, sd, nsb);
+	HIPCHK(hipStreamSynchronize(h->st));
+	memcpy(h->h_rope, rp, sizeof(rp));
+}
+
+void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->side].view(), b, (uint64_t)x, h->d_tmp);
+	uint64_t out[6];
+	HIPCHK(hipMemcpyAsync(out, h->d_tmp, 48, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	for (int s = 0; s < 6; ++s) cx[s] = (int64_t)out[s];
+}
+
+void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	void *p = nullptr;
+	HIPCHK(hipMalloc(&p, (size_t)bytes));
+	return p;
+}
+
+void rb2_hip_dev_free(rb2_hip_t *h, void *p) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipFree(p)); }
+
+void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	const uint64_t total = (uint64_t)n_reads * (read_len + 1) * (strand ? 2 : 1);
+	if (total == 0) return;
+	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand);
+	HIPCHK(hipGetLastError());
+}
+
+void rb2_hip_sync(rb2_hip_t *h) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }
+
+void rb2_hip_profile(rb2_hip_t *h, int enable) { h->prof = enable; }
+
+void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[RB2_K_COUNT], int64_t units[RB2_K_COUNT], int reset)
+{
+	for (int k = 0; k < RB2_K_COUNT; ++k) { launches[k] = h->p_launch[k]; ms[k] = h->p_ms[k]; units[k] = h->p_units[k]; }
+	if (reset) { memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units)); }
+}
+
+const char *rb2_hip_kernel_name(int k)
+{
+	static const char *nm[RB2_K_COUNT] = {"k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init"};
+	return (k >= 0 && k < RB2_K_COUNT) ? nm[k] : "?";
+}
+
+void rb2_hip_layout(int *leaf_syms, int *tile_leaves, int *string_tile)
+{
+	if (leaf_syms) *leaf_syms = LEAF;
+	if (tile_leaves) *tile_leaves = TL;
+	if (string_tile) *string_tile = STILE;
+}
+
+} // extern "C"

@@ -1,0 +1,730 @@
+// rb2_kernels.h -- the per-round kernels of the gfx950 BCR insertion engine.
+//
+// One round = one string position (mrope.c:299-342).  The reference walks each bucket
+// sequentially (mr_insert_multi_aux, mrope.c:184-233); here the same quantities are obtained from
+// prefix sums:
+//
+//   k_sym      next symbol of every active string + group heads (mrope.c:189-192)
+//   k_tscan*   prefix of the per-tile symbol histograms, nearest group head left/right of a tile
+//   k_setup    6x6 count matrix -> new rope sizes, AC offsets (mrope.c:332-336), next buckets
+//   k_prep     per string: pre-round position of its new symbol, slot in the sorted insert list,
+//              interval sizes via rank on non-empty intervals (mrope.c:199-224)
+//   k_part     merge-path split: which inserts land in which output tile
+//   k_merge    rank + positional insert: decode old run-length leaves into LDS, splice the new
+//              symbols, re-encode (rope_insert_run rope.c:114-148 / rle_insert_cached rle.c:10-89)
+//   k_meta*    rank directory of the new side (replaces the rpnode_t counts, rope.h:11-15)
+//   k_advance  new (l,u) per string + stable 6-way partition into next round's buckets
+//              (mrope.c:226-229, 303-309, 332-340)
+#pragma once
+#include "rb2_device.h"
+
+namespace rb2 {
+
+// ---------------------------------------------------------------------------------------------
+// batch set-up: find the sentinels, string starts, initial state (mrope.c:269-284)
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x)   // number of 0x00 bytes in x (exact)
+{
+	const uint32_t t = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;
+	return __popc(~t & 0x80808080u);
+}
+
+// each thread owns 64 consecutive bytes; returns them in w[16] (zero padded with 0xff beyond len)
+__device__ __forceinline__ void load64(const uint8_t *s, uint64_t len, uint64_t base, uint32_t w[16])
+{
+	if (base + 64 <= len) {
+		const uint4 *p = (const uint4*)(s + base);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { uint4 v = p[i]; w[4*i] = v.x; w[4*i+1] = v.y; w[4*i+2] = v.z; w[4*i+3] = v.w; }
+	} else {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			uint32_t x = 0;
+			for (int k = 0; k < 4; ++k) {
+				const uint64_t p = base + 4*i + k;
+				x |= (uint32_t)(p < len ? s[p] : 0xffu) << (8*k);
+			}
+			w[i] = x;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_count_zeros(const uint8_t *s, uint64_t len, uint64_t *blk)
+{
+	__shared__ uint32_t s_w[4];
+	uint32_t w[16], c = 0;
+	load64(s, len, (uint64_t)blockIdx.x * ZBLOCK + threadIdx.x * 64, w);
+#pragma unroll
+	for (int i = 0; i < 16; ++i) c += zero_bytes(w[i]);
+	uint32_t tot;
+	block_excl_add<uint32_t>(c, s_w, &tot);
+	if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+// START[id+1] = position after the id-th sentinel; START[0] = 0 is written by the host
+__global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t len, const uint64_t *blkoff, uint64_t *START)
+{
+	__shared__ uint32_t s_w[4];
+	uint32_t w[16], c = 0;
+	const uint64_t base = (uint64_t)blockIdx.x * ZBLOCK + threadIdx.x * 64;
+	load64(s, len, base, w);
+#pragma unroll
+	for (int i = 0; i < 16; ++i) c += zero_bytes(w[i]);
+	uint64_t id = blkoff[blockIdx.x] + block_excl_add<uint32_t>(c, s_w, (uint32_t*)0);
+	if (c == 0) return;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		if (zero_bytes(w[i]) == 0) continue;
+		for (int k = 0; k < 4; ++k)
+			if (((w[i] >> (8*k)) & 0xff) == 0) START[++id] = base + 4*i + k + 1;
+	}
+}
+
+__device__ __forceinline__ uint64_t pack16(const uint8_t *s, uint64_t len, uint64_t p)
+{
+	uint64_t w = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const uint64_t q = p + i;
+		w |= (uint64_t)(q < len ? (s[q] & 15) : 0) << (4*i);
+	}
+	return w;
+}
+
+__global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
+		uint64_t *L, uint64_t *U, uint32_t *ID, uint64_t *W)
+{
+	__shared__ int s_wm[4];
+	const uint64_t m = ctl->n_strings, k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	uint64_t ln = 0;
+	if (k < m) {
+		const uint64_t st = START[k], n0 = ctl->n0;
+		ln = START[k+1] - 1 - st;
+		L[k] = is_srt ? 0 : n0 + k;                 // mrope.c:280-283
+		U[k] = is_srt ? n0 : n0 + k;
+		ID[k] = (uint32_t)k;
+		W[k] = pack16(s, ctl->len, st);
+	}
+	// block max of the lengths -> ctl->max_len
+	unsigned long long v = ln;
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) { unsigned long long t = __shfl_xor(v, d); v = t > v ? t : v; }
+	(void)s_wm;
+	if (lane_id() == 0 && v) atomicMax((unsigned long long*)&ctl->max_len, v);
+}
+
+// round 0: every string sits in "bucket 0" and inserts its last symbol into rope $ (mrope.c:285)
+__global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	SegDesc &sg = ctl->seg[side];
+	for (int b = 0; b < 6; ++b) { sg.start[b] = 0; sg.cnt[b] = 0; }
+	sg.cnt[0] = m;
+	uint32_t t = 0;
+	for (int b = 0; b < 6; ++b) { sg.tile0[b] = t; t += (uint32_t)((sg.cnt[b] + STILE - 1) / STILE); }
+	sg.tile0[6] = t; sg.tile0[7] = t;
+	uint64_t n0 = 0;
+	for (int b = 0; b < 6; ++b) n0 += ctl->rope[side][b].cnt[0];
+	ctl->n0 = n0; ctl->n_strings = m; ctl->max_len = 0; ctl->len = len;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_sym: a[k].c = *a[k].p++ (mrope.c:189-190) + group heads (mrope.c:192) + tile summaries
+// ---------------------------------------------------------------------------------------------
+
+struct TileCtx { int b; uint64_t lt, base, segstart, segend; };
+
+__device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileCtx &t)
+{
+	if (tile >= sg.tile0[6]) return false;
+	int b = 0;
+	while (tile >= sg.tile0[b+1]) ++b;
+	t.b = b; t.lt = tile - sg.tile0[b];
+	t.segstart = sg.start[b]; t.segend = sg.start[b] + sg.cnt[b];
+	t.base = t.segstart + t.lt * STILE;
+	return true;
+}
+
+__global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, const uint64_t *U, const uint64_t *W,
+		uint8_t *A, TileRec *trec)
+{
+	__shared__ uint64_t s_bal[8][6], s_head[8];
+	TileCtx t;
+	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
+	const int ln = lane_id(), w = wave_id();
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int pos = h * 256 + threadIdx.x;
+		const uint64_t k = t.base + pos;
+		int sym = 7; bool head = false;
+		if (k < t.segend) {
+			sym = (int)(W[k] & 15);
+			head = (k == t.segstart) || (U[k] != U[k-1]);
+			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
+		}
+		const int c = h * 4 + w;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) s_bal[c][s] = bm; }
+		uint64_t hm = __ballot(head);
+		if (ln == 0) s_head[c] = hm;
+	}
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		const int s = threadIdx.x;
+		uint32_t run = 0, fhpre = 0, lhpre = 0; int fh = -1, lh = -1;
+		for (int c = 0; c < 8; ++c) {
+			const uint64_t hm = s_head[c], bm = s_bal[c][s];
+			if (hm) {
+				const int f = __builtin_ctzll(hm), l = 63 - __builtin_clzll(hm);
+				if (fh < 0) { fh = c * 64 + f; fhpre = run + __popcll(bm & lt_mask(f)); }
+				lh = c * 64 + l; lhpre = run + __popcll(bm & lt_mask(l));
+			}
+			run += __popcll(bm);
+		}
+		TileRec &r = trec[blockIdx.x];
+		r.hist[s] = run; r.fhpre[s] = fhpre; r.lhpre[s] = lhpre;
+		if (s == 0) { r.fh = fh; r.lh = lh; }
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile scan (3 kernels): exclusive add-scan of hist, nearest head-bearing tile to the left/right
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, const TileRec *trec, ChunkPart *part)
+{
+	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
+	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t t = blockIdx.x * SCHUNK + threadIdx.x;
+	if (blockIdx.x * SCHUNK >= nt) return;
+	const bool ok = t < nt;
+	uint32_t tot;
+	ChunkPart p;
+	for (int s = 0; s < 6; ++s) { block_excl_add<uint32_t>(ok ? trec[t].hist[s] : 0u, s_w, &tot); p.sum[s] = tot; }
+	const bool hh = ok && trec[t].fh >= 0;
+	int v = hh ? (int)t : -1;
+	v = wave_incl_max(v);
+	if (lane_id() == 63) s_wi[wave_id()] = v;
+	__syncthreads();
+	int mx = -1; for (int i = 0; i < SCHUNK / 64; ++i) mx = max(mx, s_wi[i]);
+	__syncthreads();
+	v = hh ? (int)t : INT_MAX;
+	v = wave_incl_min_down(v);
+	if (lane_id() == 0) s_wi[wave_id()] = v;
+	__syncthreads();
+	int mn = INT_MAX; for (int i = 0; i < SCHUNK / 64; ++i) mn = min(mn, s_wi[i]);
+	p.mx = mx; p.mn = mn;
+	if (threadIdx.x == 0) part[blockIdx.x] = p;
+}
+
+__global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, ChunkPart *part)
+{
+	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
+	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t nc = (nt + SCHUNK - 1) / SCHUNK;          // host guarantees nc <= SCHUNK
+	const bool ok = threadIdx.x < nc;
+	ChunkPart p;
+	if (ok) p = part[threadIdx.x];
+	else { for (int s = 0; s < 6; ++s) p.sum[s] = 0; p.mx = -1; p.mn = INT_MAX; }
+	ChunkPart o;
+	for (int s = 0; s < 6; ++s) o.sum[s] = block_excl_add<uint32_t>(p.sum[s], s_w, (uint32_t*)0);
+	o.mx = block_excl_max(p.mx, s_wi, -1);
+	o.mn = block_excl_min_down(p.mn, s_wi, INT_MAX);
+	if (ok) part[threadIdx.x] = o;
+}
+
+__global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRec *trec, const ChunkPart *part, TileScan *tsc)
+{
+	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
+	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t t = blockIdx.x * SCHUNK + threadIdx.x;
+	if (blockIdx.x * SCHUNK >= nt) return;
+	const bool ok = t < nt;
+	const ChunkPart cp = part[blockIdx.x];
+	TileScan o;
+	uint32_t h[6];
+	for (int s = 0; s < 6; ++s) {
+		h[s] = ok ? trec[t].hist[s] : 0u;
+		o.pre[s] = cp.sum[s] + block_excl_add<uint32_t>(h[s], s_w, (uint32_t*)0);
+	}
+	const bool hh = ok && trec[t].fh >= 0;
+	o.lht = max(cp.mx, block_excl_max(hh ? (int)t : -1, s_wi, -1));
+	o.nht = min(cp.mn, block_excl_min_down(hh ? (int)t : INT_MAX, s_wi, INT_MAX));
+	if (ok) tsc[t] = o;
+	if (ok && t == nt - 1) {                                  // grand total at index nt
+		TileScan e;
+		for (int s = 0; s < 6; ++s) e.pre[s] = o.pre[s] + h[s];
+		e.lht = -1; e.nht = INT_MAX;
+		tsc[nt] = e;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_setup: everything the rest of the round needs that depends on the 6x6 count matrix
+// ---------------------------------------------------------------------------------------------
+
+__global__ void k_setup(Ctl *ctl, int side, const TileScan *tsc)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	const SegDesc &sg = ctl->seg[side];
+	SegDesc &ng = ctl->seg[side ^ 1];
+	uint64_t cnt[6][6];
+	for (int b = 0; b < 6; ++b)
+		for (int a = 0; a < 6; ++a)
+			ctl->count[b][a] = cnt[b][a] = (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]);
+	// new ropes (side^1): sizes, layout in the leaf pool, merge tiles
+	uint64_t leaf = 0, mt = 0, run[6] = {0, 0, 0, 0, 0, 0};
+	for (int b = 0; b < 6; ++b) {
+		const RopeDesc &o = ctl->rope[side][b];
+		RopeDesc &n = ctl->rope[side ^ 1][b];
+		n.n = o.n + sg.cnt[b];
+		for (int a = 0; a < 6; ++a) {
+			ctl->ac[b][a] = run[a];                           // #a in ropes < b, after this round
+			n.cnt[a] = o.cnt[a] + cnt[b][a];
+			run[a] += n.cnt[a];
+		}
+		n.nleaves = (n.n + LEAF - 1) / LEAF;
+		n.leaf0 = leaf; n.sb0 = leaf / SB;
+		leaf += (n.nleaves + SB - 1) / SB * SB;
+		ctl->mt0[b] = mt;
+		mt += (n.n + MT - 1) / MT;
+	}
+	ctl->mt0[6] = mt; ctl->mt0[7] = mt;
+	ctl->nsb_total = leaf / SB;
+	// next round's buckets: bucket a = strings that inserted a, in (bucket, order) order (mrope.c:303-309)
+	uint64_t st = 0; uint32_t tl = 0;
+	for (int a = 0; a < 6; ++a) {
+		uint64_t c = 0;
+		for (int b = 0; b < 6; ++b) { ctl->dest[b][a] = st + c; c += cnt[b][a]; }
+		if (a == 0) { c = 0; for (int b = 0; b < 6; ++b) ctl->dest[b][0] = 0; }   // finished strings are dropped (mrope.c:310)
+		ng.start[a] = st; ng.cnt[a] = c;
+		ng.tile0[a] = tl;
+		tl += (uint32_t)((c + STILE - 1) / STILE);
+		st += c;
+	}
+	ng.tile0[6] = tl; ng.tile0[7] = tl;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prep
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_comp, PoolView oldp,
+		const uint64_t *L, const uint64_t *U, const uint8_t *A, const TileRec *trec, const TileScan *tsc,
+		uint64_t *INS_E, uint8_t *INS_A, uint32_t *SLOT, uint32_t *PA, uint32_t *PGA, uint64_t *SIZE)
+{
+	__shared__ uint64_t s_bal[8][6], s_head[8];
+	__shared__ uint32_t s_cpre[9][6], s_tpre[6], s_popen[6], s_pnext[6];
+	__shared__ uint32_t s_fopen;
+	TileCtx t;
+	const SegDesc &sg = ctl->seg[side];
+	if (!tile_ctx(sg, blockIdx.x, t)) return;
+	const int ln = lane_id(), w = wave_id();
+	int sym2[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		int sym = 7; bool head = false;
+		if (k < t.segend) { const uint8_t a = A[k]; sym = a & 7; head = (a & 0x80) != 0; }
+		sym2[h] = sym;
+		const int c = h * 4 + w;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) s_bal[c][s] = bm; }
+		uint64_t hm = __ballot(head);
+		if (ln == 0) s_head[c] = hm;
+	}
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		const int s = threadIdx.x;
+		const uint32_t tile = blockIdx.x, t0 = sg.tile0[t.b], t1 = sg.tile0[t.b + 1];
+		const uint32_t segbase = tsc[t0].pre[s];
+		uint32_t run = 0;
+		for (int c = 0; c < 8; ++c) { s_cpre[c][s] = run; run += __popcll(s_bal[c][s]); }
+		s_cpre[8][s] = run;
+		s_tpre[s] = tsc[tile].pre[s] - segbase;
+		const int lt = tsc[tile].lht, nt = tsc[tile].nht;
+		uint32_t po = 0;
+		if (lt >= (int)t0) po = tsc[lt].pre[s] - segbase + trec[lt].lhpre[s];
+		s_popen[s] = po;
+		s_pnext[s] = (nt < (int)t1) ? tsc[nt].pre[s] - segbase + trec[nt].fhpre[s] : tsc[t1].pre[s] - segbase;
+		if (s == 0) s_fopen = (lt >= (int)t0) ? (uint32_t)((lt - t0) * STILE + trec[lt].lh) : 0u;
+	}
+	__syncthreads();
+	const RopeDesc &rp = ctl->rope[side][t.b];
+	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int x = h * 256 + threadIdx.x;
+		const uint64_t k = t.base + x;
+		if (k >= t.segend) continue;
+		const int a = sym2[h], c = x >> 6, l6 = x & 63;
+		const uint64_t le = lt_mask(l6) | (1ull << l6);
+		int hpos = -1, npos = -1;
+		{
+			uint64_t hm = s_head[c] & le;
+			if (hm) hpos = c * 64 + 63 - __builtin_clzll(hm);
+			else for (int cc = c - 1; cc >= 0; --cc) if (s_head[cc]) { hpos = cc * 64 + 63 - __builtin_clzll(s_head[cc]); break; }
+			uint64_t nm = s_head[c] & ~le;
+			if (nm) npos = c * 64 + __builtin_ctzll(nm);
+			else for (int cc = c + 1; cc < 8; ++cc) if (s_head[cc]) { npos = cc * 64 + __builtin_ctzll(s_head[cc]); break; }
+		}
+		auto before = [&](int y, int s) -> uint32_t { return s_cpre[y >> 6][s] + __popcll(s_bal[y >> 6][s] & lt_mask(y & 63)); };
+		const uint32_t pa = s_tpre[a] + before(x, a);
+		const uint32_t pga = hpos >= 0 ? s_tpre[a] + before(hpos, a) : s_popen[a];
+		const uint64_t F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)s_fopen;
+		uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
+		const int oa = orda[a];
+		for (int s = 0; s < 6; ++s) {
+			if (orda[s] >= oa) continue;
+			const uint32_t pg = hpos >= 0 ? s_tpre[s] + before(hpos, s) : s_popen[s];
+			const uint32_t pn = npos >= 0 ? s_tpre[s] + before(npos, s) : s_pnext[s];
+			bef += pn - pg;
+		}
+		const uint64_t l0 = L[k] - F, u0 = U[k] - F;           // coordinates on the pre-round rope
+		uint64_t e = l0, size = 0;
+		if (u0 != l0) {                                        // rope_rank2a (mrope.c:202)
+			uint64_t cl[6], cu[6];
+			rank_all(oldp, rp, l0, cl);
+			rank_all(oldp, rp, u0, cu);
+			for (int s = 0; s < 6; ++s) {
+				const uint64_t d = cu[s] - cl[s];
+				if (orda[s] < oa) e += d;
+				if (s == a) size = d;
+			}
+		}
+		const uint32_t slot = (uint32_t)(F + bef + (pa - pga));
+		INS_E[t.segstart + slot] = e;
+		INS_A[t.segstart + slot] = (uint8_t)a;
+		SLOT[k] = slot; PA[k] = pa; PGA[k] = pga; SIZE[k] = size;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_part: for every output tile boundary o = j*MT of rope b, the number of inserts that land
+// before it = smallest q with E[q] + q >= o (final position of insert q is E[q] + q)
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, uint32_t *TQ)
+{
+	const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (gid >= ctl->mt0[6] + 6) return;
+	int b = 0;
+	while (gid >= ctl->mt0[b+1] + b + 1) ++b;
+	const uint64_t j = gid - ctl->mt0[b] - b;
+	const SegDesc &sg = ctl->seg[side];
+	const uint64_t *E = INS_E + sg.start[b];
+	const uint64_t o = j * MT;
+	uint64_t lo = 0, hi = sg.cnt[b];
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (E[mid] + mid >= o) hi = mid; else lo = mid + 1;
+	}
+	TQ[gid] = (uint32_t)lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_merge: one block = MT output symbols (TL leaves) of one rope
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t get_byte(const uint32_t w[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
+
+__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolView oldp, PoolView newp,
+		const uint64_t *INS_E, const uint8_t *INS_A, uint64_t *RK, const uint32_t *TQ)
+{
+	__shared__ __align__(16) uint8_t s_old[(TL + 1) * LEAF];
+	__shared__ __align__(16) uint8_t s_out[MT];
+	__shared__ __align__(16) uint8_t s_bytes[MT];
+	__shared__ uint32_t s_flag[MT / 32];
+	__shared__ uint64_t s_cplo[256], s_cphi[256];
+	__shared__ uint64_t s_w64[4];
+	__shared__ uint32_t s_w32[4];
+	__shared__ uint64_t s_base[6];
+
+	const uint64_t tile = blockIdx.x;
+	if (tile >= ctl->mt0[6]) return;
+	int b = 0;
+	while (tile >= ctl->mt0[b+1]) ++b;
+	const uint64_t j = tile - ctl->mt0[b];
+	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
+	const uint64_t segs = ctl->seg[side].start[b];
+	const uint32_t q0 = TQ[tile + b], q1 = TQ[tile + b + 1];
+	const uint64_t o0 = j * MT, o1 = min(o0 + (uint64_t)MT, nrp.n);
+	const uint64_t i0 = o0 - q0, i1 = o1 - q1;                // old symbols [i0,i1) belong to this tile
+	const uint64_t fl = i0 / LEAF;                             // first old leaf touched
+	const bool have = fl < orp.nleaves;
+	const uint32_t dlen = have ? (uint32_t)(i1 - fl * LEAF) : 0u;   // decoded region = [fl*LEAF, i1)
+	const int nl = (dlen + LEAF - 1) / LEAF;
+	const int tid = threadIdx.x, ln = lane_id(), w = wave_id();
+
+	if (tid < MT / 32) s_flag[tid] = 0;
+	if (tid < 6) {
+		uint64_t v;
+		if (have) {
+			const uint64_t gl = orp.leaf0 + fl;
+			v = oldp.sbcum[gl / SB].v[tid] - oldp.sbcum[orp.sb0].v[tid] + oldp.meta[gl].c[tid];
+		} else v = orp.cnt[tid];
+		s_base[tid] = v;
+	}
+	// ---- decode the old leaves into one symbol per byte (rle_dec1, rle.h:39-51; 1-byte runs only)
+	for (int li = w; li < nl; li += 4) {
+		const uint64_t gl = orp.leaf0 + fl + li;
+		const int nb = oldp.meta[gl].nbytes;
+		const uint4 *src = (const uint4*)(oldp.data + gl * (uint64_t)LEAF);
+		uint32_t wd[4] = {0, 0, 0, 0};
+		const int nv = min(16, max(0, nb - ln * 16));
+		if (nv > 0) { const uint4 v = src[ln]; wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
+		uint32_t mysum = 0;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) if (i < nv) mysum += get_byte(wd, i) >> 3;
+		const uint32_t start = wave_incl_add(mysum) - mysum;
+		uint8_t *dst = s_old + li * LEAF + start;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			if (i >= nv) break;
+			const uint32_t byte = get_byte(wd, i), len = byte >> 3, s = byte & 7;
+			for (uint32_t x = 0; x < len; ++x) *dst++ = (uint8_t)s;
+		}
+	}
+	__syncthreads();
+	// ---- per-32-symbol prefix counts over the decoded region (for the ranks of the inserts)
+	{
+		uint64_t lo = 0, hi = 0;
+		const uint32_t cb = tid * 32;
+		if (cb < dlen) {
+			const uint32_t ce = min(cb + 32u, dlen);
+			for (uint32_t y = cb; y < ce; ++y) {
+				const uint32_t s = s_old[y];
+				if (s < 4) lo += 1ull << (16 * s); else hi += 1ull << (16 * (s - 4));
+			}
+		}
+		s_cplo[tid] = block_excl_add<uint64_t>(lo, s_w64, (uint64_t*)0);
+		s_cphi[tid] = block_excl_add<uint64_t>(hi, s_w64, (uint64_t*)0);
+	}
+	__syncthreads();
+	// ---- inserts of this tile: rank on the old rope (return value of rope_insert_run, rope.c:147) and placement
+	for (uint32_t q = q0 + tid; q < q1; q += 256) {
+		const uint64_t e = INS_E[segs + q];
+		const uint32_t a = INS_A[segs + q];
+		const uint32_t x = (uint32_t)(e - fl * LEAF), c = x >> 5;
+		uint32_t cnt = (uint32_t)(((a < 4 ? s_cplo[c] >> (16 * a) : s_cphi[c] >> (16 * (a - 4)))) & 0xffffu);
+		for (uint32_t y = c * 32; y < x; ++y) cnt += (s_old[y] == a);
+		RK[segs + q] = s_base[a] + cnt;
+		const uint32_t p = (uint32_t)(e + q - o0);
+		s_out[p] = (uint8_t)a;
+		atomicOr(&s_flag[p >> 5], 1u << (p & 31));
+	}
+	__syncthreads();
+	// ---- assemble my 16 output symbols
+	const uint32_t nvalid = (uint32_t)(o1 - o0);
+	const uint32_t p0 = tid * 16;
+	const int myvalid = (int)min(16u, nvalid > p0 ? nvalid - p0 : 0u);
+	const uint32_t flags = (s_flag[tid >> 1] >> ((tid & 1) * 16)) & 0xffffu & ((1u << myvalid) - 1u);
+	const uint32_t nonins = myvalid - __popc(flags);
+	uint32_t oldoff = (uint32_t)(i0 - fl * LEAF) + block_excl_add<uint32_t>(nonins, s_w32, (uint32_t*)0);
+	uint32_t sy[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		uint32_t v = 0xff;
+		if (i < myvalid) v = (flags >> i & 1) ? s_out[p0 + i] : s_old[oldoff++];
+		sy[i] = v;
+	}
+	__syncthreads();
+	{
+		uint4 v;
+		v.x = sy[0] | sy[1] << 8 | sy[2] << 16 | sy[3] << 24;
+		v.y = sy[4] | sy[5] << 8 | sy[6] << 16 | sy[7] << 24;
+		v.z = sy[8] | sy[9] << 8 | sy[10] << 16 | sy[11] << 24;
+		v.w = sy[12] | sy[13] << 8 | sy[14] << 16 | sy[15] << 24;
+		*(uint4*)(s_out + p0) = v;
+	}
+	__syncthreads();
+	// ---- re-encode: one wave per output leaf (16 symbols per lane x 64 lanes = LEAF)
+	const uint32_t prev0 = ln == 0 ? 0xffu : s_out[p0 - 1];
+	const int lp0 = ln * 16;                                   // position inside the leaf
+	const int lv = (int)min((uint32_t)LEAF, nvalid > (uint32_t)(w * LEAF) ? nvalid - w * LEAF : 0u);   // valid symbols in my leaf
+	int lastnat = -1;
+	{
+		uint32_t pv = prev0;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) if (i < myvalid) { if (sy[i] != pv) lastnat = lp0 + i; pv = sy[i]; }
+	}
+	const int incmax = wave_incl_max(lastnat);
+	int rs = __shfl_up(incmax, 1);                             // start of the run open at lp0-1
+	if (ln == 0) rs = 0;
+	int lh = ln == 0 ? 0 : rs + (lp0 - 1 - rs) / 15 * 15;      // last byte boundary before lp0
+	// pass 1: count byte boundaries (heads) in my chunk
+	int hc = 0;
+	{
+		uint32_t pv = prev0; int r = rs;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) if (i < myvalid) {
+			const int p = lp0 + i;
+			const bool nat = sy[i] != pv;
+			if (nat) r = p;
+			hc += (nat || (p - r) % 15 == 0);
+			pv = sy[i];
+		}
+	}
+	const int hinc = wave_incl_add(hc);
+	const int hb = hinc - hc;
+	const int nbytes = __shfl(hinc, 63);
+	// pass 2: every head closes the run before it
+	{
+		uint32_t pv = prev0; int r = rs, seen = 0;
+		uint8_t *ob = s_bytes + w * LEAF;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) if (i < myvalid) {
+			const int p = lp0 + i;
+			const bool nat = sy[i] != pv;
+			if (nat) r = p;
+			if (nat || (p - r) % 15 == 0) {
+				if (p != 0) ob[hb + seen - 1] = (uint8_t)((p - lh) << 3 | pv);
+				lh = p; ++seen;
+			}
+			pv = sy[i];
+		}
+		if (myvalid > 0 && lp0 + myvalid == lv) ob[nbytes - 1] = (uint8_t)((lv - lh) << 3 | pv);   // last run of the leaf
+	}
+	// per-leaf symbol counts
+	uint64_t clo = 0; uint32_t chi = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) if (i < myvalid) {
+		const uint32_t s = sy[i];
+		if (s < 4) clo += 1ull << (16 * s); else chi += 1u << (16 * (s - 4));
+	}
+	clo = wave_sum(clo); chi = wave_sum(chi);
+	__syncthreads();
+	if (lv > 0) {
+		const uint64_t gl = nrp.leaf0 + j * TL + w;
+		if (ln == 0) {
+			LeafMeta m;
+			m.c[0] = (uint16_t)clo; m.c[1] = (uint16_t)(clo >> 16); m.c[2] = (uint16_t)(clo >> 32); m.c[3] = (uint16_t)(clo >> 48);
+			m.c[4] = (uint16_t)chi; m.c[5] = (uint16_t)(chi >> 16);
+			m.nbytes = (uint16_t)nbytes; m.pad = 0;
+			newp.meta[gl] = m;                                 // own counts; k_meta_sb turns them into prefixes
+		}
+		if (ln * 16 < nbytes) ((uint4*)(newp.data + gl * (uint64_t)LEAF))[ln] = ((const uint4*)(s_bytes + w * LEAF))[ln];
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank directory of the new side
+// ---------------------------------------------------------------------------------------------
+
+// one wave per superblock: per-leaf counts -> exclusive prefix inside the superblock; superblock totals
+__global__ __launch_bounds__(64) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot)
+{
+	const uint64_t sb = blockIdx.x;
+	if (sb >= ctl->nsb_total) return;
+	const int ln = lane_id();
+	const uint64_t gl = sb * SB + ln;
+	bool ok = false;
+	if (ln < SB)
+		for (int b = 0; b < 6; ++b) { const RopeDesc &r = ctl->rope[nside][b]; ok |= (gl >= r.leaf0 && gl < r.leaf0 + r.nleaves); }
+	LeafMeta m;
+	for (int s = 0; s < 6; ++s) m.c[s] = 0;
+	if (ok) m = newp.meta[gl];
+	uint32_t tot[6];
+	for (int s = 0; s < 6; ++s) {
+		const uint32_t v = m.c[s], inc = wave_incl_add(v);
+		tot[s] = __shfl(inc, 63);
+		m.c[s] = (uint16_t)(inc - v);
+	}
+	if (ok) newp.meta[gl] = m;
+	if (ln == 0) { Cnt6 c; for (int s = 0; s < 6; ++s) c.v[s] = tot[s]; sbtot[sb] = c; }
+}
+
+__global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const Cnt6 *sbtot, Cnt6 *part)
+{
+	__shared__ uint64_t s_w[16];
+	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
+	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
+	Cnt6 o;
+	for (int s = 0; s < 6; ++s) { uint64_t tot; block_excl_add<uint64_t>(i < n ? sbtot[i].v[s] : 0ull, s_w, &tot); o.v[s] = tot; }
+	if (threadIdx.x == 0) part[blockIdx.x] = o;
+}
+__global__ __launch_bounds__(SCHUNK) void k_sbscan2(const Ctl *ctl, Cnt6 *part)
+{
+	__shared__ uint64_t s_w[16];
+	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;   // host guarantees nc <= SCHUNK
+	const bool ok = threadIdx.x < nc;
+	Cnt6 p, o;
+	for (int s = 0; s < 6; ++s) p.v[s] = ok ? part[threadIdx.x].v[s] : 0ull;
+	for (int s = 0; s < 6; ++s) o.v[s] = block_excl_add<uint64_t>(p.v[s], s_w, (uint64_t*)0);
+	if (ok) part[threadIdx.x] = o;
+}
+__global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *sbtot, const Cnt6 *part, PoolView newp)
+{
+	__shared__ uint64_t s_w[16];
+	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
+	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
+	Cnt6 o;
+	for (int s = 0; s < 6; ++s) o.v[s] = part[blockIdx.x].v[s] + block_excl_add<uint64_t>(i < n ? sbtot[i].v[s] : 0ull, s_w, (uint64_t*)0);
+	if (i < n) newp.sbcum[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_advance: new interval of every string (mrope.c:226-229 + 332-340), consume one symbol, and
+// the stable 6-way partition into next round's buckets (mrope.c:303-309)
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint32_t round, const uint8_t *s,
+		const uint64_t *START, const uint8_t *A, const uint32_t *SLOT, const uint32_t *PA, const uint32_t *PGA,
+		const uint64_t *SIZE, const uint64_t *RK, const uint32_t *ID, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+{
+	TileCtx t;
+	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		if (k >= t.segend) continue;
+		const int a = A[k] & 7;
+		if (a == 0) continue;                                  // sentinel inserted: string is done (mrope.c:310)
+		const uint64_t rk = RK[t.segstart + SLOT[k]];
+		const uint64_t l = ctl->ac[t.b][a] + rk + PGA[k];
+		const uint64_t d = ctl->dest[t.b][a] + PA[k];
+		const uint32_t id = ID[k];
+		uint64_t wv = W[k] >> 4;
+		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
+		L2[d] = l; U2[d] = l + SIZE[k]; ID2[d] = id; W2[d] = wv;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// misc: synthetic reads, single rank query
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint64_t splitmix(uint64_t seed, uint64_t k)
+{
+	uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ull;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+// one thread per output byte; strand 0: [rev(read) 0]; strand 1: [rev(read) 0 comp(read) 0] (main.c:200-237)
+__global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand)
+{
+	const uint64_t per = (uint64_t)(L + 1) * (strand ? 2 : 1);
+	const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (gid >= n_reads * per) return;
+	const uint64_t r = gid / per; uint32_t off = (uint32_t)(gid % per);
+	const uint64_t i = first + r;
+	uint8_t v;
+	if (off < L) v = (uint8_t)(1 + (splitmix(seed, i * L + (L - 1 - off)) >> 62));          // reversed forward strand
+	else if (off == L) v = 0;
+	else { off -= L + 1; v = off < L ? (uint8_t)(4 - (splitmix(seed, i * L + off) >> 62)) : 0; }   // complement, original order
+	dst[gid] = v;
+}
+
+__global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out)
+{
+	if (threadIdx.x || blockIdx.x) return;
+	uint64_t c[6];
+	rank_all(pv, ctl->rope[side][b], x, c);
+	for (int s = 0; s < 6; ++s) out[s] = c[s];
+}
+
+} // namespace rb2

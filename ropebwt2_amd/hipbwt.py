@@ -1,0 +1,186 @@
+"""ctypes mirror of include/rb2_hip.h -- the C ABI of the gfx950 insertion engine.
+
+``HipBwt`` follows the reference's operator interface for this path: ``insert_multi(buf)`` takes
+exactly the buffer main.c hands to ``mr_insert_multi`` (mrope.h:46-54: concatenated, reversed,
+0-terminated nt6 strings) and mutates the six ropes; ``counts()`` is ``rope_t.c`` (rope.h:19).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+K_NAMES = ["k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init"]
+_lib = None
+
+
+def load_hip_lib():
+    """Load librb2hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path("librb2hip.so")
+    if not os.path.exists(path):
+        raise RuntimeError("%s missing: run `python -m ropebwt2_amd.build` (hipcc, gfx950) first" % path)
+    L = C.CDLL(path)
+    vp, i64, i32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64
+    sig = {
+        "rb2_hip_device_count": (i32, []),
+        "rb2_hip_create": (vp, [i32, i32]),
+        "rb2_hip_destroy": (None, [vp]),
+        "rb2_hip_sorting_order": (i32, [vp]),
+        "rb2_hip_insert_multi": (None, [vp, i64, vp]),
+        "rb2_hip_insert_multi_dev": (None, [vp, i64, vp]),
+        "rb2_hip_get_counts": (None, [vp, vp]),
+        "rb2_hip_rope_bytes": (i64, [vp, i32]),
+        "rb2_hip_download_rope": (i64, [vp, i32, vp]),
+        "rb2_hip_load_ropes": (None, [vp, vp, vp]),
+        "rb2_hip_rank1a": (None, [vp, i32, i64, vp]),
+        "rb2_hip_dev_alloc": (vp, [vp, i64]),
+        "rb2_hip_dev_free": (None, [vp, vp]),
+        "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
+        "rb2_hip_sync": (None, [vp]),
+        "rb2_hip_profile": (None, [vp, i32]),
+        "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
+        "rb2_hip_kernel_name": (C.c_char_p, [i32]),
+        "rb2_hip_layout": (None, [vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+ABI_SYMBOLS = [
+    "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order",
+    "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
+    "rb2_hip_download_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_dev_alloc",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_sync", "rb2_hip_profile",
+    "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
+]
+
+
+def expand_runs(rle):
+    """1-byte-run 43+3 stream (what the device emits) -> nt6 symbols."""
+    rle = np.asarray(rle, dtype=np.uint8)
+    return np.repeat(rle & 7, rle >> 3)
+
+
+def encode_runs(symbols):
+    """nt6 symbols -> 43+3 stream using the 1/2/4/8-byte forms (rle.h:53-75); host-side helper."""
+    symbols = np.asarray(symbols, dtype=np.uint8)
+    out = bytearray()
+    if len(symbols) == 0:
+        return np.zeros(0, np.uint8)
+    edges = np.flatnonzero(np.diff(symbols)) + 1
+    starts = np.concatenate([[0], edges])
+    lens = np.diff(np.concatenate([starts, [len(symbols)]]))
+    for c, l in zip(symbols[starts].tolist(), lens.tolist()):
+        if l < 16:
+            out.append(l << 3 | c)
+        else:
+            n = 2 if l < 256 else 4 if l < (1 << 19) else 8
+            tail = []
+            for _ in range(n - 1):
+                tail.append(0x80 | (l & 0x3f))
+                l >>= 6
+            out.append({2: 0xC0, 4: 0xE0, 8: 0xF0}[n] | l << 3 | c)
+            out.extend(reversed(tail))
+    return np.frombuffer(bytes(out), dtype=np.uint8)
+
+
+class HipBwt:
+    """Six-rope BWT resident in the HBM of one MI355X."""
+
+    def __init__(self, sorting_order=0, device=0):
+        self.L = load_hip_lib()
+        if self.L.rb2_hip_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the gfx950 engine has no CPU fallback")
+        self.h = self.L.rb2_hip_create(device, sorting_order)
+        self.so = sorting_order
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rb2_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the hot path ---------------------------------------------------------------------
+    def insert_multi(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.L.rb2_hip_insert_multi(self.h, len(buf), buf.ctypes.data)
+
+    def insert_multi_dev(self, dev_ptr, nbytes):
+        self.L.rb2_hip_insert_multi_dev(self.h, nbytes, dev_ptr)
+
+    # -- state ----------------------------------------------------------------------------
+    def counts(self):
+        c = np.zeros(36, np.int64)
+        self.L.rb2_hip_get_counts(self.h, c.ctypes.data)
+        return c.reshape(6, 6)
+
+    def rope_rle(self, b):
+        n = self.L.rb2_hip_rope_bytes(self.h, b)
+        out = np.zeros(max(n, 1), np.uint8)
+        got = self.L.rb2_hip_download_rope(self.h, b, out.ctypes.data)
+        assert got == n
+        return out[:n]
+
+    def rope(self, b):
+        return expand_runs(self.rope_rle(b))
+
+    def ropes(self):
+        return [self.rope(b) for b in range(6)]
+
+    def bwt(self):
+        return np.concatenate(self.ropes())
+
+    def load_ropes(self, rles):
+        arrs = [np.ascontiguousarray(r, dtype=np.uint8) for r in rles]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data if len(a) else None for a in arrs])
+        lens = (C.c_int64 * 6)(*[len(a) for a in arrs])
+        self.L.rb2_hip_load_ropes(self.h, ptrs, lens)
+
+    def rank1a(self, b, x):
+        c = np.zeros(6, np.int64)
+        self.L.rb2_hip_rank1a(self.h, b, x, c.ctypes.data)
+        return c
+
+    # -- measurement helpers ----------------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        return self.L.rb2_hip_dev_alloc(self.h, nbytes)
+
+    def dev_free(self, p):
+        self.L.rb2_hip_dev_free(self.h, p)
+
+    def synth_reads(self, dev_ptr, first, n_reads, read_len, seed=42, strand=0):
+        self.L.rb2_hip_synth_reads(self.h, dev_ptr, first, n_reads, read_len, seed, strand)
+
+    def sync(self):
+        self.L.rb2_hip_sync(self.h)
+
+    def profile(self, on=True):
+        self.L.rb2_hip_profile(self.h, 1 if on else 0)
+
+    def profile_get(self, reset=False):
+        n = len(K_NAMES)
+        la = np.zeros(n, np.int64)
+        ms = np.zeros(n, np.float64)
+        un = np.zeros(n, np.int64)
+        self.L.rb2_hip_profile_get(self.h, la.ctypes.data, ms.ctypes.data, un.ctypes.data, 1 if reset else 0)
+        return {K_NAMES[i]: {"launches": int(la[i]), "ms": float(ms[i]), "units": int(un[i])} for i in range(n)}
+
+    @staticmethod
+    def layout():
+        L = load_hip_lib()
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        L.rb2_hip_layout(C.byref(a), C.byref(b), C.byref(c))
+        return {"leaf_syms": a.value, "tile_leaves": b.value, "string_tile": c.value}
