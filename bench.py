@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- Gsymbols/s inserted by the gfx950 BCR engine (BASELINE.json metric).
+
+One "step" = one pass of the hot path (mr_insert_multi, /root/reference/mrope.c:258-345) over one
+`-m4g` batch of synthetic reads: 40,844,298 x 101 bp (4,166,118,396 symbols incl. sentinels),
+inserted into the index left by the previous step.  The default run (--steps 3) is exactly
+BASELINE.json configs[1]: 100 M x 101 bp, `-bsR` (RLO, forward strand), `-m4g`, 1 x MI355X
+(the third batch holds the remaining 18,311,404 reads).
+
+Inputs are generated on the device (splitmix64 stream of SURVEY.md 8c) before the timed region,
+so `value` is whole-job symbols / wall time with inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: every rank builds the BWT of its own disjoint slice of the read stream (same per-GPU
+workload as N = 1, "weak"); see DESIGN.md section 7 for what is and is not sharded yet.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SYMBOL = 50.0        # compulsory HBM traffic per inserted symbol
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def batch_reads(mem_arg_bytes, read_len):
+    m = int(mem_arg_bytes * 0.97) + 1            # main.c:136
+    per = read_len + 1
+    return -(-m // per)                          # main.c:238: flush once buf.l >= m
+
+
+def cpu_baseline(read_len, so_flag, sample_reads, budget_s=120):
+    """Time the reference CLI (oracle/_ref, built from /root/reference by oracle/Makefile) on a
+    bounded sample of the same read stream; falls back to the plain-C port (oracle/liboracle.so)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt2")
+    gen = os.path.join(ROOT, "oracle", "synth_reads")
+    ncpu = os.cpu_count() or 1
+    if os.path.exists(ref) and os.path.exists(gen):
+        try:
+            g = subprocess.Popen([gen, str(sample_reads), str(read_len), "42"], stdout=subprocess.PIPE)
+            cmd = [ref, "-L", "-R", "-b"] + ([so_flag] if so_flag else []) + ["-m4g", "-o", "/dev/null", "-"]
+            p = subprocess.run(cmd, stdin=g.stdout,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=budget_s * 4)
+            g.wait()
+            tot_s, tot_t = 0, 0.0
+            for m in re.finditer(r"inserted (\d+) symbols in ([0-9.]+) sec", p.stderr.decode()):
+                tot_s += int(m.group(1)); tot_t += float(m.group(2))
+            if tot_t > 0:
+                return {"value": tot_s / tot_t / 1e9, "unit": "Gsymbols/s", "cores": min(5, ncpu), "kind": "reference",
+                        "sample": "%d x %d bp reads of the same splitmix64 stream, ropebwt2 -L -R -b %s -m4g (5 threads: 4 workers + master, mrope.c:287-296); "
+                                  "%.1f s insert time; host has %d cores" % (sample_reads, read_len, so_flag, tot_t, ncpu)}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("[bench] reference baseline failed: %r\n" % (e,))
+    # plain-C port (single thread)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    n = min(sample_reads, 50000)
+    codes = helpers.splitmix_bases(n, read_len)
+    buf = helpers.encode_batch_fixed(codes)
+    o = helpers.Oracle({"-s": 1, "-r": 2}.get(so_flag, 0))
+    t = time.time(); o.insert_multi(buf); dt = time.time() - t
+    return {"value": len(buf) / dt / 1e9, "unit": "Gsymbols/s", "cores": 1, "kind": "port",
+            "sample": "%d x %d bp reads, oracle/bcr_oracle.c orc_insert_multi, 1 thread" % (n, read_len)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads in the whole job (configs[1]: 100 M)")
+    ap.add_argument("--read-len", type=int, default=101)
+    ap.add_argument("--batch", type=float, default=4.0, help="-m in GiB")
+    ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        sys.stderr.write("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE\n" % (world, args.gpus))
+    n_gpus = world if world > 1 else 1
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ropebwt2_amd import HipBwt, build_all
+    build_all()
+    so = {"io": 0, "rlo": 1, "rclo": 2}[args.order]
+    so_flag = {"io": "", "rlo": "-s", "rclo": "-r"}[args.order]
+    L = args.read_len
+    per_batch = batch_reads(args.batch * 1024 ** 3, L)
+    dev = local_rank if world > 1 else 0
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up: same kernels on a small scratch index (untimed)
+    for _ in range(max(0, args.warmup)):
+        w = HipBwt(so, dev)
+        n = 200_000
+        p = w.dev_alloc(n * (L + 1))
+        for i in range(2):
+            w.synth_reads(p, i * n, n, L, seed=7)
+            w.insert_multi_dev(p, n * (L + 1))
+        w.dev_free(p)
+        w.close()
+
+    # ---- the job: K consecutive -m batches of this rank's slice of the read stream
+    bwt = HipBwt(so, dev)
+    bwt.profile(True)
+    first = rank * args.reads                     # rank r owns reads [r*reads, (r+1)*reads)
+    steps = []
+    done = 0
+    for k in range(args.steps):
+        n = min(per_batch, args.reads - done) if done < args.reads else per_batch
+        steps.append((first + done, n))
+        done += n
+    bufs = []
+    for (f, n) in steps:                          # inputs resident in HBM before the clock starts
+        p = bwt.dev_alloc(n * (L + 1))
+        bwt.synth_reads(p, f, n, L, seed=42)
+        bufs.append(p)
+    bwt.sync()
+    bwt.profile_get(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for (f, n), p in zip(steps, bufs):
+        bwt.insert_multi_dev(p, n * (L + 1))
+    bwt.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    symbols = sum(n * (L + 1) for (_, n) in steps)
+    prof = bwt.profile_get()
+    counts = bwt.counts()
+    ok_counts = int(counts.sum()) == symbols and int(counts[:, 0].sum()) == sum(n for _, n in steps)
+    for p in bufs:
+        bwt.dev_free(p)
+    bwt.close()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    total_symbols = symbols * n_gpus
+    mk = prof["k_merge"]
+    ach = ALG_BYTES_PER_SYMBOL * mk["units"] / (mk["ms"] * 1e-3) / 1e9 if mk["ms"] > 0 else 0.0
+    out = {
+        "metric": "Gsymbols/s inserted (wall-clock), bit-identical .fmd",
+        "value": total_symbols / dt / 1e9,
+        "unit": "Gsymbols/s",
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / max(1, args.steps),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
+                               % (args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
+                   "reads_per_gpu": sum(n for _, n in steps), "symbols_per_gpu": symbols,
+                   "parallelism": "1 GPU" if n_gpus == 1 else "independent BWT per GPU (read stream sliced by rank)",
+                   "counts_ok": bool(ok_counts)},
+        "roofline": {"bound": "hbm", "kernel": "k_merge", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": mk["ms"] / max(1, mk["launches"]), "launches": mk["launches"],
+                     "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL},
+        "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "k_merge_traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            out["roofline"]["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

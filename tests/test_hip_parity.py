@@ -1,0 +1,242 @@
+"""GPU parity tests: the HIP hot path (through the C ABI of include/rb2_hip.h) must return exactly
+the BWT the oracle / the reference returns -- bit-exact, every rope, every count.
+
+Structure mirrors how one would test mr_insert_multi itself: build the batch buffer main.c would
+build (helpers.encode_batch*), call insert_multi, compare the six ropes.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+SO_FLAG = {0: "-LR", 1: "-LRs", 2: "-LRr"}
+
+
+def run_both(hip, so, batches):
+    o = H.Oracle(so)
+    g = hip.HipBwt(so)
+    for i, buf in enumerate(batches):
+        o.insert_multi(buf)
+        g.insert_multi(buf)
+        assert np.array_equal(o.counts(), g.counts()), "count matrix differs after batch %d" % i
+    for b in range(6):
+        ro, rg = o.rope(b), g.rope(b)
+        assert len(ro) == len(rg), "rope %d length" % b
+        assert np.array_equal(ro, rg), "rope %d differs at %s" % (b, np.flatnonzero(ro != rg)[:5])
+    return o, g
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+@pytest.mark.parametrize("both", [False, True])
+def test_kat(hip, golden, so, both):
+    reads = H.text_to_reads(golden["kat_input"].encode())
+    o, g = run_both(hip, so, [H.encode_batch(reads, True, both)])
+    flag = SO_FLAG[so] if not both else SO_FLAG[so].replace("R", "")
+    assert H.bwt_text(g.bwt()).decode() == golden["kat"][flag]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_repetitive_multibatch(hip, so):
+    """variable length 0..40, duplicates, N's, empty strings, three batches, last with both strands:
+    rank2a on non-empty intervals in every round (mrope.c:199-202)."""
+    reads = H.repetitive_reads(1500, seed=11 + so)
+    run_both(hip, so, [H.encode_batch(reads[:500]), H.encode_batch(reads[500:1000]), H.encode_batch(reads[1000:], True, True)])
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_repetitive_larger(hip, so):
+    reads = H.repetitive_reads(20000, seed=5 + so, genome_len=3000, max_len=120)
+    run_both(hip, so, [H.encode_batch(reads[:10000]), H.encode_batch(reads[10000:])])
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_random_10k_golden(hip, golden, so):
+    g = golden["sets"]["10k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    _, dev = run_both(hip, so, [H.encode_batch_fixed(codes[:5000]), H.encode_batch_fixed(codes[5000:])])
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+def test_random_10k_both_strands_golden(hip, golden):
+    g = golden["sets"]["10k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    dev = hip.HipBwt(2)
+    dev.insert_multi(H.encode_batch_fixed(codes, True, True))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"]["-Lr"]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_long_reads(hip, golden, so):
+    """config 4 shape (long strings, few per round): 200 x 10 kbp, golden from the reference."""
+    g = golden["sets"]["200_x_10k"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    dev = hip.HipBwt(so)
+    dev.insert_multi(H.encode_batch_fixed(codes))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_golden_100k(hip, golden, so):
+    g = golden["sets"]["100k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    dev = hip.HipBwt(so)
+    for i in range(0, 100000, 40000):          # uneven batches
+        dev.insert_multi(H.encode_batch_fixed(codes[i:i + 40000]))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+@pytest.mark.parametrize("so", [1, 2])
+def test_golden_1M(hip, golden, so):
+    g = golden["sets"]["1M_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    dev = hip.HipBwt(so)
+    dev.insert_multi(H.encode_batch_fixed(codes[:600000]))
+    dev.insert_multi(H.encode_batch_fixed(codes[600000:]))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+# ---- edge cases --------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_empty_and_tiny_strings(hip, so):
+    batches = [np.zeros(1, np.uint8),                                  # one empty string
+               np.zeros(7, np.uint8),                                  # only empty strings
+               np.array([3, 0], np.uint8),                             # one 1-symbol string
+               H.encode_batch([[1], [], [1], [5], [4, 4], []])]
+    run_both(hip, so, batches)
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_homopolymers_long_runs(hip, so):
+    """runs far longer than 15 (the 1-byte run limit of the device leaves) and than one leaf"""
+    lay = hip.HipBwt.layout()
+    n = lay["leaf_syms"] * lay["tile_leaves"] + 37
+    reads = [[1] * 70] * 300 + [[4] * 33] * 200 + [[2] * 5 + [5] * 3] * 100 + [[3] * (n // 64)] * 70
+    run_both(hip, so, [H.encode_batch(reads[:400]), H.encode_batch(reads[400:])])
+
+
+@pytest.mark.parametrize("so", [0, 1])
+@pytest.mark.parametrize("delta", [-1, 0, 1])
+def test_leaf_and_tile_boundaries(hip, so, delta):
+    """rope sizes that hit leaf / merge-tile / string-tile multiples exactly and off by one"""
+    lay = hip.HipBwt.layout()
+    n = lay["string_tile"] * 8 + delta             # strings: multiple of the string tile (+-1)
+    codes = H.splitmix_bases(n, 7, seed=3)
+    run_both(hip, so, [H.encode_batch_fixed(codes)])
+    T = lay["leaf_syms"] * lay["tile_leaves"]
+    one = np.concatenate([np.full(T + delta - 1, 2, np.uint8), np.zeros(1, np.uint8)])   # single string filling one tile
+    run_both(hip, so, [one, one])
+
+
+def test_single_long_string(hip):
+    codes = H.splitmix_bases(1, 50000, seed=77)
+    for so in (0, 1):
+        run_both(hip, so, [H.encode_batch_fixed(codes)])
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_incremental_on_loaded_index(hip, so):
+    """config 5 shape: seed the device from an existing index (what mr_restore would hand over,
+    with 2/4/8-byte runs in the stream), then insert more; equals the one-shot build."""
+    from ropebwt2_amd.hipbwt import encode_runs
+    reads = H.repetitive_reads(3000, seed=50 + so, genome_len=400, max_len=60) + [[1] * 300] * 40
+    o = H.Oracle(so)
+    o.insert_multi(H.encode_batch(reads[:1500]))
+    dev = hip.HipBwt(so)
+    dev.load_ropes([encode_runs(o.rope(b)) for b in range(6)])
+    assert np.array_equal(dev.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(dev.rope(b), o.rope(b))
+    buf = H.encode_batch(reads[1500:])
+    o.insert_multi(buf)
+    dev.insert_multi(buf)
+    assert np.array_equal(dev.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(dev.rope(b), o.rope(b))
+
+
+def test_rank1a_matches_oracle(hip):
+    reads = H.repetitive_reads(4000, seed=3, genome_len=500, max_len=80)
+    o, dev = run_both(hip, 1, [H.encode_batch(reads)])
+    rng = np.random.RandomState(0)
+    for b in range(6):
+        r = o.rope(b)
+        for x in [0, 1, len(r) // 2, len(r) - 1, len(r)] + list(rng.randint(0, len(r) + 1, size=5)):
+            x = int(max(0, min(len(r), x)))
+            assert np.array_equal(dev.rank1a(b, x), np.bincount(r[:x], minlength=6))
+
+
+@pytest.mark.parametrize("strand", [0, 1])
+def test_device_generator_matches_host(hip, strand):
+    """the on-device synthetic reads (bench.py input) are the SURVEY.md 8c stream, encoded as main.c would"""
+    n, L = 3000, 37
+    codes = H.splitmix_bases(n, L, seed=42, first=100)
+    a = hip.HipBwt(2)
+    a.insert_multi(H.encode_batch_fixed(codes, True, bool(strand)))
+    b = hip.HipBwt(2)
+    nbytes = n * (L + 1) * (2 if strand else 1)
+    p = b.dev_alloc(nbytes)
+    b.synth_reads(p, 100, n, L, seed=42, strand=strand)
+    b.insert_multi_dev(p, nbytes)
+    b.dev_free(p)
+    assert np.array_equal(a.counts(), b.counts())
+    for r in range(6):
+        assert np.array_equal(a.rope_rle(r), b.rope_rle(r))
+
+
+# ---- full batch size: size-independent properties ------------------------------------------------
+
+def _sym_at(dev, b, p):
+    return int(np.argmax(dev.rank1a(b, p + 1) - dev.rank1a(b, p)))
+
+
+def _walk(dev, counts, row):
+    """spell the string whose '$'-suffix sits at row `row` of rope $ by LF-mapping (inverse BWT)."""
+    out = []
+    b, p = 0, row
+    while True:
+        c = _sym_at(dev, b, p)
+        if c == 0:
+            return out
+        out.append(c)
+        p = int(counts[:b, c].sum() + dev.rank1a(b, p)[c])
+        b = c
+
+
+def test_full_batch_properties(hip):
+    """one full -m4g batch (40.8 M x 101 bp, BASELINE.json configs[1]) in input order:
+    (1) every rope's size equals the number of occurrences of its symbol (LF consistency),
+    (2) inverse-BWT walks from sampled rows of rope $ reproduce exactly the sampled reads."""
+    L = 101
+    n = -(-(int(4 * 1024 ** 3 * 0.97) + 1) // (L + 1))
+    dev = hip.HipBwt(0)
+    p = dev.dev_alloc(n * (L + 1))
+    dev.synth_reads(p, 0, n, L, seed=42)
+    dev.insert_multi_dev(p, n * (L + 1))
+    dev.dev_free(p)
+    c = dev.counts()
+    assert c.sum() == n * (L + 1)
+    assert c[:, 0].sum() == n and c[0].sum() == n
+    for b in range(1, 6):
+        assert c[b].sum() == c[:, b].sum()
+    for k in [0, 1, 12345, n // 2, n - 1]:
+        got = _walk(dev, c, k)                      # read k reversed
+        want = H.splitmix_bases(1, L, seed=42, first=k)[0][::-1].tolist()
+        assert got == want, "read %d" % k
+
+
+def test_rlo_sortedness_property(hip):
+    """RLO build of 2 M reads: strings spelled from increasing rows of rope $ are non-decreasing in
+    reverse-lexicographic order (README.md:18-19 identity), and each is a read of the input."""
+    n, L = 2_000_000, 101
+    dev = hip.HipBwt(1)
+    p = dev.dev_alloc(n * (L + 1))
+    dev.synth_reads(p, 0, n, L, seed=42)
+    dev.insert_multi_dev(p, n * (L + 1))
+    dev.dev_free(p)
+    c = dev.counts()
+    rows = sorted(set([0, 1, 2, n // 3, n // 3 + 1, n // 2, n - 2, n - 1]))
+    spelled = [_walk(dev, c, r) for r in rows]      # reversed reads
+    assert all(len(s) == L for s in spelled)
+    assert all(spelled[i] <= spelled[i + 1] for i in range(len(spelled) - 1))
