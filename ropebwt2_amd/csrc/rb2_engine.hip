@@ -48,7 +48,7 @@ struct Pool {
 	void release() { data.release(); meta.release(); sbcum.release(); cap_leaves = 0; }
 };
 
-struct ProfRec { int k; hipEvent_t a, b; int64_t units; };
+struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
 
 } // namespace
 
@@ -72,6 +72,9 @@ struct rb2_hip_s {
 	std::vector<hipEvent_t> evpool;
 	int64_t p_launch[RB2_K_COUNT]; double p_ms[RB2_K_COUNT]; int64_t p_units[RB2_K_COUNT];
 	int debug = 0;
+	int cur_round = -1;
+	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
+	int force_dense = 0;                // RB2_HIP_DENSE=1: symbol-level merge for every tile (A/B testing)
 };
 
 namespace {
@@ -93,7 +96,7 @@ struct Scope {          // times everything enqueued between construction and de
 	rb2_hip_t *h; int k; ProfRec r;
 	Scope(rb2_hip_t *h_, int k_, int64_t units) : h(h_), k(k_) {
 		if (!h->prof) return;
-		r.k = k; r.units = units; r.a = get_event(h); r.b = get_event(h);
+		r.k = k; r.units = units; r.round = h->cur_round; r.a = get_event(h); r.b = get_event(h);
 		HIPCHK(hipEventRecord(r.a, h->st));
 	}
 	~Scope() {
@@ -110,6 +113,7 @@ void drain_profile(rb2_hip_t *h)
 		float ms = 0;
 		HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
 		h->p_launch[r.k] += 1; h->p_ms[r.k] += ms; h->p_units[r.k] += r.units;
+		if (h->trace && r.round >= 0 && (r.round < 20 || r.round % 10 == 0)) fprintf(stderr, "[rb2_hip] round %3d %-10s %8.3f ms\n", r.round, rb2_hip_kernel_name(r.k), ms);
 		h->evpool.push_back(r.a); h->evpool.push_back(r.b);
 	}
 	h->recs.clear();
@@ -195,6 +199,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	// ---- one round per string position, last symbol first (mrope.c:285, 299-342)
 	int cur = 0;                                               // string array side
 	for (uint64_t r = 0; r <= max_len; ++r) {
+		h->cur_round = (int)r;
 		const int sd = h->side;
 		PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
 		const uint64_t n_new_ub = n_tot + std::min<uint64_t>(len, (r + 1) * m);
@@ -213,7 +218,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		{ Scope sc(h, RB2_K_PART, units);
 		  hipLaunchKernelGGL(k_part, dim3(cdiv(nmt + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
 		{ Scope sc(h, RB2_K_MERGE, units);
-		  hipLaunchKernelGGL(k_merge, dim3(nmt), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RK.p, h->TQ.p); }
+		  hipLaunchKernelGGL(k_merge, dim3(nmt), dim3(256), 0, st, h->ctl, sd, h->force_dense, oldp, newp, h->INS_E.p, h->INS_A.p, h->RK.p, h->TQ.p, h->trace ? (unsigned long long*)(h->d_tmp + 8) : (unsigned long long*)0); }
 		{ Scope sc(h, RB2_K_META, units);
 		  build_directory(h, sd ^ 1, std::min<uint64_t>(nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
 		{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -221,9 +226,15 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 				h->PGA.p, h->SIZE.p, h->RK.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p); }
 		h->side ^= 1; cur ^= 1;
 	}
+	h->cur_round = -1;
 	HIPCHK(hipGetLastError());
 	fetch_ropes(h);
 	drain_profile(h);
+	if (h->trace) {
+		unsigned long long st3[3];
+		HIPCHK(hipMemcpy(st3, h->d_tmp + 8, 24, hipMemcpyDeviceToHost));
+		fprintf(stderr, "[rb2_hip] merge tiles so far: dense %llu, sparse %llu, sparse->dense fallback %llu\n", st3[0], st3[1], st3[2]);
+	}
 }
 
 } // namespace
@@ -253,10 +264,14 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	rb2_hip_t *h = new rb2_hip_s();
 	h->dev = device; h->so = sorting_order;
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
+	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
+	if (h->trace) h->prof = 1;
+	h->force_dense = getenv("RB2_HIP_DENSE") ? atoi(getenv("RB2_HIP_DENSE")) : 0;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->st));
-	HIPCHK(hipMalloc((void**)&h->d_tmp, 64));
+	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
+	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
 	memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units));
 	h->pool[0].ensure(SB * 8, false, h->st); h->pool[1].ensure(SB * 8, false, h->st);

@@ -423,190 +423,9 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	TQ[gid] = (uint32_t)lo;
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_merge: one block = MT output symbols (TL leaves) of one rope
-// ---------------------------------------------------------------------------------------------
-
-__device__ __forceinline__ uint32_t get_byte(const uint32_t w[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
-
-__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolView oldp, PoolView newp,
-		const uint64_t *INS_E, const uint8_t *INS_A, uint64_t *RK, const uint32_t *TQ)
-{
-	__shared__ __align__(16) uint8_t s_old[(TL + 1) * LEAF];
-	__shared__ __align__(16) uint8_t s_out[MT];
-	__shared__ __align__(16) uint8_t s_bytes[MT];
-	__shared__ uint32_t s_flag[MT / 32];
-	__shared__ uint64_t s_cplo[256], s_cphi[256];
-	__shared__ uint64_t s_w64[4];
-	__shared__ uint32_t s_w32[4];
-	__shared__ uint64_t s_base[6];
-
-	const uint64_t tile = blockIdx.x;
-	if (tile >= ctl->mt0[6]) return;
-	int b = 0;
-	while (tile >= ctl->mt0[b+1]) ++b;
-	const uint64_t j = tile - ctl->mt0[b];
-	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
-	const uint64_t segs = ctl->seg[side].start[b];
-	const uint32_t q0 = TQ[tile + b], q1 = TQ[tile + b + 1];
-	const uint64_t o0 = j * MT, o1 = min(o0 + (uint64_t)MT, nrp.n);
-	const uint64_t i0 = o0 - q0, i1 = o1 - q1;                // old symbols [i0,i1) belong to this tile
-	const uint64_t fl = i0 / LEAF;                             // first old leaf touched
-	const bool have = fl < orp.nleaves;
-	const uint32_t dlen = have ? (uint32_t)(i1 - fl * LEAF) : 0u;   // decoded region = [fl*LEAF, i1)
-	const int nl = (dlen + LEAF - 1) / LEAF;
-	const int tid = threadIdx.x, ln = lane_id(), w = wave_id();
-
-	if (tid < MT / 32) s_flag[tid] = 0;
-	if (tid < 6) {
-		uint64_t v;
-		if (have) {
-			const uint64_t gl = orp.leaf0 + fl;
-			v = oldp.sbcum[gl / SB].v[tid] - oldp.sbcum[orp.sb0].v[tid] + oldp.meta[gl].c[tid];
-		} else v = orp.cnt[tid];
-		s_base[tid] = v;
-	}
-	// ---- decode the old leaves into one symbol per byte (rle_dec1, rle.h:39-51; 1-byte runs only)
-	for (int li = w; li < nl; li += 4) {
-		const uint64_t gl = orp.leaf0 + fl + li;
-		const int nb = oldp.meta[gl].nbytes;
-		const uint4 *src = (const uint4*)(oldp.data + gl * (uint64_t)LEAF);
-		uint32_t wd[4] = {0, 0, 0, 0};
-		const int nv = min(16, max(0, nb - ln * 16));
-		if (nv > 0) { const uint4 v = src[ln]; wd[0] = v.x; wd[1] = v.y; wd[2] = v.z; wd[3] = v.w; }
-		uint32_t mysum = 0;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < nv) mysum += get_byte(wd, i) >> 3;
-		const uint32_t start = wave_incl_add(mysum) - mysum;
-		uint8_t *dst = s_old + li * LEAF + start;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			if (i >= nv) break;
-			const uint32_t byte = get_byte(wd, i), len = byte >> 3, s = byte & 7;
-			for (uint32_t x = 0; x < len; ++x) *dst++ = (uint8_t)s;
-		}
-	}
-	__syncthreads();
-	// ---- per-32-symbol prefix counts over the decoded region (for the ranks of the inserts)
-	{
-		uint64_t lo = 0, hi = 0;
-		const uint32_t cb = tid * 32;
-		if (cb < dlen) {
-			const uint32_t ce = min(cb + 32u, dlen);
-			for (uint32_t y = cb; y < ce; ++y) {
-				const uint32_t s = s_old[y];
-				if (s < 4) lo += 1ull << (16 * s); else hi += 1ull << (16 * (s - 4));
-			}
-		}
-		s_cplo[tid] = block_excl_add<uint64_t>(lo, s_w64, (uint64_t*)0);
-		s_cphi[tid] = block_excl_add<uint64_t>(hi, s_w64, (uint64_t*)0);
-	}
-	__syncthreads();
-	// ---- inserts of this tile: rank on the old rope (return value of rope_insert_run, rope.c:147) and placement
-	for (uint32_t q = q0 + tid; q < q1; q += 256) {
-		const uint64_t e = INS_E[segs + q];
-		const uint32_t a = INS_A[segs + q];
-		const uint32_t x = (uint32_t)(e - fl * LEAF), c = x >> 5;
-		uint32_t cnt = (uint32_t)(((a < 4 ? s_cplo[c] >> (16 * a) : s_cphi[c] >> (16 * (a - 4)))) & 0xffffu);
-		for (uint32_t y = c * 32; y < x; ++y) cnt += (s_old[y] == a);
-		RK[segs + q] = s_base[a] + cnt;
-		const uint32_t p = (uint32_t)(e + q - o0);
-		s_out[p] = (uint8_t)a;
-		atomicOr(&s_flag[p >> 5], 1u << (p & 31));
-	}
-	__syncthreads();
-	// ---- assemble my 16 output symbols
-	const uint32_t nvalid = (uint32_t)(o1 - o0);
-	const uint32_t p0 = tid * 16;
-	const int myvalid = (int)min(16u, nvalid > p0 ? nvalid - p0 : 0u);
-	const uint32_t flags = (s_flag[tid >> 1] >> ((tid & 1) * 16)) & 0xffffu & ((1u << myvalid) - 1u);
-	const uint32_t nonins = myvalid - __popc(flags);
-	uint32_t oldoff = (uint32_t)(i0 - fl * LEAF) + block_excl_add<uint32_t>(nonins, s_w32, (uint32_t*)0);
-	uint32_t sy[16];
-#pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		uint32_t v = 0xff;
-		if (i < myvalid) v = (flags >> i & 1) ? s_out[p0 + i] : s_old[oldoff++];
-		sy[i] = v;
-	}
-	__syncthreads();
-	{
-		uint4 v;
-		v.x = sy[0] | sy[1] << 8 | sy[2] << 16 | sy[3] << 24;
-		v.y = sy[4] | sy[5] << 8 | sy[6] << 16 | sy[7] << 24;
-		v.z = sy[8] | sy[9] << 8 | sy[10] << 16 | sy[11] << 24;
-		v.w = sy[12] | sy[13] << 8 | sy[14] << 16 | sy[15] << 24;
-		*(uint4*)(s_out + p0) = v;
-	}
-	__syncthreads();
-	// ---- re-encode: one wave per output leaf (16 symbols per lane x 64 lanes = LEAF)
-	const uint32_t prev0 = ln == 0 ? 0xffu : s_out[p0 - 1];
-	const int lp0 = ln * 16;                                   // position inside the leaf
-	const int lv = (int)min((uint32_t)LEAF, nvalid > (uint32_t)(w * LEAF) ? nvalid - w * LEAF : 0u);   // valid symbols in my leaf
-	int lastnat = -1;
-	{
-		uint32_t pv = prev0;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < myvalid) { if (sy[i] != pv) lastnat = lp0 + i; pv = sy[i]; }
-	}
-	const int incmax = wave_incl_max(lastnat);
-	int rs = __shfl_up(incmax, 1);                             // start of the run open at lp0-1
-	if (ln == 0) rs = 0;
-	int lh = ln == 0 ? 0 : rs + (lp0 - 1 - rs) / 15 * 15;      // last byte boundary before lp0
-	// pass 1: count byte boundaries (heads) in my chunk
-	int hc = 0;
-	{
-		uint32_t pv = prev0; int r = rs;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < myvalid) {
-			const int p = lp0 + i;
-			const bool nat = sy[i] != pv;
-			if (nat) r = p;
-			hc += (nat || (p - r) % 15 == 0);
-			pv = sy[i];
-		}
-	}
-	const int hinc = wave_incl_add(hc);
-	const int hb = hinc - hc;
-	const int nbytes = __shfl(hinc, 63);
-	// pass 2: every head closes the run before it
-	{
-		uint32_t pv = prev0; int r = rs, seen = 0;
-		uint8_t *ob = s_bytes + w * LEAF;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < myvalid) {
-			const int p = lp0 + i;
-			const bool nat = sy[i] != pv;
-			if (nat) r = p;
-			if (nat || (p - r) % 15 == 0) {
-				if (p != 0) ob[hb + seen - 1] = (uint8_t)((p - lh) << 3 | pv);
-				lh = p; ++seen;
-			}
-			pv = sy[i];
-		}
-		if (myvalid > 0 && lp0 + myvalid == lv) ob[nbytes - 1] = (uint8_t)((lv - lh) << 3 | pv);   // last run of the leaf
-	}
-	// per-leaf symbol counts
-	uint64_t clo = 0; uint32_t chi = 0;
-#pragma unroll
-	for (int i = 0; i < 16; ++i) if (i < myvalid) {
-		const uint32_t s = sy[i];
-		if (s < 4) clo += 1ull << (16 * s); else chi += 1u << (16 * (s - 4));
-	}
-	clo = wave_sum(clo); chi = wave_sum(chi);
-	__syncthreads();
-	if (lv > 0) {
-		const uint64_t gl = nrp.leaf0 + j * TL + w;
-		if (ln == 0) {
-			LeafMeta m;
-			m.c[0] = (uint16_t)clo; m.c[1] = (uint16_t)(clo >> 16); m.c[2] = (uint16_t)(clo >> 32); m.c[3] = (uint16_t)(clo >> 48);
-			m.c[4] = (uint16_t)chi; m.c[5] = (uint16_t)(chi >> 16);
-			m.nbytes = (uint16_t)nbytes; m.pad = 0;
-			newp.meta[gl] = m;                                 // own counts; k_meta_sb turns them into prefixes
-		}
-		if (ln * 16 < nbytes) ((uint4*)(newp.data + gl * (uint64_t)LEAF))[ln] = ((const uint4*)(s_bytes + w * LEAF))[ln];
-	}
-}
+} // namespace rb2
+#include "rb2_merge.h"
+namespace rb2 {
 
 // ---------------------------------------------------------------------------------------------
 // rank directory of the new side
