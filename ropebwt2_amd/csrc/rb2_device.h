@@ -22,8 +22,7 @@
 namespace rb2 {
 
 constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
-constexpr int TL     = 4;             // leaves per merge tile
-constexpr int MT     = LEAF * TL;     // output symbols per merge block (4096)
+constexpr int TL     = 4;             // output leaves per merge block (one wave each)
 constexpr int SB     = 32;            // leaves per superblock
 constexpr int STILE  = 512;           // strings per string tile
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
@@ -48,7 +47,7 @@ struct SegDesc {        // where the strings of bucket b live in the current SoA
 struct Ctl {
 	RopeDesc rope[2][6];
 	SegDesc  seg[2];
-	uint64_t mt0[8];        // first merge tile per rope this round; [6] = total
+	uint64_t lf0[8];        // first output leaf (unpadded numbering) per rope this round; [6] = total
 	uint64_t ac[6][6];      // ac[b][a] = #a in ropes < b after this round (mrope.c:332-336)
 	uint64_t dest[6][6];    // where members of bucket b inserting a go in the next arrays
 	uint64_t count[6][6];   // count[b][a] = members of bucket b inserting a this round

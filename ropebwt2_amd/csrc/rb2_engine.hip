@@ -60,7 +60,8 @@ struct rb2_hip_s {
 	Ctl *ctl = nullptr;                 // device
 	RopeDesc h_rope[6];                 // host mirror of ctl->rope[side]
 	// per-string state
-	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, RK, zblk;
+	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
+	DevBuf<uint16_t> RKREL;
 	DevBuf<uint32_t> ID[2], SLOT, PA, PGA, TQ;
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<ChunkPart> cpart;
@@ -74,7 +75,6 @@ struct rb2_hip_s {
 	int debug = 0;
 	int cur_round = -1;
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
-	int force_dense = 0;                // RB2_HIP_DENSE=1: symbol-level merge for every tile (A/B testing)
 };
 
 namespace {
@@ -169,7 +169,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	}
 	// ---- capacities
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RK.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m);
 	const unsigned nst_ub = cdiv(m, STILE) + 6;                 // string tiles, upper bound for every round
 	const unsigned nsc = cdiv(nst_ub, SCHUNK);
@@ -181,8 +181,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	h->pool[h->side].ensure(leaves_ub, true, st);
 	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
 	(void)nn;
-	const uint64_t mt_ub = (n_tot + len) / MT + 6 + 1;
-	h->TQ.ensure(mt_ub + 8);
+	h->TQ.ensure(leaves_ub + 16);
 	const uint64_t nsb_ub = leaves_ub / SB + 1;
 
 	// ---- initial state (mrope.c:279-284)
@@ -203,7 +202,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		const int sd = h->side;
 		PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
 		const uint64_t n_new_ub = n_tot + std::min<uint64_t>(len, (r + 1) * m);
-		const unsigned nmt = cdiv(n_new_ub, MT) + 6;
+		const unsigned nlf = cdiv(n_new_ub, LEAF) + 6;            // output leaves, upper bound
 		const int64_t units = (int64_t)m;                      // upper bound: strings still active this round
 		{ Scope sc(h, RB2_K_SYM, units);
 		  hipLaunchKernelGGL(k_sym, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
@@ -216,25 +215,20 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		  hipLaunchKernelGGL(k_prep, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 				h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
 		{ Scope sc(h, RB2_K_PART, units);
-		  hipLaunchKernelGGL(k_part, dim3(cdiv(nmt + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
+		  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
 		{ Scope sc(h, RB2_K_MERGE, units);
-		  hipLaunchKernelGGL(k_merge, dim3(nmt), dim3(256), 0, st, h->ctl, sd, h->force_dense, oldp, newp, h->INS_E.p, h->INS_A.p, h->RK.p, h->TQ.p, h->trace ? (unsigned long long*)(h->d_tmp + 8) : (unsigned long long*)0); }
+		  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p); }
 		{ Scope sc(h, RB2_K_META, units);
 		  build_directory(h, sd ^ 1, std::min<uint64_t>(nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
 		{ Scope sc(h, RB2_K_ADVANCE, units);
-		  hipLaunchKernelGGL(k_advance, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, s, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
-				h->PGA.p, h->SIZE.p, h->RK.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p); }
+		  hipLaunchKernelGGL(k_advance, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, s, newp, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
+				h->PGA.p, h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p); }
 		h->side ^= 1; cur ^= 1;
 	}
 	h->cur_round = -1;
 	HIPCHK(hipGetLastError());
 	fetch_ropes(h);
 	drain_profile(h);
-	if (h->trace) {
-		unsigned long long st3[3];
-		HIPCHK(hipMemcpy(st3, h->d_tmp + 8, 24, hipMemcpyDeviceToHost));
-		fprintf(stderr, "[rb2_hip] merge tiles so far: dense %llu, sparse %llu, sparse->dense fallback %llu\n", st3[0], st3[1], st3[2]);
-	}
 }
 
 } // namespace
@@ -266,7 +260,6 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	if (h->trace) h->prof = 1;
-	h->force_dense = getenv("RB2_HIP_DENSE") ? atoi(getenv("RB2_HIP_DENSE")) : 0;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->st));
@@ -285,7 +278,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RK.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->zblk.release();
 	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->TQ.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);

@@ -10,8 +10,7 @@
 //   k_prep     per string: pre-round position of its new symbol, slot in the sorted insert list,
 //              interval sizes via rank on non-empty intervals (mrope.c:199-224)
 //   k_part     merge-path split: which inserts land in which output tile
-//   k_merge    rank + positional insert: decode old run-length leaves into LDS, splice the new
-//              symbols, re-encode (rope_insert_run rope.c:114-148 / rle_insert_cached rle.c:10-89)
+//   k_merge    rank + positional insert, one wave per output leaf (rb2_merge.h)
 //   k_meta*    rank directory of the new side (replaces the rpnode_t counts, rope.h:11-15)
 //   k_advance  new (l,u) per string + stable 6-way partition into next round's buckets
 //              (mrope.c:226-229, 303-309, 332-340)
@@ -287,10 +286,10 @@ __global__ void k_setup(Ctl *ctl, int side, const TileScan *tsc)
 		n.nleaves = (n.n + LEAF - 1) / LEAF;
 		n.leaf0 = leaf; n.sb0 = leaf / SB;
 		leaf += (n.nleaves + SB - 1) / SB * SB;
-		ctl->mt0[b] = mt;
-		mt += (n.n + MT - 1) / MT;
+		ctl->lf0[b] = mt;
+		mt += n.nleaves;
 	}
-	ctl->mt0[6] = mt; ctl->mt0[7] = mt;
+	ctl->lf0[6] = mt; ctl->lf0[7] = mt;
 	ctl->nsb_total = leaf / SB;
 	// next round's buckets: bucket a = strings that inserted a, in (bucket, order) order (mrope.c:303-309)
 	uint64_t st = 0; uint32_t tl = 0;
@@ -401,20 +400,20 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_part: for every output tile boundary o = j*MT of rope b, the number of inserts that land
-// before it = smallest q with E[q] + q >= o (final position of insert q is E[q] + q)
+// k_part: for every output leaf boundary o = j*LEAF of rope b, the number of inserts that land
+// before it = smallest q with E[q] + q >= o (the final position of insert q is E[q] + q)
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, uint32_t *TQ)
 {
 	const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	if (gid >= ctl->mt0[6] + 6) return;
+	if (gid >= ctl->lf0[6] + 6) return;
 	int b = 0;
-	while (gid >= ctl->mt0[b+1] + b + 1) ++b;
-	const uint64_t j = gid - ctl->mt0[b] - b;
+	while (gid >= ctl->lf0[b+1] + b + 1) ++b;
+	const uint64_t j = gid - ctl->lf0[b] - b;
 	const SegDesc &sg = ctl->seg[side];
 	const uint64_t *E = INS_E + sg.start[b];
-	const uint64_t o = j * MT;
+	const uint64_t o = j * LEAF;
 	uint64_t lo = 0, hi = sg.cnt[b];
 	while (lo < hi) {
 		const uint64_t mid = (lo + hi) >> 1;
@@ -488,21 +487,28 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint32_t round, const uint8_t *s,
+__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const uint32_t *SLOT, const uint32_t *PA, const uint32_t *PGA,
-		const uint64_t *SIZE, const uint64_t *RK, const uint32_t *ID, const uint64_t *W,
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
 {
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
+	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		if (k >= t.segend) continue;
 		const int a = A[k] & 7;
 		if (a == 0) continue;                                  // sentinel inserted: string is done (mrope.c:310)
-		const uint64_t rk = RK[t.segstart + SLOT[k]];
-		const uint64_t l = ctl->ac[t.b][a] + rk + PGA[k];
+		// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
+		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
+		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
+		const uint32_t slot = SLOT[k];
+		const uint64_t f = INS_E[t.segstart + slot] + slot;
+		const uint64_t gl = nrp.leaf0 + f / LEAF;
+		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + slot];
+		const uint64_t l = ctl->ac[t.b][a] + rk - PA[k] + PGA[k];
 		const uint64_t d = ctl->dest[t.b][a] + PA[k];
 		const uint32_t id = ID[k];
 		uint64_t wv = W[k] >> 4;
