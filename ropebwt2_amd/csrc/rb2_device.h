@@ -182,3 +182,31 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 }
 
 } // namespace rb2
+
+// ---------------------------------------------------------------------------------------------
+// DPP wave primitives (gfx9/CDNA data-parallel-primitive controls; VALU only, no LDS round trip)
+// ---------------------------------------------------------------------------------------------
+namespace rb2 {
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);   // lanes without a source read 0
+}
+// inclusive prefix sum over the 64 lanes: row_shr 1,2,4,8 then row_bcast15 / row_bcast31
+__device__ __forceinline__ uint32_t dpp_incl_add(uint32_t v)
+{
+	v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+	v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+	return v;
+}
+__device__ __forceinline__ uint32_t dpp_incl_max(uint32_t v)     // unsigned max, identity 0
+{
+	v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));
+	v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
+	return v;
+}
+__device__ __forceinline__ uint32_t dpp_prev_lane(uint32_t v) { return dpp0<0x138, 0xf>(v); }   // wave_shr:1, lane 0 reads 0
+__device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return dpp0<0x130, 0xf>(v); }   // wave_shl:1, lane 63 reads 0
+__device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+
+} // namespace rb2
