@@ -1,0 +1,28 @@
+/* rb2_fmd.h -- writer for fermi's FMD format (run-length delta BWT + rank frames), the artefact
+ * whose bytes must match the reference (`ropebwt2 -d`).  Replaces the encode side of
+ * /root/reference/rld0.c:26-244 (rld_init/rld_enc/rld_enc_finish/rld_rank_index/rld_dump) with a
+ * single streaming object.  Format notes: SURVEY.md section 8f-1.
+ */
+#ifndef RB2_FMD_H_
+#define RB2_FMD_H_
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rb2_fmd_s rb2_fmd_t;
+
+rb2_fmd_t *rb2_fmd_init(void);                                 /* rld_init(6,3) + rld_itr_init, main.c:274-276 */
+void rb2_fmd_push(rb2_fmd_t *f, int64_t len, int sym);         /* rld_enc, rld0.c:153-161 (adjacent equal symbols merge) */
+void rb2_fmd_finish(rb2_fmd_t *f);                             /* rld_enc_finish + rld_rank_index, rld0.c:163-217 */
+int  rb2_fmd_write(const rb2_fmd_t *f, FILE *fp);              /* rld_dump, rld0.c:223-244 */
+void rb2_fmd_counts(const rb2_fmd_t *f, int64_t c[7]);         /* total, $, A, C, G, T, N */
+void rb2_fmd_destroy(rb2_fmd_t *f);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

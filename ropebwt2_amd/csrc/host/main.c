@@ -1,0 +1,280 @@
+/* main.c -- command-line front end with the flags and outputs of `ropebwt2` (reference:
+ * /root/reference/main.c:89-343), on top of include/mrope.h.  Batches are inserted by the GPU
+ * engine; `-m0` (one string at a time, mr_insert1) is the only mode that builds on the CPU.
+ *
+ * Own code: option handling, a small FASTA/FASTQ/line reader over zlib, read filters, the three
+ * writers (plain text, FMR, FMD).  The undocumented CRLF output (-B) of the reference is not
+ * provided.
+ */
+#include <zlib.h>
+#include <ctype.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+#include "mrope.h"
+#include "rle.h"
+#include "rb2_fmd.h"
+
+#define RB2_VERSION "r187-hip1"
+
+/* ---- tiny growable byte string ---------------------------------------------------------------- */
+typedef struct { size_t l, m; char *s; } str_t;
+static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need + (need >> 1) + 64; s->s = (char*)realloc(s->s, s->m); } }
+static void str_putc(str_t *s, int c) { str_reserve(s, s->l + 2); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
+static void str_append(str_t *s, const char *p, size_t n) { str_reserve(s, s->l + n + 1); memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0; }
+
+/* ---- buffered reader: FASTA / FASTQ records or plain lines ------------------------------------ */
+typedef struct { gzFile fp; unsigned char buf[1 << 16]; int beg, end, eof, last; str_t seq, qual; } reader_t;
+
+static int rd_getc(reader_t *r)
+{
+	if (r->beg >= r->end) {
+		if (r->eof) return -1;
+		r->beg = 0; r->end = gzread(r->fp, r->buf, sizeof(r->buf));
+		if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
+	}
+	return r->buf[r->beg++];
+}
+/* append the rest of the line to s (s may be NULL); returns the terminating char or -1 */
+static int rd_line(reader_t *r, str_t *s, int only_graph)
+{
+	int c;
+	while ((c = rd_getc(r)) >= 0 && c != '\n')
+		if (s && c != '\r' && (!only_graph || isgraph(c))) str_putc(s, c);
+	return c;
+}
+static int read_line_record(reader_t *r)
+{
+	r->seq.l = 0; r->qual.l = 0;
+	str_reserve(&r->seq, 1); r->seq.s[0] = 0;
+	if (rd_line(r, &r->seq, 0) < 0 && r->seq.l == 0) return -1;
+	return (int)r->seq.l;
+}
+static int read_fastx_record(reader_t *r)
+{
+	int c;
+	r->seq.l = r->qual.l = 0;
+	str_reserve(&r->seq, 1); r->seq.s[0] = 0;
+	if (r->last == 0) {                                  /* look for the next header */
+		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@');
+		if (c < 0) return -1;
+	}
+	r->last = 0;
+	if (rd_line(r, 0, 0) < 0) return (int)r->seq.l;      /* name line */
+	while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@' && c != '+') {
+		if (c == '\n') continue;
+		str_putc(&r->seq, c);
+		rd_line(r, &r->seq, 1);
+	}
+	if (c == '>' || c == '@') r->last = c;
+	if (c != '+') return (int)r->seq.l;
+	rd_line(r, 0, 0);                                    /* '+' line */
+	while (r->qual.l < r->seq.l && (c = rd_getc(r)) >= 0) {
+		if (c == '\n') continue;
+		str_putc(&r->qual, c);
+		rd_line(r, &r->qual, 1);
+	}
+	return (int)r->seq.l;
+}
+
+/* ---- helpers ---------------------------------------------------------------------------------- */
+static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec); }
+static double realtime(void) { struct timeval t; gettimeofday(&t, 0); return t.tv_sec + 1e-6 * t.tv_usec; }
+
+static int nt6(int ch)                                   /* main.c:17-26: $ACGTN = 0..5 */
+{
+	switch (ch) { case 0: return 0; case 'A': case 'a': return 1; case 'C': case 'c': return 2;
+	              case 'G': case 'g': return 3; case 'T': case 't': return 4; default: return 5; }
+}
+static int comp6(int c) { return c >= 1 && c <= 4 ? 5 - c : c; }
+static int is_own_revcomp(int l, const uint8_t *s)      /* even length and s == revcomp(s) (main.c:80-87) */
+{
+	int i;
+	if (l & 1) return 0;
+	for (i = 0; i < l / 2; ++i) if (s[i] + s[l-1-i] != 5) return 0;
+	return 1;
+}
+
+enum { F_FOR = 1, F_REV = 2, F_ODD = 4, F_BIN = 8, F_TREE = 16, F_THR = 64, F_LINE = 256, F_RLD = 512, F_NON = 1024, F_CUTN = 4096 };
+
+static int usage(int block_len, int max_nodes)
+{
+	fprintf(stderr, "\nUsage:   ropebwt2-%s [options] <in.fq.gz>\n\n", RB2_VERSION);
+	fprintf(stderr, "Options: -l INT     leaf block length [%d]\n", block_len);
+	fprintf(stderr, "         -n INT     max number children per internal node [%d]\n", max_nodes);
+	fprintf(stderr, "         -s         build BWT in the reverse lexicographical order (RLO)\n");
+	fprintf(stderr, "         -r         build BWT in RCLO, overriding -s \n");
+	fprintf(stderr, "         -m INT     batch size for multi-string indexing on the GPU; 0 for single-string (CPU) [10g]\n");
+	fprintf(stderr, "         -P         accepted for compatibility (the GPU path has no thread switch)\n");
+	fprintf(stderr, "         -M INT     accepted for compatibility\n\n");
+	fprintf(stderr, "         -i FILE    read existing index in the FMR format from FILE, overriding -s/-r [null]\n");
+	fprintf(stderr, "         -L         input in the one-sequence-per-line format\n");
+	fprintf(stderr, "         -F         skip forward strand\n");
+	fprintf(stderr, "         -R         skip reverse strand\n");
+	fprintf(stderr, "         -N         skip sequences containing ambiguous bases\n");
+	fprintf(stderr, "         -x INT     cut at ambiguous bases and discard segment with length <INT [0]\n");
+	fprintf(stderr, "         -C         cut one base if forward==reverse\n");
+	fprintf(stderr, "         -q INT     hard mask bases with QUAL<INT [0]\n\n");
+	fprintf(stderr, "         -o FILE    write output to FILE [stdout]\n");
+	fprintf(stderr, "         -b         dump the index in the binary FMR format\n");
+	fprintf(stderr, "         -d         dump the index in fermi's FMD format\n");
+	fprintf(stderr, "         -T         output the index in the Newick format (for debugging)\n\n");
+	return 1;
+}
+
+static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
+{
+	const double c0 = cputime(), r0 = realtime();
+	mr_insert_multi(mr, (int64_t)buf->l, (const uint8_t*)buf->s, flag & F_THR);
+	if (verbose >= 3) fprintf(stderr, "[M::%s] inserted %ld symbols in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", (long)buf->l, realtime() - r0, cputime() - c0);
+	buf->l = 0;
+}
+
+int main(int argc, char *argv[])
+{
+	mrope_t *mr = 0;
+	reader_t *rd;
+	int64_t m = (int64_t)(.97 * 10 * 1024 * 1024 * 1024) + 1;   /* main.c:94 */
+	int c, i, block_len = ROPE_DEF_BLOCK_LEN, max_nodes = ROPE_DEF_MAX_NODES, verbose = 3, so = MR_SO_IO, min_q = 0, thr_min = -1, min_cut = 0;
+	int flag = F_FOR | F_REV | F_THR, ret = 0;
+	str_t buf = { 0, 0, 0 };
+	double t0 = realtime(), ct, rt;
+	FILE *out = stdout;
+
+	while ((c = getopt(argc, argv, "BPNLTFRCtrbdsl:n:m:v:o:i:q:M:x:")) >= 0) {
+		switch (c) {
+		case 'o': if ((out = fopen(optarg, "wb")) == 0) { fprintf(stderr, "[E::%s] fail to open '%s' for writing\n", __func__, optarg); return 1; } break;
+		case 'F': flag &= ~F_FOR; break;
+		case 'R': flag &= ~F_REV; break;
+		case 'C': flag |= F_ODD; break;
+		case 'T': flag |= F_TREE; break;
+		case 'b': flag |= F_BIN; break;
+		case 't': flag |= F_THR; break;
+		case 'L': flag |= F_LINE; break;
+		case 'd': flag |= F_RLD; break;
+		case 'N': flag |= F_NON; break;
+		case 'P': flag &= ~F_THR; break;
+		case 'B': fprintf(stderr, "[E::%s] the CRLF output (-B) is not provided by this build\n", __func__); return 1;
+		case 's': if (so != MR_SO_RCLO) so = MR_SO_RLO; break;
+		case 'r': so = MR_SO_RCLO; break;
+		case 'l': block_len = atoi(optarg); break;
+		case 'n': max_nodes = atoi(optarg); break;
+		case 'v': verbose = atoi(optarg); break;
+		case 'q': min_q = atoi(optarg); break;
+		case 'M': thr_min = atoi(optarg); break;
+		case 'x': min_cut = atoi(optarg); flag |= F_CUTN; break;
+		case 'i': {
+			FILE *fp = fopen(optarg, "rb");
+			if (fp == 0) { fprintf(stderr, "[E::%s] fail to open file '%s'\n", __func__, optarg); return 1; }
+			if (mr) mr_destroy(mr);
+			mr = mr_restore(fp);
+			fclose(fp);
+			if (mr == 0) return 1;
+			break; }
+		case 'm': {
+			char *p; double x = strtod(optarg, &p);
+			if (*p == 'K' || *p == 'k') x *= 1024;
+			else if (*p == 'M' || *p == 'm') x *= 1024 * 1024;
+			else if (*p == 'G' || *p == 'g') x *= 1024 * 1024 * 1024;
+			m = x ? (int64_t)(x * .97) + 1 : 0;              /* main.c:136 */
+			break; }
+		default: return usage(block_len, max_nodes);
+		}
+	}
+	if (optind == argc && isatty(fileno(stdin))) return usage(block_len, max_nodes);
+	if ((flag & F_CUTN) && m == 0) { fprintf(stderr, "[E::%s] option '-x' cannot be used with '-m0'\n", __func__); return 1; }
+
+	if (mr == 0) mr = mr_init(max_nodes, block_len, so);
+	if (thr_min > 0) mr_thr_min(mr, thr_min);
+	rd = (reader_t*)calloc(1, sizeof(reader_t));
+	rd->fp = optind < argc && strcmp(argv[optind], "-") ? gzopen(argv[optind], "rb") : gzdopen(fileno(stdin), "rb");
+	if (rd->fp == 0) { fprintf(stderr, "[E::%s] fail to open the input\n", __func__); return 1; }
+	ct = cputime(); rt = realtime();
+
+	while ((flag & F_LINE ? read_line_record(rd) : read_fastx_record(rd)) >= 0) {
+		uint8_t *s = (uint8_t*)rd->seq.s;
+		int l = (int)rd->seq.l;
+		if (flag & F_LINE) { for (i = 0; i < l && isalpha(s[i]); ++i); l = i; }     /* main.c:184-187 */
+		for (i = 0; i < l; ++i) s[i] = s[i] < 128 ? (uint8_t)nt6(s[i]) : 5;
+		if (!(flag & F_LINE) && rd->qual.l && min_q > 0)
+			for (i = 0; i < l && i < (int)rd->qual.l; ++i) if (rd->qual.s[i] - 33 < min_q) s[i] = 5;
+		if (flag & F_NON) { for (i = 0; i < l && s[i] != 5; ++i); if (i < l) continue; }
+		for (i = 0; i < l / 2; ++i) { uint8_t t = s[i]; s[i] = s[l-1-i]; s[l-1-i] = t; }   /* the API wants reversed strings */
+		s[l] = 0;
+		if (flag & F_CUTN) {                                 /* split at N, drop short pieces (main.c:204-218) */
+			int k = 0, b = 0;
+			for (i = 0; i <= l; ++i) {
+				if (i == l || s[i] == 5) {
+					const int seg = i - b;
+					if (seg >= min_cut) {
+						if ((flag & F_ODD) && is_own_revcomp(seg, &s[k - seg])) --k;
+						s[k++] = 0;
+					} else k -= seg;
+					b = i + 1;
+				} else s[k++] = s[i];
+			}
+			if (--k <= 0) continue;
+			l = k;
+		} else if ((flag & F_ODD) && is_own_revcomp(l, s)) {
+			if (l > 0) s[--l] = 0;
+			else if (m) continue;                            /* reference quirk (main.c:219-222): an empty read under -C vanishes in batch mode */
+		}
+		if (flag & F_FOR) {
+			if (m) str_append(&buf, (char*)s, l + 1);
+			else mr_insert1(mr, s);
+		}
+		if (flag & F_REV) {                                  /* reverse complement, again stored reversed: complement in place */
+			for (i = 0; i < l / 2; ++i) { uint8_t t = (uint8_t)comp6(s[l-1-i]); s[l-1-i] = (uint8_t)comp6(s[i]); s[i] = t; }
+			if (l & 1) s[l/2] = (uint8_t)comp6(s[l/2]);
+			if (m) str_append(&buf, (char*)s, l + 1);
+			else mr_insert1(mr, s);
+		}
+		if (m && (int64_t)buf.l >= m) flush_batch(mr, &buf, flag, verbose);
+	}
+	if (m && buf.l) flush_batch(mr, &buf, flag, verbose);
+	if (verbose >= 3) {
+		int64_t cc[6];
+		fprintf(stderr, "[M::%s] constructed FM-index in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", realtime() - rt, cputime() - ct);
+		mr_get_c(mr, cc);
+		fprintf(stderr, "[M::%s] symbol counts: ($, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
+				(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5]);
+	}
+	free(buf.s); gzclose(rd->fp); free(rd->seq.s); free(rd->qual.s); free(rd);
+
+	if (out != stdout) { fflush(stdout); if (dup2(fileno(out), fileno(stdout)) < 0) return 1; }   /* mr_print_tree writes to stdout */
+	if (flag & F_BIN) mr_dump(mr, stdout);
+	else if (flag & F_TREE) mr_print_tree(mr);
+	else {
+		mritr_t itr;
+		const uint8_t *blk;
+		rb2_fmd_t *fmd = flag & F_RLD ? rb2_fmd_init() : 0;
+		mr_itr_first(mr, &itr, 1);
+		while ((blk = mr_itr_next_block(&itr)) != 0) {
+			const uint8_t *q = blk + 2, *end = q + *rle_nptr(blk);
+			while (q < end) {
+				int sym; int64_t len, k;
+				rle_dec1(q, sym, len);
+				if (fmd) rb2_fmd_push(fmd, len, sym);
+				else for (k = 0; k < len; ++k) putchar("$ACGTN"[sym]);
+			}
+		}
+		if (fmd) {
+			int64_t cc[7];
+			rb2_fmd_finish(fmd);
+			rb2_fmd_counts(fmd, cc);
+			fprintf(stderr, "[M::%s] rld: (tot, $, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
+					(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5], (long)cc[6]);
+			rb2_fmd_write(fmd, stdout);
+			rb2_fmd_destroy(fmd);
+		} else putchar('\n');
+	}
+	fflush(stdout);
+	mr_destroy(mr);
+	fprintf(stderr, "[M::%s] Version: %s\n[M::%s] CMD:", "main", RB2_VERSION, "main");
+	for (i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
+	fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec\n", "main", realtime() - t0, cputime());
+	return ret;
+}

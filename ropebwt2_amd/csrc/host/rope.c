@@ -1,0 +1,392 @@
+/* rope.c -- one rope (B+ tree over run-length leaves), host side (API of include/rope.h).
+ *
+ * Own implementation behind the interface of /root/reference/rope.c.  Differences by design:
+ *   - insertion descends first and splits on the way back up (the reference splits full nodes
+ *     pre-emptively on the way down, rope.c:119-124);
+ *   - rope_load_runs() bulk-loads a whole rope bottom-up from a run stream -- this is how a BWT
+ *     built on the GPU (rb2_hip_download_rope) becomes a host rope;
+ *   - memory comes from two append-only arenas that are dropped as a whole.
+ * The node/bucket layout (rpnode_t, "first entry carries n and is_bottom") and the .fmr byte
+ * format are those of the reference because callers and files depend on them.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <assert.h>
+#include <stdio.h>
+#include "rle.h"
+#include "rope.h"
+
+/* ---------------------------------------------------------------------------------------------
+ * arena: fixed-size zeroed items, never freed individually
+ * ------------------------------------------------------------------------------------------- */
+
+#define ARENA_CHUNK (1 << 20)
+
+typedef struct arena_chunk_s { struct arena_chunk_s *next; } arena_chunk_t;
+typedef struct { size_t item, per_chunk, used; arena_chunk_t *head; } arena_t;
+
+static arena_t *arena_new(size_t item)
+{
+	arena_t *a = (arena_t*)calloc(1, sizeof(arena_t));
+	a->item = item;
+	a->per_chunk = ARENA_CHUNK / item ? ARENA_CHUNK / item : 1;
+	a->used = a->per_chunk;                          /* forces a chunk on first use */
+	return a;
+}
+
+static void *arena_get(arena_t *a)
+{
+	if (a->used == a->per_chunk) {
+		arena_chunk_t *c = (arena_chunk_t*)calloc(1, sizeof(arena_chunk_t) + 16 + a->item * a->per_chunk);
+		c->next = a->head; a->head = c; a->used = 0;
+	}
+	return (uint8_t*)(a->head + 1) + 16 - sizeof(arena_chunk_t) % 16 + a->item * a->used++;
+}
+
+static void arena_free(arena_t *a)
+{
+	arena_chunk_t *c, *n;
+	if (!a) return;
+	for (c = a->head; c; c = n) { n = c->next; free(c); }
+	free(a);
+}
+
+static rpnode_t *new_bucket(rope_t *r) { return (rpnode_t*)arena_get((arena_t*)r->node); }
+static uint8_t  *new_leaf(rope_t *r)   { return (uint8_t*)arena_get((arena_t*)r->leaf); }
+
+/* ---------------------------------------------------------------------------------------------
+ * construction / destruction
+ * ------------------------------------------------------------------------------------------- */
+
+static void rope_reset(rope_t *r)
+{
+	if (r->node) arena_free((arena_t*)r->node);
+	if (r->leaf) arena_free((arena_t*)r->leaf);
+	r->node = arena_new(sizeof(rpnode_t) * r->max_nodes);
+	r->leaf = arena_new(r->block_len);
+	memset(r->c, 0, sizeof(r->c));
+	r->root = new_bucket(r);
+	r->root->n = 1; r->root->is_bottom = 1;
+	r->root->p = (rpnode_t*)new_leaf(r);
+}
+
+rope_t *rope_init(int max_nodes, int block_len)
+{
+	rope_t *r = (rope_t*)calloc(1, sizeof(rope_t));
+	if (block_len < 32) block_len = 32;              /* rope.c:59 */
+	r->max_nodes = (max_nodes + 1) / 2 * 2;          /* both even, rope.c:60-61 */
+	if (r->max_nodes < 4) r->max_nodes = 4;
+	r->block_len = (block_len + 7) / 8 * 8;
+	rope_reset(r);
+	return r;
+}
+
+void rope_destroy(rope_t *r)
+{
+	if (!r) return;
+	arena_free((arena_t*)r->node);
+	arena_free((arena_t*)r->leaf);
+	free(r);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * insertion
+ * ------------------------------------------------------------------------------------------- */
+
+static void entry_sum(const rpnode_t *bucket, int from, int to, int64_t c[6], int64_t *l)
+{
+	int i, a;
+	memset(c, 0, 48); *l = 0;
+	for (i = from; i < to; ++i) { for (a = 0; a < 6; ++a) c[a] += bucket[i].c[a]; *l += bucket[i].l; }
+}
+
+/* open a zeroed slot behind position i of a bucket */
+static rpnode_t *bucket_open_slot(rpnode_t *bucket, int i)
+{
+	const int n = bucket->n;
+	if (i + 1 < n) memmove(&bucket[i + 2], &bucket[i + 1], sizeof(rpnode_t) * (n - i - 1));
+	memset(&bucket[i + 1], 0, sizeof(rpnode_t));
+	bucket->n = n + 1;                               /* n lives in entry 0, which never moves */
+	return &bucket[i + 1];
+}
+
+int64_t rope_insert_run(rope_t *rope, int64_t x, int a, int64_t rl, rpcache_t *cache)
+{
+	rpnode_t *path[ROPE_MAX_DEPTH]; int pidx[ROPE_MAX_DEPTH], depth = 0, k, j, nbytes;
+	rpnode_t *u = rope->root;
+	int64_t y = 0, z = 0, cnt[6];
+	(void)cache;                                     /* the leaf cache is an optimisation we do not need */
+	for (;;) {                                       /* a position on a boundary goes to the left child (rope.c:130) */
+		int i = 0, n = u->n;
+		while (i < n - 1 && y + (int64_t)u[i].l < x) { y += u[i].l; z += u[i].c[a]; ++i; }
+		assert(depth < ROPE_MAX_DEPTH);
+		path[depth] = u; pidx[depth] = i; ++depth;
+		if (u->is_bottom) break;
+		u = u[i].p;
+	}
+	{
+		rpnode_t *e = &path[depth-1][pidx[depth-1]];
+		nbytes = rle_insert((uint8_t*)e->p, x - y, a, rl, cnt, e->c);
+		z += cnt[a];
+	}
+	for (k = 0; k < depth; ++k) { rpnode_t *e = &path[k][pidx[k]]; e->c[a] += rl; e->l += rl; }
+	rope->c[a] += rl;
+	if (nbytes + RLE_MIN_SPACE > rope->block_len) {  /* leaf is (nearly) full: split it, then any full bucket above */
+		rpnode_t *bucket = path[depth-1], *e = &bucket[pidx[depth-1]], *ne;
+		uint8_t *nl = new_leaf(rope);
+		int64_t nc[6] = { 0, 0, 0, 0, 0, 0 }, nlen = 0;
+		rle_split((uint8_t*)e->p, nl);
+		rle_count(nl, nc);
+		for (j = 0; j < 6; ++j) { e->c[j] -= nc[j]; nlen += nc[j]; }
+		e->l -= nlen;
+		ne = bucket_open_slot(bucket, pidx[depth-1]);
+		ne->p = (rpnode_t*)nl; ne->l = nlen; memcpy(ne->c, nc, 48);
+		for (k = depth - 1; k >= 0 && (int)path[k]->n == rope->max_nodes; --k) {
+			rpnode_t *full = path[k], *right = new_bucket(rope), *parent, *pe;
+			const int half = rope->max_nodes / 2, isb = full->is_bottom;
+			int64_t sc[6], sl;
+			memcpy(right, full + half, sizeof(rpnode_t) * half);
+			right->n = half; right->is_bottom = isb;
+			full->n = half;
+			if (k == 0) {                            /* grow a new root */
+				parent = new_bucket(rope);
+				parent->n = 1; parent->is_bottom = 0;
+				parent->p = full;
+				rope->root = parent;
+				pe = ne = bucket_open_slot(parent, 0); pe = &parent[0];
+			} else {
+				parent = path[k-1];
+				ne = bucket_open_slot(parent, pidx[k-1]);
+				pe = &parent[pidx[k-1]];
+			}
+			entry_sum(full, 0, half, sc, &sl);  memcpy(pe->c, sc, 48); pe->l = sl; pe->p = full;
+			entry_sum(right, 0, half, sc, &sl); memcpy(ne->c, sc, 48); ne->l = sl; ne->p = right;
+			if (k == 0) break;
+		}
+	}
+	return z;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * rank
+ * ------------------------------------------------------------------------------------------- */
+
+static void count_prefix(const rope_t *rope, int64_t x, int64_t cx[6])
+{
+	const rpnode_t *u = rope->root;
+	int64_t y = 0;
+	int a;
+	memset(cx, 0, 48);
+	for (;;) {
+		int i = 0, n = u->n;
+		while (i < n - 1 && y + (int64_t)u[i].l < x) { for (a = 0; a < 6; ++a) cx[a] += u[i].c[a]; y += u[i].l; ++i; }
+		if (u->is_bottom) { rle_rank1a((const uint8_t*)u[i].p, x - y, cx, u[i].c); return; }
+		u = u[i].p;
+	}
+}
+
+void rope_rank2a(const rope_t *rope, int64_t x, int64_t y, int64_t *cx, int64_t *cy)
+{
+	count_prefix(rope, x, cx);
+	if (cy && y >= x) count_prefix(rope, y, cy);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * leaf iterator
+ * ------------------------------------------------------------------------------------------- */
+
+static void itr_descend(rpitr_t *it)
+{
+	while (!it->pa[it->d]->is_bottom) {
+		const rpnode_t *child = it->pa[it->d][it->ia[it->d]].p;
+		++it->d;
+		it->pa[it->d] = child; it->ia[it->d] = 0;
+	}
+}
+
+void rope_itr_first(const rope_t *rope, rpitr_t *it)
+{
+	memset(it, 0, sizeof(rpitr_t));
+	it->rope = rope;
+	it->pa[0] = rope->root;
+	itr_descend(it);
+}
+
+const uint8_t *rope_itr_next_block(rpitr_t *it)
+{
+	const uint8_t *blk;
+	if (it->d < 0) return 0;
+	assert(it->d < ROPE_MAX_DEPTH);
+	blk = (const uint8_t*)it->pa[it->d][it->ia[it->d]].p;
+	while (it->d >= 0) {                             /* climb until some level has a next sibling */
+		if (++it->ia[it->d] < (int)it->pa[it->d]->n) break;
+		it->ia[it->d--] = 0;
+	}
+	if (it->d >= 0) itr_descend(it);
+	return blk;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * debugging / serialisation (.fmr)
+ * ------------------------------------------------------------------------------------------- */
+
+void rope_print_node(const rpnode_t *p)
+{
+	int i, n = p->n;
+	putchar('(');
+	for (i = 0; i < n; ++i) {
+		if (i) putchar(',');
+		if (p->is_bottom) {
+			const uint8_t *q = (const uint8_t*)p[i].p + 2, *end = q + *rle_nptr(p[i].p);
+			while (q < end) {
+				int c; int64_t l, k;
+				q += rle_dec1_fn(q, &c, &l);
+				for (k = 0; k < l; ++k) putchar("$ACGTN"[c]);
+			}
+		} else rope_print_node(p[i].p);
+	}
+	putchar(')');
+}
+
+/* pre-order: u8 is_bottom, i16 n; bottom: n x (6 x i64 counts, u16 nbytes, bytes); else children */
+static void dump_bucket(const rpnode_t *p, FILE *fp)
+{
+	const uint8_t isb = p->is_bottom;
+	const int16_t n = (int16_t)p->n;
+	int i;
+	fwrite(&isb, 1, 1, fp);
+	fwrite(&n, 2, 1, fp);
+	for (i = 0; i < n; ++i) {
+		if (isb) {
+			fwrite(p[i].c, 8, 6, fp);
+			fwrite(p[i].p, 1, 2 + *rle_nptr(p[i].p), fp);
+		} else dump_bucket(p[i].p, fp);
+	}
+}
+
+void rope_dump(const rope_t *r, FILE *fp)
+{
+	fwrite(&r->max_nodes, 4, 1, fp);
+	fwrite(&r->block_len, 4, 1, fp);
+	dump_bucket(r->root, fp);
+}
+
+static rpnode_t *restore_bucket(rope_t *r, FILE *fp, int64_t c[6])
+{
+	uint8_t isb; int16_t n; int i, a;
+	rpnode_t *p = new_bucket(r);
+	if (fread(&isb, 1, 1, fp) != 1 || fread(&n, 2, 1, fp) != 1) { fprintf(stderr, "[E::rope_restore] truncated file\n"); exit(1); }
+	p->is_bottom = isb; p->n = n;
+	memset(c, 0, 48);
+	for (i = 0; i < n; ++i) {
+		if (isb) {
+			uint8_t *blk = new_leaf(r);
+			uint16_t nb;
+			p[i].p = (rpnode_t*)blk;
+			if (fread(p[i].c, 8, 6, fp) != 6 || fread(&nb, 2, 1, fp) != 1 || nb + 2 > r->block_len || fread(blk + 2, 1, nb, fp) != nb) {
+				fprintf(stderr, "[E::rope_restore] corrupt leaf\n"); exit(1);
+			}
+			*rle_nptr(blk) = nb;
+		} else p[i].p = restore_bucket(r, fp, p[i].c);
+		p[i].l = 0;
+		for (a = 0; a < 6; ++a) { p[i].l += p[i].c[a]; c[a] += p[i].c[a]; }   /* internal counts are not stored */
+	}
+	return p;
+}
+
+rope_t *rope_restore(FILE *fp)
+{
+	rope_t *r = (rope_t*)calloc(1, sizeof(rope_t));
+	if (fread(&r->max_nodes, 4, 1, fp) != 1 || fread(&r->block_len, 4, 1, fp) != 1 || r->max_nodes < 2 || r->block_len < 32) {
+		fprintf(stderr, "[E::rope_restore] not an FMR rope\n"); exit(1);
+	}
+	r->node = arena_new(sizeof(rpnode_t) * r->max_nodes);
+	r->leaf = arena_new(r->block_len);
+	r->root = restore_bucket(r, fp, r->c);
+	return r;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * bulk load / export
+ * ------------------------------------------------------------------------------------------- */
+
+typedef struct { rpnode_t *v; size_t n, m; } entvec_t;
+
+static rpnode_t *ent_push(entvec_t *e)
+{
+	if (e->n == e->m) { e->m = e->m ? e->m * 2 : 1024; e->v = (rpnode_t*)realloc(e->v, e->m * sizeof(rpnode_t)); }
+	memset(&e->v[e->n], 0, sizeof(rpnode_t));
+	return &e->v[e->n++];
+}
+
+void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
+{
+	const uint8_t *q = rle, *end = rle + (n_bytes > 0 ? n_bytes : 0);
+	const int fill = rope->block_len - RLE_MIN_SPACE - 2;      /* bytes of runs per leaf: leaves room for one insertion */
+	const int fan = rope->max_nodes > 4 ? rope->max_nodes - 2 : rope->max_nodes / 2;
+	entvec_t lv = { 0, 0, 0 }, up = { 0, 0, 0 };
+	rpnode_t *cur = 0;
+	uint8_t *blk = 0;
+	int pc = -1, a; int64_t pl = 0;
+	size_t i;
+	rope_reset(rope);
+	/* leaves: merge adjacent equal symbols, re-encode with the widest run form needed */
+	for (;;) {
+		int c = -1; int64_t l = 0;
+		if (q < end) { q += rle_dec1_fn(q, &c, &l); if (l == 0) continue; }
+		if (c == pc && c >= 0) { pl += l; continue; }
+		if (pc >= 0) {                                         /* flush the pending run */
+			uint8_t tmp[8];
+			const int nb = rle_enc1(tmp, pc, pl);
+			if (!cur || *rle_nptr(blk) + nb > fill) {
+				cur = ent_push(&lv);
+				blk = lv.n == 1 ? (uint8_t*)rope->root->p : new_leaf(rope);   /* reuse the empty first leaf */
+				cur->p = (rpnode_t*)blk;
+			}
+			memcpy(blk + 2 + *rle_nptr(blk), tmp, nb);
+			*rle_nptr(blk) += nb;
+			cur->c[pc] += pl; cur->l += pl; rope->c[pc] += pl;
+		}
+		if (c < 0) break;
+		pc = c; pl = l;
+	}
+	if (lv.n == 0) { free(lv.v); return; }                     /* empty stream: the reset rope is the answer */
+	/* levels above: pack `fan` entries per bucket until a single bucket (the root) remains */
+	{
+		int bottom = 1;
+		for (;;) {
+			const size_t nbk = (lv.n + fan - 1) / fan;
+			size_t b;
+			up.n = 0;
+			for (b = 0; b < nbk; ++b) {
+				const size_t from = b * fan, to = from + fan < lv.n ? from + fan : lv.n;
+				rpnode_t *bk = nbk == 1 ? rope->root : new_bucket(rope), *pe = ent_push(&up);
+				memcpy(bk, &lv.v[from], sizeof(rpnode_t) * (to - from));
+				bk->n = to - from; bk->is_bottom = bottom;
+				pe->p = bk;
+				for (i = from; i < to; ++i) { for (a = 0; a < 6; ++a) pe->c[a] += lv.v[i].c[a]; pe->l += lv.v[i].l; }
+			}
+			if (nbk == 1) break;
+			{ entvec_t t = lv; lv = up; up = t; }
+			bottom = 0;
+		}
+	}
+	free(lv.v); free(up.v);
+}
+
+int64_t rope_export_runs(const rope_t *rope, uint8_t **out)
+{
+	rpitr_t it;
+	const uint8_t *blk;
+	int64_t n = 0, m = 1 << 16;
+	uint8_t *buf = (uint8_t*)malloc(m);
+	rope_itr_first(rope, &it);
+	while ((blk = rope_itr_next_block(&it)) != 0) {
+		const int nb = *rle_nptr(blk);
+		if (n + nb > m) { while (n + nb > m) m += m >> 1; buf = (uint8_t*)realloc(buf, m); }
+		memcpy(buf + n, blk + 2, nb);
+		n += nb;
+	}
+	*out = buf;
+	return n;
+}

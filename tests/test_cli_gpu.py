@@ -1,0 +1,126 @@
+"""GPU tests of the drop-in boundary: the `ropebwt2` CLI and the mrope C API (libropebwt2.so) with
+the batch insertion running in the HIP engine.  Parity target: the reference's .fmd bytes."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+from test_host_layer import CLI, cli, make_fastx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build(hip):
+    H.build_oracle()
+
+
+@pytest.mark.parametrize("flag", ["-LR", "-LRs", "-LRr", "-L", "-Ls", "-Lr", "-LRN", "-LRT"])
+def test_kat_cli_gpu(golden, flag):
+    assert cli([flag], golden["kat_input"].encode()).decode().strip() == golden["kat"][flag]
+
+
+def test_kat_fmd_bytes_gpu(golden):
+    assert cli(["-LRd"], golden["kat_input"].encode()).hex() == golden["kat_fmd_hex"]
+
+
+@pytest.mark.parametrize("name", ["10k_x_101", "100k_x_101", "200_x_10k", "3k_x_300_s44"])
+@pytest.mark.parametrize("flag", ["-LRd", "-LRsd", "-LRrd", "-Lrd"])
+def test_fmd_golden(golden, name, flag):
+    g = golden["sets"][name]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    assert H.md5(cli([flag], text)) == g["fmd_md5"][flag]
+
+
+@pytest.mark.parametrize("flag", ["-LRsd", "-Lrd"])
+def test_fmd_golden_1M_small_batches(golden, flag):
+    """1 M reads, -m20m -> 5..10 GPU batches; .fmd is independent of the batching"""
+    g = golden["sets"]["1M_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    assert H.md5(cli([flag, "-m20m"], text)) == g["fmd_md5"][flag]
+
+
+@pytest.mark.parametrize("so_flag", ["", "s", "r"])
+def test_incremental_build(golden, so_flag, tmp_path):
+    """config 5 shape: -b on the first half, then -i + second half == one-shot build"""
+    g = golden["sets"]["10k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    half = tmp_path / "half.fmr"
+    half.write_bytes(cli(["-LRb" + so_flag], H.reads_to_text(codes[:5000])))
+    out = cli(["-LRd", "-i", str(half)], H.reads_to_text(codes[5000:]))
+    assert H.md5(out) == g["fmd_md5"]["-LR" + so_flag + "d"]
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+def test_our_fmr_restores_in_reference(golden, tmp_path):
+    g = golden["sets"]["100k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    f = tmp_path / "o.fmr"
+    f.write_bytes(cli(["-LRbr"], text))
+    ref = subprocess.run([H.REF_BIN, "-d", "-i", str(f), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert H.md5(ref) == g["fmd_md5"]["-LRrd"]
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("flags", [[], ["-N"], ["-q", "20"], ["-x", "8"], ["-x", "8", "-C"], ["-C", "-s"], ["-F"], ["-R", "-r"], ["-x", "3", "-r"]])
+def test_filters_match_reference(flags):
+    fq, fa = make_fastx()
+    for data in (fq, fa):
+        if data is fa and "-q" in flags:
+            continue
+        assert cli(flags + ["-d"], data) == H.run_ref(flags + ["-d"], data)
+
+
+def test_mrope_c_api(golden):
+    """drive libropebwt2.so the way main.c drives the reference: mr_init / mr_insert_multi /
+    inline count helpers / mr_rank2a / mr_insert1 after a GPU batch / iterator"""
+    from ropebwt2_amd.build import lib_path
+    L = C.CDLL(lib_path("libropebwt2.so"))
+    L.mr_init.restype = C.c_void_p
+    L.mr_init.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.mr_insert_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    L.mr_insert1.argtypes = [C.c_void_p, C.c_void_p]
+    L.mr_insert1.restype = C.c_int64
+    L.mr_rank2a.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.mr_destroy.argtypes = [C.c_void_p]
+    L.mr_sync_host.argtypes = [C.c_void_p]
+
+    class MRope(C.Structure):
+        _fields_ = [("so", C.c_uint8), ("thr_min", C.c_int), ("r", C.c_void_p * 6)]
+
+    class Rope(C.Structure):
+        _fields_ = [("max_nodes", C.c_int32), ("block_len", C.c_int32), ("c", C.c_int64 * 6)]
+
+    reads = H.repetitive_reads(3000, seed=77, genome_len=500, max_len=70)
+    for so in (0, 1, 2):
+        o = H.Oracle(so)
+        mr = L.mr_init(64, 512, so)
+        for part in (reads[:1200], reads[1200:2500]):
+            buf = H.encode_batch(part)
+            o.insert_multi(buf)
+            L.mr_insert_multi(mr, len(buf), buf.ctypes.data, 1)
+        m = MRope.from_address(mr)
+        counts = np.array([[Rope.from_address(m.r[a]).c[b] for b in range(6)] for a in range(6)])
+        assert np.array_equal(counts, o.counts())            # rope_t.c current right after the GPU call
+        for r in reads[2500:]:                               # -m0 style inserts on top of the GPU-built index
+            s = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint8)[::-1], np.zeros(1, np.uint8)]))
+            L.mr_insert1(mr, s.ctypes.data)
+            o.insert1(np.asarray(r, np.uint8)[::-1])
+        bwt = o.bwt()
+        rng = np.random.RandomState(so)
+        for _ in range(20):
+            x = int(rng.randint(0, len(bwt) + 1)); y = int(rng.randint(x, len(bwt) + 1))
+            cx = (C.c_int64 * 6)(); cy = (C.c_int64 * 6)()
+            L.mr_rank2a(mr, x, y, cx, cy)
+            assert list(cx) == np.bincount(bwt[:x], minlength=6).tolist()
+            assert list(cy) == np.bincount(bwt[:y], minlength=6).tolist()
+        buf = H.encode_batch(reads[:300], True, True)        # and back to the GPU: host ropes are re-uploaded
+        o.insert_multi(buf)
+        L.mr_insert_multi(mr, len(buf), buf.ctypes.data, 1)
+        m = MRope.from_address(mr)
+        counts = np.array([[Rope.from_address(m.r[a]).c[b] for b in range(6)] for a in range(6)])
+        assert np.array_equal(counts, o.counts())
+        L.mr_destroy(mr)

@@ -1,0 +1,186 @@
+"""CPU tests of the plain-C host layer (include/mrope.h, rope.h, rle.h, rb2_fmd.h) and the CLI in
+its CPU-only mode (-m0 = mr_insert1).  These pin the parity ARTEFACT writers: .fmd bytes must equal
+the reference's, .fmr must restore (in the reference too) to the same BWT.  No GPU is touched."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+ROOT = H.ROOT
+CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
+SO_FLAG = {0: "-LR", 1: "-LRs", 2: "-LRr"}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    from ropebwt2_amd import build_all
+    build_all()
+    H.build_oracle()
+
+
+def cli(flags, data, check=True):
+    p = subprocess.run([CLI] + list(flags) + ["-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if check:
+        assert p.returncode == 0, p.stderr.decode()
+    return p.stdout
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from ropebwt2_amd.build import lib_path
+    L = C.CDLL(lib_path("libropebwt2.so"))
+    L.rb2_fmd_init.restype = C.c_void_p
+    L.rb2_fmd_push.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.rb2_fmd_finish.argtypes = [C.c_void_p]
+    L.rb2_fmd_destroy.argtypes = [C.c_void_p]
+    return L
+
+
+def test_exports_reference_api(hostlib):
+    names = ["mr_init", "mr_destroy", "mr_thr_min", "mr_insert1", "mr_insert_multi", "mr_rank2a", "mr_itr_first",
+             "mr_itr_next_block", "mr_print_tree", "mr_dump", "mr_restore",
+             "rope_init", "rope_destroy", "rope_insert_run", "rope_rank2a", "rope_itr_first", "rope_itr_next_block",
+             "rope_print_node", "rope_dump", "rope_restore",
+             "rle_insert_cached", "rle_insert", "rle_split", "rle_count", "rle_rank2a", "rle_print", "rle_auxtab",
+             "rb2_fmd_init", "rb2_fmd_push", "rb2_fmd_finish", "rb2_fmd_write", "rb2_fmd_counts", "rb2_fmd_destroy"]
+    for n in names:
+        assert hasattr(hostlib, n), n
+
+
+@pytest.mark.parametrize("flag", ["-LR", "-LRs", "-LRr", "-L", "-Ls", "-Lr", "-LRN", "-LRT"])
+def test_kat_cli_m0(golden, flag):
+    assert cli([flag, "-m0"], golden["kat_input"].encode()).decode().strip() == golden["kat"][flag]
+
+
+def test_kat_fmd_and_fmr_bytes(golden):
+    kat = golden["kat_input"].encode()
+    assert cli(["-LRd", "-m0"], kat).hex() == golden["kat_fmd_hex"]
+    fmr = cli(["-LRb", "-m0"], kat)
+    assert fmr[:4] == b"RB\x02\x00"
+    # same content as the reference's tiny .fmr (tree shape is identical for a one-leaf rope)
+    assert fmr.hex() == golden["kat_fmr_hex"]
+
+
+@pytest.mark.parametrize("flag", ["-LRd", "-LRsd", "-LRrd", "-Lrd"])
+def test_fmd_golden_10k_m0(golden, flag):
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    assert H.md5(cli([flag, "-m0"], text)) == g["fmd_md5"][flag]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_fmd_writer_on_oracle_bwt(hostlib, golden, so, tmp_path):
+    """feed the oracle's BWT runs to our FMD writer: bytes equal the reference's .fmd"""
+    g = golden["sets"]["10k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    o = H.Oracle(so)
+    o.insert_multi(H.encode_batch_fixed(codes))
+    bwt = o.bwt()
+    edges = np.flatnonzero(np.diff(bwt)) + 1
+    starts = np.concatenate([[0], edges])
+    lens = np.diff(np.concatenate([starts, [len(bwt)]]))
+    f = hostlib.rb2_fmd_init()
+    for s, l in zip(bwt[starts].tolist(), lens.tolist()):
+        hostlib.rb2_fmd_push(f, l, s)
+    hostlib.rb2_fmd_finish(f)
+    out = tmp_path / "x.fmd"
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    fp = libc.fopen(str(out).encode(), b"wb")
+    hostlib.rb2_fmd_write.argtypes = [C.c_void_p, C.c_void_p]
+    assert hostlib.rb2_fmd_write(f, fp) == 0
+    libc.fclose(fp)
+    hostlib.rb2_fmd_destroy(f)
+    assert H.md5(out.read_bytes()) == g["fmd_md5"][SO_FLAG[so] + "d"]
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+def test_fmr_roundtrip_with_reference(golden, tmp_path):
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    ours = tmp_path / "ours.fmr"
+    ours.write_bytes(cli(["-LRbs", "-m0"], text))
+    ref = subprocess.run([H.REF_BIN, "-d", "-i", str(ours), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert H.md5(ref) == g["fmd_md5"]["-LRsd"]
+    theirs = tmp_path / "ref.fmr"
+    theirs.write_bytes(H.run_ref(["-LRbr"], text))
+    mine = subprocess.run([CLI, "-d", "-i", str(theirs), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert H.md5(mine) == g["fmd_md5"]["-LRrd"]
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("flags", [[], ["-N"], ["-q", "20"], ["-C"], ["-F"], ["-R", "-s"], ["-r"], ["-N", "-C", "-r"]])
+def test_fastq_fasta_parsing_and_filters(flags, tmp_path):
+    rng = np.random.RandomState(5)
+    recs = []
+    for i in range(300):
+        ln = rng.randint(0, 70)
+        seq = "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04]) for _ in range(ln))
+        if i % 7 == 0 and ln >= 4 and ln % 2 == 0:          # some reverse-complement palindromes for -C
+            h = seq[:ln // 2].replace("N", "A")
+            seq = h + h[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        qual = "".join(chr(33 + rng.randint(2, 41)) for _ in range(ln))
+        recs.append((seq, qual))
+    fq = "".join("@r%d desc\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(recs)).encode()
+    fa = "".join(">r%d\n%s\n" % (i, "\n".join(s[j:j + 25] for j in range(0, len(s), 25))) for i, (s, q) in enumerate(recs)).encode()
+    for data in (fq, fa):
+        if data is fa and "-q" in flags:
+            continue
+        ref = H.run_ref(flags + ["-m0"], data)
+        assert cli(flags + ["-m0"], data) == ref
+
+
+def test_x_needs_batch_mode():
+    p = subprocess.run([CLI, "-x", "5", "-m0", "-"], input=b">a\nACGT\n", stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"cannot be used with '-m0'" in p.stderr        # main.c:166-169
+
+
+def make_fastx(seed=5, n=300):
+    rng = np.random.RandomState(seed)
+    recs = []
+    for i in range(n):
+        ln = rng.randint(0, 70)
+        seq = "".join(rng.choice(list("ACGTN"), p=[.24, .24, .24, .24, .04]) for _ in range(ln))
+        if i % 7 == 0 and ln >= 4 and ln % 2 == 0:
+            h = seq[:ln // 2].replace("N", "A")
+            seq = h + h[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        qual = "".join(chr(33 + rng.randint(2, 41)) for _ in range(ln))
+        recs.append((seq, qual))
+    fq = "".join("@r%d desc\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(recs)).encode()
+    fa = "".join(">r%d\n%s\n" % (i, "\n".join(s[j:j + 25] for j in range(0, len(s), 25))) for i, (s, q) in enumerate(recs)).encode()
+    return fq, fa
+
+
+def test_rle_rope_random_against_model(hostlib):
+    """rope_insert_run / rope_rank2a on a small-block rope vs a python list model"""
+    L = hostlib
+    L.rope_init.restype = C.c_void_p
+    L.rope_insert_run.restype = C.c_int64
+    L.rope_insert_run.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_void_p]
+    L.rope_rank2a.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.rope_destroy.argtypes = [C.c_void_p]
+    r = L.rope_init(4, 32)                  # tiny nodes and leaves: many splits, several levels
+    model = []
+    rng = np.random.RandomState(1)
+    for it in range(3000):
+        x = int(rng.randint(0, len(model) + 1))
+        a = int(rng.randint(0, 6))
+        rl = int(rng.choice([1, 1, 1, 2, 5, 17, 300]))
+        got = L.rope_insert_run(r, x, a, rl, None)
+        assert got == model[:x].count(a)
+        model[x:x] = [a] * rl
+        if it % 50 == 0:
+            cx = (C.c_int64 * 6)()
+            cy = (C.c_int64 * 6)()
+            x = int(rng.randint(0, len(model) + 1))
+            y = int(rng.randint(x, len(model) + 1))
+            L.rope_rank2a(r, x, y, cx, cy)
+            assert list(cx) == [model[:x].count(s) for s in range(6)]
+            assert list(cy) == [model[:y].count(s) for s in range(6)]
+    L.rope_destroy(r)
