@@ -124,3 +124,19 @@ def test_mrope_c_api(golden):
         counts = np.array([[Rope.from_address(m.r[a]).c[b] for b in range(6)] for a in range(6)])
         assert np.array_equal(counts, o.counts())
         L.mr_destroy(mr)
+
+
+DROPIN = os.path.join(H.ORACLE_DIR, "_ref", "ropebwt2_dropin")
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/ropebwt2_dropin not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("flag", ["-LRd", "-LRsd", "-LRrd", "-Lrd"])
+def test_reference_main_linked_against_our_library(golden, flag):
+    """The reference's own main.c/rld0.c objects (compiled with the reference's headers) linked
+    against libropebwt2.so: mr_insert_multi runs in the HIP engine, the reference's code iterates
+    our leaves with its rle_dec1 macro and writes the .fmd -- bytes must equal the goldens."""
+    g = golden["sets"]["100k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    p = subprocess.run([DROPIN, flag, "-m3m", "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    assert H.md5(p.stdout) == g["fmd_md5"][flag]
