@@ -74,6 +74,7 @@ struct rb2_hip_s {
 	int64_t p_launch[RB2_K_COUNT]; double p_ms[RB2_K_COUNT]; int64_t p_units[RB2_K_COUNT];
 	int debug = 0;
 	int cur_round = -1;
+	int merge_dbg = 0;
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
 
@@ -217,7 +218,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		{ Scope sc(h, RB2_K_PART, units);
 		  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
 		{ Scope sc(h, RB2_K_MERGE, units);
-		  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p); }
+		  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p, h->merge_dbg); }
 		{ Scope sc(h, RB2_K_META, units);
 		  build_directory(h, sd ^ 1, std::min<uint64_t>(nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
 		{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -258,6 +259,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	rb2_hip_t *h = new rb2_hip_s();
 	h->dev = device; h->so = sorting_order;
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
+	h->merge_dbg = getenv("RB2_HIP_MERGE_DBG") ? atoi(getenv("RB2_HIP_MERGE_DBG")) : 0;
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));

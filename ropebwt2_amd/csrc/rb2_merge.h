@@ -8,17 +8,20 @@
 // Work decomposition: ONE WAVE PER OUTPUT LEAF (LEAF symbols), four independent waves per block,
 // no block-level barrier anywhere.  Lane l owns output positions [16l, 16l+16) of the leaf:
 //   1. the <= 2 old leaves that feed this leaf are loaded 16 B per lane and staged in LDS as one
-//      contiguous byte stream; SWAR + wave scan give the first symbol of every 16-byte chunk
+//      contiguous byte stream; SWAR + DPP wave scan give the first symbol of every 16-byte chunk
+//      (leaf slots are zero padded to 16 bytes, and a zero byte is a run of length 0)
 //   2. the new symbols of the leaf are scattered into a position-indexed LDS array + bit flags
 //   3. wave prefix sum of the non-insert counts -> first old symbol each lane consumes; a 7-step
-//      search finds the chunk, a register walk the byte and the offset inside its run
+//      search finds the chunk, SWAR prefix sums the byte and the offset inside its run
 //   4. 16 output symbols per lane are produced from a 16-byte shift register of run bytes
 //      (rle_dec1, rle.h:39-51) with the flagged positions taken from the insert array
-//   5. re-encode: run heads by neighbour compare, wave scan for byte offsets, one byte per run
-//      (rle_enc1's 1-byte form, rle.h:55-57); runs longer than 15 take a slower exact path
+//   5. re-encode: run heads by packed neighbour compare, wave scan for byte offsets, one byte per
+//      run (rle_enc1's 1-byte form, rle.h:55-57); runs longer than 15 take a slower exact path
 //   6. symbol counts of the leaf (new LeafMeta) and, for every new symbol, the number of equal
 //      symbols before it INSIDE the leaf (RKREL); k_advance adds the directory prefix of the new
 //      rope to obtain the reference's return value of rope_insert_run.
+// The code is written branch-free on purpose: per-position conditions become selects, so the
+// compiler does not fragment the 16-fold unrolled loops into exec-mask regions.
 #pragma once
 #include "rb2_device.h"
 
@@ -27,36 +30,42 @@ namespace rb2 {
 constexpr int MW = 4;                       // waves (= output leaves) per block
 
 struct WaveLds {
-	uint8_t  raw[2 * LEAF + 32];            // old run bytes: leaf A then leaf B, contiguous
+	uint8_t  raw[2 * LEAF + 64];            // old run bytes: leaf A then leaf B, contiguous
 	uint8_t  ins[LEAF];                     // new symbol at output position p (where flagged)
-	uint8_t  outb[LEAF];                    // encoded output leaf
+	uint8_t  outb[LEAF + 16];               // encoded output leaf (+ one dump slot)
 	uint16_t starts[128];                   // first symbol (in A|B coordinates) of each 16-byte chunk
 	uint32_t flags[LEAF / 32];              // bit p: output position p is a new symbol
 };
 
-// packed per-symbol counters: symbols 0..4 in 12-bit fields; N (5) is derived from the position
-__device__ __forceinline__ uint64_t pk_add(uint64_t acc, uint32_t sym, uint32_t len) { return sym < 5 ? acc + ((uint64_t)len << (12 * sym)) : acc; }
-__device__ __forceinline__ uint32_t pk_get(uint64_t acc, uint32_t sym) { return (uint32_t)(acc >> (12 * sym)) & 0xfffu; }
-__device__ __forceinline__ uint32_t pk_sum5(uint64_t acc) { return pk_get(acc, 0) + pk_get(acc, 1) + pk_get(acc, 2) + pk_get(acc, 3) + pk_get(acc, 4); }
-
 __device__ __forceinline__ uint32_t byte_of(const uint32_t w[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
+__device__ __forceinline__ uint32_t sel4(const uint32_t w[4], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3]; }
 
-// sum of the run lengths of the first nv bytes of a 16-byte chunk (SWAR)
-__device__ __forceinline__ uint32_t chunk_len_sum(const uint32_t w[4], int nv)
+// sum of the run lengths of a 16-byte chunk (SWAR; zero bytes count 0)
+__device__ __forceinline__ uint32_t chunk_len_sum(const uint32_t w[4])
 {
 	uint32_t s = 0;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const int v = min(4, max(0, nv - 4 * k));
-		const uint32_t m = v >= 4 ? 0xffffffffu : ((1u << (8 * v)) - 1u);
-		const uint32_t l4 = ((w[k] & m) >> 3) & 0x1f1f1f1fu;
-		s += (l4 * 0x01010101u) >> 24;
-	}
+	for (int k = 0; k < 4; ++k) s += ((((w[k] >> 3) & 0x1f1f1f1fu) * 0x01010101u) >> 24);
 	return s;
 }
 
+// 16 bytes from an arbitrary LDS byte address: five aligned dwords + funnel shifts
+__device__ __forceinline__ void lds_read16(const uint8_t *p, uint32_t out[4])
+{
+	const uint32_t a = (uint32_t)(uintptr_t)p;
+	const uint32_t *q = (const uint32_t*)(p - (a & 3));
+	const uint32_t sh = (a & 3) * 8;
+	const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+	out[0] = __builtin_amdgcn_alignbit(d1, d0, sh); out[1] = __builtin_amdgcn_alignbit(d2, d1, sh);
+	out[2] = __builtin_amdgcn_alignbit(d3, d2, sh); out[3] = __builtin_amdgcn_alignbit(d4, d3, sh);
+}
+
+// per-lane symbol counters: six 5-bit fields (a lane holds <= 16 symbols)
+__device__ __forceinline__ uint32_t c5_one(uint32_t sym) { return 1u << (sym * 5u); }
+__device__ __forceinline__ uint32_t c5_get(uint32_t acc, uint32_t sym) { return (acc >> (sym * 5u)) & 31u; }
+
 __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolView oldp, PoolView newp,
-		const uint64_t *INS_E, const uint8_t *INS_A, uint16_t *RKREL, const uint32_t *TQ)
+		const uint64_t *INS_E, const uint8_t *INS_A, uint16_t *RKREL, const uint32_t *TQ, int dbg)
 {
 	__shared__ __align__(16) WaveLds lds[MW];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -82,30 +91,29 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 
 	// ---- 1. old leaves -> registers -> LDS byte stream; chunk starts
 	uint32_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-	int nbA = 0, nva = 0, nvb = 0;
+	int nbA = 0;
 	if (haveA) {
 		const uint64_t gl = orp.leaf0 + A;
 		nbA = oldp.meta[gl].nbytes;
-		nva = min(16, max(0, nbA - ln * 16));
-		if (nva > 0) { const uint4 v = ((const uint4*)(oldp.data + gl * (uint64_t)LEAF))[ln]; wa[0] = v.x; wa[1] = v.y; wa[2] = v.z; wa[3] = v.w; }
+		if (ln * 16 < nbA) { const uint4 v = ((const uint4*)(oldp.data + gl * (uint64_t)LEAF))[ln]; wa[0] = v.x; wa[1] = v.y; wa[2] = v.z; wa[3] = v.w; }
 	}
 	if (needB) {
 		const uint64_t gl = orp.leaf0 + A + 1;
 		const int nbB = oldp.meta[gl].nbytes;
-		nvb = min(16, max(0, nbB - ln * 16));
-		if (nvb > 0) { const uint4 v = ((const uint4*)(oldp.data + gl * (uint64_t)LEAF))[ln]; wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w; }
+		if (ln * 16 < nbB) { const uint4 v = ((const uint4*)(oldp.data + gl * (uint64_t)LEAF))[ln]; wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w; }
 	}
 	if (ln < LEAF / 32) L.flags[ln] = 0;
+	((uint4*)L.outb)[ln] = make_uint4(0, 0, 0, 0);             // the stored leaf is zero padded to 16 bytes
 	((uint4*)L.raw)[ln] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
 	{
 		uint8_t *d = L.raw + nbA + ln * 16;                    // B right behind the used bytes of A
 #pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < nvb) d[i] = (uint8_t)byte_of(wb, i);
+		for (int i = 0; i < 16; ++i) d[i] = (uint8_t)byte_of(wb, i);
 	}
 	{
-		const uint32_t sa = chunk_len_sum(wa, nva), sb = chunk_len_sum(wb, nvb);
-		const uint32_t ia = wave_incl_add(sa), ib = wave_incl_add(sb);
-		const uint32_t totA = __shfl(ia, 63);
+		const uint32_t sa = chunk_len_sum(wa), sb = chunk_len_sum(wb);
+		const uint32_t ia = dpp_incl_add(sa), ib = dpp_incl_add(sb);
+		const uint32_t totA = lane63(ia);
 		L.starts[ln] = haveA ? (uint16_t)(ia - sa) : (uint16_t)0xffffu;
 		L.starts[64 + ln] = needB ? (uint16_t)(totA + ib - sb) : (uint16_t)0xffffu;
 	}
@@ -121,134 +129,157 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 	// ---- 3. what does each lane consume
 	const int p0 = ln * 16;
 	const int myvalid = min(16, max(0, nvalid - p0));
-	const uint32_t flags = ((const uint16_t*)L.flags)[ln] & ((1u << myvalid) - 1u);
-	const int kins = __popc(flags);
-	const int nonins = myvalid - kins;
-	const int oinc = wave_incl_add(nonins);
-	const int iinc = wave_incl_add(kins);
-	const int oldpos = x0 + oinc - nonins;                     // first old symbol of this lane, A|B coordinates
-	uint32_t sr[4] = {0, 0, 0, 0};                             // shift register of upcoming run bytes
-	int rem = 0; uint32_t cs = 0;
-	if (nonins > 0) {
-		int c = 0;
-#pragma unroll
-		for (int st = 64; st >= 1; st >>= 1) if (L.starts[c + st] <= (uint16_t)oldpos) c += st;   // starts[] is non-decreasing
-		const int off = oldpos - L.starts[c];
-		const int g0 = c < 64 ? c * 16 : nbA + (c - 64) * 16;
-		uint32_t cw[4];
-		__builtin_memcpy(cw, L.raw + g0, 16);
-		int bi = 0, acc = 0, dd = 0; bool found = false;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const int len = (int)(byte_of(cw, i) >> 3);
-			if (!found && acc + len > off) { bi = i; dd = off - acc; found = true; }
-			acc += len;
-		}
-		__builtin_memcpy(sr, L.raw + g0 + bi, 16);
-		rem = (int)((sr[0] & 0xff) >> 3) - dd; cs = sr[0] & 7;
-	}
-	// ---- 4. my 16 output symbols
-	uint32_t sy[16];
+	const uint32_t vmask = (1u << myvalid) - 1u;
+	const uint32_t flags = ((const uint16_t*)L.flags)[ln] & vmask;
+	const uint32_t kins = __popc(flags);
+	const uint32_t nonins = (uint32_t)myvalid - kins;
+	const uint32_t oinc = dpp_incl_add(nonins);
+	const uint32_t iinc = dpp_incl_add(kins);
+	const uint32_t oldpos = (uint32_t)x0 + oinc - nonins;      // first old symbol of this lane, A|B coordinates
+	uint32_t sr[4];                                            // shift register of upcoming run bytes
+	int rem; uint32_t cs;
 	{
-		const uint8_t *ip = L.ins + p0;
+		uint32_t c = 0;
+#pragma unroll
+		for (uint32_t st = 64; st >= 1; st >>= 1) c += (L.starts[c + st] <= (uint16_t)oldpos) ? st : 0u;   // starts[] is non-decreasing
+		const uint32_t off = oldpos - L.starts[c];
+		const uint32_t g0 = c < 64 ? c * 16 : (uint32_t)nbA + (c - 64) * 16;
+		uint32_t cw[4], pre[4];
+		lds_read16(L.raw + g0, cw);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) pre[k] = ((cw[k] >> 3) & 0x1f1f1f1fu) * 0x01010101u;   // in-dword inclusive prefix of the run lengths
+		const uint32_t t0 = pre[0] >> 24, t1 = t0 + (pre[1] >> 24), t2 = t1 + (pre[2] >> 24);
+		const uint32_t wsel = (off >= t0) + (off >= t1) + (off >= t2);                       // dword that holds symbol `off`
+		const uint32_t wbase = wsel == 0 ? 0u : wsel == 1 ? t0 : wsel == 2 ? t1 : t2;
+		const uint32_t offw = off - wbase, P = sel4(pre, wsel);
+		const uint32_t K = (255u - offw) * 0x00010001u;                                      // per byte: P > offw ?
+		const uint32_t ge = (((P & 0x00ff00ffu) + K) >> 8) & 0x00010001u, go = ((((P >> 8) & 0x00ff00ffu) + K) >> 8) & 0x00010001u;
+		const uint32_t ngt = ((ge + go) & 0xffffu) + ((ge + go) >> 16);
+		const uint32_t bw = 4u - ngt;                                                        // byte inside the dword
+		const uint32_t bi = wsel * 4u + bw;
+		const uint32_t exb = ((P << 8) >> (bw * 8u)) & 0xffu;                                // symbols of the dword before that byte
+		lds_read16(L.raw + g0 + bi, sr);
+		rem = (int)((sr[0] & 0xffu) >> 3) - (int)(offw - exb);
+		cs = sr[0] & 7u;
+		rem = nonins ? rem : 16;                               // lanes that consume nothing never advance
+	}
+	// ---- 4. my 16 output symbols, packed 4 per dword
+	uint32_t pw[4] = {0, 0, 0, 0};
+	{
+		uint32_t iw[4];
+		const uint4 v = ((const uint4*)L.ins)[ln];
+		iw[0] = v.x; iw[1] = v.y; iw[2] = v.z; iw[3] = v.w;
+		const uint32_t fx = flags | ~vmask;                    // positions past the end behave like inserts of 0xff
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
-			uint32_t v = 0xff;
-			if (i < myvalid) {
-				if (flags >> i & 1) v = ip[i];
-				else {
-					if (rem == 0) {                                // next run byte
-						sr[0] = __builtin_amdgcn_alignbyte(sr[1], sr[0], 1); sr[1] = __builtin_amdgcn_alignbyte(sr[2], sr[1], 1);
-						sr[2] = __builtin_amdgcn_alignbyte(sr[3], sr[2], 1); sr[3] >>= 8;
-						rem = (int)((sr[0] & 0xff) >> 3); cs = sr[0] & 7;
-					}
-					v = cs; --rem;
-				}
-			}
-			sy[i] = v;
+			const uint32_t fl = (fx >> i) & 1u;
+			const uint32_t insb = i < myvalid ? byte_of(iw, i) : 0xffu;
+			const bool need = !fl && rem == 0;                 // next run byte
+			const uint32_t sh = need ? 8u : 0u;
+			sr[0] = __builtin_amdgcn_alignbit(sr[1], sr[0], sh); sr[1] = __builtin_amdgcn_alignbit(sr[2], sr[1], sh);
+			sr[2] = __builtin_amdgcn_alignbit(sr[3], sr[2], sh); sr[3] >>= sh;
+			rem = need ? (int)((sr[0] & 0xffu) >> 3) : rem;
+			cs = need ? (sr[0] & 7u) : cs;
+			const uint32_t sym = fl ? insb : cs;
+			rem -= (int)(fl ^ 1u);
+			pw[i >> 2] |= sym << ((i & 3) * 8);
 		}
 	}
 	// ---- 5. re-encode
-	const uint32_t prevsym = __shfl_up(sy[15], 1);
-	uint32_t hm = 0;                                               // bit i: a run starts at my position i
+	uint32_t hm = 0;                                           // bit i: a run starts at my position i
+	uint32_t prevw = dpp_prev_lane(pw[3]);                     // NB: cross-lane reads stay outside of lane-dependent conditionals
+	if (ln == 0) prevw = 0xff000000u;
+	{
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t pv = i == 0 ? (ln == 0 ? 0xffu : prevsym) : sy[i - 1];
-		if (i < myvalid && sy[i] != pv) hm |= 1u << i;
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t ps = __builtin_amdgcn_alignbyte(pw[k], k == 0 ? prevw : pw[k - 1], 3);   // my symbols shifted by one position
+			const uint32_t x = pw[k] ^ ps;
+			const uint32_t nz = ((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7) & 0x01010101u;       // 1 per differing byte
+			hm |= ((nz * 0x01020408u) >> 24) << (4 * k);
+		}
+		hm &= vmask;
 	}
-	const uint32_t vmask = (1u << myvalid) - 1u;
-	uint32_t pm = __shfl_up(hm, 1);
-	if (ln == 0) pm = 0;
+	uint32_t pm = dpp_prev_lane(hm);
 	uint32_t cov = pm | (hm << 16);
 	cov |= cov << 1; cov |= cov << 2; cov |= cov << 4; cov |= cov << 7;   // bit set: a run start within the 14 positions before
 	const bool short_runs = ((cov >> 16) & vmask) == vmask;
-	int nbytes;
-	if (__builtin_expect(__all(short_runs), 1)) {
-		const int nh = __popc(hm);
-		const int hinc = wave_incl_add(nh);
-		int hb = hinc - nh;
-		nbytes = __shfl(hinc, 63);
-		const int nvnext = __shfl_down(myvalid, 1), hmnext = __shfl_down((int)hm, 1);
-		int tail = 0;                                              // symbols of my last run that live in the next lane
-		if (ln < 63 && nvnext > 0) tail = hmnext ? __builtin_ctz(hmnext) : nvnext;
+	uint32_t nbytes;
+	if (__builtin_expect(__all(short_runs) && !(dbg & 1), 1)) {
+		const uint32_t nh = __popc(hm);
+		const uint32_t hinc = dpp_incl_add(nh);
+		const uint32_t hb = hinc - nh;
+		nbytes = lane63(hinc);
+		const uint32_t nvnext = dpp_next_lane((uint32_t)myvalid), hmnext = dpp_next_lane(hm);
+		const uint32_t tail = nvnext ? (hmnext ? (uint32_t)__builtin_ctz(hmnext) : nvnext) : 0u;   // symbols of my last run living in the next lane
+		const uint32_t lastlen = (uint32_t)myvalid + tail;
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
-			if (hm >> i & 1) {
-				const uint32_t t = hm >> (i + 1);
-				const int len = t ? __builtin_ctz(t) + 1 : myvalid - i + tail;
-				L.outb[hb++] = (uint8_t)(len << 3 | sy[i]);
-			}
+			const uint32_t t = hm >> (i + 1);
+			const uint32_t len = t ? (uint32_t)__builtin_ctz(t) + 1u : lastlen - (uint32_t)i;
+			const uint32_t idx = (hm >> i & 1u) ? hb + __popc(hm & ((1u << i) - 1u)) : (uint32_t)LEAF;   // non-heads go to the dump slot
+			L.outb[idx] = (uint8_t)(len << 3 | byte_of(pw, i));
 		}
 	} else {
-		// exact path for runs longer than 15 symbols: a byte boundary every 15 symbols of a run
+		// exact path for runs longer than 15 symbols: a byte boundary every 15 symbols of a run.
+		// Rare on reads without long homopolymers; kept in the plain (branchy, shuffle-based) form.
+		const uint32_t prevsym = prevw >> 24;
 		int lastnat = -1;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) if (hm >> i & 1) lastnat = p0 + i;
+		for (int i = 0; i < 16; ++i) if (hm >> i & 1u) lastnat = p0 + i;
 		const int incmax = wave_incl_max(lastnat);
 		int rs = __shfl_up(incmax, 1);                             // start of the run open at p0-1
 		if (ln == 0) rs = 0;
 		int lh = ln == 0 ? 0 : rs + (p0 - 1 - rs) / 15 * 15;       // last byte boundary before p0
 		int hc = 0;
 		{
-			int since = ln == 0 ? 0 : (p0 - 1 - rs) % 15 + 1;      // symbols since the last boundary, at p0
-#pragma unroll
+			int r = rs;
 			for (int i = 0; i < 16; ++i) if (i < myvalid) {
-				const bool nat = hm >> i & 1;
-				if (nat || since == 15) { ++hc; since = 0; }
-				++since;
+				const int p = p0 + i;
+				if (hm >> i & 1u) r = p;
+				hc += ((hm >> i & 1u) || (p - r) % 15 == 0);
 			}
 		}
 		const int hinc = wave_incl_add(hc);
 		const int hb = hinc - hc;
-		nbytes = __shfl(hinc, 63);
+		nbytes = (uint32_t)__shfl(hinc, 63);
 		{
-			int since = ln == 0 ? 0 : (p0 - 1 - rs) % 15 + 1, seen = 0;
-			uint32_t pv = ln == 0 ? 0xffu : prevsym;
-#pragma unroll
+			uint32_t pv = prevsym; int r = rs, seen = 0;
 			for (int i = 0; i < 16; ++i) if (i < myvalid) {
 				const int p = p0 + i;
-				const bool nat = hm >> i & 1;
-				if (nat || since == 15) {
+				if (hm >> i & 1u) r = p;
+				if ((hm >> i & 1u) || (p - r) % 15 == 0) {
 					if (p != 0) L.outb[hb + seen - 1] = (uint8_t)((p - lh) << 3 | pv);
-					lh = p; ++seen; since = 0;
+					lh = p; ++seen;
 				}
-				++since; pv = sy[i];
+				pv = byte_of(pw, i);
 			}
 			if (myvalid > 0 && p0 + myvalid == nvalid) L.outb[nbytes - 1] = (uint8_t)((nvalid - lh) << 3 | pv);
 		}
 	}
 	// ---- 6. counts of the leaf, leaf-relative ranks of the new symbols
-	uint64_t tot = 0;
+	uint32_t c5 = 0;
 #pragma unroll
-	for (int i = 0; i < 16; ++i) if (i < myvalid) tot = pk_add(tot, sy[i], 1);
-	const uint64_t tinc = wave_incl_add(tot);
-	if (kins > 0) {
-		uint64_t rc = tinc - tot;
+	for (int i = 0; i < 16; ++i) c5 += i < myvalid ? c5_one(byte_of(pw, i)) : 0u;
+	// widen to 16-bit fields for the wave scan: (sym0,sym1) (sym2,sym3) (sym4,sym5)
+	const uint32_t e01 = (c5 & 31u) | ((c5 >> 5 & 31u) << 16), e23 = (c5 >> 10 & 31u) | ((c5 >> 15 & 31u) << 16), e45 = (c5 >> 20 & 31u) | ((c5 >> 25 & 31u) << 16);
+	const uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
+	if (__any(kins != 0)) {
+		uint32_t f = flags, n = 0;
 		uint16_t *dst = RKREL + segs + q0 + (iinc - kins);
+		while (f) {                                            // few iterations: new symbols are sparse in steady state
+			const uint32_t i = (uint32_t)__builtin_ctz(f);
+			f &= f - 1;
+			const uint32_t a = (sel4(pw, i >> 2) >> ((i & 3) * 8)) & 0xffu;
+			// equal symbols in front of position i inside my 16: packed compare + mask
+			uint32_t cnt = 0;
 #pragma unroll
-		for (int i = 0; i < 16; ++i) if (i < myvalid) {
-			if (flags >> i & 1) *dst++ = (uint16_t)(sy[i] < 5 ? pk_get(rc, sy[i]) : (uint32_t)(p0 + i) - pk_sum5(rc));
-			rc = pk_add(rc, sy[i], 1);
+			for (int k = 0; k < 4; ++k) {
+				const uint32_t x = pw[k] ^ (a * 0x01010101u);
+				const uint32_t eq = ~((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x)) & 0x80808080u;       // 0x80 per equal byte
+				const int nb = min(4, max(0, (int)i - 4 * k));                                       // bytes of this dword in front of i
+				cnt += __popc(eq & (nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u)));
+			}
+			const uint32_t w2 = a < 2 ? s01 - e01 : a < 4 ? s23 - e23 : s45 - e45;
+			dst[n++] = (uint16_t)(((w2 >> ((a & 1) * 16)) & 0xffffu) + cnt);
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
@@ -256,13 +287,12 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 		const uint64_t gl = nrp.leaf0 + j;
 		if (ln == 63) {
 			LeafMeta m;
-#pragma unroll
-			for (int s = 0; s < 5; ++s) m.c[s] = (uint16_t)pk_get(tinc, s);
-			m.c[5] = (uint16_t)((uint32_t)nvalid - pk_sum5(tinc));
+			m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
+			m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
 			m.nbytes = (uint16_t)nbytes; m.pad = 0;
-			newp.meta[gl] = m;                                     // own counts; k_meta_sb turns them into prefixes
+			newp.meta[gl] = m;                                 // own counts; k_meta_sb turns them into prefixes
 		}
-		if (ln * 16 < nbytes) ((uint4*)(newp.data + gl * (uint64_t)LEAF))[ln] = ((const uint4*)L.outb)[ln];
+		if ((uint32_t)(ln * 16) < nbytes) ((uint4*)(newp.data + gl * (uint64_t)LEAF))[ln] = ((const uint4*)L.outb)[ln];
 	}
 }
 
