@@ -13,8 +13,10 @@ so `value` is whole-job symbols / wall time with inputs resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: every rank builds the BWT of its own disjoint slice of the read stream (same per-GPU
-workload as N = 1, "weak"); see DESIGN.md section 7 for what is and is not sharded yet.
+N > 1 (default --mode sharded): ONE index, the six ropes sharded over the ranks (owner map in
+ropebwt2_amd/sharded.py), per round an all_reduce of the 6x6 count matrix and an all_to_all of
+the string state over RCCL; the job is the same configs[1] job, so scaling is "strong".
+--mode independent builds one separate BWT per GPU over disjoint read slices instead ("weak").
 """
 import argparse
 import json
@@ -80,6 +82,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=101)
     ap.add_argument("--batch", type=float, default=4.0, help="-m in GiB")
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
+    ap.add_argument("--mode", default="sharded", choices=["sharded", "independent"], help="what N > 1 ranks do (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     args = ap.parse_args()
@@ -96,11 +99,22 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # test hook for single-GPU boxes: RB2_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages
+        # the exchange through host memory (tests/test_sharded.py uses the same path)
+        if os.environ.get("RB2_BENCH_BACKEND") == "gloo":
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ropebwt2_amd import HipBwt, build_all
-    build_all()
+    if rank == 0:
+        build_all()
+    if dist is not None:
+        dist.barrier()
+    sharded = world > 1 and args.mode == "sharded"
     so = {"io": 0, "rlo": 1, "rclo": 2}[args.order]
     so_flag = {"io": "", "rlo": "-s", "rclo": "-r"}[args.order]
     L = args.read_len
@@ -112,21 +126,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up: same kernels on a small scratch index (untimed)
+    def make(so_, dev_):
+        if not sharded:
+            b_ = HipBwt(so_, dev_)
+            return b_, b_.insert_multi_dev
+        from ropebwt2_amd.sharded import ShardedBwt, TorchComm
+        b_ = ShardedBwt(so_, rank, world, dev_)
+        return b_, TorchComm(b_).insert_multi_dev
+
+    # ---- warm-up: same kernels (and collectives) on a small scratch index (untimed)
     for _ in range(max(0, args.warmup)):
-        w = HipBwt(so, dev)
+        w, w_insert = make(so, dev)
         n = 200_000
         p = w.dev_alloc(n * (L + 1))
         for i in range(2):
             w.synth_reads(p, i * n, n, L, seed=7)
-            w.insert_multi_dev(p, n * (L + 1))
+            w.sync()
+            w_insert(p, n * (L + 1))
         w.dev_free(p)
         w.close()
 
-    # ---- the job: K consecutive -m batches of this rank's slice of the read stream
-    bwt = HipBwt(so, dev)
+    # ---- the job: K consecutive -m batches (sharded: the same batches on every rank, one index;
+    # ---- independent: this rank's own slice of the read stream, its own index)
+    bwt, do_insert = make(so, dev)
     bwt.profile(True)
-    first = rank * args.reads                     # rank r owns reads [r*reads, (r+1)*reads)
+    first = 0 if sharded or world == 1 else rank * args.reads
     steps = []
     done = 0
     for k in range(args.steps):
@@ -143,7 +167,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for (f, n), p in zip(steps, bufs):
-        bwt.insert_multi_dev(p, n * (L + 1))
+        do_insert(p, n * (L + 1))
     bwt.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -163,35 +187,44 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    total_symbols = symbols * n_gpus
+    total_symbols = symbols if sharded else symbols * n_gpus
+    active, owners = 1, None
+    if sharded:
+        from ropebwt2_amd.sharded import default_owners
+        owners = default_owners(world)
+        active = len(set(owners))
     mk = prof["k_merge"]
-    ach = ALG_BYTES_PER_SYMBOL * mk["units"] / (mk["ms"] * 1e-3) / 1e9 if mk["ms"] > 0 else 0.0
+    units = mk["units"] / (active if sharded else 1)
+    ach = ALG_BYTES_PER_SYMBOL * units / (mk["ms"] * 1e-3) / 1e9 if mk["ms"] > 0 else 0.0
     out = {
         "metric": "Gsymbols/s inserted (wall-clock), bit-identical .fmd",
         "value": total_symbols / dt / 1e9,
         "unit": "Gsymbols/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / max(1, args.steps),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "configs[1]: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
                                % (args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
                    "reads_per_gpu": sum(n for _, n in steps), "symbols_per_gpu": symbols,
-                   "parallelism": "1 GPU" if n_gpus == 1 else "independent BWT per GPU (read stream sliced by rank)",
+                   "parallelism": "1 GPU" if n_gpus == 1 else
+                                  ("ropes $ACGTN sharded over %d of %d GPUs (owner map %s); per round all_reduce(6x6 counts) + all_to_all(32 B string records) over RCCL"
+                                   % (active, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
                    "counts_ok": bool(ok_counts)},
         "roofline": {"bound": "hbm", "kernel": "k_merge", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": mk["ms"] / max(1, mk["launches"]), "launches": mk["launches"],
-                     "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL},
+                     "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL,
+                     "note": None if not sharded else "rank 0 only; units per launch approximated by strings / active ranks"},
         "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
     }
     traffic_file = os.path.join(ROOT, "profiles", "k_merge_traffic.json")
-    if os.path.exists(traffic_file):
+    if os.path.exists(traffic_file) and n_gpus == 1 and args.reads == 100_000_000 and args.batch == 4.0 and args.order == "rlo" and args.steps == 3:
         try:
             out["roofline"]["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
         except Exception:  # noqa: BLE001
             pass
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and n_gpus == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
     print(json.dumps(out))
     if dist is not None:

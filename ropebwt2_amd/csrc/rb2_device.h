@@ -56,7 +56,13 @@ struct Ctl {
 	uint64_t max_len;       // longest string (without sentinel)
 	uint64_t n0;            // strings already in the index (#'$' in the BWT, mrope.c:279)
 	uint64_t len;           // batch bytes
+	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
+	uint32_t own[8];        // own[b] != 0: this rank holds rope b and processes bucket b
+	uint64_t sdest[6][6];   // sharded mode: record offset in the send buffer for members of bucket b inserting a
 };
+
+struct ShardRec { uint64_t l, u, w; uint32_t id, pad; };   // one string's state on the wire (32 B)
+struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 
 struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
 

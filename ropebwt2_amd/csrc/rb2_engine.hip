@@ -74,6 +74,10 @@ struct rb2_hip_s {
 	int64_t p_launch[RB2_K_COUNT]; double p_ms[RB2_K_COUNT]; int64_t p_units[RB2_K_COUNT];
 	int debug = 0;
 	int cur_round = -1;
+	uint64_t *gcnt = nullptr;           // device: 6x6 count matrix of the current round
+	int rank = 0, nranks = 1; int owner[6] = {0, 0, 0, 0, 0, 0};
+	void *batch = nullptr;              // BatchState of a sharded batch in flight
+	DevBuf<ShardPiece> pieces;
 	int merge_dbg = 0;
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
@@ -142,13 +146,21 @@ void fetch_ropes(rb2_hip_t *h)
 	HIPCHK(hipStreamSynchronize(h->st));
 }
 
-void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
+// ---- one batch, in phases (the single-GPU path runs them back to back; the rope-sharded path
+// ---- interleaves them with the exchanges driven by the caller, see rb2_hip_shard_*) ---------------
+
+struct BatchState {
+	const uint8_t *s = nullptr; uint64_t len = 0, m = 0, max_len = 0, n_tot = 0, nsb_ub = 0;
+	unsigned nst_ub = 0, nsc = 0;
+	int cur = 0;                            // string array side
+};
+
+// split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284)
+void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 {
 	const uint64_t len = (uint64_t)len64;
 	hipStream_t st = h->st;
-	const int is_srt = h->so != RB2_SO_IO, is_comp = h->so == RB2_SO_RCLO;
-
-	// ---- split into strings (mrope.c:269-277): count sentinels, prefix, starts
+	const int is_srt = h->so != RB2_SO_IO;
 	const unsigned nzb = cdiv(len, ZBLOCK);
 	uint64_t m = 0;
 	{
@@ -168,68 +180,91 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
 		HIPCHK(hipStreamSynchronize(st));      // hb / zero are stack/heap temporaries
 	}
-	// ---- capacities
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m);
-	const unsigned nst_ub = cdiv(m, STILE) + 6;                 // string tiles, upper bound for every round
-	const unsigned nsc = cdiv(nst_ub, SCHUNK);
-	if (nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
-	h->trec.ensure(nst_ub + 1); h->tsc.ensure(nst_ub + 2); h->cpart.ensure(nsc + 1);
-	uint64_t n_tot = 0, nn[6];
-	for (int b = 0; b < 6; ++b) n_tot += h->h_rope[b].n;
+	B.nst_ub = cdiv(m, STILE) + 6;                            // string tiles, upper bound for every round
+	B.nsc = cdiv(B.nst_ub, SCHUNK);
+	if (B.nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
+	h->trec.ensure(B.nst_ub + 1); h->tsc.ensure(B.nst_ub + 2); h->cpart.ensure(B.nsc + 1);
+	uint64_t n_tot = 0;
+	for (int b = 0; b < 6; ++b) n_tot += h->h_rope[b].n;      // symbols held by THIS rank
 	const uint64_t leaves_ub = (n_tot + len) / LEAF + 6 * (SB + 1);
 	h->pool[h->side].ensure(leaves_ub, true, st);
 	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
-	(void)nn;
 	h->TQ.ensure(leaves_ub + 16);
-	const uint64_t nsb_ub = leaves_ub / SB + 1;
-
-	// ---- initial state (mrope.c:279-284)
+	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{
 		Scope sc(h, RB2_K_INIT, 0);
 		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len);
 		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
 				h->L[0].p, h->U[0].p, h->ID[0].p, h->W[0].p);
 	}
-	uint64_t max_len = 0;
-	HIPCHK(hipMemcpyAsync(&max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(&B.max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
+}
 
-	// ---- one round per string position, last symbol first (mrope.c:285, 299-342)
-	int cur = 0;                                               // string array side
-	for (uint64_t r = 0; r <= max_len; ++r) {
-		h->cur_round = (int)r;
-		const int sd = h->side;
-		PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
-		const uint64_t n_new_ub = n_tot + std::min<uint64_t>(len, (r + 1) * m);
-		const unsigned nlf = cdiv(n_new_ub, LEAF) + 6;            // output leaves, upper bound
-		const int64_t units = (int64_t)m;                      // upper bound: strings still active this round
-		{ Scope sc(h, RB2_K_SYM, units);
-		  hipLaunchKernelGGL(k_sym, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
-		{ Scope sc(h, RB2_K_TSCAN, units);
-		  hipLaunchKernelGGL(k_tscan1, dim3(nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
-		  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
-		  hipLaunchKernelGGL(k_tscan3, dim3(nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
-		  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->tsc.p); }
-		{ Scope sc(h, RB2_K_PREP, units);
-		  hipLaunchKernelGGL(k_prep, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
-				h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
-		{ Scope sc(h, RB2_K_PART, units);
-		  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
-		{ Scope sc(h, RB2_K_MERGE, units);
-		  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p, h->merge_dbg); }
-		{ Scope sc(h, RB2_K_META, units);
-		  build_directory(h, sd ^ 1, std::min<uint64_t>(nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
-		{ Scope sc(h, RB2_K_ADVANCE, units);
-		  hipLaunchKernelGGL(k_advance, dim3(nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, s, newp, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
-				h->PGA.p, h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p); }
-		h->side ^= 1; cur ^= 1;
-	}
+// phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
+void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
+{
+	hipStream_t st = h->st;
+	const int sd = h->side, cur = B.cur;
+	const int64_t units = (int64_t)B.m;
+	h->cur_round = (int)r;
+	{ Scope sc(h, RB2_K_SYM, units);
+	  hipLaunchKernelGGL(k_sym, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+	{ Scope sc(h, RB2_K_TSCAN, units);
+	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
+	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
+	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
+	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(64), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
+}
+
+// phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
+// send == nullptr: strings go straight to the next-round arrays; else they are written as ShardRec.
+void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
+{
+	hipStream_t st = h->st;
+	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
+	const int64_t units = (int64_t)B.m;
+	PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
+	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
+	const unsigned nlf = cdiv(n_new_ub, LEAF) + 6;            // output leaves, upper bound
+	{ Scope sc(h, RB2_K_TSCAN, 0);
+	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->gcnt); }
+	{ Scope sc(h, RB2_K_PREP, units);
+	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
+	{ Scope sc(h, RB2_K_PART, units);
+	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
+	{ Scope sc(h, RB2_K_MERGE, units);
+	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p, h->merge_dbg); }
+	{ Scope sc(h, RB2_K_META, units);
+	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
+	{ Scope sc(h, RB2_K_ADVANCE, units);
+	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
+			h->PGA.p, h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
+	h->side ^= 1; B.cur ^= 1;
+}
+
+void batch_end(rb2_hip_t *h)
+{
 	h->cur_round = -1;
 	HIPCHK(hipGetLastError());
 	fetch_ropes(h);
 	drain_profile(h);
+}
+
+void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
+{
+	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); abort(); }
+	BatchState B;
+	batch_begin(h, B, len64, s);
+	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
+		round_counts(h, B, r);
+		round_merge(h, B, r, nullptr);
+	}
+	batch_end(h);
 }
 
 } // namespace
@@ -264,8 +299,9 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
-	HIPCHK(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->st));
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
+	HIPCHK(hipMalloc((void**)&h->gcnt, 36 * 8));
+	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < 6; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
 	memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units));
@@ -284,7 +320,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->TQ.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
-	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp));
+	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release();
 	HIPCHK(hipStreamDestroy(h->st));
 	delete h;
 }
@@ -372,6 +408,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		uint8_t *slot = nullptr;
 		auto open_leaf = [&]() { data.resize(data.size() + LEAF); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAF; memset(&cur, 0, sizeof(cur)); fill = 0; };
 		auto close_leaf = [&]() { meta.back() = cur; ++r.nleaves; slot = nullptr; };
+		const bool keep = h->nranks == 1 || h->owner[b] == h->rank;   // sharded: other ranks' ropes are only counted
 		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
 		while (p && p < end) {
 			int c = *p & 7; int64_t l;
@@ -380,7 +417,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			else { int nb = (*p & 0x10) ? 8 : 4; l = (*p >> 3) & 1; for (int i = 1; i < nb; ++i) l = (l << 6) | (p[i] & 0x3f); p += nb; }
 			if (c > 5) { fprintf(stderr, "[rb2_hip] load_ropes: bad symbol %d\n", c); abort(); }
 			r.n += l; r.cnt[c] += l;
-			while (l > 0) {
+			while (keep && l > 0) {
 				if (!slot) open_leaf();
 				const int64_t take = std::min<int64_t>(std::min<int64_t>(l, 15), LEAF - fill);
 				slot[cur.nbytes++] = (uint8_t)(take << 3 | c);
@@ -389,6 +426,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			}
 		}
 		if (slot) close_leaf();
+		if (!keep) r.n = 0;
 		leaf += (r.nleaves + SB - 1) / SB * SB;
 	}
 	data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
@@ -404,6 +442,137 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 	build_directory(h, sd, nsb);
 	HIPCHK(hipStreamSynchronize(h->st));
 	memcpy(h->h_rope, rp, sizeof(rp));
+}
+
+
+/* ---- rope sharding across GPUs ------------------------------------------- */
+
+void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int owner[6])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (nranks < 1 || rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] bad shard rank %d/%d\n", rank, nranks); abort(); }
+	uint32_t own[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	for (int b = 0; b < 6; ++b) {
+		if (owner[b] < 0 || owner[b] >= nranks) { fprintf(stderr, "[rb2_hip] bad owner of rope %d\n", b); abort(); }
+		h->owner[b] = owner[b]; own[b] = owner[b] == rank;
+	}
+	h->rank = rank; h->nranks = nranks;
+	HIPCHK(hipMemcpyAsync(&h->ctl->own[0], own, sizeof(own), hipMemcpyHostToDevice, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (len <= 0 || ((uintptr_t)s_dev & 15)) { fprintf(stderr, "[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); abort(); }
+	BatchState *B = new BatchState();
+	batch_begin(h, *B, len, s_dev);
+	h->batch = B;
+	return (int64_t)B->max_len + 1;                            /* rounds */
+}
+
+int64_t rb2_hip_shard_capacity(rb2_hip_t *h) { return h->batch ? (int64_t)((BatchState*)h->batch)->m : 0; }
+
+void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t local_cnt[36])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	BatchState &B = *(BatchState*)h->batch;
+	round_counts(h, B, (uint64_t)round);
+	HIPCHK(hipMemcpyAsync(local_cnt, h->gcnt, 36 * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+/* where the members of (bucket b -> symbol a) sit in the send buffer of rank `me`: per destination rank d,
+ * for a owned by d (a >= 1, ascending), for b owned by me (ascending).  The same function, evaluated for a
+ * source rank, gives the layout of what arrives from it. */
+static void shard_layout(const int owner[6], int nranks, int src, const int64_t g[36], int64_t off[6][6], int64_t per_rank[], int64_t start_rank[])
+{
+	int64_t run = 0;
+	for (int d = 0; d < nranks; ++d) {
+		start_rank[d] = run;
+		for (int a = 1; a < 6; ++a) {
+			if (owner[a] != d) continue;
+			for (int b = 0; b < 6; ++b) {
+				if (owner[b] != src) continue;
+				off[b][a] = run; run += g[b * 6 + a];
+			}
+		}
+		per_rank[d] = run - start_rank[d];
+	}
+}
+
+void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], void *send_dev, int64_t send_counts[])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	BatchState &B = *(BatchState*)h->batch;
+	int64_t off[6][6], start[64];
+	memset(off, 0, sizeof(off));
+	if (h->nranks > 64) { fprintf(stderr, "[rb2_hip] too many ranks\n"); abort(); }
+	shard_layout(h->owner, h->nranks, h->rank, global_cnt, off, send_counts, start);
+	uint64_t sd[6][6];
+	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) sd[b][a] = (uint64_t)off[b][a];
+	HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, 36 * 8, hipMemcpyHostToDevice, h->st));
+	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd), hipMemcpyHostToDevice, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));                       /* sd / global_cnt may be temporaries of the caller */
+	round_merge(h, B, (uint64_t)round, (ShardRec*)send_dev);
+	HIPCHK(hipStreamSynchronize(h->st));                       /* the send buffer is complete when we return */
+}
+
+void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], const void *recv_dev, const int64_t recv_counts[])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	BatchState &B = *(BatchState*)h->batch;
+	(void)round;
+	/* local layout of next round's buckets: owned a ascending; inside a bucket the global order of the sources b */
+	int64_t nstart[6], run = 0;
+	for (int a = 0; a < 6; ++a) {
+		nstart[a] = run;
+		if (a >= 1 && h->owner[a] == h->rank) for (int b = 0; b < 6; ++b) run += global_cnt[b * 6 + a];
+	}
+	std::vector<ShardPiece> pcs;
+	int64_t base = 0;
+	for (int s = 0; s < h->nranks; ++s) {
+		int64_t off[6][6], per[64], start[64];
+		memset(off, 0, sizeof(off));
+		shard_layout(h->owner, h->nranks, s, global_cnt, off, per, start);
+		if (per[h->rank] != recv_counts[s]) { fprintf(stderr, "[rb2_hip] shard_finish: rank %d expected %lld records from rank %d, caller says %lld\n", h->rank, (long long)per[h->rank], s, (long long)recv_counts[s]); abort(); }
+		for (int a = 1; a < 6; ++a) {
+			if (h->owner[a] != h->rank) continue;
+			for (int b = 0; b < 6; ++b) {
+				if (h->owner[b] != s || global_cnt[b * 6 + a] == 0) continue;
+				int64_t before = 0;
+				for (int bb = 0; bb < b; ++bb) before += global_cnt[bb * 6 + a];
+				ShardPiece p; p.src = (uint64_t)(base + off[b][a] - start[h->rank]); p.dst = (uint64_t)(nstart[a] + before); p.cnt = (uint64_t)global_cnt[b * 6 + a];
+				pcs.push_back(p);
+			}
+		}
+		base += recv_counts[s];
+	}
+	if (base > 0) {
+		h->pieces.ensure(pcs.size() + 1);
+		HIPCHK(hipMemcpyAsync(h->pieces.p, pcs.data(), pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
+		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
+		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base,
+				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
+	}
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+void rb2_hip_shard_end(rb2_hip_t *h)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	batch_end(h);
+	delete (BatchState*)h->batch;
+	h->batch = nullptr;
+}
+
+/* plain copies for callers that stage exchange buffers themselves: kind 0 host->device, 1 device->host, 2 device->device */
+void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (bytes <= 0) return;
+	HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
 }
 
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])

@@ -119,7 +119,7 @@ __global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len)
 	if (threadIdx.x || blockIdx.x) return;
 	SegDesc &sg = ctl->seg[side];
 	for (int b = 0; b < 6; ++b) { sg.start[b] = 0; sg.cnt[b] = 0; }
-	sg.cnt[0] = m;
+	sg.cnt[0] = ctl->own[0] ? m : 0;                        // sharded: only the owner of rope $ starts with the strings
 	uint32_t t = 0;
 	for (int b = 0; b < 6; ++b) { sg.tile0[b] = t; t += (uint32_t)((sg.cnt[b] + STILE - 1) / STILE); }
 	sg.tile0[6] = t; sg.tile0[7] = t;
@@ -263,7 +263,19 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // k_setup: everything the rest of the round needs that depends on the 6x6 count matrix
 // ---------------------------------------------------------------------------------------------
 
-__global__ void k_setup(Ctl *ctl, int side, const TileScan *tsc)
+// rows of the count matrix this rank can see: count[b][a] = members of (local) bucket b inserting a
+__global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, uint64_t *gcnt)
+{
+	const int i = threadIdx.x;
+	if (blockIdx.x || i >= 36) return;
+	const SegDesc &sg = ctl->seg[side];
+	const int b = i / 6, a = i % 6;
+	gcnt[i] = sg.tile0[6] ? (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]) : 0ull;
+}
+
+// gcnt = the GLOBAL 6x6 count matrix of the round (== the local one on a single GPU; the sum over
+// ranks when ropes are sharded)
+__global__ void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	const SegDesc &sg = ctl->seg[side];
@@ -271,15 +283,16 @@ __global__ void k_setup(Ctl *ctl, int side, const TileScan *tsc)
 	uint64_t cnt[6][6];
 	for (int b = 0; b < 6; ++b)
 		for (int a = 0; a < 6; ++a)
-			ctl->count[b][a] = cnt[b][a] = (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]);
-	// new ropes (side^1): sizes, layout in the leaf pool, merge tiles
+			ctl->count[b][a] = cnt[b][a] = gcnt[b * 6 + a];
+	// new ropes (side^1): sizes, layout in the leaf pool, output leaves.  Ropes of other ranks keep
+	// n = 0 here but their symbol counts are tracked (needed for AC and for n0).
 	uint64_t leaf = 0, mt = 0, run[6] = {0, 0, 0, 0, 0, 0};
 	for (int b = 0; b < 6; ++b) {
 		const RopeDesc &o = ctl->rope[side][b];
 		RopeDesc &n = ctl->rope[side ^ 1][b];
 		n.n = o.n + sg.cnt[b];
 		for (int a = 0; a < 6; ++a) {
-			ctl->ac[b][a] = run[a];                           // #a in ropes < b, after this round
+			ctl->ac[b][a] = run[a];                           // #a in ropes < b, after this round (mrope.c:332-336)
 			n.cnt[a] = o.cnt[a] + cnt[b][a];
 			run[a] += n.cnt[a];
 		}
@@ -291,12 +304,13 @@ __global__ void k_setup(Ctl *ctl, int side, const TileScan *tsc)
 	}
 	ctl->lf0[6] = mt; ctl->lf0[7] = mt;
 	ctl->nsb_total = leaf / SB;
-	// next round's buckets: bucket a = strings that inserted a, in (bucket, order) order (mrope.c:303-309)
+	// next round's buckets: bucket a = strings that inserted a, in (bucket, order) order (mrope.c:303-309);
+	// only the buckets of ropes held here are laid out locally
 	uint64_t st = 0; uint32_t tl = 0;
 	for (int a = 0; a < 6; ++a) {
 		uint64_t c = 0;
 		for (int b = 0; b < 6; ++b) { ctl->dest[b][a] = st + c; c += cnt[b][a]; }
-		if (a == 0) { c = 0; for (int b = 0; b < 6; ++b) ctl->dest[b][0] = 0; }   // finished strings are dropped (mrope.c:310)
+		if (a == 0 || !ctl->own[a]) c = 0;                    // finished strings are dropped (mrope.c:310)
 		ng.start[a] = st; ng.cnt[a] = c;
 		ng.tile0[a] = tl;
 		tl += (uint32_t)((c + STILE - 1) / STILE);
@@ -490,7 +504,7 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const uint32_t *SLOT, const uint32_t *PA, const uint32_t *PGA,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint32_t *ID, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
@@ -513,8 +527,24 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint3
 		const uint32_t id = ID[k];
 		uint64_t wv = W[k] >> 4;
 		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
-		L2[d] = l; U2[d] = l + SIZE[k]; ID2[d] = id; W2[d] = wv;
+		if (send) {                                            // sharded: the string travels to the owner of rope a
+			ShardRec r; r.l = l; r.u = l + SIZE[k]; r.w = wv; r.id = id; r.pad = 0;
+			send[ctl->sdest[t.b][a] + PA[k]] = r;
+		} else { L2[d] = l; U2[d] = l + SIZE[k]; ID2[d] = id; W2[d] = wv; }
 	}
+}
+
+// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
+__global__ __launch_bounds__(256) void k_unpack(const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i >= total) return;
+	int lo = 0, hi = npieces - 1;                              // last piece with src <= i (pieces tile recv[] in order)
+	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].src <= i) lo = mid; else hi = mid - 1; }
+	const ShardRec r = recv[i];
+	const uint64_t d = pc[lo].dst + (i - pc[lo].src);
+	L2[d] = r.l; U2[d] = r.u; ID2[d] = r.id; W2[d] = r.w;
 }
 
 // ---------------------------------------------------------------------------------------------

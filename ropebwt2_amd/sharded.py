@@ -1,0 +1,250 @@
+"""Rope-sharded multi-GPU insertion: one process (and one HIP engine) per GPU.
+
+Partitioning: rank ``owner[b]`` holds rope ``b`` and processes bucket ``b``.
+Inside a round the ropes are independent (the reference runs them on separate pthreads,
+mrope.c:312-329).  Between rounds
+
+* every rank needs the 6x6 matrix "members of bucket b that insert a" (the reference's master reads
+  ``r[b]->c[]`` of all ropes, mrope.c:332-340)          -> ``all_reduce`` of 36 int64;
+* every string moves to the owner of the rope of the symbol it just inserted (the stable scatter of
+  mrope.c:303-309)                                      -> ``all_to_all_single`` of 32-byte records.
+
+The GPU work of each phase is in librb2hip.so (``rb2_hip_shard_*``); this module only moves the two
+buffers.  The per-batch protocol is written once, as a generator that yields at every
+communication point, and is driven either by ``TorchComm`` (torch.distributed: RCCL on device
+tensors, or gloo with host staging) or by ``VirtualCluster`` (N engines in one process on one GPU
+-- how the sharded path is validated bit-for-bit on a single-GPU box).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .hipbwt import HipBwt, load_hip_lib
+
+REC_BYTES = 32          # sizeof(ShardRec), rb2_device.h
+
+
+def default_owners(nranks):
+    """rope -> rank.  Ropes A,C,G,T carry the load on DNA; $ and N ride along.  More than four
+    ranks leave ranks >= 4 without a rope (sub-rope splitting is future work)."""
+    if nranks <= 1:
+        return [0] * 6
+    if nranks == 2:
+        return [0, 0, 0, 1, 1, 1]
+    if nranks == 3:
+        return [0, 0, 1, 1, 2, 2]
+    return [0, 0, 1, 2, 3, 3]
+
+
+def exchange_layout(owner, nranks, src, g):
+    """Python twin of shard_layout() in rb2_engine.hip: for source rank ``src`` and count matrix
+    ``g`` (6x6), the number of records it sends to every rank.  Layout inside a destination block:
+    for a owned by the destination (a >= 1, ascending), for b owned by src (ascending): g[b][a] records."""
+    g = np.asarray(g, dtype=np.int64).reshape(6, 6)
+    per = [0] * nranks
+    for d in range(nranks):
+        for a in range(1, 6):
+            if owner[a] != d:
+                continue
+            for b in range(6):
+                if owner[b] == src:
+                    per[d] += int(g[b, a])
+    return per
+
+
+class ShardedBwt(HipBwt):
+    """The slice of a sharded BWT that lives on one GPU."""
+
+    def __init__(self, sorting_order, rank, nranks, device=0, owners=None):
+        super().__init__(sorting_order, device)
+        self.rank, self.nranks = rank, nranks
+        self.owner = list(owners) if owners is not None else default_owners(nranks)
+        arr = (C.c_int * 6)(*self.owner)
+        self.L.rb2_hip_shard_setup(self.h, rank, nranks, arr)
+
+    def owned(self):
+        return [b for b in range(6) if self.owner[b] == self.rank]
+
+    # staging hooks used when the collective runs on host memory (gloo)
+    def stage_out(self, host_ptr, dev_ptr, nbytes):
+        self.L.rb2_hip_memcpy(self.h, host_ptr, dev_ptr, nbytes, 1)
+
+    def stage_in(self, dev_ptr, host_ptr, nbytes):
+        self.L.rb2_hip_memcpy(self.h, dev_ptr, host_ptr, nbytes, 0)
+
+    def batch_protocol(self, dev_ptr, nbytes, send_ptr_of, recv_ptr_of):
+        """Generator: yields ('allreduce', int64[36]) and ('alltoall', send_counts, recv_counts);
+        expects the reduced matrix to be sent back for the former.  ``send_ptr_of(n_records)`` /
+        ``recv_ptr_of(n_records)`` return device pointers of buffers with that capacity."""
+        L, h = self.L, self.h
+        rounds = L.rb2_hip_shard_begin(h, nbytes, dev_ptr)
+        cap = L.rb2_hip_shard_capacity(h)
+        send_ptr, recv_ptr = send_ptr_of(cap), recv_ptr_of(cap)
+        loc = np.zeros(36, np.int64)
+        for r in range(rounds):
+            L.rb2_hip_shard_counts(h, r, loc.ctypes.data)
+            g = yield ("allreduce", loc.copy())
+            g = np.ascontiguousarray(g, dtype=np.int64)
+            nsend = (C.c_int64 * self.nranks)()
+            L.rb2_hip_shard_merge(h, r, g.ctypes.data, send_ptr, nsend)
+            send_counts = list(nsend)
+            recv_counts = [exchange_layout(self.owner, self.nranks, s, g)[self.rank] for s in range(self.nranks)]
+            yield ("alltoall", send_counts, recv_counts)
+            nrecv = (C.c_int64 * self.nranks)(*recv_counts)
+            L.rb2_hip_shard_finish(h, r, g.ctypes.data, recv_ptr, nrecv)
+        L.rb2_hip_shard_end(h)
+
+
+# ---------------------------------------------------------------------------------------------
+# driver 1: torch.distributed (one process per GPU)
+# ---------------------------------------------------------------------------------------------
+
+class TorchComm:
+    """all_reduce + all_to_all_single over the default process group.  With the nccl (= RCCL)
+    backend the exchange buffers are device tensors handed to the engine by pointer; with gloo they
+    are staged through host memory (used to test the multi-process path without RCCL)."""
+
+    def __init__(self, bwt):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.bwt = torch, dist, bwt
+        self.backend = dist.get_backend()
+        self.on_device = self.backend == "nccl"
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.on_device else torch.device("cpu")
+        self.send_t = self.recv_t = None
+        self.send_dev = self.recv_dev = None      # raw engine buffers when staging
+        self.cap = 0
+
+    def _ensure(self, n_records):
+        if n_records <= self.cap:
+            return
+        torch = self.torch
+        nbytes = max(1, n_records) * REC_BYTES
+        if self.on_device:
+            self.send_t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self.recv_t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+        else:
+            if self.send_dev:
+                self.bwt.dev_free(self.send_dev); self.bwt.dev_free(self.recv_dev)
+            self.send_dev, self.recv_dev = self.bwt.dev_alloc(nbytes), self.bwt.dev_alloc(nbytes)
+            self.send_t = torch.empty(nbytes, dtype=torch.uint8)
+            self.recv_t = torch.empty(nbytes, dtype=torch.uint8)
+        self.cap = n_records
+
+    def send_ptr(self, n):
+        self._ensure(n)
+        return self.send_t.data_ptr() if self.on_device else self.send_dev
+
+    def recv_ptr(self, n):
+        self._ensure(n)
+        return self.recv_t.data_ptr() if self.on_device else self.recv_dev
+
+    def insert_multi_dev(self, dev_ptr, nbytes):
+        torch, dist, bwt = self.torch, self.dist, self.bwt
+        gen = bwt.batch_protocol(dev_ptr, nbytes, self.send_ptr, self.recv_ptr)
+        msg = next(gen)
+        try:
+            while True:
+                if msg[0] == "allreduce":
+                    t = torch.from_numpy(msg[1]).to(self.dev)
+                    dist.all_reduce(t)
+                    msg = gen.send(t.cpu().numpy())
+                else:
+                    _, sc, rc = msg
+                    ns, nr = sum(sc) * REC_BYTES, sum(rc) * REC_BYTES
+                    if not self.on_device and ns:
+                        bwt.stage_out(self.send_t.data_ptr(), self.send_dev, ns)
+                    dist.all_to_all_single(self.recv_t[:nr], self.send_t[:ns],
+                                           [c * REC_BYTES for c in rc], [c * REC_BYTES for c in sc])
+                    if self.on_device:
+                        torch.cuda.synchronize()
+                    elif nr:
+                        bwt.stage_in(self.recv_dev, self.recv_t.data_ptr(), nr)
+                    msg = next(gen)
+        except StopIteration:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+# driver 2: N virtual ranks in one process (validation on a single GPU)
+# ---------------------------------------------------------------------------------------------
+
+class VirtualCluster:
+    """N sharded engines on one device, stepped in lockstep; collectives are done in numpy."""
+
+    def __init__(self, sorting_order, nranks, device=0, owners=None):
+        self.n = nranks
+        self.ranks = [ShardedBwt(sorting_order, r, nranks, device, owners) for r in range(nranks)]
+        self.bufs = [[None, None, 0] for _ in range(nranks)]
+
+    def close(self):
+        for k, r in enumerate(self.ranks):
+            if self.bufs[k][0]:
+                r.dev_free(self.bufs[k][0]); r.dev_free(self.bufs[k][1])
+            r.close()
+
+    def _ptr(self, k, which, n):
+        b = self.bufs[k]
+        if n > b[2] or b[0] is None:
+            if b[0]:
+                self.ranks[k].dev_free(b[0]); self.ranks[k].dev_free(b[1])
+            nb = max(1, n) * REC_BYTES
+            b[0], b[1], b[2] = self.ranks[k].dev_alloc(nb), self.ranks[k].dev_alloc(nb), n
+        return b[which]
+
+    def insert_multi(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        ptrs = []
+        for r in self.ranks:                       # every rank sees the whole batch
+            p = r.dev_alloc(len(buf) + 64)
+            r.L.rb2_hip_memcpy(r.h, p, buf.ctypes.data, len(buf), 0)
+            ptrs.append(p)
+        gens = [r.batch_protocol(ptrs[k], len(buf), lambda n, k=k: self._ptr(k, 0, n), lambda n, k=k: self._ptr(k, 1, n))
+                for k, r in enumerate(self.ranks)]
+        msgs = [next(g) for g in gens]
+        done = False
+        while not done:
+            kind = msgs[0][0]
+            assert all(m[0] == kind for m in msgs)
+            if kind == "allreduce":
+                tot = np.sum([m[1] for m in msgs], axis=0)
+                msgs = [g.send(tot.copy()) for g in gens]
+            else:
+                # all_to_all in numpy: rank d receives, in source order, the block every source cut for it
+                host = []
+                for k, m in enumerate(msgs):
+                    n = sum(m[1]) * REC_BYTES
+                    a = np.zeros(max(n, 1), np.uint8)
+                    if n:
+                        self.ranks[k].L.rb2_hip_memcpy(self.ranks[k].h, a.ctypes.data, self.bufs[k][0], n, 1)
+                    host.append(a)
+                for d in range(self.n):
+                    parts = []
+                    for s in range(self.n):
+                        sc = msgs[s][1]
+                        off = sum(sc[:d]) * REC_BYTES
+                        parts.append(host[s][off:off + sc[d] * REC_BYTES])
+                        assert sc[d] == msgs[d][2][s], "send/recv plans disagree"
+                    r = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0, np.uint8)
+                    if len(r):
+                        self.ranks[d].L.rb2_hip_memcpy(self.ranks[d].h, self.bufs[d][1], r.ctypes.data, len(r), 0)
+                nxt = []
+                for g in gens:
+                    try:
+                        nxt.append(next(g))
+                    except StopIteration:
+                        nxt.append(None)
+                if all(x is None for x in nxt):
+                    done = True
+                msgs = nxt
+        for k, r in enumerate(self.ranks):
+            r.dev_free(ptrs[k])
+
+    def counts(self):
+        return self.ranks[0].counts()
+
+    def rope(self, b):
+        return self.ranks[self.ranks[0].owner[b]].rope(b)
+
+    def rope_rle(self, b):
+        return self.ranks[self.ranks[0].owner[b]].rope_rle(b)
