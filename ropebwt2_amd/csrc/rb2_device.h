@@ -161,7 +161,10 @@ __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane ? (~0ull >> 
 __device__ __forceinline__ int sym_ord(int a, int is_comp) { return (is_comp && a >= 1 && a <= 4) ? 5 - a : a; }
 
 // counts of all six symbols in [0,p) of a rope on pool side `pv` (rope_rank1a, rope.h:45):
-// superblock prefix + leaf-relative prefix + sequential decode of one leaf (rle.c:147-158)
+// superblock prefix + leaf-relative prefix + scan of one leaf (rle.c:147-158).  The leaf is read
+// 16 bytes at a time (slots are zero padded to 16 bytes; a zero byte is a run of length 0); chunks
+// that end before p are added wholesale.  Symbols 0..4 are counted in 12-bit fields of one u64,
+// N follows from the position.
 __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
 {
 	if (p >= rp.n) {
@@ -175,16 +178,37 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	const LeafMeta m = pv.meta[gl];
 #pragma unroll
 	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s];
-	const uint8_t *q = pv.data + gl * (uint64_t)LEAF;
+	const uint4 *q = (const uint4*)(pv.data + gl * (uint64_t)LEAF);
 	uint32_t acc = 0;
+	uint64_t pk = 0;
 	while (acc < off) {
-		const uint32_t byte = *q++;
-		const uint32_t len = byte >> 3, s = byte & 7;
-		const uint32_t take = min(len, off - acc);
+		const uint4 v = *q++;
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		uint32_t tot = 0;
 #pragma unroll
-		for (int t = 0; t < 6; ++t) out[t] += (s == (uint32_t)t) ? take : 0u;
-		acc += len;
+		for (int k = 0; k < 4; ++k) tot += ((((w[k] >> 3) & 0x1f1f1f1fu) * 0x01010101u) >> 24);
+		const uint32_t room = off - acc;                      // symbols still to count
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t bt = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu, len = bt >> 3, s = bt & 7;
+			if (tot <= room) { if (s < 5) pk += (uint64_t)len << (12 * s); }
+		}
+		if (tot <= room) { acc += tot; continue; }
+		// the chunk that holds position p: walk its runs
+		uint32_t a2 = acc;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const uint32_t bt = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu, len = bt >> 3, s = bt & 7;
+			const uint32_t take = a2 < off ? min(len, off - a2) : 0u;
+			if (s < 5) pk += (uint64_t)take << (12 * s);
+			a2 += len;
+		}
+		acc = off;
 	}
+	uint32_t sum5 = 0;
+#pragma unroll
+	for (int s = 0; s < 5; ++s) { const uint32_t v = (uint32_t)(pk >> (12 * s)) & 0xfffu; out[s] += v; sum5 += v; }
+	out[5] += off - sum5;
 }
 
 } // namespace rb2
