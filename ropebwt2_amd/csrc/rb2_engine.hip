@@ -84,13 +84,6 @@ struct rb2_hip_s {
 
 namespace {
 
-uint64_t total_leaves_needed(const uint64_t n[6])
-{
-	uint64_t t = 0;
-	for (int b = 0; b < 6; ++b) t += ((n[b] + LEAF - 1) / LEAF + SB - 1) / SB * SB;
-	return t;
-}
-
 hipEvent_t get_event(rb2_hip_t *h)
 {
 	if (!h->evpool.empty()) { hipEvent_t e = h->evpool.back(); h->evpool.pop_back(); return e; }

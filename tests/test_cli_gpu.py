@@ -140,3 +140,33 @@ def test_reference_main_linked_against_our_library(golden, flag):
     p = subprocess.run([DROPIN, flag, "-m3m", "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0, p.stderr.decode()
     assert H.md5(p.stdout) == g["fmd_md5"][flag]
+
+
+@pytest.mark.parametrize("opts", [["-l", "64", "-n", "8"], ["-l", "2048", "-n", "128"], ["-P", "-M", "5"], ["-m", "300k"], ["-m", "0.002g"]])
+def test_layout_and_batch_options_do_not_change_the_bwt(golden, opts):
+    """-l/-n only shape the host tree, -P/-M are accepted, -m only cuts batches: same .fmd"""
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    assert H.md5(cli(["-LRds"] + opts, text)) == g["fmd_md5"]["-LRsd"]
+
+
+def test_misaligned_device_buffer(hip):
+    """insert_multi_dev with a device pointer that is not 16-byte aligned (kernels use 16-byte loads)"""
+    codes = H.splitmix_bases(5000, 33, seed=12)
+    buf = H.encode_batch_fixed(codes)
+    a = hip.HipBwt(1)
+    a.insert_multi(buf)
+    b = hip.HipBwt(1)
+    p = b.dev_alloc(len(buf) + 64)
+    b.L.rb2_hip_memcpy(b.h, p + 5, buf.ctypes.data, len(buf), 0)
+    b.insert_multi_dev(p + 5, len(buf))
+    b.dev_free(p)
+    for r in range(6):
+        assert np.array_equal(a.rope_rle(r), b.rope_rle(r))
+
+
+def test_restore_rejects_garbage(tmp_path):
+    f = tmp_path / "bad.fmr"
+    f.write_bytes(b"not an fmr file at all")
+    p = subprocess.run([CLI, "-d", "-i", str(f), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and b"not an FMR file" in p.stderr
