@@ -38,13 +38,36 @@ static int rd_getc(reader_t *r)
 	}
 	return r->buf[r->beg++];
 }
-/* append the rest of the line to s (s may be NULL); returns the terminating char or -1 */
+/* append the rest of the line to s (s may be NULL); returns the terminating char or -1.
+ * Works on whole buffer spans (memchr), not character by character. */
 static int rd_line(reader_t *r, str_t *s, int only_graph)
 {
-	int c;
-	while ((c = rd_getc(r)) >= 0 && c != '\n')
-		if (s && c != '\r' && (!only_graph || isgraph(c))) str_putc(s, c);
-	return c;
+	for (;;) {
+		unsigned char *b, *nl;
+		int n;
+		if (r->beg >= r->end) {
+			if (r->eof) return -1;
+			r->beg = 0; r->end = gzread(r->fp, r->buf, sizeof(r->buf));
+			if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
+		}
+		b = r->buf + r->beg;
+		nl = (unsigned char*)memchr(b, '\n', r->end - r->beg);
+		n = nl ? (int)(nl - b) : r->end - r->beg;
+		if (s && n) {
+			if (!only_graph) {
+				int k = n;
+				if (b[k-1] == '\r') --k;                  /* CR of a CRLF line end */
+				str_append(s, (const char*)b, k);
+			} else {
+				int i;
+				str_reserve(s, s->l + n + 1);
+				for (i = 0; i < n; ++i) if (isgraph(b[i])) s->s[s->l++] = (char)b[i];
+				s->s[s->l] = 0;
+			}
+		}
+		r->beg += n + (nl ? 1 : 0);
+		if (nl) return '\n';
+	}
 }
 static int read_line_record(reader_t *r)
 {
@@ -84,10 +107,14 @@ static int read_fastx_record(reader_t *r)
 static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec); }
 static double realtime(void) { struct timeval t; gettimeofday(&t, 0); return t.tv_sec + 1e-6 * t.tv_usec; }
 
-static int nt6(int ch)                                   /* main.c:17-26: $ACGTN = 0..5 */
+static uint8_t nt6_tab[256];                            /* main.c:17-26: $ACGTN = 0..5, everything else N */
+static void nt6_init(void)
 {
-	switch (ch) { case 0: return 0; case 'A': case 'a': return 1; case 'C': case 'c': return 2;
-	              case 'G': case 'g': return 3; case 'T': case 't': return 4; default: return 5; }
+	int i;
+	for (i = 0; i < 256; ++i) nt6_tab[i] = 5;
+	nt6_tab[0] = 0;
+	nt6_tab['A'] = nt6_tab['a'] = 1; nt6_tab['C'] = nt6_tab['c'] = 2;
+	nt6_tab['G'] = nt6_tab['g'] = 3; nt6_tab['T'] = nt6_tab['t'] = 4;
 }
 static int comp6(int c) { return c >= 1 && c <= 4 ? 5 - c : c; }
 static int is_own_revcomp(int l, const uint8_t *s)      /* even length and s == revcomp(s) (main.c:80-87) */
@@ -187,6 +214,7 @@ int main(int argc, char *argv[])
 	if (optind == argc && isatty(fileno(stdin))) return usage(block_len, max_nodes);
 	if ((flag & F_CUTN) && m == 0) { fprintf(stderr, "[E::%s] option '-x' cannot be used with '-m0'\n", __func__); return 1; }
 
+	nt6_init();
 	if (mr == 0) mr = mr_init(max_nodes, block_len, so);
 	if (thr_min > 0) mr_thr_min(mr, thr_min);
 	rd = (reader_t*)calloc(1, sizeof(reader_t));
@@ -197,8 +225,8 @@ int main(int argc, char *argv[])
 	while ((flag & F_LINE ? read_line_record(rd) : read_fastx_record(rd)) >= 0) {
 		uint8_t *s = (uint8_t*)rd->seq.s;
 		int l = (int)rd->seq.l;
-		if (flag & F_LINE) { for (i = 0; i < l && isalpha(s[i]); ++i); l = i; }     /* main.c:184-187 */
-		for (i = 0; i < l; ++i) s[i] = s[i] < 128 ? (uint8_t)nt6(s[i]) : 5;
+		if (flag & F_LINE) { for (i = 0; i < l && (((s[i] | 32) - 'a') < 26u); ++i); l = i; }   /* keep the leading letters (main.c:184-187) */
+		for (i = 0; i < l; ++i) s[i] = nt6_tab[s[i]];
 		if (!(flag & F_LINE) && rd->qual.l && min_q > 0)
 			for (i = 0; i < l && i < (int)rd->qual.l; ++i) if (rd->qual.s[i] - 33 < min_q) s[i] = 5;
 		if (flag & F_NON) { for (i = 0; i < l && s[i] != 5; ++i); if (i < l) continue; }
