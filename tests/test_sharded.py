@@ -63,6 +63,24 @@ def test_virtual_ranks_match_oracle(hip, so, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 8])
+def test_virtual_ranks_with_idle_ranks(hip, n):
+    """more ranks than ropes with load: ranks >= 4 own nothing but take part in every collective"""
+    from ropebwt2_amd.sharded import VirtualCluster
+    codes = H.splitmix_bases(6000, 50, seed=21)
+    reads = H.repetitive_reads(1200, seed=33)
+    o = H.Oracle(2)
+    vc = VirtualCluster(2, n)
+    for buf in (H.encode_batch_fixed(codes, True, True), H.encode_batch(reads)):
+        o.insert_multi(buf)
+        vc.insert_multi(buf)
+    assert np.array_equal(vc.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(vc.rope(b), o.rope(b)), "rope %d" % b
+    vc.close()
+
+
+@pytest.mark.gpu
 def test_virtual_ranks_golden(hip, golden):
     from ropebwt2_amd.sharded import VirtualCluster
     g = golden["sets"]["100k_x_101"]
