@@ -71,11 +71,14 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
 
 /* ---- rope sharding across GPUs ---------------------------------------------------------------
- * One handle per GPU (one process per GPU).  owner[b] = rank that holds rope b and processes bucket
- * b; every rank sees the whole batch buffer.  Inside a round the ropes are independent (the
- * reference runs them on separate threads, mrope.c:312-329); between rounds every rank needs the
- * 6x6 count matrix (the master reads r[b]->c[] of all ropes, mrope.c:332-340) and strings move to
- * the owner of the rope of the symbol they just inserted (mrope.c:303-309).  The library does the
+ * One handle per GPU (one process per GPU).  The unit of ownership is a SUB-ROPE: rope b is kept as
+ * six independent pieces (b,x), x = the symbol that follows b in the row's suffix (piece (b,x) holds
+ * exactly the b-symbols of rope x; rope $ is one piece; NR = 31 pieces, see rb2_device.h).
+ * owner[r] = rank that holds piece r and processes its bucket; every rank sees the whole batch
+ * buffer.  Inside a round the pieces are independent (the reference runs the ropes on separate
+ * threads, mrope.c:312-329); between rounds every rank needs the NR x 6 count matrix (the master
+ * reads r[b]->c[] of all ropes, mrope.c:332-340) and strings move from piece (b,x) to the owner of
+ * piece (a,b) for the symbol a they just inserted (mrope.c:303-309).  The library does the
  * GPU work of each phase; the caller moves the two buffers with its collective of choice
  * (ropebwt2_amd/sharded.py: torch.distributed all_reduce + all_to_all_single over RCCL):
  *
@@ -86,12 +89,13 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
  *       rb2_hip_shard_finish(h, r, global, recv, nrecv)
  *   rb2_hip_shard_end(h)
  */
-void    rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int owner[6]);
+int     rb2_hip_num_subropes(void);                    /* NR = 31: rope $ + pieces (b,x), index 1+(b-1)*6+x */
+void    rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner /* [NR] */);
 int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev);
 int64_t rb2_hip_shard_capacity(rb2_hip_t *h);          /* records the send / receive buffers must hold */
-void    rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t local_cnt[36]);
-void    rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], void *send_dev, int64_t send_counts[]);
-void    rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], const void *recv_dev, const int64_t recv_counts[]);
+void    rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt /* [NR*6] */);
+void    rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, void *send_dev, int64_t send_counts[]);
+void    rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[]);
 void    rb2_hip_shard_end(rb2_hip_t *h);
 void    rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind);
 

@@ -28,6 +28,16 @@ constexpr int STILE  = 512;           // strings per string tile
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
 constexpr int ZBLOCK = 16384;         // bytes per block when locating sentinels
 
+// Sub-ropes.  Rope b (the rows that start with symbol b) is kept as six independent pieces (b,x),
+// x = the symbol that FOLLOWS b in the row's suffix; piece (b,x) holds exactly the b-symbols of rope x,
+// in order (LF-mapping), so the pieces of rope b in the order x = $,A,C,G,T,N concatenate to rope b.
+// A string that sits in (b,x) and inserts a moves to (a,b).  Rope $ is one piece.  Pieces never
+// interact inside a round, which is what lets more than four GPUs share the work.
+constexpr int NR = 31;
+__host__ __device__ inline int rope_sym(int r)  { return r == 0 ? 0 : 1 + (r - 1) / 6; }   // b
+__host__ __device__ inline int rope_prev(int r) { return r == 0 ? 0 : (r - 1) % 6; }       // x
+__host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (a - 1) * 6 + b; }
+
 struct LeafMeta { uint16_t c[6]; uint16_t nbytes; uint16_t pad; };
 struct Cnt6 { uint64_t v[6]; };
 
@@ -39,26 +49,26 @@ struct RopeDesc {
 	uint64_t cnt[6];    // marginal counts (rope_t.c, rope.h:19)
 };
 
-struct SegDesc {        // where the strings of bucket b live in the current SoA arrays
-	uint64_t start[6], cnt[6];
-	uint32_t tile0[8];  // first string tile of each segment; [6] = total
+struct SegDesc {        // where the strings of bucket r (= sub-rope r) live in the current SoA arrays
+	uint64_t start[NR], cnt[NR];
+	uint32_t tile0[NR + 3];  // first string tile of each segment; [NR] = total
 };
 
 struct Ctl {
-	RopeDesc rope[2][6];
+	RopeDesc rope[2][NR];
 	SegDesc  seg[2];
-	uint64_t lf0[8];        // first output leaf (unpadded numbering) per rope this round; [6] = total
-	uint64_t ac[6][6];      // ac[b][a] = #a in ropes < b after this round (mrope.c:332-336)
-	uint64_t dest[6][6];    // where members of bucket b inserting a go in the next arrays
-	uint64_t count[6][6];   // count[b][a] = members of bucket b inserting a this round
+	uint64_t lf0[NR + 3];   // first output leaf (unpadded numbering) per sub-rope this round; [NR] = total
+	uint64_t ac[NR][6];     // ac[r][a] = #a in the pieces of the same rope in front of piece r, after this round (mrope.c:332-336)
+	uint64_t dest[NR][6];   // where members of bucket r inserting a go in the next arrays
+	uint64_t count[NR][6];  // count[r][a] = members of bucket r inserting a this round
 	uint64_t nsb_total;     // superblocks in use on the new side
 	uint64_t n_strings;     // strings in this batch
 	uint64_t max_len;       // longest string (without sentinel)
 	uint64_t n0;            // strings already in the index (#'$' in the BWT, mrope.c:279)
 	uint64_t len;           // batch bytes
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
-	uint32_t own[8];        // own[b] != 0: this rank holds rope b and processes bucket b
-	uint64_t sdest[6][6];   // sharded mode: record offset in the send buffer for members of bucket b inserting a
+	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
+	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
 };
 
 struct ShardRec { uint64_t l, u, w; uint32_t id, pad; };   // one string's state on the wire (32 B)

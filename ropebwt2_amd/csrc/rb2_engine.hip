@@ -58,7 +58,7 @@ struct rb2_hip_s {
 	Pool pool[2];
 	int side = 0;                       // pool side holding the current BWT
 	Ctl *ctl = nullptr;                 // device
-	RopeDesc h_rope[6];                 // host mirror of ctl->rope[side]
+	RopeDesc h_rope[NR];                // host mirror of ctl->rope[side] (sub-ropes)
 	// per-string state
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
@@ -75,7 +75,7 @@ struct rb2_hip_s {
 	int debug = 0;
 	int cur_round = -1;
 	uint64_t *gcnt = nullptr;           // device: 6x6 count matrix of the current round
-	int rank = 0, nranks = 1; int owner[6] = {0, 0, 0, 0, 0, 0};
+	int rank = 0, nranks = 1; int owner[NR] = {0};
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;
 	int merge_dbg = 0;
@@ -135,7 +135,7 @@ void build_directory(rb2_hip_t *h, int sd, uint64_t nsb_ub)
 
 void fetch_ropes(rb2_hip_t *h)
 {
-	HIPCHK(hipMemcpyAsync(h->h_rope, &h->ctl->rope[h->side][0], sizeof(RopeDesc) * 6, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipMemcpyAsync(h->h_rope, &h->ctl->rope[h->side][0], sizeof(RopeDesc) * NR, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 }
 
@@ -176,16 +176,16 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m);
-	B.nst_ub = cdiv(m, STILE) + 6;                            // string tiles, upper bound for every round
+	B.nst_ub = cdiv(m, STILE) + NR;                           // string tiles, upper bound for every round
 	B.nsc = cdiv(B.nst_ub, SCHUNK);
 	if (B.nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
 	h->trec.ensure(B.nst_ub + 1); h->tsc.ensure(B.nst_ub + 2); h->cpart.ensure(B.nsc + 1);
 	uint64_t n_tot = 0;
-	for (int b = 0; b < 6; ++b) n_tot += h->h_rope[b].n;      // symbols held by THIS rank
-	const uint64_t leaves_ub = (n_tot + len) / LEAF + 6 * (SB + 1);
+	for (int b = 0; b < NR; ++b) n_tot += h->h_rope[b].n;     // symbols held by THIS rank
+	const uint64_t leaves_ub = (n_tot + len) / LEAF + NR * (SB + 1);
 	h->pool[h->side].ensure(leaves_ub, true, st);
 	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
-	h->TQ.ensure(leaves_ub + 16);
+	h->TQ.ensure(leaves_ub + NR + 16);
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{
 		Scope sc(h, RB2_K_INIT, 0);
@@ -210,7 +210,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
-	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(64), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
+	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(256), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
 }
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
@@ -222,18 +222,18 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const int64_t units = (int64_t)B.m;
 	PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
-	const unsigned nlf = cdiv(n_new_ub, LEAF) + 6;            // output leaves, upper bound
+	const unsigned nlf = cdiv(n_new_ub, LEAF) + NR;           // output leaves, upper bound
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->gcnt); }
 	{ Scope sc(h, RB2_K_PREP, units);
 	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + 6, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
+	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p, h->merge_dbg); }
 	{ Scope sc(h, RB2_K_META, units);
-	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + 7)); }
+	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
 			h->PGA.p, h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
@@ -293,8 +293,8 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
-	HIPCHK(hipMalloc((void**)&h->gcnt, 36 * 8));
-	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < 6; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
+	HIPCHK(hipMalloc((void**)&h->gcnt, NR * 6 * 8));
+	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
 	memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units));
@@ -343,84 +343,126 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 
 void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
 {
-	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) c[b * 6 + a] = (int64_t)h->h_rope[b].cnt[a];
+	for (int i = 0; i < 36; ++i) c[i] = 0;
+	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) c[rope_sym(r) * 6 + a] += (int64_t)h->h_rope[r].cnt[a];   // rope b = its pieces (b,x)
 }
 
-static void fetch_meta(rb2_hip_t *h, int b, std::vector<LeafMeta> &m)
+static void fetch_meta(rb2_hip_t *h, int r, std::vector<LeafMeta> &m)
 {
-	const RopeDesc &r = h->h_rope[b];
-	m.resize(r.nleaves);
-	if (r.nleaves) {
-		HIPCHK(hipMemcpyAsync(m.data(), h->pool[h->side].meta.p + r.leaf0, r.nleaves * sizeof(LeafMeta), hipMemcpyDeviceToHost, h->st));
+	const RopeDesc &d = h->h_rope[r];
+	m.resize(d.nleaves);
+	if (d.nleaves) {
+		HIPCHK(hipMemcpyAsync(m.data(), h->pool[h->side].meta.p + d.leaf0, d.nleaves * sizeof(LeafMeta), hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
 	}
 }
 
+/* rope b = its pieces (b,x) in the order x = $,A,C,G,T,N (rb2_device.h) */
 int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	std::vector<LeafMeta> m;
-	fetch_meta(h, b, m);
 	int64_t t = 0;
-	for (auto &x : m) t += x.nbytes;
+	for (int r = 0; r < NR; ++r) {
+		if (rope_sym(r) != b) continue;
+		std::vector<LeafMeta> m;
+		fetch_meta(h, r, m);
+		for (auto &x : m) t += x.nbytes;
+	}
 	return t;
 }
 
 int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	std::vector<LeafMeta> m;
-	fetch_meta(h, b, m);
-	const RopeDesc &r = h->h_rope[b];
 	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB)
-	std::vector<uint8_t> stage(std::min<uint64_t>(CH, std::max<uint64_t>(r.nleaves, 1)) * LEAF);
+	std::vector<uint8_t> stage;
 	int64_t k = 0;
-	for (uint64_t l0 = 0; l0 < r.nleaves; l0 += CH) {
-		const uint64_t nl = std::min<uint64_t>(CH, r.nleaves - l0);
-		HIPCHK(hipMemcpyAsync(stage.data(), h->pool[h->side].data.p + (r.leaf0 + l0) * LEAF, nl * LEAF, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
-		for (uint64_t i = 0; i < nl; ++i) { memcpy(dst + k, stage.data() + i * LEAF, m[l0 + i].nbytes); k += m[l0 + i].nbytes; }
+	for (int r = 0; r < NR; ++r) {
+		if (rope_sym(r) != b) continue;
+		std::vector<LeafMeta> m;
+		fetch_meta(h, r, m);
+		const RopeDesc &d = h->h_rope[r];
+		if (stage.size() < std::min<uint64_t>(CH, d.nleaves) * LEAF) stage.resize(std::min<uint64_t>(CH, d.nleaves) * LEAF);
+		for (uint64_t l0 = 0; l0 < d.nleaves; l0 += CH) {
+			const uint64_t nl = std::min<uint64_t>(CH, d.nleaves - l0);
+			HIPCHK(hipMemcpyAsync(stage.data(), h->pool[h->side].data.p + (d.leaf0 + l0) * LEAF, nl * LEAF, hipMemcpyDeviceToHost, h->st));
+			HIPCHK(hipStreamSynchronize(h->st));
+			for (uint64_t i = 0; i < nl; ++i) { memcpy(dst + k, stage.data() + i * LEAF, m[l0 + i].nbytes); k += m[l0 + i].nbytes; }
+		}
 	}
 	return k;
+}
+
+static inline const uint8_t *dec43(const uint8_t *p, int *c, int64_t *l)   /* one run of the 43+3 codec (rle.h:39-51) */
+{
+	*c = *p & 7;
+	if ((*p & 0x80) == 0) { *l = *p >> 3; return p + 1; }
+	if ((*p >> 5) == 6) { *l = ((int64_t)(*p & 0x18) << 3) | (p[1] & 0x3f); return p + 2; }
+	const int nb = (*p & 0x10) ? 8 : 4;
+	int64_t v = (*p >> 3) & 1;
+	for (int i = 1; i < nb; ++i) v = (v << 6) | (p[i] & 0x3f);
+	*l = v;
+	return p + nb;
 }
 
 void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6])
 {
 	HIPCHK(hipSetDevice(h->dev));
-	// decode the 43+3 streams (rle.h:39-51) and re-chunk into LEAF-symbol leaves of 1-byte runs
-	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
-	RopeDesc rp[6];
-	uint64_t leaf = 0;
+	// pass 1: symbol counts of the six ropes.  Piece (b,x) of rope b has as many rows as rope x has b's.
+	int64_t tot[6][6];
+	memset(tot, 0, sizeof(tot));
 	for (int b = 0; b < 6; ++b) {
-		RopeDesc &r = rp[b];
-		memset(&r, 0, sizeof(r));
-		r.leaf0 = leaf; r.sb0 = leaf / SB;
-		data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
-		LeafMeta cur; memset(&cur, 0, sizeof(cur));
-		uint32_t fill = 0;                            // symbols in the open leaf
-		uint8_t *slot = nullptr;
-		auto open_leaf = [&]() { data.resize(data.size() + LEAF); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAF; memset(&cur, 0, sizeof(cur)); fill = 0; };
-		auto close_leaf = [&]() { meta.back() = cur; ++r.nleaves; slot = nullptr; };
-		const bool keep = h->nranks == 1 || h->owner[b] == h->rank;   // sharded: other ranks' ropes are only counted
 		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
 		while (p && p < end) {
-			int c = *p & 7; int64_t l;
-			if ((*p & 0x80) == 0) { l = *p++ >> 3; }
-			else if ((*p >> 5) == 6) { l = ((int64_t)(*p & 0x18) << 3) | (p[1] & 0x3f); p += 2; }
-			else { int nb = (*p & 0x10) ? 8 : 4; l = (*p >> 3) & 1; for (int i = 1; i < nb; ++i) l = (l << 6) | (p[i] & 0x3f); p += nb; }
+			int c; int64_t l;
+			p = dec43(p, &c, &l);
 			if (c > 5) { fprintf(stderr, "[rb2_hip] load_ropes: bad symbol %d\n", c); abort(); }
-			r.n += l; r.cnt[c] += l;
-			while (keep && l > 0) {
-				if (!slot) open_leaf();
-				const int64_t take = std::min<int64_t>(std::min<int64_t>(l, 15), LEAF - fill);
-				slot[cur.nbytes++] = (uint8_t)(take << 3 | c);
-				cur.c[c] += (uint16_t)take; fill += (uint32_t)take; l -= take;
-				if (fill == LEAF) close_leaf();
-			}
+			tot[b][c] += l;
 		}
-		if (slot) close_leaf();
-		if (!keep) r.n = 0;
-		leaf += (r.nleaves + SB - 1) / SB * SB;
+	}
+	// pass 2: decode again and re-chunk into LEAF-symbol leaves of 1-byte runs, cutting rope b into its pieces
+	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
+	RopeDesc rp[NR];
+	uint64_t leaf = 0;
+	for (int r = 0; r < NR; ++r) memset(&rp[r], 0, sizeof(RopeDesc));
+	for (int b = 0; b < 6; ++b) {
+		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
+		int c = 0; int64_t l = 0;                     // run being consumed
+		for (int x = 0; x < (b == 0 ? 1 : 6); ++x) {
+			const int r = b == 0 ? 0 : rope_of(b, x);
+			int64_t quota = 0;
+			if (b == 0) { for (int a = 0; a < 6; ++a) quota += tot[0][a]; }
+			else quota = tot[x][b];
+			const bool keep = h->nranks == 1 || h->owner[r] == h->rank;   // sharded: other ranks' pieces are only counted
+			RopeDesc &d = rp[r];
+			d.leaf0 = leaf; d.sb0 = leaf / SB;
+			data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
+			LeafMeta cur; memset(&cur, 0, sizeof(cur));
+			uint32_t fill = 0; uint8_t *slot = nullptr;
+			auto open_leaf = [&]() { data.resize(data.size() + LEAF); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAF; memset(&cur, 0, sizeof(cur)); fill = 0; };
+			auto close_leaf = [&]() { meta.back() = cur; ++d.nleaves; slot = nullptr; };
+			while (quota > 0) {
+				if (l == 0) {
+					if (!(p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); abort(); }
+					p = dec43(p, &c, &l);
+					continue;
+				}
+				int64_t part = std::min<int64_t>(l, quota);
+				l -= part; quota -= part;
+				d.cnt[c] += part; d.n += part;
+				while (keep && part > 0) {
+					if (!slot) open_leaf();
+					const int64_t take = std::min<int64_t>(std::min<int64_t>(part, 15), LEAF - fill);
+					slot[cur.nbytes++] = (uint8_t)(take << 3 | c);
+					cur.c[c] += (uint16_t)take; fill += (uint32_t)take; part -= take;
+					if (fill == LEAF) close_leaf();
+				}
+			}
+			if (slot) close_leaf();
+			if (!keep) d.n = 0;
+			leaf += (d.nleaves + SB - 1) / SB * SB;
+		}
+		if (l != 0 || (p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
 	}
 	data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
 	const int sd = h->side;
@@ -437,22 +479,24 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 	memcpy(h->h_rope, rp, sizeof(rp));
 }
 
-
 /* ---- rope sharding across GPUs ------------------------------------------- */
 
-void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int owner[6])
+void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (nranks < 1 || rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] bad shard rank %d/%d\n", rank, nranks); abort(); }
-	uint32_t own[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	for (int b = 0; b < 6; ++b) {
-		if (owner[b] < 0 || owner[b] >= nranks) { fprintf(stderr, "[rb2_hip] bad owner of rope %d\n", b); abort(); }
-		h->owner[b] = owner[b]; own[b] = owner[b] == rank;
+	uint32_t own[NR + 1];
+	memset(own, 0, sizeof(own));
+	for (int r = 0; r < NR; ++r) {
+		if (owner[r] < 0 || owner[r] >= nranks) { fprintf(stderr, "[rb2_hip] bad owner of sub-rope %d\n", r); abort(); }
+		h->owner[r] = owner[r]; own[r] = owner[r] == rank;
 	}
 	h->rank = rank; h->nranks = nranks;
 	HIPCHK(hipMemcpyAsync(&h->ctl->own[0], own, sizeof(own), hipMemcpyHostToDevice, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 }
+
+int rb2_hip_num_subropes(void) { return NR; }
 
 int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
@@ -466,82 +510,89 @@ int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 
 int64_t rb2_hip_shard_capacity(rb2_hip_t *h) { return h->batch ? (int64_t)((BatchState*)h->batch)->m : 0; }
 
-void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t local_cnt[36])
+void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	BatchState &B = *(BatchState*)h->batch;
 	round_counts(h, B, (uint64_t)round);
-	HIPCHK(hipMemcpyAsync(local_cnt, h->gcnt, 36 * 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipMemcpyAsync(local_cnt, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 }
 
-/* where the members of (bucket b -> symbol a) sit in the send buffer of rank `me`: per destination rank d,
- * for a owned by d (a >= 1, ascending), for b owned by me (ascending).  The same function, evaluated for a
- * source rank, gives the layout of what arrives from it. */
-static void shard_layout(const int owner[6], int nranks, int src, const int64_t g[36], int64_t off[6][6], int64_t per_rank[], int64_t start_rank[])
+/* where the members of (piece r -> symbol a) sit in the send buffer of rank `src`: per destination rank d,
+ * for the pieces r2 = (a,b) owned by d (ascending), for the pieces r of rope b owned by src (ascending):
+ * g[r][a] records.  Evaluated for another source rank it gives the layout of what arrives from it. */
+static void shard_layout(const int owner[NR], int nranks, int src, const int64_t *g, int64_t off[NR][6], int64_t per_rank[], int64_t start_rank[])
 {
 	int64_t run = 0;
 	for (int d = 0; d < nranks; ++d) {
 		start_rank[d] = run;
-		for (int a = 1; a < 6; ++a) {
-			if (owner[a] != d) continue;
-			for (int b = 0; b < 6; ++b) {
-				if (owner[b] != src) continue;
-				off[b][a] = run; run += g[b * 6 + a];
+		for (int r2 = 1; r2 < NR; ++r2) {
+			if (owner[r2] != d) continue;
+			const int a = rope_sym(r2), b = rope_prev(r2);
+			for (int r = 0; r < NR; ++r) {
+				if (rope_sym(r) != b || owner[r] != src) continue;
+				off[r][a] = run; run += g[r * 6 + a];
 			}
 		}
 		per_rank[d] = run - start_rank[d];
 	}
 }
 
-void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], void *send_dev, int64_t send_counts[])
+void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, void *send_dev, int64_t send_counts[])
 {
 	HIPCHK(hipSetDevice(h->dev));
 	BatchState &B = *(BatchState*)h->batch;
-	int64_t off[6][6], start[64];
+	int64_t off[NR][6], start[64];
 	memset(off, 0, sizeof(off));
 	if (h->nranks > 64) { fprintf(stderr, "[rb2_hip] too many ranks\n"); abort(); }
 	shard_layout(h->owner, h->nranks, h->rank, global_cnt, off, send_counts, start);
-	uint64_t sd[6][6];
-	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) sd[b][a] = (uint64_t)off[b][a];
-	HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, 36 * 8, hipMemcpyHostToDevice, h->st));
+	uint64_t sd[NR][6];
+	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) sd[r][a] = (uint64_t)off[r][a];
+	HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, NR * 6 * 8, hipMemcpyHostToDevice, h->st));
 	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd), hipMemcpyHostToDevice, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));                       /* sd / global_cnt may be temporaries of the caller */
 	round_merge(h, B, (uint64_t)round, (ShardRec*)send_dev);
 	HIPCHK(hipStreamSynchronize(h->st));                       /* the send buffer is complete when we return */
 }
 
-void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t global_cnt[36], const void *recv_dev, const int64_t recv_counts[])
+void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[])
 {
 	HIPCHK(hipSetDevice(h->dev));
 	BatchState &B = *(BatchState*)h->batch;
 	(void)round;
-	/* local layout of next round's buckets: owned a ascending; inside a bucket the global order of the sources b */
-	int64_t nstart[6], run = 0;
-	for (int a = 0; a < 6; ++a) {
-		nstart[a] = run;
-		if (a >= 1 && h->owner[a] == h->rank) for (int b = 0; b < 6; ++b) run += global_cnt[b * 6 + a];
+	/* local layout of next round's buckets (same rule as k_setup): owned pieces ascending; inside bucket (a,b)
+	 * the sources (b,x) in the order of x */
+	int64_t nstart[NR], run = 0;
+	for (int r2 = 0; r2 < NR; ++r2) {
+		nstart[r2] = run;
+		if (r2 >= 1 && h->owner[r2] == h->rank) {
+			const int a = rope_sym(r2), b = rope_prev(r2);
+			for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) run += global_cnt[r * 6 + a];
+		}
 	}
 	std::vector<ShardPiece> pcs;
 	int64_t base = 0;
 	for (int s = 0; s < h->nranks; ++s) {
-		int64_t off[6][6], per[64], start[64];
+		int64_t off[NR][6], per[64], start[64];
 		memset(off, 0, sizeof(off));
 		shard_layout(h->owner, h->nranks, s, global_cnt, off, per, start);
 		if (per[h->rank] != recv_counts[s]) { fprintf(stderr, "[rb2_hip] shard_finish: rank %d expected %lld records from rank %d, caller says %lld\n", h->rank, (long long)per[h->rank], s, (long long)recv_counts[s]); abort(); }
-		for (int a = 1; a < 6; ++a) {
-			if (h->owner[a] != h->rank) continue;
-			for (int b = 0; b < 6; ++b) {
-				if (h->owner[b] != s || global_cnt[b * 6 + a] == 0) continue;
+		for (int r2 = 1; r2 < NR; ++r2) {
+			if (h->owner[r2] != h->rank) continue;
+			const int a = rope_sym(r2), b = rope_prev(r2);
+			for (int r = 0; r < NR; ++r) {
+				if (rope_sym(r) != b || h->owner[r] != s || global_cnt[r * 6 + a] == 0) continue;
 				int64_t before = 0;
-				for (int bb = 0; bb < b; ++bb) before += global_cnt[bb * 6 + a];
-				ShardPiece p; p.src = (uint64_t)(base + off[b][a] - start[h->rank]); p.dst = (uint64_t)(nstart[a] + before); p.cnt = (uint64_t)global_cnt[b * 6 + a];
+				for (int rr = 0; rr < r; ++rr) if (rope_sym(rr) == b) before += global_cnt[rr * 6 + a];
+				ShardPiece p; p.src = (uint64_t)(base + off[r][a] - start[h->rank]); p.dst = (uint64_t)(nstart[r2] + before); p.cnt = (uint64_t)global_cnt[r * 6 + a];
 				pcs.push_back(p);
 			}
 		}
 		base += recv_counts[s];
 	}
 	if (base > 0) {
+		std::sort(pcs.begin(), pcs.end(), [](const ShardPiece &x, const ShardPiece &y) { return x.src < y.src; });
 		h->pieces.ensure(pcs.size() + 1);
 		HIPCHK(hipMemcpyAsync(h->pieces.p, pcs.data(), pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
 		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
@@ -571,11 +622,18 @@ void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
 {
 	HIPCHK(hipSetDevice(h->dev));
-	hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->side].view(), b, (uint64_t)x, h->d_tmp);
-	uint64_t out[6];
-	HIPCHK(hipMemcpyAsync(out, h->d_tmp, 48, hipMemcpyDeviceToHost, h->st));
-	HIPCHK(hipStreamSynchronize(h->st));
-	for (int s = 0; s < 6; ++s) cx[s] = (int64_t)out[s];
+	for (int s = 0; s < 6; ++s) cx[s] = 0;
+	for (int r = 0; r < NR && x > 0; ++r) {              /* whole pieces in front of x, then a scan inside one piece */
+		if (rope_sym(r) != b) continue;
+		const RopeDesc &d = h->h_rope[r];
+		if ((uint64_t)x >= d.n) { for (int s = 0; s < 6; ++s) cx[s] += (int64_t)d.cnt[s]; x -= (int64_t)d.n; continue; }
+		hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->side].view(), r, (uint64_t)x, h->d_tmp);
+		uint64_t out[6];
+		HIPCHK(hipMemcpyAsync(out, h->d_tmp, 48, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+		for (int s = 0; s < 6; ++s) cx[s] += (int64_t)out[s];
+		x = 0;
+	}
 }
 
 void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)

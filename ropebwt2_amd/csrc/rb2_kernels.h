@@ -118,13 +118,13 @@ __global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	SegDesc &sg = ctl->seg[side];
-	for (int b = 0; b < 6; ++b) { sg.start[b] = 0; sg.cnt[b] = 0; }
+	for (int b = 0; b < NR; ++b) { sg.start[b] = 0; sg.cnt[b] = 0; }
 	sg.cnt[0] = ctl->own[0] ? m : 0;                        // sharded: only the owner of rope $ starts with the strings
 	uint32_t t = 0;
-	for (int b = 0; b < 6; ++b) { sg.tile0[b] = t; t += (uint32_t)((sg.cnt[b] + STILE - 1) / STILE); }
-	sg.tile0[6] = t; sg.tile0[7] = t;
+	for (int b = 0; b < NR; ++b) { sg.tile0[b] = t; t += (uint32_t)((sg.cnt[b] + STILE - 1) / STILE); }
+	sg.tile0[NR] = t; sg.tile0[NR + 1] = t;
 	uint64_t n0 = 0;
-	for (int b = 0; b < 6; ++b) n0 += ctl->rope[side][b].cnt[0];
+	for (int b = 0; b < NR; ++b) n0 += ctl->rope[side][b].cnt[0];
 	ctl->n0 = n0; ctl->n_strings = m; ctl->max_len = 0; ctl->len = len;
 }
 
@@ -136,7 +136,7 @@ struct TileCtx { int b; uint64_t lt, base, segstart, segend; };
 
 __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileCtx &t)
 {
-	if (tile >= sg.tile0[6]) return false;
+	if (tile >= sg.tile0[NR]) return false;
 	int b = 0;
 	while (tile >= sg.tile0[b+1]) ++b;
 	t.b = b; t.lt = tile - sg.tile0[b];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, const uin
 __global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, const TileRec *trec, ChunkPart *part)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
-	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t nt = ctl->seg[side].tile0[NR];
 	const uint32_t t = blockIdx.x * SCHUNK + threadIdx.x;
 	if (blockIdx.x * SCHUNK >= nt) return;
 	const bool ok = t < nt;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, con
 __global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, ChunkPart *part)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
-	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t nt = ctl->seg[side].tile0[NR];
 	const uint32_t nc = (nt + SCHUNK - 1) / SCHUNK;          // host guarantees nc <= SCHUNK
 	const bool ok = threadIdx.x < nc;
 	ChunkPart p;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, Chu
 __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRec *trec, const ChunkPart *part, TileScan *tsc)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
-	const uint32_t nt = ctl->seg[side].tile0[6];
+	const uint32_t nt = ctl->seg[side].tile0[NR];
 	const uint32_t t = blockIdx.x * SCHUNK + threadIdx.x;
 	if (blockIdx.x * SCHUNK >= nt) return;
 	const bool ok = t < nt;
@@ -263,60 +263,64 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // k_setup: everything the rest of the round needs that depends on the 6x6 count matrix
 // ---------------------------------------------------------------------------------------------
 
-// rows of the count matrix this rank can see: count[b][a] = members of (local) bucket b inserting a
+// rows of the count matrix this rank can see: count[r][a] = members of (local) bucket r inserting a
 __global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, uint64_t *gcnt)
 {
 	const int i = threadIdx.x;
-	if (blockIdx.x || i >= 36) return;
+	if (blockIdx.x || i >= NR * 6) return;
 	const SegDesc &sg = ctl->seg[side];
 	const int b = i / 6, a = i % 6;
-	gcnt[i] = sg.tile0[6] ? (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]) : 0ull;
+	gcnt[i] = sg.tile0[NR] ? (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]) : 0ull;
 }
 
-// gcnt = the GLOBAL 6x6 count matrix of the round (== the local one on a single GPU; the sum over
-// ranks when ropes are sharded)
+// gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
+// over ranks when sub-ropes are sharded)
 __global__ void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	const SegDesc &sg = ctl->seg[side];
 	SegDesc &ng = ctl->seg[side ^ 1];
-	uint64_t cnt[6][6];
-	for (int b = 0; b < 6; ++b)
-		for (int a = 0; a < 6; ++a)
-			ctl->count[b][a] = cnt[b][a] = gcnt[b * 6 + a];
-	// new ropes (side^1): sizes, layout in the leaf pool, output leaves.  Ropes of other ranks keep
-	// n = 0 here but their symbol counts are tracked (needed for AC and for n0).
+	// new sub-ropes (side^1): sizes, layout in the leaf pool, output leaves.  Pieces held by other ranks
+	// keep n = 0 here but their symbol counts are tracked (needed for AC and for n0).
 	uint64_t leaf = 0, mt = 0, run[6] = {0, 0, 0, 0, 0, 0};
-	for (int b = 0; b < 6; ++b) {
-		const RopeDesc &o = ctl->rope[side][b];
-		RopeDesc &n = ctl->rope[side ^ 1][b];
-		n.n = o.n + sg.cnt[b];
+	for (int r = 0; r < NR; ++r) {
+		const RopeDesc &o = ctl->rope[side][r];
+		RopeDesc &n = ctl->rope[side ^ 1][r];
+		if (rope_prev(r) == 0) for (int a = 0; a < 6; ++a) run[a] = 0;      // first piece of a rope
+		n.n = o.n + sg.cnt[r];
 		for (int a = 0; a < 6; ++a) {
-			ctl->ac[b][a] = run[a];                           // #a in ropes < b, after this round (mrope.c:332-336)
-			n.cnt[a] = o.cnt[a] + cnt[b][a];
+			const uint64_t c = gcnt[r * 6 + a];
+			ctl->count[r][a] = c;
+			ctl->ac[r][a] = run[a];                           // #a in this rope in front of piece r, after the round (mrope.c:332-336)
+			n.cnt[a] = o.cnt[a] + c;
 			run[a] += n.cnt[a];
 		}
 		n.nleaves = (n.n + LEAF - 1) / LEAF;
 		n.leaf0 = leaf; n.sb0 = leaf / SB;
 		leaf += (n.nleaves + SB - 1) / SB * SB;
-		ctl->lf0[b] = mt;
+		ctl->lf0[r] = mt;
 		mt += n.nleaves;
 	}
-	ctl->lf0[6] = mt; ctl->lf0[7] = mt;
+	ctl->lf0[NR] = mt; ctl->lf0[NR + 1] = mt;
 	ctl->nsb_total = leaf / SB;
-	// next round's buckets: bucket a = strings that inserted a, in (bucket, order) order (mrope.c:303-309);
-	// only the buckets of ropes held here are laid out locally
+	// next round's buckets: bucket (a,b) = strings that sat in a piece of rope b and inserted a, in
+	// (piece, order) order -- the stable scatter of mrope.c:303-309; only buckets of pieces held here
+	// are laid out locally; strings that inserted $ are dropped (mrope.c:310)
 	uint64_t st = 0; uint32_t tl = 0;
-	for (int a = 0; a < 6; ++a) {
+	for (int r2 = 0; r2 < NR; ++r2) {
 		uint64_t c = 0;
-		for (int b = 0; b < 6; ++b) { ctl->dest[b][a] = st + c; c += cnt[b][a]; }
-		if (a == 0 || !ctl->own[a]) c = 0;                    // finished strings are dropped (mrope.c:310)
-		ng.start[a] = st; ng.cnt[a] = c;
-		ng.tile0[a] = tl;
+		if (r2 != 0) {
+			const int a = rope_sym(r2), b = rope_prev(r2);
+			if (b == 0) { ctl->dest[0][a] = st; c = gcnt[a]; }
+			else for (int x = 0; x < 6; ++x) { const int r = rope_of(b, x); ctl->dest[r][a] = st + c; c += gcnt[r * 6 + a]; }
+			if (!ctl->own[r2]) c = 0;
+		}
+		ng.start[r2] = st; ng.cnt[r2] = c;
+		ng.tile0[r2] = tl;
 		tl += (uint32_t)((c + STILE - 1) / STILE);
 		st += c;
 	}
-	ng.tile0[6] = tl; ng.tile0[7] = tl;
+	ng.tile0[NR] = tl; ng.tile0[NR + 1] = tl;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, uint32_t *TQ)
 {
 	const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	if (gid >= ctl->lf0[6] + 6) return;
+	if (gid >= ctl->lf0[NR] + NR) return;
 	int b = 0;
 	while (gid >= ctl->lf0[b+1] + b + 1) ++b;
 	const uint64_t j = gid - ctl->lf0[b] - b;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(64) void k_meta_sb(const Ctl *ctl, int nside, PoolV
 	const uint64_t gl = sb * SB + ln;
 	bool ok = false;
 	if (ln < SB)
-		for (int b = 0; b < 6; ++b) { const RopeDesc &r = ctl->rope[nside][b]; ok |= (gl >= r.leaf0 && gl < r.leaf0 + r.nleaves); }
+		for (int b = 0; b < NR; ++b) { const RopeDesc &r = ctl->rope[nside][b]; ok |= (gl >= r.leaf0 && gl < r.leaf0 + r.nleaves); }
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
 	if (ok) m = newp.meta[gl];

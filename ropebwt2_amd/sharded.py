@@ -1,12 +1,15 @@
 """Rope-sharded multi-GPU insertion: one process (and one HIP engine) per GPU.
 
-Partitioning: rank ``owner[b]`` holds rope ``b`` and processes bucket ``b``.
-Inside a round the ropes are independent (the reference runs them on separate pthreads,
-mrope.c:312-329).  Between rounds
+Partitioning: the unit of ownership is a SUB-ROPE.  Rope b is kept as six
+independent pieces (b,x), x = the symbol that follows b in the row's suffix; piece (b,x) holds exactly
+the b-symbols of rope x, so rope b is the concatenation of its pieces for x = $,A,C,G,T,N.  Rope $ is
+one piece: NR = 31.  Rank ``owner[r]`` holds piece r and processes its bucket.  Inside a round the
+pieces are independent (the reference runs the ropes on separate pthreads, mrope.c:312-329).  Between
+rounds
 
-* every rank needs the 6x6 matrix "members of bucket b that insert a" (the reference's master reads
-  ``r[b]->c[]`` of all ropes, mrope.c:332-340)          -> ``all_reduce`` of 36 int64;
-* every string moves to the owner of the rope of the symbol it just inserted (the stable scatter of
+* every rank needs the NR x 6 matrix "members of bucket r that insert a" (the reference's master reads
+  ``r[b]->c[]`` of all ropes, mrope.c:332-340)          -> ``all_reduce`` of 186 int64;
+* a string in piece (b,x) that inserted a moves to the owner of piece (a,b) (the stable scatter of
   mrope.c:303-309)                                      -> ``all_to_all_single`` of 32-byte records.
 
 The GPU work of each phase is in librb2hip.so (``rb2_hip_shard_*``); this module only moves the two
@@ -22,33 +25,49 @@ import numpy as np
 from .hipbwt import HipBwt, load_hip_lib
 
 REC_BYTES = 32          # sizeof(ShardRec), rb2_device.h
+NR = 31                 # sub-ropes, rb2_device.h (checked against the library in ShardedBwt)
+
+
+def rope_sym(r):
+    """rope the piece belongs to (0 = $ ... 5 = N)"""
+    return 0 if r == 0 else (r - 1) // 6 + 1
+
+
+def rope_prev(r):
+    """x of piece (b,x): the symbol following b in the suffix"""
+    return 0 if r == 0 else (r - 1) % 6
+
+
+def rope_of(b, x):
+    return 0 if b == 0 else 1 + (b - 1) * 6 + x
 
 
 def default_owners(nranks):
-    """rope -> rank.  Ropes A,C,G,T carry the load on DNA; $ and N ride along.  More than four
-    ranks leave ranks >= 4 without a rope (sub-rope splitting is future work)."""
+    """piece -> rank.  On DNA the 16 pieces (b,x), b,x in ACGT, carry ~1/16 of the rows each; they are
+    dealt out in contiguous blocks, so up to 16 ranks get load.  The light pieces ((b,$): one row per
+    read; everything with N) ride with a neighbour, rope $ with rank 0."""
+    own = [0] * NR
     if nranks <= 1:
-        return [0] * 6
-    if nranks == 2:
-        return [0, 0, 0, 1, 1, 1]
-    if nranks == 3:
-        return [0, 0, 1, 1, 2, 2]
-    return [0, 0, 1, 2, 3, 3]
+        return own
+    for b in range(1, 6):
+        for x in range(6):
+            k = (min(b, 4) - 1) * 4 + (min(max(x, 1), 4) - 1)
+            own[rope_of(b, x)] = min(k * nranks // 16, nranks - 1)
+    return own
 
 
 def exchange_layout(owner, nranks, src, g):
     """Python twin of shard_layout() in rb2_engine.hip: for source rank ``src`` and count matrix
-    ``g`` (6x6), the number of records it sends to every rank.  Layout inside a destination block:
-    for a owned by the destination (a >= 1, ascending), for b owned by src (ascending): g[b][a] records."""
-    g = np.asarray(g, dtype=np.int64).reshape(6, 6)
+    ``g`` (NR x 6), the number of records it sends to every rank.  Layout inside a destination block:
+    for the pieces r2 = (a,b) owned by the destination (ascending), for the pieces r of rope b owned by
+    src (ascending): g[r][a] records."""
+    g = np.asarray(g, dtype=np.int64).reshape(NR, 6)
     per = [0] * nranks
-    for d in range(nranks):
-        for a in range(1, 6):
-            if owner[a] != d:
-                continue
-            for b in range(6):
-                if owner[b] == src:
-                    per[d] += int(g[b, a])
+    for r2 in range(1, NR):
+        a, b = rope_sym(r2), rope_prev(r2)
+        for r in range(NR):
+            if rope_sym(r) == b and owner[r] == src:
+                per[owner[r2]] += int(g[r, a])
     return per
 
 
@@ -59,11 +78,26 @@ class ShardedBwt(HipBwt):
         super().__init__(sorting_order, device)
         self.rank, self.nranks = rank, nranks
         self.owner = list(owners) if owners is not None else default_owners(nranks)
-        arr = (C.c_int * 6)(*self.owner)
+        assert self.L.rb2_hip_num_subropes() == NR and len(self.owner) == NR
+        arr = (C.c_int * NR)(*self.owner)
         self.L.rb2_hip_shard_setup(self.h, rank, nranks, arr)
 
     def owned(self):
-        return [b for b in range(6) if self.owner[b] == self.rank]
+        """pieces held by this rank"""
+        return [r for r in range(NR) if self.owner[r] == self.rank]
+
+    def piece(self, r):
+        """symbols of piece r as seen by this rank (empty unless owned).  rb2_hip_download_rope(b) returns
+        the owned pieces of rope b back to back; their sizes are column sums of the count matrix."""
+        b = rope_sym(r)
+        whole = self.rope(b)
+        c = self.counts()
+        off = 0
+        for x in range(rope_prev(r) if b else 0):
+            if self.owner[rope_of(b, x)] == self.rank:
+                off += int(c[x, b])
+        n = int(c[rope_prev(r), b]) if b else int(c[0].sum())
+        return whole[off:off + n] if self.owner[r] == self.rank else whole[:0]
 
     # staging hooks used when the collective runs on host memory (gloo)
     def stage_out(self, host_ptr, dev_ptr, nbytes):
@@ -73,14 +107,14 @@ class ShardedBwt(HipBwt):
         self.L.rb2_hip_memcpy(self.h, dev_ptr, host_ptr, nbytes, 0)
 
     def batch_protocol(self, dev_ptr, nbytes, send_ptr_of, recv_ptr_of):
-        """Generator: yields ('allreduce', int64[36]) and ('alltoall', send_counts, recv_counts);
+        """Generator: yields ('allreduce', int64[NR*6]) and ('alltoall', send_counts, recv_counts);
         expects the reduced matrix to be sent back for the former.  ``send_ptr_of(n_records)`` /
         ``recv_ptr_of(n_records)`` return device pointers of buffers with that capacity."""
         L, h = self.L, self.h
         rounds = L.rb2_hip_shard_begin(h, nbytes, dev_ptr)
         cap = L.rb2_hip_shard_capacity(h)
         send_ptr, recv_ptr = send_ptr_of(cap), recv_ptr_of(cap)
-        loc = np.zeros(36, np.int64)
+        loc = np.zeros(NR * 6, np.int64)
         for r in range(rounds):
             L.rb2_hip_shard_counts(h, r, loc.ctypes.data)
             g = yield ("allreduce", loc.copy())
@@ -243,8 +277,28 @@ class VirtualCluster:
     def counts(self):
         return self.ranks[0].counts()
 
-    def rope(self, b):
-        return self.ranks[self.ranks[0].owner[b]].rope(b)
-
     def rope_rle(self, b):
-        return self.ranks[self.ranks[0].owner[b]].rope_rle(b)
+        """rope b = its pieces in the order x = $,A,C,G,T,N, each fetched from its owner.  A rank returns
+        its owned pieces of rope b back to back, so consecutive pieces with one owner are one download."""
+        own = self.ranks[0].owner
+        parts = {k: self.ranks[k].rope_rle(b) for k in set(own[r] for r in range(NR) if rope_sym(r) == b)}
+        if len(parts) == 1:
+            return next(iter(parts.values()))
+        c = self.counts()
+        cum = {k: np.cumsum(v >> 3, dtype=np.int64) for k, v in parts.items()}   # device leaves hold 1-byte runs only
+        out, pos, syms = [], {k: 0 for k in parts}, {k: 0 for k in parts}
+        for r in range(NR):
+            if rope_sym(r) != b:
+                continue
+            n, k = int(c[rope_prev(r), b]), own[r]     # rows of piece (b,x) = number of b's in rope x
+            if n == 0:
+                continue
+            syms[k] += n
+            i = int(np.searchsorted(cum[k], syms[k], side="left")) + 1
+            assert cum[k][i - 1] == syms[k], "piece boundary inside a run"
+            out.append(parts[k][pos[k]:i]); pos[k] = i
+        return np.concatenate(out) if out else np.zeros(0, np.uint8)
+
+    def rope(self, b):
+        from .hipbwt import expand_runs
+        return expand_runs(self.rope_rle(b))

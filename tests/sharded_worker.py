@@ -37,23 +37,39 @@ def main():
             comm.insert_multi_dev(p, len(buf))
             bwt.dev_free(p)
             assert np.array_equal(bwt.counts(), o.counts()), "rank %d: count matrix differs" % rank
-        for b in bwt.owned():
-            assert np.array_equal(bwt.rope(b), o.rope(b)), "rank %d: rope %d differs" % (rank, b)
-        for b in range(6):
-            if b not in bwt.owned():
-                assert len(bwt.rope_rle(b)) == 0
+        c = o.counts()
+        for r in range(sharded.NR):
+            b, x = sharded.rope_sym(r), sharded.rope_prev(r)
+            lo = int(c[:x, b].sum()) if b else 0                    # piece (b,x) = the b-symbols of rope x
+            n = int(c[x, b]) if b else int(c[0].sum())
+            want = o.rope(b)[lo:lo + n]
+            if r in bwt.owned():
+                assert np.array_equal(bwt.piece(r), want), "rank %d: piece %d differs" % (rank, r)
+            else:
+                assert len(bwt.piece(r)) == 0
         print("rank %d/%d so %d owned %s ok" % (rank, n, so, bwt.owned()))
     else:
         owner = sharded.default_owners(n)
+        NR, sym, prev = sharded.NR, sharded.rope_sym, sharded.rope_prev
         rng = np.random.RandomState(7)                      # same matrices on every rank
-        mats = [rng.randint(0, 40, size=(6, 6)).astype(np.int64) for _ in range(5)]
+        mats = [rng.randint(0, 12, size=(NR, 6)).astype(np.int64) for _ in range(5)]
+
+        def plan(src, dst, g):
+            """records src sends to dst, in the engine's order: tagged (round-less) (r, a, index)"""
+            out = []
+            for r2 in range(1, NR):
+                if owner[r2] != dst: continue
+                a, b = sym(r2), prev(r2)
+                for r in range(NR):
+                    if sym(r) != b or owner[r] != src: continue
+                    out += [(r, a, i) for i in range(int(g[r, a]))]
+            return out
 
         class Toy:
             """stands in for ShardedBwt: host memory plays the device"""
             def __init__(self):
                 self.rank, self.nranks, self.owner = rank, n, owner
                 self.keep = []
-                self.received = []
             def dev_alloc(self, nb):
                 a = np.zeros(nb, np.uint8); self.keep.append(a); return a.ctypes.data
             def dev_free(self, p):
@@ -64,42 +80,29 @@ def main():
                 import ctypes; ctypes.memmove(dev_ptr, host_ptr, nb)
             def batch_protocol(self, dev_ptr, nbytes, send_ptr_of, recv_ptr_of):
                 import ctypes
-                cap = 6 * 6 * 40 * n
+                cap = NR * 6 * 12
                 sp, rp = send_ptr_of(cap), recv_ptr_of(cap)
-                for r, g in enumerate(mats):
-                    loc = np.zeros((6, 6), np.int64)
-                    for b in range(6):
-                        if owner[b] == rank:
-                            loc[b] = g[b]
+                for rnd, g in enumerate(mats):
+                    loc = np.zeros((NR, 6), np.int64)
+                    for r in range(NR):
+                        if owner[r] == rank:
+                            loc[r] = g[r]
                     tot = yield ("allreduce", loc.reshape(-1).copy())
-                    assert np.array_equal(tot.reshape(6, 6), g)
-                    # records tagged (round, b, a, index), written in the engine's send layout
-                    recs = []
-                    for d in range(n):
-                        for a in range(1, 6):
-                            if owner[a] != d: continue
-                            for b in range(6):
-                                if owner[b] != rank: continue
-                                for i in range(int(g[b, a])):
-                                    recs.append((r, b, a, i))
+                    assert np.array_equal(tot.reshape(NR, 6), g)
+                    recs = [(rnd,) + t for d in range(n) for t in plan(rank, d, g)]
                     arr = np.zeros((len(recs), 4), np.int64)
                     if recs: arr[:] = recs
                     raw = arr.view(np.uint8).reshape(-1)
                     ctypes.memmove(sp, raw.ctypes.data, len(raw)) if len(raw) else None
                     sc = sharded.exchange_layout(owner, n, rank, g)
                     rc = [sharded.exchange_layout(owner, n, s, g)[rank] for s in range(n)]
+                    assert sc == [len(plan(rank, d, g)) for d in range(n)]
                     yield ("alltoall", sc, rc)
                     tot_r = sum(rc)
                     got = np.zeros((tot_r, 4), np.int64)
                     if tot_r: ctypes.memmove(got.ctypes.data, rp, tot_r * 32)
-                    want = []
-                    for s in range(n):
-                        for a in range(1, 6):
-                            if owner[a] != rank: continue
-                            for b in range(6):
-                                if owner[b] != s: continue
-                                want += [(r, b, a, i) for i in range(int(g[b, a]))]
-                    assert got.tolist() == [list(w) for w in want], "round %d: records out of place" % r
+                    want = [(rnd,) + t for s in range(n) for t in plan(s, rank, g)]
+                    assert got.tolist() == [list(w) for w in want], "round %d: records out of place" % rnd
 
         toy = Toy()
         comm = sharded.TorchComm(toy)

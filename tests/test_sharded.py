@@ -21,18 +21,52 @@ def launch(n, args, port):
     return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
 
 
+def test_subrope_indexing():
+    from ropebwt2_amd.sharded import NR, rope_sym, rope_prev, rope_of
+    assert NR == 31 and rope_sym(0) == 0 and rope_prev(0) == 0
+    seen = set()
+    for b in range(1, 6):
+        for x in range(6):
+            r = rope_of(b, x)
+            assert 1 <= r < NR and rope_sym(r) == b and rope_prev(r) == x
+            seen.add(r)
+    assert len(seen) == 30
+    # pieces of one rope are contiguous and ordered by x: concatenating pieces in index order gives rope order
+    assert [rope_sym(r) for r in range(NR)] == sorted(rope_sym(r) for r in range(NR))
+
+
 def test_exchange_layout_is_consistent():
-    from ropebwt2_amd.sharded import default_owners, exchange_layout
+    from ropebwt2_amd.sharded import NR, default_owners, exchange_layout, rope_sym, rope_prev
     rng = np.random.RandomState(0)
-    for n in (1, 2, 3, 4, 8):
+    for n in (1, 2, 3, 4, 8, 16, 20):
         owner = default_owners(n)
-        assert len(owner) == 6 and max(owner) < n
-        g = rng.randint(0, 1000, size=(6, 6))
+        assert len(owner) == NR and max(owner) < n
+        if n <= 16:
+            assert len(set(owner)) == n                    # every rank up to 16 carries load
+        g = rng.randint(0, 1000, size=(NR, 6))
         sent = np.array([exchange_layout(owner, n, s, g) for s in range(n)])
-        # everything that inserts a symbol 1..5 is sent exactly once, to the owner of that rope
+        # everything that inserts a symbol 1..5 is sent exactly once, to the owner of piece (a, b)
         assert sent.sum() == g[:, 1:].sum()
         for d in range(n):
-            assert sent[:, d].sum() == sum(g[:, a].sum() for a in range(1, 6) if owner[a] == d)
+            want = 0
+            for r in range(NR):
+                for a in range(1, 6):
+                    r2 = 1 + (a - 1) * 6 + rope_sym(r)
+                    if owner[r2] == d:
+                        want += g[r, a]
+            assert sent[:, d].sum() == want
+
+
+def test_default_owners_balance_dna():
+    """uniform DNA: 16 heavy pieces; the heaviest rank holds at most ceil(16/n) of them"""
+    from ropebwt2_amd.sharded import default_owners, rope_of
+    for n in (2, 4, 8, 16):
+        owner = default_owners(n)
+        load = [0] * n
+        for b in range(1, 5):
+            for x in range(1, 5):
+                load[owner[rope_of(b, x)]] += 1
+        assert max(load) == -(-16 // n) and min(load) == 16 // n
 
 
 @pytest.mark.parametrize("n", [2, 3])
@@ -63,9 +97,9 @@ def test_virtual_ranks_match_oracle(hip, so, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [6, 8])
-def test_virtual_ranks_with_idle_ranks(hip, n):
-    """more ranks than ropes with load: ranks >= 4 own nothing but take part in every collective"""
+@pytest.mark.parametrize("n", [6, 8, 18])
+def test_virtual_ranks_many(hip, n):
+    """8 ranks: two heavy pieces each; 18 ranks: ranks >= 16 own nothing but take part in every collective"""
     from ropebwt2_amd.sharded import VirtualCluster
     codes = H.splitmix_bases(6000, 50, seed=21)
     reads = H.repetitive_reads(1200, seed=33)
