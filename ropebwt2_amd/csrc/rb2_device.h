@@ -96,6 +96,15 @@ struct ChunkPart { uint32_t sum[6]; int32_t mx, mn; };
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// segment lookup in a monotone table tab[0..NR] for a WAVE-UNIFORM value v: the s with tab[s] <= v < tab[s+1].
+// All 64 lanes must call it together.
+template <class T> __device__ __forceinline__ int seg_of(const T *tab, uint64_t v)
+{
+	const int l = threadIdx.x & 63;
+	const T e = tab[l < NR ? l + 1 : NR];
+	return __popcll(__ballot(l < NR && v >= (uint64_t)e));
+}
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 template <typename T> __device__ __forceinline__ T wave_incl_add(T v)

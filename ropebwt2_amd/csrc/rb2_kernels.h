@@ -137,8 +137,7 @@ struct TileCtx { int b; uint64_t lt, base, segstart, segend; };
 __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileCtx &t)
 {
 	if (tile >= sg.tile0[NR]) return false;
-	int b = 0;
-	while (tile >= sg.tile0[b+1]) ++b;
+	const int b = seg_of(sg.tile0, tile);                  // wave-uniform: one load + ballot instead of a walk over NR entries
 	t.b = b; t.lt = tile - sg.tile0[b];
 	t.segstart = sg.start[b]; t.segend = sg.start[b] + sg.cnt[b];
 	t.base = t.segstart + t.lt * STILE;

@@ -73,8 +73,7 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 	const int ln = lane_id();
 	const uint64_t gleaf = (uint64_t)blockIdx.x * MW + wv;
 	if (gleaf >= ctl->lf0[NR]) return;
-	int b = 0;
-	while (gleaf >= ctl->lf0[b+1]) ++b;
+	const int b = seg_of(ctl->lf0, gleaf);
 	const uint64_t j = gleaf - ctl->lf0[b];
 	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
 	const uint64_t segs = ctl->seg[side].start[b];
