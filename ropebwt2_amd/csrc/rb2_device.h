@@ -24,6 +24,7 @@ namespace rb2 {
 constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
 constexpr int TL     = 4;             // output leaves per merge block (one wave each)
 constexpr int SB     = 32;            // leaves per superblock
+constexpr int LEAFB  = LEAF / 2;       // bytes per leaf: 4 bits per symbol
 constexpr int STILE  = 512;           // strings per string tile
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
 constexpr int ZBLOCK = 16384;         // bytes per block when locating sentinels
@@ -179,11 +180,30 @@ __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane ? (~0ull >> 
 // RLO / input order: $ A C G T N;  RCLO: $ T G C A N
 __device__ __forceinline__ int sym_ord(int a, int is_comp) { return (is_comp && a >= 1 && a <= 4) ? 5 - a : a; }
 
-// counts of all six symbols in [0,p) of a rope on pool side `pv` (rope_rank1a, rope.h:45):
-// superblock prefix + leaf-relative prefix + scan of one leaf (rle.c:147-158).  The leaf is read
-// 16 bytes at a time (slots are zero padded to 16 bytes; a zero byte is a run of length 0); chunks
-// that end before p are added wholesale.  Symbols 0..4 are counted in 12-bit fields of one u64,
-// N follows from the position.
+// symbol counts of packed 4-bit symbols.  Valid symbols are 0..5 = 000..101, so with the bit planes
+// b0,b1,b2 (one bit per nibble): #3 = |b0&b1|, #2 = |b1|-#3, #5 = |b0&b2|, #4 = |b2|-#5, #1 = |b0|-#3-#5.
+struct NibAcc { uint32_t p0 = 0, p1 = 0, p2 = 0, p01 = 0, p02 = 0; };
+__device__ __forceinline__ void nib_acc(NibAcc &A, uint64_t x, uint64_t M /* 0x1111.. of the nibbles to count */)
+{
+	const uint64_t b0 = x & M, b1 = (x >> 1) & M, b2 = (x >> 2) & M;
+	A.p0 += (uint32_t)__popcll(b0); A.p1 += (uint32_t)__popcll(b1); A.p2 += (uint32_t)__popcll(b2);
+	A.p01 += (uint32_t)__popcll(b0 & b1); A.p02 += (uint32_t)__popcll(b0 & b2);
+}
+__device__ __forceinline__ void nib_finish(const NibAcc &A, uint32_t n, uint32_t c[6])
+{
+	c[3] = A.p01; c[2] = A.p1 - A.p01; c[5] = A.p02; c[4] = A.p2 - A.p02; c[1] = A.p0 - A.p01 - A.p02;
+	c[0] = n - (c[1] + c[2] + c[3] + c[4] + c[5]);
+}
+__device__ __forceinline__ void nib_counts(uint64_t x, uint64_t VM, uint32_t n, uint32_t c[6])
+{
+	NibAcc A;
+	nib_acc(A, x, VM & 0x1111111111111111ull);
+	nib_finish(A, n, c);
+}
+
+// counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
+// superblock prefix + leaf-relative prefix + a scan of the packed leaf up to p, 32 symbols per load
+// (the reference walks the runs of one leaf, rle.c:147-158).
 __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
 {
 	if (p >= rp.n) {
@@ -197,37 +217,25 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	const LeafMeta m = pv.meta[gl];
 #pragma unroll
 	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s];
-	const uint4 *q = (const uint4*)(pv.data + gl * (uint64_t)LEAF);
-	uint32_t acc = 0;
-	uint64_t pk = 0;
-	while (acc < off) {
-		const uint4 v = *q++;
-		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-		uint32_t tot = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) tot += ((((w[k] >> 3) & 0x1f1f1f1fu) * 0x01010101u) >> 24);
-		const uint32_t room = off - acc;                      // symbols still to count
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const uint32_t bt = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu, len = bt >> 3, s = bt & 7;
-			if (tot <= room) { if (s < 5) pk += (uint64_t)len << (12 * s); }
-		}
-		if (tot <= room) { acc += tot; continue; }
-		// the chunk that holds position p: walk its runs
-		uint32_t a2 = acc;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const uint32_t bt = (w[i >> 2] >> ((i & 3) * 8)) & 0xffu, len = bt >> 3, s = bt & 7;
-			const uint32_t take = a2 < off ? min(len, off - a2) : 0u;
-			if (s < 5) pk += (uint64_t)take << (12 * s);
-			a2 += len;
-		}
-		acc = off;
+	const uint4 *q = (const uint4*)(pv.data + gl * (uint64_t)LEAFB);
+	const uint64_t M1 = 0x1111111111111111ull;
+	NibAcc A;
+	const uint32_t nfull = off >> 5, rem = off & 31;
+	for (uint32_t k = 0; k < nfull; ++k) {
+		const uint4 v = q[k];
+		nib_acc(A, (uint64_t)v.y << 32 | v.x, M1);
+		nib_acc(A, (uint64_t)v.w << 32 | v.z, M1);
 	}
-	uint32_t sum5 = 0;
+	if (rem) {
+		const uint4 v = q[nfull];
+		const uint32_t r1 = min(rem, 16u), r2 = rem - r1;
+		nib_acc(A, (uint64_t)v.y << 32 | v.x, r1 >= 16 ? M1 : M1 & ((1ull << (4 * r1)) - 1ull));
+		if (r2) nib_acc(A, (uint64_t)v.w << 32 | v.z, M1 & ((1ull << (4 * r2)) - 1ull));
+	}
+	uint32_t c[6];
+	nib_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 5; ++s) { const uint32_t v = (uint32_t)(pk >> (12 * s)) & 0xfffu; out[s] += v; sum5 += v; }
-	out[5] += off - sum5;
+	for (int s = 0; s < 6; ++s) out[s] += c[s];
 }
 
 } // namespace rb2

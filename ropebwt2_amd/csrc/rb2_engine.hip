@@ -41,7 +41,7 @@ struct Pool {
 		if (leaves <= cap_leaves) return;
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
-		data.ensure(nl * LEAF, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st);
+		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st);
 		cap_leaves = nl;
 	}
 	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p}; }
@@ -78,7 +78,7 @@ struct rb2_hip_s {
 	int rank = 0, nranks = 1; int owner[NR] = {0};
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;
-	int merge_dbg = 0;
+	DevBuf<uint8_t> xstage; DevBuf<uint16_t> xnb;   // k_export staging
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
 
@@ -231,7 +231,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p, h->merge_dbg); }
+	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -287,7 +287,6 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	rb2_hip_t *h = new rb2_hip_s();
 	h->dev = device; h->so = sorting_order;
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
-	h->merge_dbg = getenv("RB2_HIP_MERGE_DBG") ? atoi(getenv("RB2_HIP_MERGE_DBG")) : 0;
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -313,7 +312,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->TQ.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
-	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release();
+	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();
 	HIPCHK(hipStreamDestroy(h->st));
 	delete h;
 }
@@ -347,14 +346,31 @@ void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
 	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) c[rope_sym(r) * 6 + a] += (int64_t)h->h_rope[r].cnt[a];   // rope b = its pieces (b,x)
 }
 
-static void fetch_meta(rb2_hip_t *h, int r, std::vector<LeafMeta> &m)
+/* run-length export of sub-rope r in chunks of CH leaves: k_export writes one 43+3 byte per run into a staging
+ * buffer (slot stride LEAF) + the byte count of every leaf; dst == NULL only counts.  Returns the bytes. */
+static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst)
 {
+	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB of run bytes)
 	const RopeDesc &d = h->h_rope[r];
-	m.resize(d.nleaves);
-	if (d.nleaves) {
-		HIPCHK(hipMemcpyAsync(m.data(), h->pool[h->side].meta.p + d.leaf0, d.nleaves * sizeof(LeafMeta), hipMemcpyDeviceToHost, h->st));
+	if (d.nleaves == 0) return 0;
+	const uint64_t ch = std::min<uint64_t>(CH, d.nleaves);
+	h->xstage.ensure(ch * LEAF); h->xnb.ensure(ch);
+	std::vector<uint8_t> stage(dst ? ch * LEAF : 0);
+	std::vector<uint16_t> nb(ch);
+	int64_t k = 0;
+	for (uint64_t l0 = 0; l0 < d.nleaves; l0 += CH) {
+		const uint64_t nl = std::min<uint64_t>(CH, d.nleaves - l0);
+		hipLaunchKernelGGL(k_export, dim3(cdiv(nl, MW)), dim3(256), 0, h->st, h->pool[h->side].view(), d.leaf0, d.n, l0, (uint32_t)nl, h->xstage.p, h->xnb.p);
+		HIPCHK(hipGetLastError());
+		if (dst) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nl * LEAF, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nl * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
+		for (uint64_t i = 0; i < nl; ++i) {
+			if (dst) memcpy(dst + k, stage.data() + i * LEAF, nb[i]);
+			k += nb[i];
+		}
 	}
+	return k;
 }
 
 /* rope b = its pieces (b,x) in the order x = $,A,C,G,T,N (rb2_device.h) */
@@ -362,34 +378,15 @@ int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	int64_t t = 0;
-	for (int r = 0; r < NR; ++r) {
-		if (rope_sym(r) != b) continue;
-		std::vector<LeafMeta> m;
-		fetch_meta(h, r, m);
-		for (auto &x : m) t += x.nbytes;
-	}
+	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) t += export_piece(h, r, nullptr);
 	return t;
 }
 
 int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB)
-	std::vector<uint8_t> stage;
 	int64_t k = 0;
-	for (int r = 0; r < NR; ++r) {
-		if (rope_sym(r) != b) continue;
-		std::vector<LeafMeta> m;
-		fetch_meta(h, r, m);
-		const RopeDesc &d = h->h_rope[r];
-		if (stage.size() < std::min<uint64_t>(CH, d.nleaves) * LEAF) stage.resize(std::min<uint64_t>(CH, d.nleaves) * LEAF);
-		for (uint64_t l0 = 0; l0 < d.nleaves; l0 += CH) {
-			const uint64_t nl = std::min<uint64_t>(CH, d.nleaves - l0);
-			HIPCHK(hipMemcpyAsync(stage.data(), h->pool[h->side].data.p + (d.leaf0 + l0) * LEAF, nl * LEAF, hipMemcpyDeviceToHost, h->st));
-			HIPCHK(hipStreamSynchronize(h->st));
-			for (uint64_t i = 0; i < nl; ++i) { memcpy(dst + k, stage.data() + i * LEAF, m[l0 + i].nbytes); k += m[l0 + i].nbytes; }
-		}
-	}
+	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) k += export_piece(h, r, dst + k);
 	return k;
 }
 
@@ -420,7 +417,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			tot[b][c] += l;
 		}
 	}
-	// pass 2: decode again and re-chunk into LEAF-symbol leaves of 1-byte runs, cutting rope b into its pieces
+	// pass 2: decode again into LEAF-symbol leaves of packed 4-bit symbols, cutting rope b into its pieces
 	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
 	RopeDesc rp[NR];
 	uint64_t leaf = 0;
@@ -436,10 +433,10 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			const bool keep = h->nranks == 1 || h->owner[r] == h->rank;   // sharded: other ranks' pieces are only counted
 			RopeDesc &d = rp[r];
 			d.leaf0 = leaf; d.sb0 = leaf / SB;
-			data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
+			data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
 			LeafMeta cur; memset(&cur, 0, sizeof(cur));
 			uint32_t fill = 0; uint8_t *slot = nullptr;
-			auto open_leaf = [&]() { data.resize(data.size() + LEAF); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAF; memset(&cur, 0, sizeof(cur)); fill = 0; };
+			auto open_leaf = [&]() { data.resize(data.size() + LEAFB); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAFB; memset(&cur, 0, sizeof(cur)); fill = 0; };
 			auto close_leaf = [&]() { meta.back() = cur; ++d.nleaves; slot = nullptr; };
 			while (quota > 0) {
 				if (l == 0) {
@@ -452,9 +449,12 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 				d.cnt[c] += part; d.n += part;
 				while (keep && part > 0) {
 					if (!slot) open_leaf();
-					const int64_t take = std::min<int64_t>(std::min<int64_t>(part, 15), LEAF - fill);
-					slot[cur.nbytes++] = (uint8_t)(take << 3 | c);
-					cur.c[c] += (uint16_t)take; fill += (uint32_t)take; part -= take;
+					const int64_t take = std::min<int64_t>(part, LEAF - fill);
+					int64_t t = take;
+					if (t && (fill & 1)) { slot[fill >> 1] |= (uint8_t)(c << 4); ++fill; --t; }
+					if (t >= 2) { memset(slot + (fill >> 1), c | c << 4, (size_t)(t >> 1)); fill += (uint32_t)(t & ~1ll); t &= 1; }
+					if (t) { slot[fill >> 1] |= (uint8_t)c; ++fill; }
+					cur.c[c] += (uint16_t)take; part -= take;
 					if (fill == LEAF) close_leaf();
 				}
 			}
@@ -464,7 +464,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		}
 		if (l != 0 || (p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
 	}
-	data.resize((size_t)leaf * LEAF); meta.resize((size_t)leaf);
+	data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
 	const int sd = h->side;
 	h->pool[sd].ensure(leaf + SB, false, h->st);
 	if (leaf) {
