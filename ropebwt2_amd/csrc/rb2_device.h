@@ -75,6 +75,14 @@ struct Ctl {
 struct ShardRec { uint64_t l, u, w; uint32_t id, pad; };   // one string's state on the wire (32 B)
 struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 
+struct LeafDesc {           // work order of one output leaf, written by k_part, read by k_merge (32 B)
+	uint64_t i0;            // position (in the old sub-rope) of the first old symbol the leaf consumes = j*LEAF - q0
+	uint64_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL
+	uint64_t gl;            // leaf slot on the new pool side
+	uint32_t oleaf0;        // first leaf slot of the sub-rope on the old pool side
+	uint16_t ni, nvalid;    // new symbols / symbols in the leaf
+};
+
 struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
 
 struct TileRec {            // per string tile, written by k_sym

@@ -62,7 +62,8 @@ struct rb2_hip_s {
 	// per-string state
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
-	DevBuf<uint32_t> ID[2], SLOT, PA, PGA, TQ;
+	DevBuf<uint32_t> ID[2], SLOT, PA, PGA;
+	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<ChunkPart> cpart;
 	DevBuf<Cnt6> sbtot, sbpart;
@@ -185,7 +186,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	const uint64_t leaves_ub = (n_tot + len) / LEAF + NR * (SB + 1);
 	h->pool[h->side].ensure(leaves_ub, true, st);
 	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
-	h->TQ.ensure(leaves_ub + NR + 16);
+	h->LD.ensure(leaves_ub + NR + 16);
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{
 		Scope sc(h, RB2_K_INIT, 0);
@@ -229,9 +230,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 256)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->TQ.p); }
+	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, sd, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->TQ.p); }
+	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -309,7 +310,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->zblk.release();
-	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->TQ.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
+	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();

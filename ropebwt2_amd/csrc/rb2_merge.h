@@ -29,34 +29,36 @@ namespace rb2 {
 
 constexpr int MW = 4;                       // waves (= output leaves) per block
 
-__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolView oldp, PoolView newp,
-		const uint64_t *INS_E, const uint8_t *INS_A, uint16_t *RKREL, const uint32_t *TQ)
+__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ uint64_t lds[MW][64];
+	__shared__ uint64_t lds[MW][64 + 68];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv];
+	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;
 	const int ln = lane_id();
 	const uint64_t gleaf = (uint64_t)blockIdx.x * MW + wv;
 	if (gleaf >= ctl->lf0[NR]) return;
-	const int b = seg_of(ctl->lf0, gleaf);
-	const uint64_t j = gleaf - ctl->lf0[b];
-	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
-	const uint64_t segs = ctl->seg[side].start[b];
-	const uint32_t q0 = TQ[gleaf + b], q1 = TQ[gleaf + b + 1];
-	const uint64_t o0 = j * LEAF;
-	const int nvalid = (int)min((uint64_t)LEAF, nrp.n - o0);
-	const int ni = (int)(q1 - q0);
-	const uint64_t i0 = o0 - q0;                                // first old symbol this leaf consumes
+	const LeafDesc d = LD[gleaf];
+	const int nvalid = d.nvalid, ni = d.ni;
+	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this leaf
+	const uint32_t sh0 = (uint32_t)d.i0 & 15u;
+	const uint32_t nw = (sh0 + nold + 15) >> 4;                 // words of the old side they live in (<= 65)
 
-	// ---- 1. new symbols of this leaf, by output position
+	// ---- 1. new symbols of this leaf, by output position; the old words it draws from
 	LX[ln] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+	const uint64_t *ob = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 * (LEAFB / 8) + (d.i0 >> 4));
+	uint64_t wa = 0, wb = 0;
+	if ((uint32_t)ln < nw) wa = ob[ln];
+	if ((uint32_t)ln + 64 < nw) wb = ob[ln + 64];
 	for (int jj = ln; jj < ni; jj += 64) {
-		const uint64_t e = INS_E[segs + q0 + jj];
-		const uint32_t a = INS_A[segs + q0 + jj];
-		const uint32_t p = (uint32_t)(e + q0 + jj - o0);          // final position = E[q] + q
+		const uint64_t e = INS_E[d.ins0 + jj];
+		const uint32_t a = INS_A[d.ins0 + jj];
+		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the leaf
 		atomicOr((uint32_t*)LX + (p >> 3), (8u | a) << ((p & 7) * 4));
 	}
+	LO[ln] = wa;
+	if (ln < 4) LO[64 + ln] = wb;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	const uint64_t X = LX[ln];
 
@@ -69,14 +71,12 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 	const uint32_t nonins = (uint32_t)myvalid - kins;
 	const uint32_t oinc = dpp_incl_add(nonins);
 	const uint32_t iinc = dpp_incl_add(kins);
-	uint64_t old = 0;
-	if (nonins) {
-		const uint64_t op = i0 + (oinc - nonins);                 // position in the old sub-rope
-		const uint64_t *ob = (const uint64_t*)(oldp.data + orp.leaf0 * (uint64_t)LEAFB) + (op >> 4);
-		const uint32_t sh = (uint32_t)(op & 15) * 4;
-		const uint64_t w0 = ob[0];
-		old = w0 >> sh;
-		if (sh + nonins * 4 > 64) old |= ob[1] << (64 - sh);      // sh > 0 here
+	uint64_t old;
+	{
+		const uint32_t op = sh0 + (oinc - nonins);                // first old symbol of this lane, in nibbles of LO[]
+		const uint32_t k = op >> 4, sh = (op & 15) * 4;
+		const uint64_t w0 = LO[k], w1 = LO[k + 1];               // k + 1 <= 65
+		old = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
 	}
 
 	// ---- 3. deal the old symbols to the not-new positions
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 	const uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
 	if (__any(kins != 0)) {
 		uint64_t f = F; uint32_t n = 0;
-		uint16_t *dst = RKREL + segs + q0 + (iinc - kins);
+		uint16_t *dst = RKREL + d.ins0 + (iinc - kins);
 		while (f) {                                            // few iterations: new symbols are sparse in steady state
 			const int i4 = __builtin_ctzll(f) - 3;
 			f &= f - 1;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, int side, PoolVie
 			dst[n++] = (uint16_t)(((w2 >> ((a & 1) * 16)) & 0xffffu) + cnt);
 		}
 	}
-	const uint64_t gl = nrp.leaf0 + j;
+	const uint64_t gl = d.gl;
 	if (ln == 63) {
 		LeafMeta m;
 		m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
