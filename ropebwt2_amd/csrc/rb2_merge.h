@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	const uint64_t F = X & 0x8888888888888888ull;
 	const uint32_t kins = (uint32_t)__popcll(F);
 	const uint32_t nonins = (uint32_t)myvalid - kins;
-	const uint32_t oinc = dpp_incl_add(nonins);
-	const uint32_t iinc = dpp_incl_add(kins);
+	const uint32_t sc2 = dpp_incl_add(nonins | kins << 16);     // both prefix sums in one scan (each < 2^11)
+	const uint32_t oinc = sc2 & 0xffffu, iinc = sc2 >> 16;
 	uint64_t old;
 	{
 		const uint32_t op = sh0 + (oinc - nonins);                // first old symbol of this lane, in nibbles of LO[]
@@ -80,17 +80,32 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	}
 
 	// ---- 3. deal the old symbols to the not-new positions
-	const uint64_t G = ~X & VM;                                 // bit 4i+3: position i takes an old symbol
-	const uint32_t glo = (uint32_t)G, ghi = (uint32_t)(G >> 32);
-	uint32_t olo = 0, ohi = 0;
+	uint64_t out;
+	if (!__any(kins > 5)) {
+		// steady state: few new symbols per lane.  Open one gap per new symbol, in ascending position.
+		out = old;
+		uint64_t f = F;
+		while (__any(f != 0)) {
+			if (f) {
+				const uint64_t lm = (1ull << (__builtin_ctzll(f) - 3)) - 1ull;   // nibbles below the new symbol
+				f &= f - 1;
+				out = (out & lm) | ((out & ~lm) << 4);
+			}
+		}
+		out = (out & VM) | (X & 0x7777777777777777ull);
+	} else {
+		const uint64_t G = ~X & VM;                             // bit 4i+3: position i takes an old symbol
+		const uint32_t glo = (uint32_t)G, ghi = (uint32_t)(G >> 32);
+		uint32_t olo = 0, ohi = 0;
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const int nm = __builtin_amdgcn_sbfe(i < 8 ? glo : ghi, 4 * (i & 7) + 3, 1);   // -1: old symbol here
-		const uint32_t nib = (uint32_t)old & (uint32_t)nm & 15u;
-		if (i < 8) olo |= nib << (4 * i); else ohi |= nib << (4 * (i - 8));
-		old >>= (nm & 4);
+		for (int i = 0; i < 16; ++i) {
+			const int nm = __builtin_amdgcn_sbfe(i < 8 ? glo : ghi, 4 * (i & 7) + 3, 1);   // -1: old symbol here
+			const uint32_t nib = (uint32_t)old & (uint32_t)nm & 15u;
+			if (i < 8) olo |= nib << (4 * i); else ohi |= nib << (4 * (i - 8));
+			old >>= (nm & 4);
+		}
+		out = ((uint64_t)ohi << 32 | olo) | (X & 0x7777777777777777ull);
 	}
-	const uint64_t out = ((uint64_t)ohi << 32 | olo) | (X & 0x7777777777777777ull);
 
 	// ---- 4. counts of the leaf, leaf-relative ranks of the new symbols
 	uint32_t c[6];
