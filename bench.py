@@ -162,6 +162,10 @@ def main():
         p = bwt.dev_alloc(n * (L + 1))
         bwt.synth_reads(p, f, n, L, seed=42)
         bufs.append(p)
+    # capacity hint (rb2_hip_reserve): the job's size is known up front, as it is to `ropebwt2 -m`; without it
+    # the engine grows its buffers batch by batch (hipMalloc + copy + hipFree inside the timed region)
+    tot_syms = sum(n for _, n in steps) * (L + 1)
+    bwt.reserve(max(n for _, n in steps) * (L + 1), max(n for _, n in steps), tot_syms if not sharded else int(tot_syms * 1.25 / world))
     bwt.sync()
     bwt.profile_get(reset=True)
     barrier()

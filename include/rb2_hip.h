@@ -67,6 +67,11 @@ int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst);
  * host ropes (mr_restore, mrope.c:145-160; rope_restore, rope.c:308-318). */
 void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6]);
 
+/* optional capacity hint (like the reference sizing its buffers from -m, main.c:136): make room for batches
+ * of up to batch_bytes bytes / batch_strings strings and an index of total_symbols symbols, so that
+ * rb2_hip_insert_multi* never has to grow (reallocate + copy) a buffer.  Any argument may be 0. */
+void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols);
+
 /* rank of all six symbols in [0,x) of rope b, computed on the device (rope_rank1a, rope.h:45) */
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
 

@@ -149,6 +149,16 @@ struct BatchState {
 	int cur = 0;                            // string array side
 };
 
+// per-string arrays + tile tables for batches of up to m strings
+void ensure_strings(rb2_hip_t *h, uint64_t m)
+{
+	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
+	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
+	const uint64_t nst = cdiv(m, STILE) + NR;
+	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
+}
+
 // split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284)
 void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 {
@@ -174,13 +184,10 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
 		HIPCHK(hipStreamSynchronize(st));      // hb / zero are stack/heap temporaries
 	}
-	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
-	h->A.ensure(m); h->INS_A.ensure(m);
+	ensure_strings(h, m);
 	B.nst_ub = cdiv(m, STILE) + NR;                           // string tiles, upper bound for every round
 	B.nsc = cdiv(B.nst_ub, SCHUNK);
 	if (B.nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
-	h->trec.ensure(B.nst_ub + 1); h->tsc.ensure(B.nst_ub + 2); h->cpart.ensure(B.nsc + 1);
 	uint64_t n_tot = 0;
 	for (int b = 0; b < NR; ++b) n_tot += h->h_rope[b].n;     // symbols held by THIS rank
 	const uint64_t leaves_ub = (n_tot + len) / LEAF + NR * (SB + 1);
@@ -654,6 +661,19 @@ void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int
 	if (total == 0) return;
 	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand);
 	HIPCHK(hipGetLastError());
+}
+
+void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (batch_bytes > 0) h->zblk.ensure(cdiv((uint64_t)batch_bytes, ZBLOCK) + 1);
+	if (batch_strings > 0) ensure_strings(h, (uint64_t)batch_strings);
+	if (total_symbols > 0) {
+		const uint64_t leaves = (uint64_t)total_symbols / LEAF + NR * (SB + 1);
+		h->pool[h->side].ensure(leaves, true, h->st);
+		h->pool[h->side ^ 1].ensure(leaves, false, h->st);
+		h->LD.ensure(leaves + NR + 16);
+	}
 }
 
 void rb2_hip_sync(rb2_hip_t *h) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }

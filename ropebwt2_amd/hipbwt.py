@@ -37,6 +37,7 @@ def load_hip_lib():
         "rb2_hip_download_rope": (i64, [vp, i32, vp]),
         "rb2_hip_load_ropes": (None, [vp, vp, vp]),
         "rb2_hip_rank1a": (None, [vp, i32, i64, vp]),
+        "rb2_hip_reserve": (None, [vp, i64, i64, i64]),
         "rb2_hip_num_subropes": (i32, []),
         "rb2_hip_shard_setup": (None, [vp, i32, i32, vp]),
         "rb2_hip_shard_begin": (i64, [vp, i64, vp]),
@@ -66,7 +67,7 @@ def load_hip_lib():
 ABI_SYMBOLS = [
     "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order",
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
-    "rb2_hip_download_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_dev_alloc",
+    "rb2_hip_download_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy",
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_sync", "rb2_hip_profile",
@@ -159,6 +160,9 @@ class HipBwt:
         ptrs = (C.c_void_p * 6)(*[a.ctypes.data if len(a) else None for a in arrs])
         lens = (C.c_int64 * 6)(*[len(a) for a in arrs])
         self.L.rb2_hip_load_ropes(self.h, ptrs, lens)
+
+    def reserve(self, batch_bytes=0, batch_strings=0, total_symbols=0):
+        self.L.rb2_hip_reserve(self.h, batch_bytes, batch_strings, total_symbols)
 
     def rank1a(self, b, x):
         c = np.zeros(6, np.int64)
