@@ -62,7 +62,7 @@ struct rb2_hip_s {
 	// per-string state
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
-	DevBuf<uint32_t> ID[2], SLOT, PA, PGA;
+	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<ChunkPart> cpart;
@@ -153,7 +153,7 @@ struct BatchState {
 void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->SLOT.ensure(m); h->PA.ensure(m); h->PGA.ensure(m);
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
 	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
@@ -171,18 +171,12 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		Scope sc(h, RB2_K_INIT, 0);
 		h->zblk.ensure(nzb + 1);
 		hipLaunchKernelGGL(k_count_zeros, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p);
-		std::vector<uint64_t> hb(nzb + 1);
-		HIPCHK(hipMemcpyAsync(hb.data(), h->zblk.p, nzb * 8, hipMemcpyDeviceToHost, st));
+		hipLaunchKernelGGL(k_zscan, dim3(1), dim3(SCHUNK), 0, st, h->zblk.p, nzb);
+		HIPCHK(hipMemcpyAsync(&m, h->zblk.p + nzb, 8, hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
-		for (unsigned i = 0; i < nzb; ++i) { uint64_t c = hb[i]; hb[i] = m; m += c; }   // 8 B per 16 KiB of input: host prefix
-		hb[nzb] = m;
-		HIPCHK(hipMemcpyAsync(h->zblk.p, hb.data(), (nzb + 1) * 8, hipMemcpyHostToDevice, st));
 		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { fprintf(stderr, "[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); abort(); }
 		h->START.ensure(m + 1);
-		const uint64_t zero = 0;
-		HIPCHK(hipMemcpyAsync(h->START.p, &zero, 8, hipMemcpyHostToDevice, st));
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
-		HIPCHK(hipStreamSynchronize(st));      // hb / zero are stack/heap temporaries
 	}
 	ensure_strings(h, m);
 	B.nst_ub = cdiv(m, STILE) + NR;                           // string tiles, upper bound for every round
@@ -235,7 +229,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->gcnt); }
 	{ Scope sc(h, RB2_K_PREP, units);
 	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
-			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SLOT.p, h->PA.p, h->PGA.p, h->SIZE.p); }
+			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
@@ -243,8 +237,8 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->SLOT.p, h->PA.p,
-			h->PGA.p, h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
+	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->trec.p, h->tsc.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
 	h->side ^= 1; B.cur ^= 1;
 }
 
@@ -317,7 +311,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->zblk.release();
-	h->SLOT.release(); h->PA.release(); h->PGA.release(); h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
+	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();

@@ -61,13 +61,30 @@ __global__ __launch_bounds__(256) void k_count_zeros(const uint8_t *s, uint64_t 
 	if (threadIdx.x == 0) blk[blockIdx.x] = tot;
 }
 
-// START[id+1] = position after the id-th sentinel; START[0] = 0 is written by the host
+// in-place exclusive scan of the per-block sentinel counts (one block); blk[n] = total = number of strings
+__global__ __launch_bounds__(SCHUNK) void k_zscan(uint64_t *blk, uint32_t n)
+{
+	__shared__ uint64_t s_w[16];
+	uint64_t run = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += SCHUNK) {
+		const uint32_t i = i0 + threadIdx.x;
+		const uint64_t v = i < n ? blk[i] : 0ull;
+		uint64_t tot;
+		const uint64_t ex = block_excl_add<uint64_t>(v, s_w, &tot);
+		if (i < n) blk[i] = run + ex;
+		run += tot;
+	}
+	if (threadIdx.x == 0) blk[n] = run;
+}
+
+// START[id+1] = position after the id-th sentinel; START[0] = 0
 __global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t len, const uint64_t *blkoff, uint64_t *START)
 {
 	__shared__ uint32_t s_w[4];
 	uint32_t w[16], c = 0;
 	const uint64_t base = (uint64_t)blockIdx.x * ZBLOCK + threadIdx.x * 64;
 	load64(s, len, base, w);
+	if (blockIdx.x == 0 && threadIdx.x == 0) START[0] = 0;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) c += zero_bytes(w[i]);
 	uint64_t id = blkoff[blockIdx.x] + block_excl_add<uint32_t>(c, s_w, (uint32_t*)0);
@@ -326,29 +343,30 @@ __global__ void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
 // k_prep
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_comp, PoolView oldp,
-		const uint64_t *L, const uint64_t *U, const uint8_t *A, const TileRec *trec, const TileScan *tsc,
-		uint64_t *INS_E, uint8_t *INS_A, uint32_t *SLOT, uint32_t *PA, uint32_t *PGA, uint64_t *SIZE)
+// Who is where inside a bucket: shared by k_prep (which needs the slot of every new symbol) and
+// k_advance (which recomputes the same numbers instead of reading them back from HBM).
+struct GroupLds {
+	uint64_t bal[8][6], head[8];                // per wave-chunk of the tile: lanes with symbol s / group heads
+	uint32_t cpre[9][6], tpre[6], popen[6], pnext[6];
+	uint32_t fopen;
+};
+
+// fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none)
+__device__ __forceinline__ void group_setup(GroupLds &G, const SegDesc &sg, const TileCtx &t, const uint8_t *A,
+		const TileRec *trec, const TileScan *tsc, int sym2[2], int flag2[2])
 {
-	__shared__ uint64_t s_bal[8][6], s_head[8];
-	__shared__ uint32_t s_cpre[9][6], s_tpre[6], s_popen[6], s_pnext[6];
-	__shared__ uint32_t s_fopen;
-	TileCtx t;
-	const SegDesc &sg = ctl->seg[side];
-	if (!tile_ctx(sg, blockIdx.x, t)) return;
 	const int ln = lane_id(), w = wave_id();
-	int sym2[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		int sym = 7; bool head = false;
-		if (k < t.segend) { const uint8_t a = A[k]; sym = a & 7; head = (a & 0x80) != 0; }
-		sym2[h] = sym;
+		int sym = 7, fl = 0; bool head = false;
+		if (k < t.segend) { const uint8_t a = A[k]; sym = a & 7; head = (a & 0x80) != 0; fl = a & 0x40; }
+		sym2[h] = sym; flag2[h] = fl;
 		const int c = h * 4 + w;
 #pragma unroll
-		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) s_bal[c][s] = bm; }
+		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) G.bal[c][s] = bm; }
 		uint64_t hm = __ballot(head);
-		if (ln == 0) s_head[c] = hm;
+		if (ln == 0) G.head[c] = hm;
 	}
 	__syncthreads();
 	if (threadIdx.x < 6) {
@@ -356,17 +374,64 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 		const uint32_t tile = blockIdx.x, t0 = sg.tile0[t.b], t1 = sg.tile0[t.b + 1];
 		const uint32_t segbase = tsc[t0].pre[s];
 		uint32_t run = 0;
-		for (int c = 0; c < 8; ++c) { s_cpre[c][s] = run; run += __popcll(s_bal[c][s]); }
-		s_cpre[8][s] = run;
-		s_tpre[s] = tsc[tile].pre[s] - segbase;
+		for (int c = 0; c < 8; ++c) { G.cpre[c][s] = run; run += __popcll(G.bal[c][s]); }
+		G.cpre[8][s] = run;
+		G.tpre[s] = tsc[tile].pre[s] - segbase;
 		const int lt = tsc[tile].lht, nt = tsc[tile].nht;
 		uint32_t po = 0;
 		if (lt >= (int)t0) po = tsc[lt].pre[s] - segbase + trec[lt].lhpre[s];
-		s_popen[s] = po;
-		s_pnext[s] = (nt < (int)t1) ? tsc[nt].pre[s] - segbase + trec[nt].fhpre[s] : tsc[t1].pre[s] - segbase;
-		if (s == 0) s_fopen = (lt >= (int)t0) ? (uint32_t)((lt - t0) * STILE + trec[lt].lh) : 0u;
+		G.popen[s] = po;
+		G.pnext[s] = (nt < (int)t1) ? tsc[nt].pre[s] - segbase + trec[nt].fhpre[s] : tsc[t1].pre[s] - segbase;
+		if (s == 0) G.fopen = (lt >= (int)t0) ? (uint32_t)((lt - t0) * STILE + trec[lt].lh) : 0u;
 	}
 	__syncthreads();
+}
+
+struct Member { uint32_t pa, pga, slot; uint64_t F; };
+
+// string x of the tile, inserting a: pa = members of the bucket in front of it inserting a, pga = the same count
+// in front of its group, F = first member of its group, slot = its place in the bucket's insert list
+// (group, symbol order, array order)
+__device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx &t, int x, int a, const int orda[6])
+{
+	const int c = x >> 6, l6 = x & 63;
+	const uint64_t le = lt_mask(l6) | (1ull << l6);
+	int hpos = -1, npos = -1;
+	{
+		uint64_t hm = G.head[c] & le;
+		if (hm) hpos = c * 64 + 63 - __builtin_clzll(hm);
+		else for (int cc = c - 1; cc >= 0; --cc) if (G.head[cc]) { hpos = cc * 64 + 63 - __builtin_clzll(G.head[cc]); break; }
+		uint64_t nm = G.head[c] & ~le;
+		if (nm) npos = c * 64 + __builtin_ctzll(nm);
+		else for (int cc = c + 1; cc < 8; ++cc) if (G.head[cc]) { npos = cc * 64 + __builtin_ctzll(G.head[cc]); break; }
+	}
+	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
+	Member m;
+	m.pa = G.tpre[a] + before(x, a);
+	m.pga = hpos >= 0 ? G.tpre[a] + before(hpos, a) : G.popen[a];
+	m.F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)G.fopen;
+	uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
+	const int oa = orda[a];
+	for (int s = 0; s < 6; ++s) {
+		if (orda[s] >= oa) continue;
+		const uint32_t pg = hpos >= 0 ? G.tpre[s] + before(hpos, s) : G.popen[s];
+		const uint32_t pn = npos >= 0 ? G.tpre[s] + before(npos, s) : G.pnext[s];
+		bef += pn - pg;
+	}
+	m.slot = (uint32_t)(m.F + bef + (m.pa - m.pga));
+	return m;
+}
+
+__global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_comp, PoolView oldp,
+		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileRec *trec, const TileScan *tsc,
+		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
+{
+	__shared__ GroupLds G;
+	TileCtx t;
+	const SegDesc &sg = ctl->seg[side];
+	if (!tile_ctx(sg, blockIdx.x, t)) return;
+	int sym2[2], flag2[2];
+	group_setup(G, sg, t, A, trec, tsc, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
@@ -374,33 +439,13 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 		const int x = h * 256 + threadIdx.x;
 		const uint64_t k = t.base + x;
 		if (k >= t.segend) continue;
-		const int a = sym2[h], c = x >> 6, l6 = x & 63;
-		const uint64_t le = lt_mask(l6) | (1ull << l6);
-		int hpos = -1, npos = -1;
-		{
-			uint64_t hm = s_head[c] & le;
-			if (hm) hpos = c * 64 + 63 - __builtin_clzll(hm);
-			else for (int cc = c - 1; cc >= 0; --cc) if (s_head[cc]) { hpos = cc * 64 + 63 - __builtin_clzll(s_head[cc]); break; }
-			uint64_t nm = s_head[c] & ~le;
-			if (nm) npos = c * 64 + __builtin_ctzll(nm);
-			else for (int cc = c + 1; cc < 8; ++cc) if (s_head[cc]) { npos = cc * 64 + __builtin_ctzll(s_head[cc]); break; }
-		}
-		auto before = [&](int y, int s) -> uint32_t { return s_cpre[y >> 6][s] + __popcll(s_bal[y >> 6][s] & lt_mask(y & 63)); };
-		const uint32_t pa = s_tpre[a] + before(x, a);
-		const uint32_t pga = hpos >= 0 ? s_tpre[a] + before(hpos, a) : s_popen[a];
-		const uint64_t F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)s_fopen;
-		uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
-		const int oa = orda[a];
-		for (int s = 0; s < 6; ++s) {
-			if (orda[s] >= oa) continue;
-			const uint32_t pg = hpos >= 0 ? s_tpre[s] + before(hpos, s) : s_popen[s];
-			const uint32_t pn = npos >= 0 ? s_tpre[s] + before(npos, s) : s_pnext[s];
-			bef += pn - pg;
-		}
-		const uint64_t l0 = L[k] - F, u0 = U[k] - F;           // coordinates on the pre-round rope
-		uint64_t e = l0, size = 0;
+		const int a = sym2[h];
+		const Member m = group_member(G, t, x, a, orda);
+		const uint64_t l0 = L[k] - m.F, u0 = U[k] - m.F;       // coordinates on the pre-round rope
+		uint64_t e = l0;
 		if (u0 != l0) {                                        // rope_rank2a (mrope.c:202)
-			uint64_t cl[6], cu[6];
+			uint64_t cl[6], cu[6], size = 0;
+			const int oa = orda[a];
 			rank_all(oldp, rp, l0, cl);
 			rank_all(oldp, rp, u0, cu);
 			for (int s = 0; s < 6; ++s) {
@@ -408,11 +453,11 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 				if (orda[s] < oa) e += d;
 				if (s == a) size = d;
 			}
+			SIZE[k] = size;                                    // only non-empty intervals have one (flag 0x40 in A)
+			A[k] = (uint8_t)(a | 0x40 | (G.head[x >> 6] >> (x & 63) & 1 ? 0x80 : 0));
 		}
-		const uint32_t slot = (uint32_t)(F + bef + (pa - pga));
-		INS_E[t.segstart + slot] = e;
-		INS_A[t.segstart + slot] = (uint8_t)a;
-		SLOT[k] = slot; PA[k] = pa; PGA[k] = pga; SIZE[k] = size;
+		INS_E[t.segstart + m.slot] = e;
+		INS_A[t.segstart + m.slot] = (uint8_t)a;
 	}
 }
 
@@ -527,36 +572,43 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, uint32_t round, const uint8_t *s, PoolView newp,
-		const uint64_t *START, const uint8_t *A, const uint32_t *SLOT, const uint32_t *PA, const uint32_t *PGA,
+__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
+		const uint64_t *START, const uint8_t *A, const TileRec *trec, const TileScan *tsc,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
+	__shared__ GroupLds G;
 	TileCtx t;
-	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
+	const SegDesc &sg = ctl->seg[side];
+	if (!tile_ctx(sg, blockIdx.x, t)) return;
+	int sym2[2], flag2[2];
+	group_setup(G, sg, t, A, trec, tsc, sym2, flag2);
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
+	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		const int x = h * 256 + threadIdx.x;
+		const uint64_t k = t.base + x;
 		if (k >= t.segend) continue;
-		const int a = A[k] & 7;
+		const int a = sym2[h];
 		if (a == 0) continue;                                  // sentinel inserted: string is done (mrope.c:310)
+		const Member m = group_member(G, t, x, a, orda);
 		// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
 		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
 		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
-		const uint32_t slot = SLOT[k];
-		const uint64_t f = INS_E[t.segstart + slot] + slot;
+		const uint64_t f = INS_E[t.segstart + m.slot] + m.slot;
 		const uint64_t gl = nrp.leaf0 + f / LEAF;
-		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + slot];
-		const uint64_t l = ctl->ac[t.b][a] + rk - PA[k] + PGA[k];
-		const uint64_t d = ctl->dest[t.b][a] + PA[k];
+		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + m.slot];
+		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
+		const uint64_t u = l + (flag2[h] ? SIZE[k] : 0ull);
+		const uint64_t d = ctl->dest[t.b][a] + m.pa;
 		const uint32_t id = ID[k];
 		uint64_t wv = W[k] >> 4;
 		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
-		if (send) {                                            // sharded: the string travels to the owner of rope a
-			ShardRec r; r.l = l; r.u = l + SIZE[k]; r.w = wv; r.id = id; r.pad = 0;
-			send[ctl->sdest[t.b][a] + PA[k]] = r;
-		} else { L2[d] = l; U2[d] = l + SIZE[k]; ID2[d] = id; W2[d] = wv; }
+		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
+			ShardRec r; r.l = l; r.u = u; r.w = wv; r.id = id; r.pad = 0;
+			send[ctl->sdest[t.b][a] + m.pa] = r;
+		} else { L2[d] = l; U2[d] = u; ID2[d] = id; W2[d] = wv; }
 	}
 }
 
