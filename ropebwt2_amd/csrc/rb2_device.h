@@ -209,6 +209,24 @@ __device__ __forceinline__ void nib_counts(uint64_t x, uint64_t VM, uint32_t n, 
 	nib_finish(A, n, c);
 }
 
+// accumulate the symbols at [from, to) of one packed leaf (16-byte loads; edge chunks are masked)
+__device__ __forceinline__ uint64_t nib_below(uint32_t n) { return n >= 16 ? ~0ull : (1ull << (4 * n)) - 1ull; }
+__device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, NibAcc &A)
+{
+	if (from >= to) return;
+	const uint64_t M1 = 0x1111111111111111ull;
+	const uint32_t c0 = from >> 5, c1 = (to - 1) >> 5;
+	for (uint32_t c = c0; c <= c1; ++c) {
+		const uint4 v = q[c];
+		const uint64_t x0 = (uint64_t)v.y << 32 | v.x, x1 = (uint64_t)v.w << 32 | v.z;
+		if (c != c0 && c != c1) { nib_acc(A, x0, M1); nib_acc(A, x1, M1); continue; }
+		const uint32_t base = c * 32;
+		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, 32u);      // in-chunk range [lo, hi)
+		nib_acc(A, x0, M1 & nib_below(min(hi, 16u)) & ~nib_below(min(lo, 16u)));
+		nib_acc(A, x1, M1 & nib_below(hi > 16 ? hi - 16 : 0u) & ~nib_below(lo > 16 ? lo - 16 : 0u));
+	}
+}
+
 // counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
 // superblock prefix + leaf-relative prefix + a scan of the packed leaf up to p, 32 symbols per load
 // (the reference walks the runs of one leaf, rle.c:147-158).
@@ -223,27 +241,28 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	const uint32_t off = (uint32_t)(p % LEAF);
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	const LeafMeta m = pv.meta[gl];
-#pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s];
-	const uint4 *q = (const uint4*)(pv.data + gl * (uint64_t)LEAFB);
-	const uint64_t M1 = 0x1111111111111111ull;
 	NibAcc A;
-	const uint32_t nfull = off >> 5, rem = off & 31;
-	for (uint32_t k = 0; k < nfull; ++k) {
-		const uint4 v = q[k];
-		nib_acc(A, (uint64_t)v.y << 32 | v.x, M1);
-		nib_acc(A, (uint64_t)v.w << 32 | v.z, M1);
-	}
-	if (rem) {
-		const uint4 v = q[nfull];
-		const uint32_t r1 = min(rem, 16u), r2 = rem - r1;
-		nib_acc(A, (uint64_t)v.y << 32 | v.x, r1 >= 16 ? M1 : M1 & ((1ull << (4 * r1)) - 1ull));
-		if (r2) nib_acc(A, (uint64_t)v.w << 32 | v.z, M1 & ((1ull << (4 * r2)) - 1ull));
-	}
+	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), 0, off, A);
 	uint32_t c[6];
 	nib_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] += c[s];
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
+}
+
+// rank of all six symbols at both ends of [l, u), l < u (rope_rank2a, rope.c:179-194): when both ends
+// fall into one leaf the second scan only covers [l, u), as rle_rank2a does (rle.c:134-191)
+__device__ inline void rank2_all(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t cl[6], uint64_t cu[6])
+{
+	rank_all(pv, rp, l, cl);
+	if (u < rp.n && u / LEAF == l / LEAF) {
+		NibAcc A;
+		const uint32_t ol = (uint32_t)(l % LEAF), ou = (uint32_t)(u % LEAF);
+		leaf_count((const uint4*)(pv.data + (rp.leaf0 + l / LEAF) * (uint64_t)LEAFB), ol, ou, A);
+		uint32_t c[6];
+		nib_finish(A, ou - ol, c);
+#pragma unroll
+		for (int s = 0; s < 6; ++s) cu[s] = cl[s] + c[s];
+	} else rank_all(pv, rp, u, cu);
 }
 
 } // namespace rb2

@@ -97,10 +97,25 @@ __global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t
 	}
 }
 
+// the next 16 symbols of a string, 4 bits each: s[p .. p+16) (bytes past the end of the batch read as 0).
+// Five aligned dword loads + funnel shifts instead of 16 byte loads (the batch buffer is 16-byte aligned).
+__device__ __forceinline__ uint32_t nib4(uint32_t x)      // low nibbles of 4 bytes -> 16 bits
+{
+	x &= 0x0f0f0f0fu;
+	x = (x | x >> 4) & 0x00ff00ffu;
+	return (x | x >> 8) & 0xffffu;
+}
 __device__ __forceinline__ uint64_t pack16(const uint8_t *s, uint64_t len, uint64_t p)
 {
+	if (p + 20 <= len) {
+		const uint32_t *q = (const uint32_t*)(s + (p & ~3ull));
+		const uint32_t sh = (uint32_t)(p & 3) * 8;
+		const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+		const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+		const uint32_t w2 = __builtin_amdgcn_alignbit(d3, d2, sh), w3 = __builtin_amdgcn_alignbit(d4, d3, sh);
+		return (uint64_t)(nib4(w0) | nib4(w1) << 16) | (uint64_t)(nib4(w2) | nib4(w3) << 16) << 32;
+	}
 	uint64_t w = 0;
-#pragma unroll
 	for (int i = 0; i < 16; ++i) {
 		const uint64_t q = p + i;
 		w |= (uint64_t)(q < len ? (s[q] & 15) : 0) << (4*i);
@@ -446,8 +461,7 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 		if (u0 != l0) {                                        // rope_rank2a (mrope.c:202)
 			uint64_t cl[6], cu[6], size = 0;
 			const int oa = orda[a];
-			rank_all(oldp, rp, l0, cl);
-			rank_all(oldp, rp, u0, cu);
+			rank2_all(oldp, rp, l0, u0, cl, cu);
 			for (int s = 0; s < 6; ++s) {
 				const uint64_t d = cu[s] - cl[s];
 				if (orda[s] < oa) e += d;
