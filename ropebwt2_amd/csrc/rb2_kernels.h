@@ -423,6 +423,10 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
 	Member m;
 	m.pa = G.tpre[a] + before(x, a);
+	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
+		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F;
+		return m;
+	}
 	m.pga = hpos >= 0 ? G.tpre[a] + before(hpos, a) : G.popen[a];
 	m.F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)G.fopen;
 	uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
