@@ -540,9 +540,12 @@ __global__ __launch_bounds__(64) void k_meta_sb(const Ctl *ctl, int nside, PoolV
 	if (sb >= ctl->nsb_total) return;
 	const int ln = lane_id();
 	const uint64_t gl = sb * SB + ln;
-	bool ok = false;
-	if (ln < SB)
-		for (int b = 0; b < NR; ++b) { const RopeDesc &r = ctl->rope[nside][b]; ok |= (gl >= r.leaf0 && gl < r.leaf0 + r.nleaves); }
+	// sub-ropes start on superblock boundaries, in ascending order: the one that owns this superblock is the
+	// last with sb0 <= sb (one strided load + ballot, see seg_of); its tail leaves may be padding
+	const uint64_t sb0 = ctl->rope[nside][ln < NR ? ln : NR - 1].sb0;
+	const int r = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sb)) - 1);
+	const RopeDesc &rp = ctl->rope[nside][r];
+	const bool ok = ln < SB && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
 	if (ok) m = newp.meta[gl];
