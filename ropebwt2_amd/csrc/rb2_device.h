@@ -25,6 +25,8 @@ constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
 constexpr int TL     = 4;             // output leaves per merge block (one wave each)
 constexpr int SB     = 32;            // leaves per superblock
 constexpr int LEAFB  = LEAF / 2;       // bytes per leaf: 4 bits per symbol
+constexpr int WPL    = 2;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
+constexpr int WIN    = WPL * LEAF;     // symbols per window
 constexpr int STILE  = 512;           // strings per string tile
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
 constexpr int ZBLOCK = 16384;         // bytes per block when locating sentinels
@@ -58,7 +60,7 @@ struct SegDesc {        // where the strings of bucket r (= sub-rope r) live in 
 struct Ctl {
 	RopeDesc rope[2][NR];
 	SegDesc  seg[2];
-	uint64_t lf0[NR + 3];   // first output leaf (unpadded numbering) per sub-rope this round; [NR] = total
+	uint64_t wf0[NR + 3];   // first output window (WPL consecutive leaves, one merge wave) per sub-rope this round; [NR] = total
 	uint64_t ac[NR][6];     // ac[r][a] = #a in the pieces of the same rope in front of piece r, after this round (mrope.c:332-336)
 	uint64_t dest[NR][6];   // where members of bucket r inserting a go in the next arrays
 	uint64_t count[NR][6];  // count[r][a] = members of bucket r inserting a this round
@@ -75,12 +77,12 @@ struct Ctl {
 struct ShardRec { uint64_t l, u, w; uint32_t id, pad; };   // one string's state on the wire (32 B)
 struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 
-struct LeafDesc {           // work order of one output leaf, written by k_part, read by k_merge (32 B)
-	uint64_t i0;            // position (in the old sub-rope) of the first old symbol the leaf consumes = j*LEAF - q0
+struct LeafDesc {           // work order of one output window (WPL leaves), written by k_part, read by k_merge (32 B)
+	uint64_t i0;            // position (in the old sub-rope) of the first old symbol the window consumes = j*WIN - q0
 	uint64_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL
-	uint64_t gl;            // leaf slot on the new pool side
+	uint64_t gl;            // first leaf slot on the new pool side
 	uint32_t oleaf0;        // first leaf slot of the sub-rope on the old pool side
-	uint16_t ni, nvalid;    // new symbols / symbols in the leaf
+	uint16_t ni, nvalid;    // new symbols / symbols in the window
 };
 
 struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };

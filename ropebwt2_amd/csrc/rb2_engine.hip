@@ -224,7 +224,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const int64_t units = (int64_t)B.m;
 	PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
-	const unsigned nlf = cdiv(n_new_ub, LEAF) + NR;           // output leaves, upper bound
+	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->gcnt); }
 	{ Scope sc(h, RB2_K_PREP, units);

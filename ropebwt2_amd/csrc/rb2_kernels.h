@@ -329,10 +329,10 @@ __global__ void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
 		n.nleaves = (n.n + LEAF - 1) / LEAF;
 		n.leaf0 = leaf; n.sb0 = leaf / SB;
 		leaf += (n.nleaves + SB - 1) / SB * SB;
-		ctl->lf0[r] = mt;
-		mt += n.nleaves;
+		ctl->wf0[r] = mt;
+		mt += (n.nleaves + WPL - 1) / WPL;
 	}
-	ctl->lf0[NR] = mt; ctl->lf0[NR + 1] = mt;
+	ctl->wf0[NR] = mt; ctl->wf0[NR + 1] = mt;
 	ctl->nsb_total = leaf / SB;
 	// next round's buckets: bucket (a,b) = strings that sat in a piece of rope b and inserted a, in
 	// (piece, order) order -- the stable scatter of mrope.c:303-309; only buckets of pieces held here
@@ -480,28 +480,28 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_part: for every output leaf boundary o = j*LEAF of sub-rope b, the number of inserts that land
+// k_part: for every output window boundary o = j*WIN of sub-rope b, the number of inserts that land
 // before it = smallest q with E[q] + q >= o (the final position of insert q is E[q] + q).  Two
-// neighbouring boundaries make the work order of one output leaf (LeafDesc): everything k_merge
+// neighbouring boundaries make the work order of one output window (LeafDesc): everything k_merge
 // needs, in one 32-byte record, so that the merge has no dependent descriptor loads.
-// A block covers 256 boundaries = 255 leaves (boundaries overlap by one between blocks).
+// A block covers 256 boundaries = 255 windows (boundaries overlap by one between blocks).
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, LeafDesc *LD)
 {
-	__shared__ uint64_t s_lf0[NR + 1];
+	__shared__ uint64_t s_wf0[NR + 1];
 	__shared__ uint32_t s_q[256];
-	if (threadIdx.x <= NR) s_lf0[threadIdx.x] = ctl->lf0[threadIdx.x];
+	if (threadIdx.x <= NR) s_wf0[threadIdx.x] = ctl->wf0[threadIdx.x];
 	__syncthreads();
-	const uint64_t gid = (uint64_t)blockIdx.x * 255 + threadIdx.x;      // boundary number: leaf (b,j) <-> lf0[b] + b + j
-	const bool ok = gid < s_lf0[NR] + NR;
+	const uint64_t gid = (uint64_t)blockIdx.x * 255 + threadIdx.x;      // boundary number: window (b,j) <-> wf0[b] + b + j
+	const bool ok = gid < s_wf0[NR] + NR;
 	int b = 0; uint64_t j = 0; uint32_t q = 0;
 	if (ok) {
-		while (gid >= s_lf0[b+1] + b + 1) ++b;
-		j = gid - s_lf0[b] - b;
+		while (gid >= s_wf0[b+1] + b + 1) ++b;
+		j = gid - s_wf0[b] - b;
 		const SegDesc &sg = ctl->seg[side];
 		const uint64_t *E = INS_E + sg.start[b];
-		const uint64_t o = j * LEAF;
+		const uint64_t o = j * WIN;
 		uint64_t lo = 0, hi = sg.cnt[b];
 		while (lo < hi) {
 			const uint64_t mid = (lo + hi) >> 1;
@@ -511,18 +511,18 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	}
 	s_q[threadIdx.x] = q;
 	__syncthreads();
-	if (!ok || threadIdx.x == 255 || j >= s_lf0[b+1] - s_lf0[b]) return;   // the closing boundary of a piece is no leaf
+	if (!ok || threadIdx.x == 255 || j >= s_wf0[b+1] - s_wf0[b]) return;   // the closing boundary of a piece is no window
 	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
 	const uint32_t q1 = s_q[threadIdx.x + 1];
-	const uint64_t o0 = j * LEAF, i0 = o0 - q;
+	const uint64_t o0 = j * WIN, i0 = o0 - q;
 	LeafDesc d;
 	d.i0 = i0;
 	d.ins0 = ctl->seg[side].start[b] + q;
-	d.gl = nrp.leaf0 + j;
+	d.gl = nrp.leaf0 + j * WPL;
 	d.oleaf0 = (uint32_t)orp.leaf0;
 	d.ni = (uint16_t)(q1 - q);
-	d.nvalid = (uint16_t)min((uint64_t)LEAF, nrp.n - o0);
-	LD[s_lf0[b] + j] = d;
+	d.nvalid = (uint16_t)min((uint64_t)WIN, nrp.n - o0);
+	LD[s_wf0[b] + j] = d;
 }
 
 } // namespace rb2

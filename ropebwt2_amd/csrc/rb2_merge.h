@@ -10,131 +10,188 @@
 // decoding, no re-encoding, no length-dependent paths.  Run-length coding is applied once, by
 // k_export, when the host asks for the ropes (mr_sync_host -> .fmd/.fmr writers).
 //
-// k_merge work decomposition: ONE WAVE PER OUTPUT LEAF, four independent waves per block, no
-// block-level barrier anywhere.  Lane l owns output positions [16l, 16l+16) = one 64-bit word:
-//   1. the new symbols of the leaf are OR-ed into a position-indexed nibble array in LDS as 8|a
-//      (bit 3 doubles as the "this position is new" flag), one LDS atomic per new symbol
-//   2. wave prefix sum of the not-new counts -> first old symbol each lane consumes; its <= 16 old
-//      symbols are one unaligned 64-bit window of the old sub-rope (two loads + funnel shift)
-//   3. expand: the old nibbles are dealt to the not-new positions (16 branch-free steps), the new
-//      symbols are already in place
-//   4. symbol counts of the leaf (new LeafMeta) from three bit planes + five popcounts, and for
-//      every new symbol the number of equal symbols before it INSIDE the leaf (RKREL); k_advance
-//      adds the directory prefix of the new sub-rope to obtain the reference's return value of
-//      rope_insert_run.
+// k_merge work decomposition: ONE WAVE PER OUTPUT WINDOW of WPL consecutive leaves, four
+// independent waves per block, no block-level barrier anywhere.  Lane l owns output positions
+// [16*WPL*l, 16*WPL*(l+1)) = WPL consecutive 64-bit words (64/WPL lanes per leaf):
+//   1. the new symbols of the window are OR-ed into a position-indexed nibble array in LDS as 8|a
+//      (bit 3 doubles as the "this position is new" flag), one LDS atomic per new symbol; the old
+//      words the window draws from are loaded at the same time and staged in LDS
+//   2. one packed wave prefix sum (not-new count | new count) -> first old symbol each lane
+//      consumes; the old symbols of each of its words are an unaligned 64-bit window of the stage
+//   3. expand: open one nibble gap per new symbol (wave-uniform loop, 1-2 trips in steady state;
+//      16-step branch-free deal when some lane has many); the new symbols are already in place
+//   4. symbol counts per lane from three bit planes + five popcounts, three packed scans -> new
+//      LeafMeta of each leaf of the window
+//   5. RKREL: every new symbol gets the number of equal symbols before it INSIDE its leaf, one new
+//      symbol per lane (prefix of the owning lane + a masked compare of its words, both read back
+//      from LDS); k_advance adds the directory prefix of the new sub-rope to obtain the reference's
+//      return value of rope_insert_run.
 #pragma once
 #include "rb2_device.h"
 
 namespace rb2 {
 
-constexpr int MW = 4;                       // waves (= output leaves) per block
+constexpr int MW = 4;                       // waves (= output windows) per block
+constexpr int NXW = 64 * WPL;               // words per window
+constexpr int LPW = 64 / WPL;               // lanes per leaf
+
+__device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 4i set: nibble i of w == a
+{
+	uint64_t x = w ^ (a * 0x1111111111111111ull);
+	x |= x >> 1; x |= x >> 2;
+	return ~x & 0x1111111111111111ull;
+}
 
 __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ uint64_t lds[MW][64 + 68];
+	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;
+	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
 	const int ln = lane_id();
-	const uint64_t gleaf = (uint64_t)blockIdx.x * MW + wv;
-	if (gleaf >= ctl->lf0[NR]) return;
-	const LeafDesc d = LD[gleaf];
+	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	if (gw >= ctl->wf0[NR]) return;
+	const LeafDesc d = LD[gw];
 	const int nvalid = d.nvalid, ni = d.ni;
-	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this leaf
+	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
 	const uint32_t sh0 = (uint32_t)d.i0 & 15u;
-	const uint32_t nw = (sh0 + nold + 15) >> 4;                 // words of the old side they live in (<= 65)
+	const uint32_t nw = (sh0 + nold + 15) >> 4;                 // words of the old side they live in (<= NXW + 1)
 
-	// ---- 1. new symbols of this leaf, by output position; the old words it draws from
-	LX[ln] = 0;
+	// ---- 1. new symbols of this window, by output position; the old words it draws from
+#pragma unroll
+	for (int w = 0; w < WPL; ++w) LX[ln + 64 * w] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	const uint64_t *ob = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 * (LEAFB / 8) + (d.i0 >> 4));
-	uint64_t wa = 0, wb = 0;
-	if ((uint32_t)ln < nw) wa = ob[ln];
-	if ((uint32_t)ln + 64 < nw) wb = ob[ln + 64];
+	uint64_t wa[WPL], wt = 0;
+#pragma unroll
+	for (int w = 0; w < WPL; ++w) { wa[w] = 0; if ((uint32_t)(ln + 64 * w) < nw) wa[w] = ob[ln + 64 * w]; }
+	if (ln < 2 && (uint32_t)(NXW + ln) < nw) wt = ob[NXW + ln];
 	for (int jj = ln; jj < ni; jj += 64) {
 		const uint64_t e = INS_E[d.ins0 + jj];
 		const uint32_t a = INS_A[d.ins0 + jj];
-		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the leaf
+		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the window
 		atomicOr((uint32_t*)LX + (p >> 3), (8u | a) << ((p & 7) * 4));
 	}
-	LO[ln] = wa;
-	if (ln < 4) LO[64 + ln] = wb;
+#pragma unroll
+	for (int w = 0; w < WPL; ++w) LO[ln + 64 * w] = wa[w];
+	if (ln < 2) LO[NXW + ln] = wt;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	const uint64_t X = LX[ln];
 
 	// ---- 2. what does each lane consume
-	const int p0 = ln * 16;
-	const int myvalid = min(16, max(0, nvalid - p0));
-	const uint64_t VM = myvalid >= 16 ? ~0ull : ((1ull << (4 * myvalid)) - 1ull);    // nibbles of valid positions
-	const uint64_t F = X & 0x8888888888888888ull;
-	const uint32_t kins = (uint32_t)__popcll(F);
-	const uint32_t nonins = (uint32_t)myvalid - kins;
-	const uint32_t sc2 = dpp_incl_add(nonins | kins << 16);     // both prefix sums in one scan (each < 2^11)
-	const uint32_t oinc = sc2 & 0xffffu, iinc = sc2 >> 16;
-	uint64_t old;
+	uint64_t X[WPL], VM[WPL], F[WPL];
+	uint32_t kin[WPL], non[WPL], ntot = 0, ktot = 0, vtot = 0;
+	const int p0 = ln * 16 * WPL;
+#pragma unroll
+	for (int w = 0; w < WPL; ++w) {
+		X[w] = LX[WPL * ln + w];
+		const int v = min(16, max(0, nvalid - p0 - 16 * w));
+		VM[w] = v >= 16 ? ~0ull : ((1ull << (4 * v)) - 1ull);     // nibbles of valid positions
+		F[w] = X[w] & 0x8888888888888888ull;
+		kin[w] = (uint32_t)__popcll(F[w]);
+		non[w] = (uint32_t)v - kin[w];
+		ntot += non[w]; ktot += kin[w]; vtot += (uint32_t)v;
+	}
+	const uint32_t sc2 = dpp_incl_add(ntot | ktot << 16);       // both prefix sums in one scan (each <= WIN < 2^16)
+	uint64_t out[WPL];
 	{
-		const uint32_t op = sh0 + (oinc - nonins);                // first old symbol of this lane, in nibbles of LO[]
-		const uint32_t k = op >> 4, sh = (op & 15) * 4;
-		const uint64_t w0 = LO[k], w1 = LO[k + 1];               // k + 1 <= 65
-		old = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+		uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);             // first old symbol of this lane, in nibbles of LO[]
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) {
+			const uint32_t k = op >> 4, sh = (op & 15) * 4;
+			const uint64_t w0 = LO[k], w1 = LO[k + 1];           // k + 1 <= NXW + 1
+			out[w] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+			op += non[w];
+		}
 	}
 
 	// ---- 3. deal the old symbols to the not-new positions
-	uint64_t out;
-	if (!__any(kins > 5)) {
-		// steady state: few new symbols per lane.  Open one gap per new symbol, in ascending position.
-		out = old;
-		uint64_t f = F;
-		while (__any(f != 0)) {
-			if (f) {
-				const uint64_t lm = (1ull << (__builtin_ctzll(f) - 3)) - 1ull;   // nibbles below the new symbol
-				f &= f - 1;
-				out = (out & lm) | ((out & ~lm) << 4);
+	uint32_t kmax = kin[0];
+#pragma unroll
+	for (int w = 1; w < WPL; ++w) kmax = max(kmax, kin[w]);
+	if (!__any(kmax > 5)) {
+		// steady state: few new symbols per word.  Open one gap per new symbol, in ascending position.
+		uint64_t f[WPL], fany = 0;
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) { f[w] = F[w]; fany |= f[w]; }
+		while (__any(fany != 0)) {
+			fany = 0;
+#pragma unroll
+			for (int w = 0; w < WPL; ++w) {
+				if (f[w]) {
+					const uint64_t lm = (1ull << (__builtin_ctzll(f[w]) - 3)) - 1ull;   // nibbles below the new symbol
+					f[w] &= f[w] - 1;
+					out[w] = (out[w] & lm) | ((out[w] & ~lm) << 4);
+				}
+				fany |= f[w];
 			}
 		}
-		out = (out & VM) | (X & 0x7777777777777777ull);
-	} else {
-		const uint64_t G = ~X & VM;                             // bit 4i+3: position i takes an old symbol
-		const uint32_t glo = (uint32_t)G, ghi = (uint32_t)(G >> 32);
-		uint32_t olo = 0, ohi = 0;
 #pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const int nm = __builtin_amdgcn_sbfe(i < 8 ? glo : ghi, 4 * (i & 7) + 3, 1);   // -1: old symbol here
-			const uint32_t nib = (uint32_t)old & (uint32_t)nm & 15u;
-			if (i < 8) olo |= nib << (4 * i); else ohi |= nib << (4 * (i - 8));
-			old >>= (nm & 4);
+		for (int w = 0; w < WPL; ++w) out[w] = (out[w] & VM[w]) | (X[w] & 0x7777777777777777ull);
+	} else {
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) {
+			const uint64_t G = ~X[w] & VM[w];                      // bit 4i+3: position i takes an old symbol
+			const uint32_t glo = (uint32_t)G, ghi = (uint32_t)(G >> 32);
+			uint32_t olo = 0, ohi = 0;
+			uint64_t old = out[w];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int nm = __builtin_amdgcn_sbfe(i < 8 ? glo : ghi, 4 * (i & 7) + 3, 1);   // -1: old symbol here
+				const uint32_t nib = (uint32_t)old & (uint32_t)nm & 15u;
+				if (i < 8) olo |= nib << (4 * i); else ohi |= nib << (4 * (i - 8));
+				old >>= (nm & 4);
+			}
+			out[w] = ((uint64_t)ohi << 32 | olo) | (X[w] & 0x7777777777777777ull);
 		}
-		out = ((uint64_t)ohi << 32 | olo) | (X & 0x7777777777777777ull);
 	}
 
-	// ---- 4. counts of the leaf, leaf-relative ranks of the new symbols
+	// ---- 4. counts per lane -> prefix over the window -> LeafMeta of its leaves
 	uint32_t c[6];
-	nib_counts(out, VM, (uint32_t)myvalid, c);
+	{
+		NibAcc A;
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) nib_acc(A, out[w], VM[w] & 0x1111111111111111ull);
+		nib_finish(A, vtot, c);
+	}
 	const uint32_t e01 = c[0] | c[1] << 16, e23 = c[2] | c[3] << 16, e45 = c[4] | c[5] << 16;
 	const uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
-	if (__any(kins != 0)) {
-		uint64_t f = F; uint32_t n = 0;
-		uint16_t *dst = RKREL + d.ins0 + (iinc - kins);
-		while (f) {                                            // few iterations: new symbols are sparse in steady state
-			const int i4 = __builtin_ctzll(f) - 3;
-			f &= f - 1;
-			const uint32_t a = (uint32_t)(out >> i4) & 7u;
-			uint64_t x = out ^ (a * 0x1111111111111111ull);       // zero nibble = equal symbol
-			x |= x >> 1; x |= x >> 2;
-			const uint32_t cnt = (uint32_t)__popcll(~x & 0x1111111111111111ull & ((1ull << i4) - 1ull));
-			const uint32_t w2 = a < 2 ? s01 - e01 : a < 4 ? s23 - e23 : s45 - e45;
-			dst[n++] = (uint16_t)(((w2 >> ((a & 1) * 16)) & 0xffffu) + cnt);
+	// publish my words and my exclusive prefixes (the old-word stage is dead by now)
+	uint32_t *LP = (uint32_t*)LO;
+#pragma unroll
+	for (int w = 0; w < WPL; ++w) LX[WPL * ln + w] = out[w];
+	LP[4 * ln + 0] = s01 - e01; LP[4 * ln + 1] = s23 - e23; LP[4 * ln + 2] = s45 - e45;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+
+	// ---- 5. leaf-relative rank of every new symbol, one per lane
+	for (int jj = ln; jj < ni; jj += 64) {
+		const uint64_t e = INS_E[d.ins0 + jj];
+		const uint32_t a = INS_A[d.ins0 + jj];
+		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;
+		const uint32_t lo = p / (16 * WPL), wi = (p >> 4) % WPL, below = (p & 15) * 4;
+		const uint32_t bl = (p / LEAF) * LPW;                    // first lane of its leaf
+		const uint32_t sh = (a & 1) * 16;
+		uint32_t r = ((LP[4 * lo + (a >> 1)] >> sh) & 0xffffu) - ((LP[4 * bl + (a >> 1)] >> sh) & 0xffffu);
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) {
+			const uint64_t m = (uint32_t)w < wi ? ~0ull : ((uint32_t)w == wi ? (1ull << below) - 1ull : 0ull);
+			r += (uint32_t)__popcll(nib_eq(LX[WPL * lo + w], a) & m);
 		}
+		RKREL[d.ins0 + jj] = (uint16_t)r;
 	}
-	const uint64_t gl = d.gl;
-	if (ln == 63) {
+	if ((ln % LPW) == LPW - 1 && (ln / LPW) * LEAF < nvalid) {   // last lane of a leaf that exists
+		const uint32_t bl = (uint32_t)(ln / LPW) * LPW;
+		const uint32_t t01 = s01 - LP[4 * bl + 0], t23 = s23 - LP[4 * bl + 1], t45 = s45 - LP[4 * bl + 2];
 		LeafMeta m;
-		m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
-		m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
+		m.c[0] = (uint16_t)t01; m.c[1] = (uint16_t)(t01 >> 16); m.c[2] = (uint16_t)t23; m.c[3] = (uint16_t)(t23 >> 16);
+		m.c[4] = (uint16_t)t45; m.c[5] = (uint16_t)(t45 >> 16);
 		m.nbytes = 0; m.pad = 0;
-		newp.meta[gl] = m;                                     // own counts; k_meta_sb turns them into prefixes
+		newp.meta[d.gl + ln / LPW] = m;                         // own counts; k_meta_sb turns them into prefixes
 	}
-	((uint64_t*)(newp.data + gl * (uint64_t)LEAFB))[ln] = out;
+	{
+		uint64_t *dst = (uint64_t*)(newp.data + d.gl * (uint64_t)LEAFB) + WPL * ln;
+#pragma unroll
+		for (int w = 0; w < WPL; ++w) dst[w] = out[w];           // leaves past the end of the piece are padding slots of the same piece
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
