@@ -25,7 +25,7 @@ constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
 constexpr int TL     = 4;             // output leaves per merge block (one wave each)
 constexpr int SB     = 32;            // leaves per superblock
 constexpr int LEAFB  = LEAF / 2;       // bytes per leaf: 4 bits per symbol
-constexpr int WPL    = 2;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
+constexpr int WPL    = 4;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
 constexpr int WIN    = WPL * LEAF;     // symbols per window
 constexpr int STILE  = 512;           // strings per string tile
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
