@@ -42,17 +42,11 @@ __device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 4i s
 	return ~x & 0x1111111111111111ull;
 }
 
-__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
+// FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid
+template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint64_t *LO, const int ln,
+		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8];
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
-	const int ln = lane_id();
-	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
-	if (gw >= ctl->wf0[NR]) return;
-	const LeafDesc d = LD[gw];
-	const int nvalid = d.nvalid, ni = d.ni;
+	const int nvalid = FULL ? WIN : d.nvalid, ni = d.ni;
 	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
 	const uint32_t sh0 = (uint32_t)d.i0 & 15u;
 	const uint32_t nw = (sh0 + nold + 15) >> 4;                 // words of the old side they live in (<= NXW + 1)
@@ -84,8 +78,8 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) {
 		X[w] = LX[WPL * ln + w];
-		const int v = min(16, max(0, nvalid - p0 - 16 * w));
-		VM[w] = v >= 16 ? ~0ull : ((1ull << (4 * v)) - 1ull);     // nibbles of valid positions
+		const int v = FULL ? 16 : min(16, max(0, nvalid - p0 - 16 * w));
+		VM[w] = FULL || v >= 16 ? ~0ull : ((1ull << (4 * v)) - 1ull);     // nibbles of valid positions
 		F[w] = X[w] & 0x8888888888888888ull;
 		kin[w] = (uint32_t)__popcll(F[w]);
 		non[w] = (uint32_t)v - kin[w];
@@ -110,19 +104,16 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	for (int w = 1; w < WPL; ++w) kmax = max(kmax, kin[w]);
 	if (!__any(kmax > 5)) {
 		// steady state: few new symbols per word.  Open one gap per new symbol, in ascending position.
-		uint64_t f[WPL], fany = 0;
+		// One loop per word index: its trip count is the largest number of new symbols any lane has in THAT word.
 #pragma unroll
-		for (int w = 0; w < WPL; ++w) { f[w] = F[w]; fany |= f[w]; }
-		while (__any(fany != 0)) {
-			fany = 0;
-#pragma unroll
-			for (int w = 0; w < WPL; ++w) {
-				if (f[w]) {
-					const uint64_t lm = (1ull << (__builtin_ctzll(f[w]) - 3)) - 1ull;   // nibbles below the new symbol
-					f[w] &= f[w] - 1;
+		for (int w = 0; w < WPL; ++w) {
+			uint64_t f = F[w];
+			while (__any(f != 0)) {
+				if (f) {
+					const uint64_t lm = (1ull << (__builtin_ctzll(f) - 3)) - 1ull;   // nibbles below the new symbol
+					f &= f - 1;
 					out[w] = (out[w] & lm) | ((out[w] & ~lm) << 4);
 				}
-				fany |= f[w];
 			}
 		}
 #pragma unroll
@@ -192,6 +183,20 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) dst[w] = out[w];           // leaves past the end of the piece are padding slots of the same piece
 	}
+}
+
+__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
+{
+	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
+	const int ln = lane_id();
+	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	if (gw >= ctl->wf0[NR]) return;
+	const LeafDesc d = LD[gw];
+	if (d.nvalid == WIN) merge_window<true>(d, LX, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
+	else merge_window<false>(d, LX, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -56,19 +56,23 @@ def default_owners(nranks):
     return own
 
 
+def exchange_tensor(owner, nranks):
+    """T[src, dst, r, a] = 1 when the members of bucket r (held by src) that insert a travel to dst, i.e.
+    owner[r] == src and owner[(a, rope_sym(r))] == dst.  counts[src, dst] = sum_{r,a} T * g."""
+    T = np.zeros((nranks, nranks, NR, 6), np.int64)
+    for r in range(NR):
+        for a in range(1, 6):
+            T[owner[r], owner[rope_of(a, rope_sym(r))], r, a] = 1
+    return T
+
+
 def exchange_layout(owner, nranks, src, g):
     """Python twin of shard_layout() in rb2_engine.hip: for source rank ``src`` and count matrix
     ``g`` (NR x 6), the number of records it sends to every rank.  Layout inside a destination block:
     for the pieces r2 = (a,b) owned by the destination (ascending), for the pieces r of rope b owned by
     src (ascending): g[r][a] records."""
     g = np.asarray(g, dtype=np.int64).reshape(NR, 6)
-    per = [0] * nranks
-    for r2 in range(1, NR):
-        a, b = rope_sym(r2), rope_prev(r2)
-        for r in range(NR):
-            if rope_sym(r) == b and owner[r] == src:
-                per[owner[r2]] += int(g[r, a])
-    return per
+    return [int(x) for x in np.tensordot(exchange_tensor(owner, nranks)[src], g, axes=([1, 2], [0, 1]))]
 
 
 class ShardedBwt(HipBwt):
@@ -79,6 +83,7 @@ class ShardedBwt(HipBwt):
         self.rank, self.nranks = rank, nranks
         self.owner = list(owners) if owners is not None else default_owners(nranks)
         assert self.L.rb2_hip_num_subropes() == NR and len(self.owner) == NR
+        self.xt = exchange_tensor(self.owner, nranks)        # per round: one tensordot instead of Python loops
         arr = (C.c_int * NR)(*self.owner)
         self.L.rb2_hip_shard_setup(self.h, rank, nranks, arr)
 
@@ -107,7 +112,8 @@ class ShardedBwt(HipBwt):
         self.L.rb2_hip_memcpy(self.h, dev_ptr, host_ptr, nbytes, 0)
 
     def batch_protocol(self, dev_ptr, nbytes, send_ptr_of, recv_ptr_of):
-        """Generator: yields ('allreduce', int64[NR*6]) and ('alltoall', send_counts, recv_counts);
+        """Generator: yields ('allreduce', int64[NR*6]) and ('alltoall', send_counts, recv_counts, records in flight
+        over all ranks);
         expects the reduced matrix to be sent back for the former.  ``send_ptr_of(n_records)`` /
         ``recv_ptr_of(n_records)`` return device pointers of buffers with that capacity."""
         L, h = self.L, self.h
@@ -122,8 +128,10 @@ class ShardedBwt(HipBwt):
             nsend = (C.c_int64 * self.nranks)()
             L.rb2_hip_shard_merge(h, r, g.ctypes.data, send_ptr, nsend)
             send_counts = list(nsend)
-            recv_counts = [exchange_layout(self.owner, self.nranks, s, g)[self.rank] for s in range(self.nranks)]
-            yield ("alltoall", send_counts, recv_counts)
+            cnt = np.tensordot(self.xt, g.reshape(NR, 6), axes=([2, 3], [0, 1]))       # [src, dst]
+            assert send_counts == [int(x) for x in cnt[self.rank]]
+            recv_counts = [int(x) for x in cnt[:, self.rank]]
+            yield ("alltoall", send_counts, recv_counts, int(cnt.sum()))
             nrecv = (C.c_int64 * self.nranks)(*recv_counts)
             L.rb2_hip_shard_finish(h, r, g.ctypes.data, recv_ptr, nrecv)
         L.rb2_hip_shard_end(h)
@@ -184,16 +192,17 @@ class TorchComm:
                     dist.all_reduce(t)
                     msg = gen.send(t.cpu().numpy())
                 else:
-                    _, sc, rc = msg
+                    _, sc, rc, total = msg
                     ns, nr = sum(sc) * REC_BYTES, sum(rc) * REC_BYTES
-                    if not self.on_device and ns:
-                        bwt.stage_out(self.send_t.data_ptr(), self.send_dev, ns)
-                    dist.all_to_all_single(self.recv_t[:nr], self.send_t[:ns],
-                                           [c * REC_BYTES for c in rc], [c * REC_BYTES for c in sc])
-                    if self.on_device:
-                        torch.cuda.synchronize()
-                    elif nr:
-                        bwt.stage_in(self.recv_dev, self.recv_t.data_ptr(), nr)
+                    if total:                              # same number on every rank: nobody enters an empty collective
+                        if not self.on_device and ns:
+                            bwt.stage_out(self.send_t.data_ptr(), self.send_dev, ns)
+                        dist.all_to_all_single(self.recv_t[:nr], self.send_t[:ns],
+                                               [c * REC_BYTES for c in rc], [c * REC_BYTES for c in sc])
+                        if self.on_device:
+                            torch.cuda.synchronize()
+                        elif nr:
+                            bwt.stage_in(self.recv_dev, self.recv_t.data_ptr(), nr)
                     msg = next(gen)
         except StopIteration:
             pass

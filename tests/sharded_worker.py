@@ -97,7 +97,7 @@ def main():
                     sc = sharded.exchange_layout(owner, n, rank, g)
                     rc = [sharded.exchange_layout(owner, n, s, g)[rank] for s in range(n)]
                     assert sc == [len(plan(rank, d, g)) for d in range(n)]
-                    yield ("alltoall", sc, rc)
+                    yield ("alltoall", sc, rc, int(g[:, 1:].sum()))
                     tot_r = sum(rc)
                     got = np.zeros((tot_r, 4), np.int64)
                     if tot_r: ctypes.memmove(got.ctypes.data, rp, tot_r * 32)
