@@ -226,7 +226,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(1), 0, st, h->ctl, sd, h->gcnt); }
+	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt); }
 	{ Scope sc(h, RB2_K_PREP, units);
 	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }

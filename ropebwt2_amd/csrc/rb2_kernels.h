@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, cons
 #pragma unroll
 	for (int d = 32; d >= 1; d >>= 1) { unsigned long long t = __shfl_xor(v, d); v = t > v ? t : v; }
 	(void)s_wm;
-	if (lane_id() == 0 && v) atomicMax((unsigned long long*)&ctl->max_len, v);
+	// one atomic per wave only while the maximum still grows (40 M strings of equal length: a handful in total)
+	if (lane_id() == 0 && v > *(volatile uint64_t*)&ctl->max_len) atomicMax((unsigned long long*)&ctl->max_len, v);
 }
 
 // round 0: every string sits in "bucket 0" and inserts its last symbol into rope $ (mrope.c:285)
@@ -305,53 +306,59 @@ __global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, ui
 }
 
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
-// over ranks when sub-ropes are sharded)
-__global__ void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
+// over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
+// sequential formulation (mrope.c:332-340) are wave scans.
+__global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
 {
-	if (threadIdx.x || blockIdx.x) return;
+	if (blockIdx.x) return;
+	const int r = threadIdx.x;
+	const bool ok = r < NR;
+	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
 	SegDesc &ng = ctl->seg[side ^ 1];
-	// new sub-ropes (side^1): sizes, layout in the leaf pool, output leaves.  Pieces held by other ranks
+	const RopeDesc o = ctl->rope[side][rr];
+	// new sub-ropes (side^1): sizes, layout in the leaf pool, output windows.  Pieces held by other ranks
 	// keep n = 0 here but their symbol counts are tracked (needed for AC and for n0).
-	uint64_t leaf = 0, mt = 0, run[6] = {0, 0, 0, 0, 0, 0};
-	for (int r = 0; r < NR; ++r) {
-		const RopeDesc &o = ctl->rope[side][r];
-		RopeDesc &n = ctl->rope[side ^ 1][r];
-		if (rope_prev(r) == 0) for (int a = 0; a < 6; ++a) run[a] = 0;      // first piece of a rope
-		n.n = o.n + sg.cnt[r];
-		for (int a = 0; a < 6; ++a) {
-			const uint64_t c = gcnt[r * 6 + a];
-			ctl->count[r][a] = c;
-			ctl->ac[r][a] = run[a];                           // #a in this rope in front of piece r, after the round (mrope.c:332-336)
-			n.cnt[a] = o.cnt[a] + c;
-			run[a] += n.cnt[a];
-		}
-		n.nleaves = (n.n + LEAF - 1) / LEAF;
-		n.leaf0 = leaf; n.sb0 = leaf / SB;
-		leaf += (n.nleaves + SB - 1) / SB * SB;
-		ctl->wf0[r] = mt;
-		mt += (n.nleaves + WPL - 1) / WPL;
+	RopeDesc n;
+	n.n = ok ? o.n + sg.cnt[rr] : 0;
+	const int first = rope_of(rope_sym(rr), 0);               // first piece of my rope
+	for (int a = 0; a < 6; ++a) {
+		const uint64_t c = ok ? gcnt[rr * 6 + a] : 0ull;
+		n.cnt[a] = ok ? o.cnt[a] + c : 0ull;
+		const uint64_t inc = wave_incl_add<uint64_t>(n.cnt[a]);
+		const uint64_t ex = inc - n.cnt[a];
+		const uint64_t exf = __shfl(ex, first);
+		if (ok) { ctl->count[r][a] = c; ctl->ac[r][a] = ex - exf; }   // #a in this rope in front of piece r, after the round (mrope.c:332-336)
 	}
-	ctl->wf0[NR] = mt; ctl->wf0[NR + 1] = mt;
-	ctl->nsb_total = leaf / SB;
+	n.nleaves = (n.n + LEAF - 1) / LEAF;
+	const uint64_t padded = (n.nleaves + SB - 1) / SB * SB, nwin = (n.nleaves + WPL - 1) / WPL;
+	const uint64_t pinc = wave_incl_add<uint64_t>(padded), winc = wave_incl_add<uint64_t>(nwin);
+	n.leaf0 = pinc - padded; n.sb0 = n.leaf0 / SB;
+	if (ok) { ctl->rope[side ^ 1][r] = n; ctl->wf0[r] = winc - nwin; }
+	if (r == 63) { ctl->wf0[NR] = winc; ctl->wf0[NR + 1] = winc; ctl->nsb_total = pinc / SB; }
 	// next round's buckets: bucket (a,b) = strings that sat in a piece of rope b and inserted a, in
 	// (piece, order) order -- the stable scatter of mrope.c:303-309; only buckets of pieces held here
 	// are laid out locally; strings that inserted $ are dropped (mrope.c:310)
-	uint64_t st = 0; uint32_t tl = 0;
-	for (int r2 = 0; r2 < NR; ++r2) {
-		uint64_t c = 0;
-		if (r2 != 0) {
-			const int a = rope_sym(r2), b = rope_prev(r2);
-			if (b == 0) { ctl->dest[0][a] = st; c = gcnt[a]; }
-			else for (int x = 0; x < 6; ++x) { const int r = rope_of(b, x); ctl->dest[r][a] = st + c; c += gcnt[r * 6 + a]; }
-			if (!ctl->own[r2]) c = 0;
-		}
-		ng.start[r2] = st; ng.cnt[r2] = c;
-		ng.tile0[r2] = tl;
-		tl += (uint32_t)((c + STILE - 1) / STILE);
-		st += c;
+	uint64_t c2 = 0;
+	if (ok && r != 0 && ctl->own[r]) {
+		const int a = rope_sym(r), b = rope_prev(r);
+		if (b == 0) c2 = gcnt[a];
+		else for (int x = 0; x < 6; ++x) c2 += gcnt[rope_of(b, x) * 6 + a];
 	}
-	ng.tile0[NR] = tl; ng.tile0[NR + 1] = tl;
+	const uint64_t cinc = wave_incl_add<uint64_t>(c2), st = cinc - c2;
+	const uint32_t nt = (uint32_t)((c2 + STILE - 1) / STILE);
+	const uint32_t tinc = wave_incl_add<uint32_t>(nt);
+	if (ok) { ng.start[r] = st; ng.cnt[r] = c2; ng.tile0[r] = tinc - nt; }
+	if (r == 63) { ng.tile0[NR] = tinc; ng.tile0[NR + 1] = tinc; }
+	// dest[r][a]: where the members of bucket r = (b,x) that insert a start inside bucket (a,b)
+	for (int a = 1; a < 6; ++a) {
+		const int r2 = rope_of(a, rope_sym(rr));
+		const uint64_t st2 = __shfl(st, r2);
+		uint64_t before = 0;
+		if (rope_sym(rr) != 0) for (int x = 0; x < rope_prev(rr); ++x) before += gcnt[rope_of(rope_sym(rr), x) * 6 + a];
+		if (ok) ctl->dest[r][a] = st2 + before;
+	}
+	if (ok) ctl->dest[r][0] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
