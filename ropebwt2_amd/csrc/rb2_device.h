@@ -100,6 +100,13 @@ struct TileScan {           // per string tile (+1), written by the tile scan
 	int32_t  nht;           // first tile after this one that contains a head (INT_MAX if none)
 };
 
+struct TileFix {            // per string tile, written by k_tfix: what group_setup needs, relative to the tile's segment
+	uint32_t tpre[6];       // members of the segment in front of this tile that insert s
+	uint32_t popen[6];      // the same count in front of the group that is open at the start of the tile
+	uint32_t pnext[6];      // ... in front of the first group head after the tile (segment total if none)
+	uint32_t fopen;         // first member (segment-relative index) of the group open at the start of the tile
+};
+
 struct ChunkPart { uint32_t sum[6]; int32_t mx, mn; };
 
 // ---------------------------------------------------------------------------------------------

@@ -65,7 +65,7 @@ struct rb2_hip_s {
 	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
-	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<ChunkPart> cpart;
+	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<TileFix> tfix; DevBuf<ChunkPart> cpart;
 	DevBuf<Cnt6> sbtot, sbpart;
 	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
 	// profiling
@@ -156,7 +156,7 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
-	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
+	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
 
 // split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284)
@@ -212,6 +212,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
+	  hipLaunchKernelGGL(k_tfix, dim3(cdiv(B.nst_ub, 256)), dim3(256), 0, st, h->ctl, sd, h->trec.p, h->tsc.p, h->tfix.p);
 	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(256), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
 }
 
@@ -229,7 +230,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt); }
 	{ Scope sc(h, RB2_K_PREP, units);
 	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
-			h->trec.p, h->tsc.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
+			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
@@ -237,7 +238,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->trec.p, h->tsc.p,
+	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
 	h->side ^= 1; B.cur ^= 1;
 }
@@ -312,7 +313,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
-	h->trec.release(); h->tsc.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
+	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();
 	HIPCHK(hipStreamDestroy(h->st));

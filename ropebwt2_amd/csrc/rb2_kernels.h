@@ -305,6 +305,35 @@ __global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, ui
 	gcnt[i] = sg.tile0[NR] ? (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]) : 0ull;
 }
 
+// one thread per string tile: fold the tile scans into the numbers group_setup needs, so that k_prep and
+// k_advance read one 76-byte record per block instead of chasing tsc[lt] / trec[lt] / tsc[nt] / trec[nt]
+__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const TileRec *trec, const TileScan *tsc, TileFix *tf)
+{
+	__shared__ uint32_t s_t0[NR + 1];
+	const SegDesc &sg = ctl->seg[side];
+	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
+	__syncthreads();
+	const uint32_t tile = blockIdx.x * 256 + threadIdx.x;
+	if (tile >= s_t0[NR]) return;
+	int b = 0;
+	while (tile >= s_t0[b+1]) ++b;
+	const uint32_t t0 = s_t0[b], t1 = s_t0[b+1];
+	const TileScan me = tsc[tile], first = tsc[t0];
+	const int lt = me.lht, nt = me.nht;
+	TileFix f;
+	TileScan sl, sn; TileRec rl, rn;
+	const bool hl = lt >= (int)t0, hn = nt < (int)t1;
+	if (hl) { sl = tsc[lt]; rl = trec[lt]; }
+	if (hn) { sn = tsc[nt]; rn = trec[nt]; } else sn = tsc[t1];
+	for (int s = 0; s < 6; ++s) {
+		f.tpre[s] = me.pre[s] - first.pre[s];
+		f.popen[s] = hl ? sl.pre[s] - first.pre[s] + rl.lhpre[s] : 0u;
+		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? rn.fhpre[s] : 0u);
+	}
+	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + rl.lh) : 0u;
+	tf[tile] = f;
+}
+
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.
@@ -369,15 +398,15 @@ __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t
 // k_advance (which recomputes the same numbers instead of reading them back from HBM).
 struct GroupLds {
 	uint64_t bal[8][6], head[8];                // per wave-chunk of the tile: lanes with symbol s / group heads
-	uint32_t cpre[9][6], tpre[6], popen[6], pnext[6];
-	uint32_t fopen;
+	uint32_t cpre[9][6];
+	TileFix fix;                                // tpre, popen, pnext, fopen of this tile (k_tfix)
 };
 
 // fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none)
-__device__ __forceinline__ void group_setup(GroupLds &G, const SegDesc &sg, const TileCtx &t, const uint8_t *A,
-		const TileRec *trec, const TileScan *tsc, int sym2[2], int flag2[2])
+__device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint8_t *A, const TileFix *tf, int sym2[2], int flag2[2])
 {
 	const int ln = lane_id(), w = wave_id();
+	if (threadIdx.x < sizeof(TileFix) / 4) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[blockIdx.x])[threadIdx.x];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
@@ -393,18 +422,9 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const SegDesc &sg, cons
 	__syncthreads();
 	if (threadIdx.x < 6) {
 		const int s = threadIdx.x;
-		const uint32_t tile = blockIdx.x, t0 = sg.tile0[t.b], t1 = sg.tile0[t.b + 1];
-		const uint32_t segbase = tsc[t0].pre[s];
 		uint32_t run = 0;
 		for (int c = 0; c < 8; ++c) { G.cpre[c][s] = run; run += __popcll(G.bal[c][s]); }
 		G.cpre[8][s] = run;
-		G.tpre[s] = tsc[tile].pre[s] - segbase;
-		const int lt = tsc[tile].lht, nt = tsc[tile].nht;
-		uint32_t po = 0;
-		if (lt >= (int)t0) po = tsc[lt].pre[s] - segbase + trec[lt].lhpre[s];
-		G.popen[s] = po;
-		G.pnext[s] = (nt < (int)t1) ? tsc[nt].pre[s] - segbase + trec[nt].fhpre[s] : tsc[t1].pre[s] - segbase;
-		if (s == 0) G.fopen = (lt >= (int)t0) ? (uint32_t)((lt - t0) * STILE + trec[lt].lh) : 0u;
 	}
 	__syncthreads();
 }
@@ -429,19 +449,19 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	}
 	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
 	Member m;
-	m.pa = G.tpre[a] + before(x, a);
+	m.pa = G.fix.tpre[a] + before(x, a);
 	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
 		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F;
 		return m;
 	}
-	m.pga = hpos >= 0 ? G.tpre[a] + before(hpos, a) : G.popen[a];
-	m.F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)G.fopen;
+	m.pga = hpos >= 0 ? G.fix.tpre[a] + before(hpos, a) : G.fix.popen[a];
+	m.F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)G.fix.fopen;
 	uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
 	const int oa = orda[a];
 	for (int s = 0; s < 6; ++s) {
 		if (orda[s] >= oa) continue;
-		const uint32_t pg = hpos >= 0 ? G.tpre[s] + before(hpos, s) : G.popen[s];
-		const uint32_t pn = npos >= 0 ? G.tpre[s] + before(npos, s) : G.pnext[s];
+		const uint32_t pg = hpos >= 0 ? G.fix.tpre[s] + before(hpos, s) : G.fix.popen[s];
+		const uint32_t pn = npos >= 0 ? G.fix.tpre[s] + before(npos, s) : G.fix.pnext[s];
 		bef += pn - pg;
 	}
 	m.slot = (uint32_t)(m.F + bef + (m.pa - m.pga));
@@ -449,7 +469,7 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 }
 
 __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_comp, PoolView oldp,
-		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileRec *trec, const TileScan *tsc,
+		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
 	__shared__ GroupLds G;
@@ -457,7 +477,14 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 	const SegDesc &sg = ctl->seg[side];
 	if (!tile_ctx(sg, blockIdx.x, t)) return;
 	int sym2[2], flag2[2];
-	group_setup(G, sg, t, A, trec, tsc, sym2, flag2);
+	uint64_t l2[2], u2[2];                                     // issued before the barriers of group_setup
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		l2[h] = u2[h] = 0;
+		if (k < t.segend) { l2[h] = L[k]; u2[h] = U[k]; }
+	}
+	group_setup(G, t, A, tf, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 		if (k >= t.segend) continue;
 		const int a = sym2[h];
 		const Member m = group_member(G, t, x, a, orda);
-		const uint64_t l0 = L[k] - m.F, u0 = U[k] - m.F;       // coordinates on the pre-round rope
+		const uint64_t l0 = l2[h] - m.F, u0 = u2[h] - m.F;     // coordinates on the pre-round rope
 		uint64_t e = l0;
 		if (u0 != l0) {                                        // rope_rank2a (mrope.c:202)
 			uint64_t cl[6], cu[6], size = 0;
@@ -601,7 +628,7 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
-		const uint64_t *START, const uint8_t *A, const TileRec *trec, const TileScan *tsc,
+		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
@@ -610,7 +637,14 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 	const SegDesc &sg = ctl->seg[side];
 	if (!tile_ctx(sg, blockIdx.x, t)) return;
 	int sym2[2], flag2[2];
-	group_setup(G, sg, t, A, trec, tsc, sym2, flag2);
+	uint32_t id2[2]; uint64_t w2[2];                           // issued before the barriers of group_setup
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		id2[h] = 0; w2[h] = 0;
+		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; }
+	}
+	group_setup(G, t, A, tf, sym2, flag2);
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
@@ -630,8 +664,8 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + (flag2[h] ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
-		const uint32_t id = ID[k];
-		uint64_t wv = W[k] >> 4;
+		const uint32_t id = id2[h];
+		uint64_t wv = w2[h] >> 4;
 		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
 			ShardRec r; r.l = l; r.u = u; r.w = wv; r.id = id; r.pad = 0;
