@@ -629,7 +629,7 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 
 __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint32_t *ID, const uint64_t *W,
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
 	__shared__ GroupLds G;
@@ -637,12 +637,12 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 	const SegDesc &sg = ctl->seg[side];
 	if (!tile_ctx(sg, blockIdx.x, t)) return;
 	int sym2[2], flag2[2];
-	uint32_t id2[2]; uint64_t w2[2];                           // issued before the barriers of group_setup
+	uint32_t id2[2]; uint64_t w2[2], l2[2];                    // issued before the barriers of group_setup
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		id2[h] = 0; w2[h] = 0;
-		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; }
+		id2[h] = 0; w2[h] = 0; l2[h] = 0;
+		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; l2[h] = L[k]; }
 	}
 	group_setup(G, t, A, tf, sym2, flag2);
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
@@ -658,7 +658,8 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 		// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
 		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
 		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
-		const uint64_t f = INS_E[t.segstart + m.slot] + m.slot;
+		// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
+		const uint64_t f = (flag2[h] ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
 		const uint64_t gl = nrp.leaf0 + f / LEAF;
 		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
