@@ -13,9 +13,9 @@ so `value` is whole-job symbols / wall time with inputs resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (default --mode sharded): ONE index, the six ropes sharded over the ranks (owner map in
-ropebwt2_amd/sharded.py), per round an all_reduce of the 6x6 count matrix and an all_to_all of
-the string state over RCCL; the job is the same configs[1] job, so scaling is "strong".
+N > 1 (default --mode sharded): ONE index, its 31 sub-ropes sharded over the ranks (owner map in
+ropebwt2_amd/sharded.py), per round an all_reduce of the 31x6 count matrix and an all_to_all of
+16-byte string records over RCCL; the job is the same configs[1] job, so scaling is "strong".
 --mode independent builds one separate BWT per GPU over disjoint read slices instead ("weak").
 """
 import argparse
@@ -212,7 +212,7 @@ def main():
                                % (args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
                    "reads_per_gpu": sum(n for _, n in steps), "symbols_per_gpu": symbols,
                    "parallelism": "1 GPU" if n_gpus == 1 else
-                                  ("ropes $ACGTN sharded over %d of %d GPUs (owner map %s); per round all_reduce(6x6 counts) + all_to_all(32 B string records) over RCCL"
+                                  ("31 sub-ropes (b,x) sharded over %d of %d GPUs (owner map %s); per round all_reduce(31x6 counts) + all_to_all(16 B string records) over RCCL"
                                    % (active, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
                    "counts_ok": bool(ok_counts)},
         "roofline": {"bound": "hbm", "kernel": "k_merge", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

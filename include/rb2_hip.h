@@ -90,7 +90,7 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
  *   rounds = rb2_hip_shard_begin(h, len, s_dev)
  *   for r in 0..rounds-1:
  *       rb2_hip_shard_counts(h, r, local)              ->  global = all_reduce_sum(local)
- *       rb2_hip_shard_merge(h, r, global, send, nsend) ->  recv = all_to_all(send, nsend)   (32-byte records)
+ *       rb2_hip_shard_merge(h, r, global, send, nsend) ->  recv = all_to_all(send, nsend)   (16-byte records)
  *       rb2_hip_shard_finish(h, r, global, recv, nrecv)
  *   rb2_hip_shard_end(h)
  */

@@ -74,7 +74,13 @@ struct Ctl {
 	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
 };
 
-struct ShardRec { uint64_t l, u, w; uint32_t id, pad; };   // one string's state on the wire (32 B)
+// one string's state on the wire (16 B): a = l (48 bits) | size[15:0] << 48;  b = id | size[47:16] << 32.
+// The 16-symbol cursor W does not travel: every rank holds the batch text and rebuilds it on arrival.
+struct ShardRec { uint64_t a, b; };
+__host__ __device__ inline ShardRec shard_pack(uint64_t l, uint64_t size, uint32_t id)
+{
+	ShardRec r; r.a = (l & 0xffffffffffffull) | (size & 0xffffull) << 48; r.b = (uint64_t)id | (size >> 16) << 32; return r;
+}
 struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 
 struct LeafDesc {           // work order of one output window (WPL leaves), written by k_part, read by k_merge (32 B)

@@ -563,7 +563,6 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 {
 	HIPCHK(hipSetDevice(h->dev));
 	BatchState &B = *(BatchState*)h->batch;
-	(void)round;
 	/* local layout of next round's buckets (same rule as k_setup): owned pieces ascending; inside bucket (a,b)
 	 * the sources (b,x) in the order of x */
 	int64_t nstart[NR], run = 0;
@@ -599,7 +598,7 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 		h->pieces.ensure(pcs.size() + 1);
 		HIPCHK(hipMemcpyAsync(h->pieces.p, pcs.data(), pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
 		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
-		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base,
+		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->START.p, (uint32_t)round,
 				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
 	}
 	HIPCHK(hipStreamSynchronize(h->st));

@@ -669,15 +669,15 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 		uint64_t wv = w2[h] >> 4;
 		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
-			ShardRec r; r.l = l; r.u = u; r.w = wv; r.id = id; r.pad = 0;
-			send[ctl->sdest[t.b][a] + m.pa] = r;
+			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id);
 		} else { L2[d] = l; U2[d] = u; ID2[d] = id; W2[d] = wv; }
 	}
 }
 
-// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
-__global__ __launch_bounds__(256) void k_unpack(const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order; the symbol
+// cursor W is rebuilt from the batch text (one 20-byte gather per string)
+__global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
+		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	if (i >= total) return;
@@ -685,7 +685,10 @@ __global__ __launch_bounds__(256) void k_unpack(const ShardRec *recv, const Shar
 	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].src <= i) lo = mid; else hi = mid - 1; }
 	const ShardRec r = recv[i];
 	const uint64_t d = pc[lo].dst + (i - pc[lo].src);
-	L2[d] = r.l; U2[d] = r.u; ID2[d] = r.id; W2[d] = r.w;
+	const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
+	const uint32_t id = (uint32_t)r.b;
+	L2[d] = l; U2[d] = l + size; ID2[d] = id;
+	W2[d] = pack16(s, ctl->len, START[id] + round + 1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ rounds
 * every rank needs the NR x 6 matrix "members of bucket r that insert a" (the reference's master reads
   ``r[b]->c[]`` of all ropes, mrope.c:332-340)          -> ``all_reduce`` of 186 int64;
 * a string in piece (b,x) that inserted a moves to the owner of piece (a,b) (the stable scatter of
-  mrope.c:303-309)                                      -> ``all_to_all_single`` of 32-byte records.
+  mrope.c:303-309)                                      -> ``all_to_all_single`` of 16-byte records.
 
 The GPU work of each phase is in librb2hip.so (``rb2_hip_shard_*``); this module only moves the two
 buffers.  The per-batch protocol is written once, as a generator that yields at every
@@ -24,7 +24,7 @@ import numpy as np
 
 from .hipbwt import HipBwt, load_hip_lib
 
-REC_BYTES = 32          # sizeof(ShardRec), rb2_device.h
+REC_BYTES = 16          # sizeof(ShardRec), rb2_device.h: {l:48, size:48, id:32}; the symbol cursor is rebuilt on arrival
 NR = 31                 # sub-ropes, rb2_device.h (checked against the library in ShardedBwt)
 
 
