@@ -128,7 +128,7 @@ void build_directory(rb2_hip_t *h, int sd, uint64_t nsb_ub)
 	if (nchunk > SCHUNK) { fprintf(stderr, "[rb2_hip] index too large for one device (%llu superblocks)\n", (unsigned long long)nsb_ub); abort(); }
 	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
 	PoolView pv = h->pool[sd].view();
-	hipLaunchKernelGGL(k_meta_sb, dim3((unsigned)nsb_ub), dim3(64), 0, h->st, h->ctl, sd, pv, h->sbtot.p);
+	hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p);
 	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);

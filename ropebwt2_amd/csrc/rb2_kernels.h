@@ -567,30 +567,42 @@ namespace rb2 {
 // rank directory of the new side
 // ---------------------------------------------------------------------------------------------
 
-// one wave per superblock: per-leaf counts -> exclusive prefix inside the superblock; superblock totals
-__global__ __launch_bounds__(64) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot)
+// one wave per TWO superblocks (lanes 0-31 / 32-63): per-leaf counts -> exclusive prefix inside the superblock;
+// superblock totals.  Counts are <= LEAF per leaf, prefixes < 2^16: two symbols per packed DPP scan.
+__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot)
 {
-	const uint64_t sb = blockIdx.x;
-	if (sb >= ctl->nsb_total) return;
 	const int ln = lane_id();
-	const uint64_t gl = sb * SB + ln;
-	// sub-ropes start on superblock boundaries, in ascending order: the one that owns this superblock is the
-	// last with sb0 <= sb (one strided load + ballot, see seg_of); its tail leaves may be padding
+	const uint64_t sb = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2 + (ln >> 5);
+	const uint64_t nsb = ctl->nsb_total;
+	if (sb - (ln >> 5) >= nsb) return;                        // wave-uniform
+	const bool live = sb < nsb;
+	const uint64_t gl = sb * SB + (ln & 31);
+	// sub-ropes start on superblock boundaries, in ascending order: the one that owns a superblock is the
+	// last with sb0 <= sb (one strided load + ballot per half, see seg_of); its tail leaves may be padding
 	const uint64_t sb0 = ctl->rope[nside][ln < NR ? ln : NR - 1].sb0;
-	const int r = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sb)) - 1);
-	const RopeDesc &rp = ctl->rope[nside][r];
-	const bool ok = ln < SB && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
+	const uint64_t sbA = sb - (ln >> 5);
+	const int rA = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA)) - 1);
+	const int rB = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA + 1)) - 1);
+	const RopeDesc &rp = ctl->rope[nside][(ln >> 5) ? rB : rA];
+	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
 	if (ok) m = newp.meta[gl];
-	uint32_t tot[6];
-	for (int s = 0; s < 6; ++s) {
-		const uint32_t v = m.c[s], inc = wave_incl_add(v);
-		tot[s] = __shfl(inc, 63);
-		m.c[s] = (uint16_t)(inc - v);
+	const uint32_t e01 = m.c[0] | (uint32_t)m.c[1] << 16, e23 = m.c[2] | (uint32_t)m.c[3] << 16, e45 = m.c[4] | (uint32_t)m.c[5] << 16;
+	uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
+	const uint32_t h01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 31), h23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 31), h45 = (uint32_t)__builtin_amdgcn_readlane((int)s45, 31);
+	if (ln >> 5) { s01 -= h01; s23 -= h23; s45 -= h45; }      // second superblock: prefix relative to its own first leaf
+	const uint32_t x01 = s01 - e01, x23 = s23 - e23, x45 = s45 - e45;
+	if (ok) {
+		m.c[0] = (uint16_t)x01; m.c[1] = (uint16_t)(x01 >> 16); m.c[2] = (uint16_t)x23; m.c[3] = (uint16_t)(x23 >> 16);
+		m.c[4] = (uint16_t)x45; m.c[5] = (uint16_t)(x45 >> 16);
+		newp.meta[gl] = m;
 	}
-	if (ok) newp.meta[gl] = m;
-	if (ln == 0) { Cnt6 c; for (int s = 0; s < 6; ++s) c.v[s] = tot[s]; sbtot[sb] = c; }
+	if ((ln & 31) == 31 && live) {                            // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
+		Cnt6 c;
+		c.v[0] = s01 & 0xffffu; c.v[1] = s01 >> 16; c.v[2] = s23 & 0xffffu; c.v[3] = s23 >> 16; c.v[4] = s45 & 0xffffu; c.v[5] = s45 >> 16;
+		sbtot[sb] = c;
+	}
 }
 
 __global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const Cnt6 *sbtot, Cnt6 *part)
