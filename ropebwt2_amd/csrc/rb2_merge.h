@@ -93,7 +93,7 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		for (int w = 0; w < WPL; ++w) {
 			const uint32_t k = op >> 4, sh = (op & 15) * 4;
 			const uint64_t w0 = LO[k], w1 = LO[k + 1];           // k + 1 <= NXW + 1
-			out[w] = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+			out[w] = (w0 >> sh) | ((w1 << 1) << (63 - sh));       // sh == 0: the second term shifts out
 			op += non[w];
 		}
 	}
