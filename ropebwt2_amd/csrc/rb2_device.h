@@ -2,13 +2,15 @@
 //
 // Layout in HBM (all sizes are compile-time constants below):
 //
-//   leaf          LEAF symbols of one rope, stored as <= LEAF one-byte runs of ropebwt2's 43+3 codec
-//                 (byte = len<<3 | sym, 1 <= len <= 15; reference format: rle.h:53-57).  Every
-//                 leaf of a rope holds exactly LEAF symbols except the last, so "which leaf holds
-//                 position p" is p / LEAF -- no B+ tree descent (the reference walks rpnode_t
-//                 buckets, rope.c:119-134).  Slot stride is LEAF bytes.
+//   sub-rope      rope b is kept as six independent pieces (b,x), x = the symbol following b in the
+//                 row's suffix; NR = 31 pieces (see below).  A piece is a flat array of 4-bit symbols.
+//   leaf          LEAF symbols of one piece, 4 bits each (LEAFB bytes; symbol i in bits 4(i%16).. of
+//                 64-bit word i/16).  Every leaf of a piece holds exactly LEAF symbols except the
+//                 last, so "which leaf holds position p" is p / LEAF -- no B+ tree descent (the
+//                 reference walks rpnode_t buckets, rope.c:119-134).  Run-length coding (rle.h:39-75)
+//                 only happens on export (k_export).
 //   LeafMeta      16 B per leaf: per-symbol counts of the preceding leaves of the same superblock
-//                 (u16 x 6) + number of bytes used.
+//                 (u16 x 6).
 //   superblock    SB consecutive leaves; Cnt6 (6 x u64) exclusive prefix of symbol counts over
 //                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf scan  (rope_rank2a,
 //                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
@@ -21,8 +23,7 @@
 
 namespace rb2 {
 
-constexpr int LEAF   = 1024;          // symbols per leaf == slot bytes
-constexpr int TL     = 4;             // output leaves per merge block (one wave each)
+constexpr int LEAF   = 1024;          // symbols per leaf
 constexpr int SB     = 32;            // leaves per superblock
 constexpr int LEAFB  = LEAF / 2;       // bytes per leaf: 4 bits per symbol
 constexpr int WPL    = 4;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)

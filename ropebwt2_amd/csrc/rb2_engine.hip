@@ -689,7 +689,7 @@ const char *rb2_hip_kernel_name(int k)
 void rb2_hip_layout(int *leaf_syms, int *tile_leaves, int *string_tile)
 {
 	if (leaf_syms) *leaf_syms = LEAF;
-	if (tile_leaves) *tile_leaves = TL;
+	if (tile_leaves) *tile_leaves = WPL;          /* leaves per merge window */
 	if (string_tile) *string_tile = STILE;
 }
 

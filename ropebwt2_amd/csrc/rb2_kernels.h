@@ -6,11 +6,12 @@
 //
 //   k_sym      next symbol of every active string + group heads (mrope.c:189-192)
 //   k_tscan*   prefix of the per-tile symbol histograms, nearest group head left/right of a tile
-//   k_setup    6x6 count matrix -> new rope sizes, AC offsets (mrope.c:332-336), next buckets
+//   k_tfix     the same, folded into one record per tile for k_prep / k_advance
+//   k_setup    NR x 6 count matrix -> new sub-rope sizes, AC offsets (mrope.c:332-336), next buckets
 //   k_prep     per string: pre-round position of its new symbol, slot in the sorted insert list,
 //              interval sizes via rank on non-empty intervals (mrope.c:199-224)
-//   k_part     merge-path split: which inserts land in which output tile
-//   k_merge    rank + positional insert, one wave per output leaf (rb2_merge.h)
+//   k_part     merge-path split: which inserts land in which output window -> LeafDesc work orders
+//   k_merge    rank + positional insert, one wave per output window of WPL leaves (rb2_merge.h)
 //   k_meta*    rank directory of the new side (replaces the rpnode_t counts, rope.h:11-15)
 //   k_advance  new (l,u) per string + stable 6-way partition into next round's buckets
 //              (mrope.c:226-229, 303-309, 332-340)

@@ -129,6 +129,31 @@ def test_leaf_and_tile_boundaries(hip, so, delta):
     run_both(hip, so, [one, one])
 
 
+def test_reserve_is_only_a_hint(hip):
+    """rb2_hip_reserve before, between and after batches (smaller and larger than needed) never changes the result"""
+    codes = H.splitmix_bases(6000, 40, seed=12)
+    bufs = [H.encode_batch_fixed(codes[:2500]), H.encode_batch_fixed(codes[2500:])]
+    o = H.Oracle(1)
+    dev = hip.HipBwt(1)
+    dev.reserve(10, 1, 100)                                 # far too small: grows on demand
+    for i, buf in enumerate(bufs):
+        o.insert_multi(buf); dev.insert_multi(buf)
+        dev.reserve(len(buf) * 3, 20000, 5_000_000)         # larger than needed, index already populated
+    assert np.array_equal(dev.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(dev.rope(b), o.rope(b))
+
+
+@pytest.mark.parametrize("so", [0, 1])
+def test_sparse_inserts_into_large_index(hip, so):
+    """steady state of a long job: a small batch into an index hundreds of merge windows long (few new symbols
+    per window: the gap-opening path), then a batch with long homopolymers (many per word: the dense path)"""
+    base = H.splitmix_bases(30000, 101, seed=5)
+    small = H.splitmix_bases(700, 101, seed=6)
+    dense = [[1] * 90] * 400 + [[2, 2, 2, 3] * 20] * 300
+    run_both(hip, so, [H.encode_batch_fixed(base), H.encode_batch_fixed(small), H.encode_batch(dense)])
+
+
 def test_single_long_string(hip):
     codes = H.splitmix_bases(1, 50000, seed=77)
     for so in (0, 1):
