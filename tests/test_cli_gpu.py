@@ -43,6 +43,23 @@ def test_fmd_golden_1M_small_batches(golden, flag):
     assert H.md5(cli([flag, "-m20m"], text)) == g["fmd_md5"][flag]
 
 
+@pytest.mark.parametrize("flags", ["-LRds", "-LRd"])
+def test_fmd_golden_10M_streamed(flags):
+    """10 M x 101 bp (1.02 G symbols) streamed from the generator through the CLI in ~400 MB batches: the .fmd md5
+    equals the one the real reference produced (tests/golden/golden_large.json, make_golden_large.py)"""
+    import hashlib, json
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))
+    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
+    assert os.path.exists(gen), "oracle/synth_reads not built"
+    pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
+    pc = subprocess.Popen([CLI, flags, "-m400m", "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h = hashlib.md5()
+    for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+        h.update(chunk)
+    assert pc.wait() == 0 and pg.wait() == 0
+    assert h.hexdigest() == g["fmd_md5"][flags]
+
+
 @pytest.mark.parametrize("so_flag", ["", "s", "r"])
 def test_incremental_build(golden, so_flag, tmp_path):
     """config 5 shape: -b on the first half, then -i + second half == one-shot build"""
