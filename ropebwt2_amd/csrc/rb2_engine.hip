@@ -125,7 +125,6 @@ void build_directory(rb2_hip_t *h, int sd, uint64_t nsb_ub)
 {
 	if (nsb_ub == 0) return;
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
-	if (nchunk > SCHUNK) { fprintf(stderr, "[rb2_hip] index too large for one device (%llu superblocks)\n", (unsigned long long)nsb_ub); abort(); }
 	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
 	PoolView pv = h->pool[sd].view();
 	hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p);
@@ -653,7 +652,8 @@ void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int
 	HIPCHK(hipSetDevice(h->dev));
 	const uint64_t total = (uint64_t)n_reads * (read_len + 1) * (strand ? 2 : 1);
 	if (total == 0) return;
-	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand);
+	if ((uintptr_t)dst_dev & 15) { fprintf(stderr, "[rb2_hip] synth_reads: destination must be 16-byte aligned\n"); abort(); }
+	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256 * 16)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand);
 	HIPCHK(hipGetLastError());
 }
 

@@ -618,12 +618,17 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const Cnt6 *
 __global__ __launch_bounds__(SCHUNK) void k_sbscan2(const Ctl *ctl, Cnt6 *part)
 {
 	__shared__ uint64_t s_w[16];
-	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;   // host guarantees nc <= SCHUNK
-	const bool ok = threadIdx.x < nc;
-	Cnt6 p, o;
-	for (int s = 0; s < 6; ++s) p.v[s] = ok ? part[threadIdx.x].v[s] : 0ull;
-	for (int s = 0; s < 6; ++s) o.v[s] = block_excl_add<uint64_t>(p.v[s], s_w, (uint64_t*)0);
-	if (ok) part[threadIdx.x] = o;
+	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;   // any number of chunks: SCHUNK at a time with a running total
+	Cnt6 run;
+	for (int s = 0; s < 6; ++s) run.v[s] = 0;
+	for (uint64_t i0 = 0; i0 < nc; i0 += SCHUNK) {
+		const uint64_t i = i0 + threadIdx.x;
+		const bool ok = i < nc;
+		Cnt6 p, o;
+		for (int s = 0; s < 6; ++s) p.v[s] = ok ? part[i].v[s] : 0ull;
+		for (int s = 0; s < 6; ++s) { uint64_t tot; o.v[s] = run.v[s] + block_excl_add<uint64_t>(p.v[s], s_w, &tot); run.v[s] += tot; }
+		if (ok) part[i] = o;
+	}
 }
 __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *sbtot, const Cnt6 *part, PoolView newp)
 {
@@ -716,19 +721,28 @@ __device__ __forceinline__ uint64_t splitmix(uint64_t seed, uint64_t k)
 	return z ^ (z >> 31);
 }
 
-// one thread per output byte; strand 0: [rev(read) 0]; strand 1: [rev(read) 0 comp(read) 0] (main.c:200-237)
+// 16 output bytes per thread (one 16-byte store; HIP caps a launch at 2^32 threads, a -m10g batch has 10^10 bytes);
+// strand 0: [rev(read) 0]; strand 1: [rev(read) 0 comp(read) 0] (main.c:200-237)
+__device__ __forceinline__ uint8_t synth_byte(uint64_t g, uint64_t first, uint64_t per, uint32_t L, uint64_t seed)
+{
+	const uint64_t r = g / per; uint32_t off = (uint32_t)(g % per);
+	const uint64_t i = first + r;
+	if (off < L) return (uint8_t)(1 + (splitmix(seed, i * L + (L - 1 - off)) >> 62));         // reversed forward strand
+	if (off == L) return 0;
+	off -= L + 1;
+	return off < L ? (uint8_t)(4 - (splitmix(seed, i * L + off) >> 62)) : 0;                  // complement, original order
+}
 __global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand)
 {
-	const uint64_t per = (uint64_t)(L + 1) * (strand ? 2 : 1);
-	const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	if (gid >= n_reads * per) return;
-	const uint64_t r = gid / per; uint32_t off = (uint32_t)(gid % per);
-	const uint64_t i = first + r;
-	uint8_t v;
-	if (off < L) v = (uint8_t)(1 + (splitmix(seed, i * L + (L - 1 - off)) >> 62));          // reversed forward strand
-	else if (off == L) v = 0;
-	else { off -= L + 1; v = off < L ? (uint8_t)(4 - (splitmix(seed, i * L + off) >> 62)) : 0; }   // complement, original order
-	dst[gid] = v;
+	const uint64_t per = (uint64_t)(L + 1) * (strand ? 2 : 1), total = n_reads * per;
+	const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+	if (g0 >= total) return;
+	if (g0 + 16 <= total) {
+		uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed) << ((k & 3) * 8);
+		*(uint4*)(dst + g0) = make_uint4(w[0], w[1], w[2], w[3]);
+	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed);
 }
 
 __global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out)
