@@ -154,6 +154,32 @@ def test_sparse_inserts_into_large_index(hip, so):
     run_both(hip, so, [H.encode_batch_fixed(base), H.encode_batch_fixed(small), H.encode_batch(dense)])
 
 
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_fuzz_small_shapes(hip, so):
+    """many random small jobs: string counts around the tile / window / leaf sizes, lengths 0..80 with a heavy tail,
+    N's, duplicates, 1-3 batches, both strands now and then; every rope compared with the oracle"""
+    rng = np.random.RandomState(1000 + so)
+    for it in range(24):
+        nb = rng.randint(1, 4)
+        batches = []
+        for _ in range(nb):
+            n = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 511, 512, 513, 1500]))
+            pool = [list(rng.randint(1, 5, size=rng.randint(1, 30))) for _ in range(5)]       # shared substrings -> equal suffixes
+            reads = []
+            for _ in range(n):
+                L = int(rng.choice([0, 1, 2, 5, 17, 40, 80], p=[.05, .1, .1, .2, .25, .2, .1]))
+                if rng.rand() < 0.3:
+                    r = (pool[rng.randint(5)] * 4)[:L]
+                else:
+                    r = list(rng.randint(1, 5, size=L))
+                if len(r) and rng.rand() < 0.1:
+                    r[rng.randint(len(r))] = 5
+                reads.append([int(x) for x in r])
+            both = rng.rand() < 0.25
+            batches.append(H.encode_batch(reads, True, True) if both else H.encode_batch(reads))
+        run_both(hip, so, batches)
+
+
 def test_single_long_string(hip):
     codes = H.splitmix_bases(1, 50000, seed=77)
     for so in (0, 1):

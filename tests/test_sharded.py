@@ -115,6 +115,29 @@ def test_virtual_ranks_many(hip, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_virtual_ranks_random_owner_maps(hip, seed):
+    """any assignment of the 31 sub-ropes to ranks gives the same BWT (pieces of one rope scattered over ranks,
+    ranks that own only light pieces, a rank that owns nothing)"""
+    from ropebwt2_amd.sharded import NR, VirtualCluster
+    rng = np.random.RandomState(seed)
+    n = 5
+    owners = [int(x) for x in rng.randint(0, n - 1, size=NR)]          # rank n-1 owns nothing
+    so = seed % 3
+    reads = H.repetitive_reads(2000, seed=70 + seed, genome_len=600, max_len=70)
+    codes = H.splitmix_bases(3000, 64, seed=9 + seed)
+    o = H.Oracle(so)
+    vc = VirtualCluster(so, n, owners=owners)
+    for buf in (H.encode_batch(reads[:1200]), H.encode_batch_fixed(codes), H.encode_batch(reads[1200:], True, True)):
+        o.insert_multi(buf)
+        vc.insert_multi(buf)
+    assert np.array_equal(vc.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(vc.rope(b), o.rope(b)), "rope %d" % b
+    vc.close()
+
+
+@pytest.mark.gpu
 def test_virtual_ranks_golden(hip, golden):
     from ropebwt2_amd.sharded import VirtualCluster
     g = golden["sets"]["100k_x_101"]
