@@ -108,6 +108,13 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
 			uint64_t f = F[w];
+			{	// first new symbol of the word, branch-free (most words have none or one)
+				const bool has = f != 0;
+				const uint64_t lm = (1ull << ((has ? __builtin_ctzll(f) : 3) - 3)) - 1ull;
+				const uint64_t g = (out[w] & lm) | ((out[w] & ~lm) << 4);
+				out[w] = has ? g : out[w];
+				f &= f - 1;
+			}
 			while (__any(f != 0)) {
 				if (f) {
 					const uint64_t lm = (1ull << (__builtin_ctzll(f) - 3)) - 1ull;   // nibbles below the new symbol
