@@ -70,6 +70,9 @@ struct Ctl {
 	uint64_t max_len;       // longest string (without sentinel)
 	uint64_t n0;            // strings already in the index (#'$' in the BWT, mrope.c:279)
 	uint64_t len;           // batch bytes
+	// ne[p] != 0: some string has a NON-EMPTY interval in the arrays read by rounds of parity p.  Zero (always in input
+	// order; on random reads from round ~14 of a batch on) selects the kernel variants that never touch U / SIZE.
+	uint32_t ne[2];
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
 	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
 	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a

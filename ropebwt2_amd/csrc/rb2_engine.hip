@@ -190,7 +190,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{
 		Scope sc(h, RB2_K_INIT, 0);
-		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len);
+		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len, is_srt);
 		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
 				h->L[0].p, h->U[0].p, h->ID[0].p, h->W[0].p);
 	}
@@ -206,7 +206,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	const int64_t units = (int64_t)B.m;
 	h->cur_round = (int)r;
 	{ Scope sc(h, RB2_K_SYM, units);
-	  hipLaunchKernelGGL(k_sym, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+	  hipLaunchKernelGGL(k_sym, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
 	{ Scope sc(h, RB2_K_TSCAN, units);
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
@@ -226,9 +226,11 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt); }
+	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  hipLaunchKernelGGL(k_prep, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  hipLaunchKernelGGL(k_prep<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
+	  hipLaunchKernelGGL(k_prep<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
@@ -237,7 +239,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  hipLaunchKernelGGL(k_advance, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  hipLaunchKernelGGL(k_advance<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send);
+	  hipLaunchKernelGGL(k_advance<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
 	h->side ^= 1; B.cur ^= 1;
 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, cons
 }
 
 // round 0: every string sits in "bucket 0" and inserts its last symbol into rope $ (mrope.c:285)
-__global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len)
+__global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len, int is_srt)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	SegDesc &sg = ctl->seg[side];
@@ -160,6 +160,8 @@ __global__ void k_batch_setup(Ctl *ctl, int side, uint64_t m, uint64_t len)
 	uint64_t n0 = 0;
 	for (int b = 0; b < NR; ++b) n0 += ctl->rope[side][b].cnt[0];
 	ctl->n0 = n0; ctl->n_strings = m; ctl->max_len = 0; ctl->len = len;
+	ctl->ne[0] = (is_srt && n0) ? 1u : 0u;          // round 0: [0, n0) for every string in the sorted modes (mrope.c:280-283)
+	ctl->ne[1] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -178,10 +180,12 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 	return true;
 }
 
-__global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, const uint64_t *U, const uint64_t *W,
+// When every interval of the round is empty (u == l, ctl->ne[par] == 0) U is dead and L is read in its place.
+__global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
 		uint8_t *A, TileRec *trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
+	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
 	const int ln = lane_id(), w = wave_id();
@@ -338,10 +342,11 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.
-__global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt)
+__global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
 {
 	if (blockIdx.x) return;
 	const int r = threadIdx.x;
+	if (r == 0) ctl->ne[par ^ 1] = 0;                          // k_advance / k_unpack of this round count into it
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
@@ -469,11 +474,12 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	return m;
 }
 
-__global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_comp, PoolView oldp,
+template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
 	__shared__ GroupLds G;
+	if ((ctl->ne[par] == 0) != AE) return;
 	TileCtx t;
 	const SegDesc &sg = ctl->seg[side];
 	if (!tile_ctx(sg, blockIdx.x, t)) return;
@@ -483,7 +489,7 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		l2[h] = u2[h] = 0;
-		if (k < t.segend) { l2[h] = L[k]; u2[h] = U[k]; }
+		if (k < t.segend) { l2[h] = L[k]; u2[h] = AE ? l2[h] : U[k]; }
 	}
 	group_setup(G, t, A, tf, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int is_c
 		const Member m = group_member(G, t, x, a, orda);
 		const uint64_t l0 = l2[h] - m.F, u0 = u2[h] - m.F;     // coordinates on the pre-round rope
 		uint64_t e = l0;
-		if (u0 != l0) {                                        // rope_rank2a (mrope.c:202)
+		if (!AE && u0 != l0) {                                 // rope_rank2a (mrope.c:202)
 			uint64_t cl[6], cu[6], size = 0;
 			const int oa = orda[a];
 			rank2_all(oldp, rp, l0, u0, cl, cu);
@@ -645,12 +651,13 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
+template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
 	__shared__ GroupLds G;
+	if ((ctl->ne[round & 1] == 0) != AE) return;
 	TileCtx t;
 	const SegDesc &sg = ctl->seg[side];
 	if (!tile_ctx(sg, blockIdx.x, t)) return;
@@ -663,6 +670,7 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; l2[h] = L[k]; }
 	}
 	group_setup(G, t, A, tf, sym2, flag2);
+	uint32_t nz = 0;
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
@@ -677,18 +685,24 @@ __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int i
 		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
 		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
 		// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
-		const uint64_t f = (flag2[h] ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
+		const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
 		const uint64_t gl = nrp.leaf0 + f / LEAF;
 		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
-		const uint64_t u = l + (flag2[h] ? SIZE[k] : 0ull);
+		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
 		const uint32_t id = id2[h];
 		uint64_t wv = w2[h] >> 4;
 		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id);
-		} else { L2[d] = l; U2[d] = u; ID2[d] = id; W2[d] = wv; }
+		} else {
+			L2[d] = l; ID2[d] = id; W2[d] = wv;
+			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
+		}
+	}
+	if (!AE && !send) {                                        // does the next round see a non-empty interval?  (a flag: plain store, no atomic)
+		if (__any(nz != 0) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;
 	}
 }
 
@@ -698,7 +712,8 @@ __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *
 		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	if (i >= total) return;
+	bool nonempty = false;
+	if (i < total) {
 	int lo = 0, hi = npieces - 1;                              // last piece with src <= i (pieces tile recv[] in order)
 	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].src <= i) lo = mid; else hi = mid - 1; }
 	const ShardRec r = recv[i];
@@ -707,6 +722,9 @@ __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *
 	const uint32_t id = (uint32_t)r.b;
 	L2[d] = l; U2[d] = l + size; ID2[d] = id;
 	W2[d] = pack16(s, ctl->len, START[id] + round + 1);
+	nonempty = size != 0;
+	}
+	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
 }
 
 // ---------------------------------------------------------------------------------------------
