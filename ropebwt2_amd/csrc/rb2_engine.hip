@@ -146,6 +146,7 @@ struct BatchState {
 	const uint8_t *s = nullptr; uint64_t len = 0, m = 0, max_len = 0, n_tot = 0, nsb_ub = 0;
 	unsigned nst_ub = 0, nsc = 0;
 	int cur = 0;                            // string array side
+	bool known_ae = false;                  // the host can tell that every interval of the batch is empty: input order, or an empty index
 };
 
 // per-string arrays + tile tables for batches of up to m strings
@@ -188,6 +189,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
 	h->LD.ensure(leaves_ub + NR + 16);
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
+	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
 	{
 		Scope sc(h, RB2_K_INIT, 0);
 		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len, is_srt);
@@ -228,7 +230,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  hipLaunchKernelGGL(k_prep<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) hipLaunchKernelGGL(k_prep<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
 	  hipLaunchKernelGGL(k_prep<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
@@ -239,7 +241,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  hipLaunchKernelGGL(k_advance<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) hipLaunchKernelGGL(k_advance<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send);
 	  hipLaunchKernelGGL(k_advance<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
