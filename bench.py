@@ -13,10 +13,13 @@ so `value` is whole-job symbols / wall time with inputs resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 (default --mode sharded): ONE index, its 31 sub-ropes sharded over the ranks (owner map in
-ropebwt2_amd/sharded.py), per round an all_reduce of the 31x6 count matrix and an all_to_all of
-16-byte string records over RCCL; the job is the same configs[1] job, so scaling is "strong".
---mode independent builds one separate BWT per GPU over disjoint read slices instead ("weak").
+N > 1: ONE index, its 31 sub-ropes sharded over the ranks (owner map in ropebwt2_amd/sharded.py), per
+round an all_reduce of the 31x6 count matrix and an all_to_all of 16-byte string records over RCCL.
+  --mode weak (default)   the job grows with N: N x 100 M reads in three batches of -m(4N)g, so every GPU
+                          keeps ~40.8 M strings per round and 1/N of an N-times larger index ("weak";
+                          N = 8 is within a factor 1.5 of BASELINE.json configs[2]'s 1.2 B reads)
+  --mode strong           the configs[1] job itself, split N ways ("strong")
+  --mode independent      one separate BWT per GPU over disjoint read slices, no collectives ("weak")
 """
 import argparse
 import json
@@ -82,7 +85,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=101)
     ap.add_argument("--batch", type=float, default=4.0, help="-m in GiB")
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
-    ap.add_argument("--mode", default="sharded", choices=["sharded", "independent"], help="what N > 1 ranks do (see module docstring)")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong", "independent"], help="what N > 1 ranks do (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     args = ap.parse_args()
@@ -114,7 +117,10 @@ def main():
         build_all()
     if dist is not None:
         dist.barrier()
-    sharded = world > 1 and args.mode == "sharded"
+    sharded = world > 1 and args.mode in ("weak", "strong")
+    if sharded and args.mode == "weak":                 # per-GPU work fixed: N times the reads, N times the batch
+        args.reads *= world
+        args.batch *= world
     so = {"io": 0, "rlo": 1, "rclo": 2}[args.order]
     so_flag = {"io": "", "rlo": "-s", "rclo": "-r"}[args.order]
     L = args.read_len
@@ -206,11 +212,13 @@ def main():
         "unit": "Gsymbols/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / max(1, args.steps),
-        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if (sharded and args.mode == "strong") else "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
-                               % (args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
-                   "reads_per_gpu": sum(n for _, n in steps), "symbols_per_gpu": symbols,
+        "config": {"workload": "%s: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
+                               % ("configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % world,
+                                  args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
+                   "reads": sum(n for _, n in steps) * (1 if sharded else n_gpus), "symbols": total_symbols,
+                   "reads_per_gpu": sum(n for _, n in steps) // (n_gpus if sharded else 1), "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
                    "parallelism": "1 GPU" if n_gpus == 1 else
                                   ("31 sub-ropes (b,x) sharded over %d of %d GPUs (owner map %s); per round all_reduce(31x6 counts) + all_to_all(16 B string records) over RCCL"
                                    % (active, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
