@@ -559,9 +559,8 @@ void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt,
 	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) sd[r][a] = (uint64_t)off[r][a];
 	HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, NR * 6 * 8, hipMemcpyHostToDevice, h->st));
 	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd), hipMemcpyHostToDevice, h->st));
-	HIPCHK(hipStreamSynchronize(h->st));                       /* sd / global_cnt may be temporaries of the caller */
 	round_merge(h, B, (uint64_t)round, (ShardRec*)send_dev);
-	HIPCHK(hipStreamSynchronize(h->st));                       /* the send buffer is complete when we return */
+	HIPCHK(hipStreamSynchronize(h->st));                       /* the send buffer is complete (and sd / global_cnt consumed) when we return */
 }
 
 void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[])
