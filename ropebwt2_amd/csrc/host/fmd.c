@@ -33,7 +33,7 @@ struct rb2_fmd_s {
 
 static const int hdr_words[3] = { 2, 4, 7 };   /* (7*16+63)/64, (7*32+63)/64, 7 */
 
-static int ilog2_u64(uint64_t v) { int k = -1; while (v) { ++k; v >>= 1; } return k; }   /* ilog2(0) = -1 like rld0.c:26-43 */
+static int ilog2_u64(uint64_t v) { return v ? 63 - __builtin_clzll(v) : -1; }   /* ilog2(0) = -1 like rld0.c:26-43 */
 
 static void reserve(rb2_fmd_t *f, size_t n_words)
 {

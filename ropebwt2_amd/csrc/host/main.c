@@ -104,6 +104,29 @@ static int read_fastx_record(reader_t *r)
 }
 
 /* ---- helpers ---------------------------------------------------------------------------------- */
+/* output: one chunk of 43+3 run bytes -> .fmd encoder (user != 0) or plain text */
+static void emit_runs(void *user, const uint8_t *q, int64_t n)
+{
+	rb2_fmd_t *fmd = (rb2_fmd_t*)user;
+	const uint8_t *end = q + n;
+	while (q < end) {
+		int sym; int64_t len, k;
+		rle_dec1(q, sym, len);
+		if (fmd) rb2_fmd_push(fmd, len, sym);
+		else {                                                 /* plain text: one fwrite per 64 KiB instead of a putchar per symbol */
+			static char tbuf[1 << 16];
+			static size_t tl = 0;
+			for (k = len; k > 0; ) {
+				const size_t room = sizeof(tbuf) - tl, take = (size_t)k < room ? (size_t)k : room;
+				memset(tbuf + tl, "$ACGTN"[sym], take);
+				tl += take; k -= (int64_t)take;
+				if (tl == sizeof(tbuf)) { fwrite(tbuf, 1, tl, stdout); tl = 0; }
+			}
+			if (q == end && tl) { fwrite(tbuf, 1, tl, stdout); tl = 0; }   /* end of chunk: keep stdout in order with the caller's putchar */
+		}
+	}
+}
+
 static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec); }
 static double realtime(void) { struct timeval t; gettimeofday(&t, 0); return t.tv_sec + 1e-6 * t.tv_usec; }
 
@@ -276,19 +299,8 @@ int main(int argc, char *argv[])
 	if (flag & F_BIN) mr_dump(mr, stdout);
 	else if (flag & F_TREE) mr_print_tree(mr);
 	else {
-		mritr_t itr;
-		const uint8_t *blk;
 		rb2_fmd_t *fmd = flag & F_RLD ? rb2_fmd_init() : 0;
-		mr_itr_first(mr, &itr, 1);
-		while ((blk = mr_itr_next_block(&itr)) != 0) {
-			const uint8_t *q = blk + 2, *end = q + *rle_nptr(blk);
-			while (q < end) {
-				int sym; int64_t len, k;
-				rle_dec1(q, sym, len);
-				if (fmd) rb2_fmd_push(fmd, len, sym);
-				else for (k = 0; k < len; ++k) putchar("$ACGTN"[sym]);
-			}
-		}
+		mr_stream_runs(mr, emit_runs, fmd);                    /* the reference walks mr_itr_next_block here (main.c:288-305) */
 		if (fmd) {
 			int64_t cc[7];
 			rb2_fmd_finish(fmd);

@@ -85,6 +85,21 @@ void mr_sync_host(mrope_t *mr)
 	x->host_ok = 1;
 }
 
+/* the BWT as run bytes, without materialising host trees when the device has it (include/mrope.h) */
+void mr_stream_runs(mrope_t *mr, void (*cb)(void *user, const uint8_t *runs, int64_t n_bytes), void *user)
+{
+	mrx_t *x = X(mr);
+	int a;
+	if (!x->host_ok && x->dev && x->dev_ok) {
+		for (a = 0; a < 6; ++a) rb2_hip_stream_rope(x->dev, a, cb, user);
+	} else {
+		mritr_t itr;
+		const uint8_t *blk;
+		mr_itr_first(mr, &itr, 0);
+		while ((blk = mr_itr_next_block(&itr)) != 0) cb(user, blk + 2, *rle_nptr(blk));
+	}
+}
+
 /* host ropes -> device */
 static void sync_dev(mrope_t *mr)
 {

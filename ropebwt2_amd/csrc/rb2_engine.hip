@@ -356,28 +356,38 @@ void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
 
 /* run-length export of sub-rope r in chunks of CH leaves: k_export writes one 43+3 byte per run into a staging
  * buffer (slot stride LEAF) + the byte count of every leaf; dst == NULL only counts.  Returns the bytes. */
-static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst)
+static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb = nullptr, void *user = nullptr)
 {
 	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB of run bytes)
 	const RopeDesc &d = h->h_rope[r];
 	if (d.nleaves == 0) return 0;
 	const uint64_t ch = std::min<uint64_t>(CH, d.nleaves);
+	const bool want = dst || cb;
 	h->xstage.ensure(ch * LEAF); h->xnb.ensure(ch);
-	std::vector<uint8_t> stage(dst ? ch * LEAF : 0);
+	std::vector<uint8_t> stage(want ? ch * LEAF : 0);
 	std::vector<uint16_t> nb(ch);
 	int64_t k = 0;
 	for (uint64_t l0 = 0; l0 < d.nleaves; l0 += CH) {
 		const uint64_t nl = std::min<uint64_t>(CH, d.nleaves - l0);
 		hipLaunchKernelGGL(k_export, dim3(cdiv(nl, MW)), dim3(256), 0, h->st, h->pool[h->side].view(), d.leaf0, d.n, l0, (uint32_t)nl, h->xstage.p, h->xnb.p);
 		HIPCHK(hipGetLastError());
-		if (dst) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nl * LEAF, hipMemcpyDeviceToHost, h->st));
+		if (want) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nl * LEAF, hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nl * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
 		for (uint64_t i = 0; i < nl; ++i) {
 			if (dst) memcpy(dst + k, stage.data() + i * LEAF, nb[i]);
+			if (cb) cb(user, stage.data() + i * LEAF, nb[i]);
 			k += nb[i];
 		}
 	}
+	return k;
+}
+
+int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	int64_t k = 0;
+	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) k += export_piece(h, r, nullptr, cb, user);
 	return k;
 }
 
