@@ -208,6 +208,26 @@ class Oracle:
         return c.reshape(6, 6)
 
 
+def decode_runs(rle):
+    """43+3 run bytes (any run width, rle.h:39-51) -> nt6 symbols; small inputs only (Python loop)"""
+    rle = np.asarray(rle, dtype=np.uint8)
+    out, i, n = [], 0, len(rle)
+    while i < n:
+        b = int(rle[i]); c = b & 7
+        if b & 0x80 == 0:
+            l = b >> 3; i += 1
+        elif b >> 5 == 6:
+            l = (b & 0x18) << 3 | (int(rle[i + 1]) & 0x3f); i += 2
+        else:
+            nb = 8 if b & 0x10 else 4
+            l = (b >> 3) & 1
+            for k in range(1, nb):
+                l = l << 6 | (int(rle[i + k]) & 0x3f)
+            i += nb
+        out.append(np.full(l, c, np.uint8))
+    return np.concatenate(out) if out else np.zeros(0, np.uint8)
+
+
 def bwt_text(codes):
     return SYMS[np.asarray(codes, dtype=np.uint8)].tobytes()
 

@@ -140,6 +140,16 @@ def test_mrope_c_api(golden):
         m = MRope.from_address(mr)
         counts = np.array([[Rope.from_address(m.r[a]).c[b] for b in range(6)] for a in range(6)])
         assert np.array_equal(counts, o.counts())
+        # mr_stream_runs: the BWT as run bytes straight from the device (no host trees), then again from the host leaves
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint8), C.c_int64)
+        L.mr_stream_runs.argtypes = [C.c_void_p, CB, C.c_void_p]
+        for sync_first in (False, True):
+            chunks = []
+            if sync_first:
+                L.mr_sync_host(mr)
+            L.mr_stream_runs(mr, CB(lambda u, q, n: chunks.append(bytes(q[:n]))), None)
+            syms = H.decode_runs(np.frombuffer(b"".join(chunks), np.uint8))
+            assert np.array_equal(syms, o.bwt()), "mr_stream_runs (host trees: %s)" % sync_first
         L.mr_destroy(mr)
 
 
