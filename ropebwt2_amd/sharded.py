@@ -156,21 +156,24 @@ class TorchComm:
         self.send_t = self.recv_t = None
         self.send_dev = self.recv_dev = None      # raw engine buffers when staging
         self.cap = 0
+        self.EPR = REC_BYTES // 8                 # int64 elements per record
 
     def _ensure(self, n_records):
+        """exchange buffers as int64 tensors (2 elements per 16-byte record): element counts stay small even for
+        multi-GB exchanges"""
         if n_records <= self.cap:
             return
         torch = self.torch
-        nbytes = max(1, n_records) * REC_BYTES
+        nel = max(1, n_records) * self.EPR
         if self.on_device:
-            self.send_t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
-            self.recv_t = torch.empty(nbytes, dtype=torch.uint8, device=self.dev)
+            self.send_t = torch.empty(nel, dtype=torch.int64, device=self.dev)
+            self.recv_t = torch.empty(nel, dtype=torch.int64, device=self.dev)
         else:
             if self.send_dev:
                 self.bwt.dev_free(self.send_dev); self.bwt.dev_free(self.recv_dev)
-            self.send_dev, self.recv_dev = self.bwt.dev_alloc(nbytes), self.bwt.dev_alloc(nbytes)
-            self.send_t = torch.empty(nbytes, dtype=torch.uint8)
-            self.recv_t = torch.empty(nbytes, dtype=torch.uint8)
+            self.send_dev, self.recv_dev = self.bwt.dev_alloc(nel * 8), self.bwt.dev_alloc(nel * 8)
+            self.send_t = torch.empty(nel, dtype=torch.int64)
+            self.recv_t = torch.empty(nel, dtype=torch.int64)
         self.cap = n_records
 
     def send_ptr(self, n):
@@ -193,16 +196,16 @@ class TorchComm:
                     msg = gen.send(t.cpu().numpy())
                 else:
                     _, sc, rc, total = msg
-                    ns, nr = sum(sc) * REC_BYTES, sum(rc) * REC_BYTES
+                    E = self.EPR
+                    ns, nr = sum(sc) * E, sum(rc) * E
                     if total:                              # same number on every rank: nobody enters an empty collective
                         if not self.on_device and ns:
-                            bwt.stage_out(self.send_t.data_ptr(), self.send_dev, ns)
-                        dist.all_to_all_single(self.recv_t[:nr], self.send_t[:ns],
-                                               [c * REC_BYTES for c in rc], [c * REC_BYTES for c in sc])
+                            bwt.stage_out(self.send_t.data_ptr(), self.send_dev, ns * 8)
+                        dist.all_to_all_single(self.recv_t[:nr], self.send_t[:ns], [c * E for c in rc], [c * E for c in sc])
                         if self.on_device:
                             torch.cuda.synchronize()
                         elif nr:
-                            bwt.stage_in(self.recv_dev, self.recv_t.data_ptr(), nr)
+                            bwt.stage_in(self.recv_dev, self.recv_t.data_ptr(), nr * 8)
                     msg = next(gen)
         except StopIteration:
             pass
