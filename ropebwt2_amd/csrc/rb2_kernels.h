@@ -435,7 +435,7 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 	__syncthreads();
 }
 
-struct Member { uint32_t pa, pga, slot; uint64_t F; };
+struct Member { uint32_t pa, pga, slot; uint64_t F; int lead; };   // lead: first member of my group inside this tile
 
 // string x of the tile, inserting a: pa = members of the bucket in front of it inserting a, pga = the same count
 // in front of its group, F = first member of its group, slot = its place in the bucket's insert list
@@ -457,7 +457,7 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	Member m;
 	m.pa = G.fix.tpre[a] + before(x, a);
 	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
-		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F;
+		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F; m.lead = x;
 		return m;
 	}
 	m.pga = hpos >= 0 ? G.fix.tpre[a] + before(hpos, a) : G.fix.popen[a];
@@ -471,6 +471,7 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 		bef += pn - pg;
 	}
 	m.slot = (uint32_t)(m.F + bef + (m.pa - m.pga));
+	m.lead = hpos >= 0 ? hpos : 0;
 	return m;
 }
 
@@ -494,29 +495,59 @@ template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl,
 	group_setup(G, t, A, tf, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
+	if (AE) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const int x = h * 256 + threadIdx.x;
+			const uint64_t k = t.base + x;
+			if (k >= t.segend) continue;
+			const int a = sym2[h];
+			const Member m = group_member(G, t, x, a, orda);
+			INS_E[t.segstart + m.slot] = l2[h] - m.F;          // empty interval: the new symbol goes to l (pre-round coordinates)
+			INS_A[t.segstart + m.slot] = (uint8_t)a;
+		}
+		return;
+	}
+	// Non-empty intervals: the members of a group share [l, u) (mrope.c:192-202), so rope_rank2a is evaluated once per
+	// group and tile -- by the group's first member inside the tile -- and handed to the others through LDS.
+	__shared__ uint64_t s_d[AE ? 1 : STILE][6];                // #s in [l, u) of the group led by string x of the tile
+	Member mm[2];
+	uint64_t l0[2], u0[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int x = h * 256 + threadIdx.x;
+		const uint64_t k = t.base + x;
+		l0[h] = u0[h] = 0; mm[h].lead = -1;
+		if (k >= t.segend) continue;
+		mm[h] = group_member(G, t, x, sym2[h], orda);
+		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
+		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
+			uint64_t cl[6], cu[6];
+			rank2_all(oldp, rp, l0[h], u0[h], cl, cu);
+			for (int s = 0; s < 6; ++s) s_d[x][s] = cu[s] - cl[s];
+		}
+	}
+	__syncthreads();
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
 		const uint64_t k = t.base + x;
 		if (k >= t.segend) continue;
 		const int a = sym2[h];
-		const Member m = group_member(G, t, x, a, orda);
-		const uint64_t l0 = l2[h] - m.F, u0 = u2[h] - m.F;     // coordinates on the pre-round rope
-		uint64_t e = l0;
-		if (!AE && u0 != l0) {                                 // rope_rank2a (mrope.c:202)
-			uint64_t cl[6], cu[6], size = 0;
+		uint64_t e = l0[h];
+		if (u0[h] != l0[h]) {
 			const int oa = orda[a];
-			rank2_all(oldp, rp, l0, u0, cl, cu);
+			uint64_t size = 0;
 			for (int s = 0; s < 6; ++s) {
-				const uint64_t d = cu[s] - cl[s];
+				const uint64_t d = s_d[mm[h].lead][s];
 				if (orda[s] < oa) e += d;
 				if (s == a) size = d;
 			}
 			SIZE[k] = size;                                    // only non-empty intervals have one (flag 0x40 in A)
 			A[k] = (uint8_t)(a | 0x40 | (G.head[x >> 6] >> (x & 63) & 1 ? 0x80 : 0));
 		}
-		INS_E[t.segstart + m.slot] = e;
-		INS_A[t.segstart + m.slot] = (uint8_t)a;
+		INS_E[t.segstart + mm[h].slot] = e;
+		INS_A[t.segstart + mm[h].slot] = (uint8_t)a;
 	}
 }
 
