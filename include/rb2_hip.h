@@ -120,6 +120,10 @@ void  rb2_hip_dev_free(rb2_hip_t *h, void *p);
  * strand: 0 = forward strand only; 1 = forward followed by reverse complement (buffer doubles). */
 void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads,
                          int read_len, uint64_t seed, int strand);
+/* the same, but the reads are windows of one random genome of genome_len bases (uniform start positions): overlapping
+ * reads as from sequencing at coverage n_reads*read_len/genome_len -- large groups, non-empty intervals in every round */
+void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads,
+                             int read_len, uint64_t seed, int strand, int64_t genome_len);
 
 void rb2_hip_sync(rb2_hip_t *h);
 

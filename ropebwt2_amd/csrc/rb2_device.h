@@ -95,7 +95,12 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 	uint16_t ni, nvalid;    // new symbols / symbols in the window
 };
 
-struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
+// in-leaf rank checkpoints: c[q][s-1] = number of symbol s (1..5; $ follows from the position) in the first (q+1)*QLEAF
+// symbols of the leaf, so that a rank query scans at most QLEAF symbols (the reference scans a 512-byte leaf, rle.c:134-191)
+constexpr int QLEAF = LEAF / 4;
+struct LeafMid { uint16_t c[3][5]; uint16_t pad; };
+
+struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; LeafMid *mid; };
 
 struct TileRec {            // per string tile, written by k_sym
 	uint32_t hist[6];
@@ -235,15 +240,29 @@ __device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, Ni
 	if (from >= to) return;
 	const uint64_t M1 = 0x1111111111111111ull;
 	const uint32_t c0 = from >> 5, c1 = (to - 1) >> 5;
-	for (uint32_t c = c0; c <= c1; ++c) {
+	auto edge = [&](uint32_t c) {
 		const uint4 v = q[c];
 		const uint64_t x0 = (uint64_t)v.y << 32 | v.x, x1 = (uint64_t)v.w << 32 | v.z;
-		if (c != c0 && c != c1) { nib_acc(A, x0, M1); nib_acc(A, x1, M1); continue; }
 		const uint32_t base = c * 32;
 		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, 32u);      // in-chunk range [lo, hi)
 		nib_acc(A, x0, M1 & nib_below(min(hi, 16u)) & ~nib_below(min(lo, 16u)));
 		nib_acc(A, x1, M1 & nib_below(hi > 16 ? hi - 16 : 0u) & ~nib_below(lo > 16 ? lo - 16 : 0u));
+	};
+	edge(c0);
+	if (c1 == c0) return;
+	uint32_t c = c0 + 1;
+	for (; c + 4 <= c1; c += 4) {                              // interior chunks, four loads in flight (the scan is latency-bound)
+		const uint4 v0 = q[c], v1 = q[c + 1], v2 = q[c + 2], v3 = q[c + 3];
+		nib_acc(A, (uint64_t)v0.y << 32 | v0.x, M1); nib_acc(A, (uint64_t)v0.w << 32 | v0.z, M1);
+		nib_acc(A, (uint64_t)v1.y << 32 | v1.x, M1); nib_acc(A, (uint64_t)v1.w << 32 | v1.z, M1);
+		nib_acc(A, (uint64_t)v2.y << 32 | v2.x, M1); nib_acc(A, (uint64_t)v2.w << 32 | v2.z, M1);
+		nib_acc(A, (uint64_t)v3.y << 32 | v3.x, M1); nib_acc(A, (uint64_t)v3.w << 32 | v3.z, M1);
 	}
+	for (; c < c1; ++c) {
+		const uint4 v = q[c];
+		nib_acc(A, (uint64_t)v.y << 32 | v.x, M1); nib_acc(A, (uint64_t)v.w << 32 | v.z, M1);
+	}
+	edge(c1);
 }
 
 // counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
@@ -260,12 +279,20 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	const uint32_t off = (uint32_t)(p % LEAF);
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	const LeafMeta m = pv.meta[gl];
-	NibAcc A;
-	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), 0, off, A);
-	uint32_t c[6];
-	nib_finish(A, off, c);
+	const uint32_t qi = off / QLEAF;                           // checkpoints in front of p (LeafMid)
+	uint32_t c[6], base[6] = {0, 0, 0, 0, 0, 0};
+	if (qi) {
+		const uint16_t *row = &pv.mid[gl].c[qi - 1][0];
+		uint32_t sum = 0;
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
+		for (int s = 1; s < 6; ++s) { base[s] = row[s - 1]; sum += base[s]; }
+		base[0] = qi * QLEAF - sum;
+	}
+	NibAcc A;
+	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), qi * QLEAF, off, A);
+	nib_finish(A, off - qi * QLEAF, c);
+#pragma unroll
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + base[s] + c[s];
 }
 
 // rank of all six symbols at both ends of [l, u), l < u (rope_rank2a, rope.c:179-194): when both ends

@@ -772,16 +772,24 @@ __device__ __forceinline__ uint64_t splitmix(uint64_t seed, uint64_t k)
 
 // 16 output bytes per thread (one 16-byte store; HIP caps a launch at 2^32 threads, a -m10g batch has 10^10 bytes);
 // strand 0: [rev(read) 0]; strand 1: [rev(read) 0 comp(read) 0] (main.c:200-237)
-__device__ __forceinline__ uint8_t synth_byte(uint64_t g, uint64_t first, uint64_t per, uint32_t L, uint64_t seed)
+// genome_len == 0: i.i.d. bases.  genome_len > 0: read i is a window of a random "genome" of that many
+// bases (base p = splitmix(seed, p) >> 62), starting at splitmix(seed ^ COV_SALT, i) % (genome_len - L + 1): reads overlap
+// like sequencing reads at coverage n*L/genome_len, so suffix-array intervals stay non-empty and groups stay large.
+constexpr uint64_t COV_SALT = 0x5bd1e995c0f3a1d7ull;
+__device__ __forceinline__ uint64_t synth_base_index(uint64_t i, uint32_t j, uint32_t L, uint64_t seed, uint64_t genome_len)
+{
+	return genome_len ? splitmix(seed ^ COV_SALT, i) % (genome_len - L + 1) + j : i * L + j;
+}
+__device__ __forceinline__ uint8_t synth_byte(uint64_t g, uint64_t first, uint64_t per, uint32_t L, uint64_t seed, uint64_t genome_len)
 {
 	const uint64_t r = g / per; uint32_t off = (uint32_t)(g % per);
 	const uint64_t i = first + r;
-	if (off < L) return (uint8_t)(1 + (splitmix(seed, i * L + (L - 1 - off)) >> 62));         // reversed forward strand
+	if (off < L) return (uint8_t)(1 + (splitmix(seed, synth_base_index(i, L - 1 - off, L, seed, genome_len)) >> 62));   // reversed forward strand
 	if (off == L) return 0;
 	off -= L + 1;
-	return off < L ? (uint8_t)(4 - (splitmix(seed, i * L + off) >> 62)) : 0;                  // complement, original order
+	return off < L ? (uint8_t)(4 - (splitmix(seed, synth_base_index(i, off, L, seed, genome_len)) >> 62)) : 0;       // complement, original order
 }
-__global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand)
+__global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand, uint64_t genome_len)
 {
 	const uint64_t per = (uint64_t)(L + 1) * (strand ? 2 : 1), total = n_reads * per;
 	const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
@@ -789,9 +797,9 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uin
 	if (g0 + 16 <= total) {
 		uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed) << ((k & 3) * 8);
+		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed, genome_len) << ((k & 3) * 8);
 		*(uint4*)(dst + g0) = make_uint4(w[0], w[1], w[2], w[3]);
-	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed);
+	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed, genome_len);
 }
 
 __global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out)

@@ -51,6 +51,7 @@ def load_hip_lib():
         "rb2_hip_dev_alloc": (vp, [vp, i64]),
         "rb2_hip_dev_free": (None, [vp, vp]),
         "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
+        "rb2_hip_synth_reads_cov": (None, [vp, vp, i64, i64, i32, u64, i32, i64]),
         "rb2_hip_sync": (None, [vp]),
         "rb2_hip_profile": (None, [vp, i32]),
         "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
@@ -71,7 +72,7 @@ ABI_SYMBOLS = [
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy",
-    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_sync", "rb2_hip_profile",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
 ]
 
@@ -177,8 +178,8 @@ class HipBwt:
     def dev_free(self, p):
         self.L.rb2_hip_dev_free(self.h, p)
 
-    def synth_reads(self, dev_ptr, first, n_reads, read_len, seed=42, strand=0):
-        self.L.rb2_hip_synth_reads(self.h, dev_ptr, first, n_reads, read_len, seed, strand)
+    def synth_reads(self, dev_ptr, first, n_reads, read_len, seed=42, strand=0, genome_len=0):
+        self.L.rb2_hip_synth_reads_cov(self.h, dev_ptr, first, n_reads, read_len, seed, strand, genome_len)
 
     def sync(self):
         self.L.rb2_hip_sync(self.h)

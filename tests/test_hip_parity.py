@@ -180,6 +180,32 @@ def test_fuzz_small_shapes(hip, so):
         run_both(hip, so, batches)
 
 
+@pytest.mark.parametrize("so,strand", [(0, 0), (1, 0), (2, 1)])
+def test_coverage_reads_match_oracle(hip, so, strand):
+    """reads cut from one random genome at ~60x coverage (rb2_hip_synth_reads_cov): every round has large groups and
+    non-empty intervals -- the regime of real sequencing data, which i.i.d. reads leave after ~14 rounds.  Two batches."""
+    n, L, glen = 12000, 50, 10000
+    per = (L + 1) * (2 if strand else 1)
+    o = H.Oracle(so)
+    dev = hip.HipBwt(so)
+    p = dev.dev_alloc(n * per + 64)
+    for first in (0, n):
+        dev.synth_reads(p, first, n, L, seed=11, strand=strand, genome_len=glen)
+        dev.sync()
+        host = np.empty(n * per, np.uint8)
+        dev.L.rb2_hip_memcpy(dev.h, host.ctypes.data, p, n * per, 1)
+        assert host[-1] == 0 and int((host == 0).sum()) == n * (2 if strand else 1)
+        dev.insert_multi_dev(p, n * per)
+        o.insert_multi(host)
+        assert np.array_equal(dev.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(dev.rope(b), o.rope(b)), "rope %d" % b
+    # the reads really overlap: far fewer distinct 20-mers than i.i.d. reads would have
+    kmers = {bytes(host[i * per + 5:i * per + 25]) for i in range(0, n, 7)}
+    assert len(kmers) < 0.95 * len(range(0, n, 7))
+    dev.dev_free(p)
+
+
 def test_single_long_string(hip):
     codes = H.splitmix_bases(1, 50000, seed=77)
     for so in (0, 1):

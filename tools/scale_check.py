@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--batch", type=float, default=10.0, help="-m in GiB (ropebwt2 default: 10g)")
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
     ap.add_argument("--both-strands", action="store_true")
+    ap.add_argument("--genome-len", type=int, default=0, help="> 0: reads are windows of one random genome of this many bases (coverage data)")
     args = ap.parse_args()
     from ropebwt2_amd import HipBwt, build_all
     build_all()
@@ -33,7 +34,7 @@ def main():
     done, times = 0, []
     while done < args.reads:
         n = min(per_batch, args.reads - done)
-        bwt.synth_reads(buf, done, n, L, seed=42, strand=1 if args.both_strands else 0)
+        bwt.synth_reads(buf, done, n, L, seed=42, strand=1 if args.both_strands else 0, genome_len=args.genome_len)
         bwt.sync()
         t0 = time.perf_counter()
         bwt.insert_multi_dev(buf, n * per_read)
@@ -61,7 +62,7 @@ def main():
             prev = r
     bwt.dev_free(buf)
     bwt.close()
-    print(json.dumps({"reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "batch_gib": args.batch,
+    print(json.dumps({"reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "genome_len": args.genome_len, "batch_gib": args.batch,
                       "batches": len(times), "symbols": total, "insert_s": sum(times), "gsym_per_s": total / sum(times) / 1e9,
                       "batch_s": [round(t, 3) for t in times], "counts_ok": ok, "lf_ok": ok_lf, "rank_ok": ok_rank}))
 
