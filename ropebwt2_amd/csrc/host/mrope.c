@@ -166,9 +166,11 @@ int64_t mr_insert1(mrope_t *mr, const uint8_t *str)
 }
 
 void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy)
-{	/* the six ropes are one sequence $,A,C,G,T,N (mrope.c:70-105) */
+{	/* the six ropes are one sequence $,A,C,G,T,N (mrope.c:70-105).  While the BWT only lives in HBM the in-rope
+	 * rank is asked from the device (rb2_hip_rank1a) instead of materialising the host trees for a few queries. */
 	int a, b, pass;
-	mr_sync_host((mrope_t*)mr);
+	const mrx_t *xx = X(mr);
+	const int on_dev = !xx->host_ok && xx->dev && xx->dev_ok;
 	for (pass = 0; pass < 2; ++pass) {
 		int64_t pos = pass == 0 ? x : y, *out = pass == 0 ? cx : cy, z = 0, acc[6] = { 0, 0, 0, 0, 0, 0 };
 		if (pass == 1 && (cy == 0 || y < 0)) break;
@@ -181,6 +183,7 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
 		}
 		assert(a < 6);
 		if (pos == z) memset(out, 0, 48);
+		else if (on_dev) rb2_hip_rank1a(xx->dev, a, pos - z, out);
 		else rope_rank1a(mr->r[a], pos - z, out);
 		for (b = 0; b < 6; ++b) out[b] += acc[b];
 	}

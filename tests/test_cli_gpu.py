@@ -122,6 +122,14 @@ def test_mrope_c_api(golden):
         m = MRope.from_address(mr)
         counts = np.array([[Rope.from_address(m.r[a]).c[b] for b in range(6)] for a in range(6)])
         assert np.array_equal(counts, o.counts())            # rope_t.c current right after the GPU call
+        bwt0 = o.bwt()                                       # mr_rank2a while the BWT only lives in HBM: answered by the device
+        rng0 = np.random.RandomState(100 + so)
+        for _ in range(12):
+            x = int(rng0.randint(0, len(bwt0) + 1)); y = int(rng0.randint(x, len(bwt0) + 1))
+            cx = (C.c_int64 * 6)(); cy = (C.c_int64 * 6)()
+            L.mr_rank2a(mr, x, y, cx, cy)
+            assert list(cx) == np.bincount(bwt0[:x], minlength=6).tolist()
+            assert list(cy) == np.bincount(bwt0[:y], minlength=6).tolist()
         for r in reads[2500:]:                               # -m0 style inserts on top of the GPU-built index
             s = np.ascontiguousarray(np.concatenate([np.asarray(r, np.uint8)[::-1], np.zeros(1, np.uint8)]))
             L.mr_insert1(mr, s.ctypes.data)
