@@ -295,20 +295,27 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + base[s] + c[s];
 }
 
-// rank of all six symbols at both ends of [l, u), l < u (rope_rank2a, rope.c:179-194): when both ends
-// fall into one leaf the second scan only covers [l, u), as rle_rank2a does (rle.c:134-191)
-__device__ inline void rank2_all(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t cl[6], uint64_t cu[6])
+// occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],
+// mrope.c:202-224).  When the interval lies in one leaf -- the common case: intervals are short -- this is a scan of the
+// interval itself, no directory and no prefix (rle_rank2a counts the same way, rle.c:134-191); else two full ranks.
+__device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
 {
-	rank_all(pv, rp, l, cl);
-	if (u < rp.n && u / LEAF == l / LEAF) {
+	const uint64_t lf = l / LEAF;
+	if ((u - 1) / LEAF == lf) {
 		NibAcc A;
-		const uint32_t ol = (uint32_t)(l % LEAF), ou = (uint32_t)(u % LEAF);
-		leaf_count((const uint4*)(pv.data + (rp.leaf0 + l / LEAF) * (uint64_t)LEAFB), ol, ou, A);
+		const uint32_t ol = (uint32_t)(l - lf * LEAF), ou = (uint32_t)(u - lf * LEAF);
+		leaf_count((const uint4*)(pv.data + (rp.leaf0 + lf) * (uint64_t)LEAFB), ol, ou, A);
 		uint32_t c[6];
 		nib_finish(A, ou - ol, c);
 #pragma unroll
-		for (int s = 0; s < 6; ++s) cu[s] = cl[s] + c[s];
-	} else rank_all(pv, rp, u, cu);
+		for (int s = 0; s < 6; ++s) d[s] = c[s];
+	} else {
+		uint64_t cl[6], cu[6];
+		rank_all(pv, rp, l, cl);
+		rank_all(pv, rp, u, cu);
+#pragma unroll
+		for (int s = 0; s < 6; ++s) d[s] = cu[s] - cl[s];
+	}
 }
 
 } // namespace rb2

@@ -522,9 +522,9 @@ template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl,
 		mm[h] = group_member(G, t, x, sym2[h], orda);
 		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
-			uint64_t cl[6], cu[6];
-			rank2_all(oldp, rp, l0[h], u0[h], cl, cu);
-			for (int s = 0; s < 6; ++s) s_d[x][s] = cu[s] - cl[s];
+			uint64_t d[6];
+			range_counts(oldp, rp, l0[h], u0[h], d);
+			for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
 		}
 	}
 	__syncthreads();
