@@ -95,12 +95,7 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 	uint16_t ni, nvalid;    // new symbols / symbols in the window
 };
 
-// in-leaf rank checkpoints: c[q][s-1] = number of symbol s (1..5; $ follows from the position) in the first (q+1)*QLEAF
-// symbols of the leaf, so that a rank query scans at most QLEAF symbols (the reference scans a 512-byte leaf, rle.c:134-191)
-constexpr int QLEAF = LEAF / 4;
-struct LeafMid { uint16_t c[3][5]; uint16_t pad; };
-
-struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; LeafMid *mid; };
+struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
 
 struct TileRec {            // per string tile, written by k_sym
 	uint32_t hist[6];
@@ -279,20 +274,12 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 	const uint32_t off = (uint32_t)(p % LEAF);
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	const LeafMeta m = pv.meta[gl];
-	const uint32_t qi = off / QLEAF;                           // checkpoints in front of p (LeafMid)
-	uint32_t c[6], base[6] = {0, 0, 0, 0, 0, 0};
-	if (qi) {
-		const uint16_t *row = &pv.mid[gl].c[qi - 1][0];
-		uint32_t sum = 0;
-#pragma unroll
-		for (int s = 1; s < 6; ++s) { base[s] = row[s - 1]; sum += base[s]; }
-		base[0] = qi * QLEAF - sum;
-	}
 	NibAcc A;
-	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), qi * QLEAF, off, A);
-	nib_finish(A, off - qi * QLEAF, c);
+	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), 0, off, A);
+	uint32_t c[6];
+	nib_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + base[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
 }
 
 // occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],

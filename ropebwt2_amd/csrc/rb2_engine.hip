@@ -35,17 +35,17 @@ template <typename T> struct DevBuf {
 };
 
 struct Pool {
-	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta; DevBuf<Cnt6> sbcum; DevBuf<LeafMid> mid;
+	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta; DevBuf<Cnt6> sbcum;
 	uint64_t cap_leaves = 0;
 	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
 		if (leaves <= cap_leaves) return;
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
-		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st); mid.ensure(nl, keep, st);
+		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st);
 		cap_leaves = nl;
 	}
-	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p, mid.p}; }
-	void release() { data.release(); meta.release(); sbcum.release(); mid.release(); cap_leaves = 0; }
+	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p}; }
+	void release() { data.release(); meta.release(); sbcum.release(); cap_leaves = 0; }
 };
 
 struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
@@ -436,7 +436,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		}
 	}
 	// pass 2: decode again into LEAF-symbol leaves of packed 4-bit symbols, cutting rope b into its pieces
-	std::vector<uint8_t> data; std::vector<LeafMeta> meta; std::vector<LeafMid> mid;
+	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
 	RopeDesc rp[NR];
 	uint64_t leaf = 0;
 	for (int r = 0; r < NR; ++r) memset(&rp[r], 0, sizeof(RopeDesc));
@@ -451,10 +451,10 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			const bool keep = h->nranks == 1 || h->owner[r] == h->rank;   // sharded: other ranks' pieces are only counted
 			RopeDesc &d = rp[r];
 			d.leaf0 = leaf; d.sb0 = leaf / SB;
-			data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf); mid.resize((size_t)leaf);
+			data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
 			LeafMeta cur; memset(&cur, 0, sizeof(cur));
 			uint32_t fill = 0; uint8_t *slot = nullptr;
-			auto open_leaf = [&]() { data.resize(data.size() + LEAFB); meta.resize(meta.size() + 1); mid.resize(mid.size() + 1); memset(&mid.back(), 0, sizeof(LeafMid)); slot = data.data() + data.size() - LEAFB; memset(&cur, 0, sizeof(cur)); fill = 0; };
+			auto open_leaf = [&]() { data.resize(data.size() + LEAFB); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAFB; memset(&cur, 0, sizeof(cur)); fill = 0; };
 			auto close_leaf = [&]() { meta.back() = cur; ++d.nleaves; slot = nullptr; };
 			while (quota > 0) {
 				if (l == 0) {
@@ -467,13 +467,12 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 				d.cnt[c] += part; d.n += part;
 				while (keep && part > 0) {
 					if (!slot) open_leaf();
-					const int64_t take = std::min<int64_t>(part, (int64_t)(fill / QLEAF + 1) * QLEAF - fill);   // stop at the rank checkpoints
+					const int64_t take = std::min<int64_t>(part, LEAF - fill);
 					int64_t t = take;
 					if (t && (fill & 1)) { slot[fill >> 1] |= (uint8_t)(c << 4); ++fill; --t; }
 					if (t >= 2) { memset(slot + (fill >> 1), c | c << 4, (size_t)(t >> 1)); fill += (uint32_t)(t & ~1ll); t &= 1; }
 					if (t) { slot[fill >> 1] |= (uint8_t)c; ++fill; }
 					cur.c[c] += (uint16_t)take; part -= take;
-					if (fill % QLEAF == 0 && fill < LEAF) for (int sy = 1; sy < 6; ++sy) mid.back().c[fill / QLEAF - 1][sy - 1] = cur.c[sy];
 					if (fill == LEAF) close_leaf();
 				}
 			}
@@ -483,13 +482,12 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		}
 		if (l != 0 || (p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
 	}
-	data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf); mid.resize((size_t)leaf);
+	data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
 	const int sd = h->side;
 	h->pool[sd].ensure(leaf + SB, false, h->st);
 	if (leaf) {
 		HIPCHK(hipMemcpyAsync(h->pool[sd].data.p, data.data(), data.size(), hipMemcpyHostToDevice, h->st));
 		HIPCHK(hipMemcpyAsync(h->pool[sd].meta.p, meta.data(), meta.size() * sizeof(LeafMeta), hipMemcpyHostToDevice, h->st));
-		HIPCHK(hipMemcpyAsync(h->pool[sd].mid.p, mid.data(), mid.size() * sizeof(LeafMid), hipMemcpyHostToDevice, h->st));
 	}
 	HIPCHK(hipMemcpyAsync(&h->ctl->rope[sd][0], rp, sizeof(rp), hipMemcpyHostToDevice, h->st));
 	const uint64_t nsb = leaf / SB;

@@ -184,25 +184,6 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		m.c[4] = (uint16_t)t45; m.c[5] = (uint16_t)(t45 >> 16);
 		m.nbytes = 0; m.pad = 0;
 		newp.meta[d.gl + ln / LPW] = m;                         // own counts; k_meta_sb turns them into prefixes
-		// rank checkpoints at the quarter points of the leaf: exclusive prefixes of the lanes that start a quarter
-		const uint32_t b01 = LP[4 * bl + 0], b23 = LP[4 * bl + 1], b45 = LP[4 * bl + 2];
-		uint32_t q[3][3];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			const uint32_t lq = bl + (k + 1) * (LPW / 4);
-			q[k][0] = LP[4 * lq + 0] - b01; q[k][1] = LP[4 * lq + 1] - b23; q[k][2] = LP[4 * lq + 2] - b45;
-		}
-		// LeafMid.c[k] = symbols 1..5 = {hi(01), lo(23), hi(23), lo(45), hi(45)}: 15 u16 + pad = eight dwords
-		uint32_t h16[16];
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			h16[5 * k + 0] = q[k][0] >> 16; h16[5 * k + 1] = q[k][1] & 0xffffu; h16[5 * k + 2] = q[k][1] >> 16;
-			h16[5 * k + 3] = q[k][2] & 0xffffu; h16[5 * k + 4] = q[k][2] >> 16;
-		}
-		h16[15] = 0;
-		uint4 *md = (uint4*)&newp.mid[d.gl + ln / LPW];
-		md[0] = make_uint4(h16[0] | h16[1] << 16, h16[2] | h16[3] << 16, h16[4] | h16[5] << 16, h16[6] | h16[7] << 16);
-		md[1] = make_uint4(h16[8] | h16[9] << 16, h16[10] | h16[11] << 16, h16[12] | h16[13] << 16, h16[14] | h16[15] << 16);
 	}
 	{
 		uint64_t *dst = (uint64_t*)(newp.data + d.gl * (uint64_t)LEAFB) + WPL * ln;
