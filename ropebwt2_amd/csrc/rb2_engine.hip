@@ -169,11 +169,15 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	uint64_t m = 0;
 	{
 		Scope sc(h, RB2_K_INIT, 0);
-		h->zblk.ensure(nzb + 1);
-		hipLaunchKernelGGL(k_count_zeros, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p);
+		h->zblk.ensure(nzb + 2);
+		uint64_t res[2] = {0, 0};                                // [0] number of strings, [1] input-validation flag
+		HIPCHK(hipMemsetAsync(h->zblk.p + nzb + 1, 0, 8, st));
+		hipLaunchKernelGGL(k_count_zeros, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->zblk.p + nzb + 1);
 		hipLaunchKernelGGL(k_zscan, dim3(1), dim3(SCHUNK), 0, st, h->zblk.p, nzb);
-		HIPCHK(hipMemcpyAsync(&m, h->zblk.p + nzb, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipMemcpyAsync(res, h->zblk.p + nzb, 16, hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
+		m = res[0];
+		if (res[1]) { fprintf(stderr, "[rb2_hip] the batch contains bytes that are not nt6 codes 0..5 ($ACGTN)\n"); abort(); }
 		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { fprintf(stderr, "[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); abort(); }
 		h->START.ensure(m + 1);
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
@@ -681,7 +685,7 @@ void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int
 void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (batch_bytes > 0) h->zblk.ensure(cdiv((uint64_t)batch_bytes, ZBLOCK) + 1);
+	if (batch_bytes > 0) h->zblk.ensure(cdiv((uint64_t)batch_bytes, ZBLOCK) + 2);
 	if (batch_strings > 0) ensure_strings(h, (uint64_t)batch_strings);
 	if (total_symbols > 0) {
 		const uint64_t leaves = (uint64_t)total_symbols / LEAF + NR * (SB + 1);

@@ -50,16 +50,24 @@ __device__ __forceinline__ void load64(const uint8_t *s, uint64_t len, uint64_t 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_count_zeros(const uint8_t *s, uint64_t len, uint64_t *blk)
+// also validates the input: *bad_flag is set when a byte is not an nt6 code 0..5 (the reference indexes arrays with
+// these bytes unchecked, mrope.c:204; here a stray value would corrupt the bucket bookkeeping silently)
+__global__ __launch_bounds__(256) void k_count_zeros(const uint8_t *s, uint64_t len, uint64_t *blk, uint64_t *bad_flag)
 {
 	__shared__ uint32_t s_w[4];
-	uint32_t w[16], c = 0;
-	load64(s, len, (uint64_t)blockIdx.x * ZBLOCK + threadIdx.x * 64, w);
+	uint32_t w[16], c = 0, bad = 0;
+	const uint64_t base = (uint64_t)blockIdx.x * ZBLOCK + threadIdx.x * 64;
+	load64(s, len, base, w);
 #pragma unroll
 	for (int i = 0; i < 16; ++i) c += zero_bytes(w[i]);
+	if (base + 64 <= len) {
+#pragma unroll
+		for (int i = 0; i < 16; ++i) bad |= (w[i] & 0xf8f8f8f8u) | ((w[i] >> 1) & (w[i] >> 2) & 0x01010101u);   // > 7, or 6/7
+	} else for (uint64_t p = base; p < len; ++p) bad |= s[p] > 5;
 	uint32_t tot;
 	block_excl_add<uint32_t>(c, s_w, &tot);
 	if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+	if (bad) *bad_flag = 1;
 }
 
 // in-place exclusive scan of the per-block sentinel counts (one block); blk[n] = total = number of strings

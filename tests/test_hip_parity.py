@@ -206,6 +206,18 @@ def test_coverage_reads_match_oracle(hip, so, strand):
     dev.dev_free(p)
 
 
+@pytest.mark.parametrize("badval,pos", [(6, 5), (7, 70), (200, 3000), (9, -2)])
+def test_invalid_symbols_fail_loudly(hip, badval, pos):
+    """a byte outside 0..5 would corrupt the bucket bookkeeping: the engine refuses the batch (in a child process: abort)"""
+    import subprocess, sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from ropebwt2_amd import HipBwt; "
+            "b = np.tile(np.array([1, 2, 3, 4, 0], np.uint8), 1000); b[%d] = %d; HipBwt(1).insert_multi(b); print('inserted')"
+            % (H.ROOT, pos, badval))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode != 0 and b"inserted" not in p.stdout
+    assert b"not nt6 codes" in p.stderr
+
+
 def test_single_long_string(hip):
     codes = H.splitmix_bases(1, 50000, seed=77)
     for so in (0, 1):
