@@ -216,7 +216,7 @@ def main():
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "%s: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
                                % ("configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % world,
-                                  args.reads, L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
+                                  sum(n for _, n in steps), L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
                    "reads": sum(n for _, n in steps) * (1 if sharded else n_gpus), "symbols": total_symbols,
                    "reads_per_gpu": sum(n for _, n in steps) // (n_gpus if sharded else 1), "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
                    "parallelism": "1 GPU" if n_gpus == 1 else
