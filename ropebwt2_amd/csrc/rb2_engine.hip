@@ -75,7 +75,7 @@ struct rb2_hip_s {
 	int64_t p_launch[RB2_K_COUNT]; double p_ms[RB2_K_COUNT]; int64_t p_units[RB2_K_COUNT];
 	int debug = 0;
 	int cur_round = -1;
-	uint64_t *gcnt = nullptr;           // device: 6x6 count matrix of the current round
+	uint64_t *gcnt = nullptr;           // device: NR x 6 count matrix of the current round
 	int rank = 0, nranks = 1; int owner[NR] = {0};
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_setup: everything the rest of the round needs that depends on the 6x6 count matrix
+// k_setup: everything the rest of the round needs that depends on the NR x 6 count matrix
 // ---------------------------------------------------------------------------------------------
 
 // rows of the count matrix this rank can see: count[r][a] = members of (local) bucket r inserting a

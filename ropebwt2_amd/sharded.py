@@ -297,7 +297,7 @@ class VirtualCluster:
         if len(parts) == 1:
             return next(iter(parts.values()))
         c = self.counts()
-        cum = {k: np.cumsum(v >> 3, dtype=np.int64) for k, v in parts.items()}   # device leaves hold 1-byte runs only
+        cum = {k: np.cumsum(v >> 3, dtype=np.int64) for k, v in parts.items()}   # the exported stream holds 1-byte runs only
         out, pos, syms = [], {k: 0 for k in parts}, {k: 0 for k in parts}
         for r in range(NR):
             if rope_sym(r) != b:
