@@ -185,7 +185,6 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	ensure_strings(h, m);
 	B.nst_ub = cdiv(m, STILE) + NR;                           // string tiles, upper bound for every round
 	B.nsc = cdiv(B.nst_ub, SCHUNK);
-	if (B.nsc > SCHUNK) { fprintf(stderr, "[rb2_hip] batch has too many strings (%llu)\n", (unsigned long long)m); abort(); }
 	uint64_t n_tot = 0;
 	for (int b = 0; b < NR; ++b) n_tot += h->h_rope[b].n;     // symbols held by THIS rank
 	const uint64_t leaves_ub = (n_tot + len) / LEAF + NR * (SB + 1);

@@ -262,20 +262,48 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, con
 	if (threadIdx.x == 0) part[blockIdx.x] = p;
 }
 
+__device__ __forceinline__ int block_all_max(int v, int *s_w)      // maximum over the block, returned to every thread
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));
+	if (lane_id() == 0) s_w[wave_id()] = v;
+	__syncthreads();
+	int m = s_w[0];
+	for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = max(m, s_w[i]);
+	__syncthreads();
+	return m;
+}
+
+// one block, any number of chunks: SCHUNK at a time with running carries (sums and the last head run forwards, the
+// next head runs backwards)
 __global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, ChunkPart *part)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
 	const uint32_t nt = ctl->seg[side].tile0[NR];
-	const uint32_t nc = (nt + SCHUNK - 1) / SCHUNK;          // host guarantees nc <= SCHUNK
-	const bool ok = threadIdx.x < nc;
-	ChunkPart p;
-	if (ok) p = part[threadIdx.x];
-	else { for (int s = 0; s < 6; ++s) p.sum[s] = 0; p.mx = -1; p.mn = INT_MAX; }
-	ChunkPart o;
-	for (int s = 0; s < 6; ++s) o.sum[s] = block_excl_add<uint32_t>(p.sum[s], s_w, (uint32_t*)0);
-	o.mx = block_excl_max(p.mx, s_wi, -1);
-	o.mn = block_excl_min_down(p.mn, s_wi, INT_MAX);
-	if (ok) part[threadIdx.x] = o;
+	const uint32_t nc = (nt + SCHUNK - 1) / SCHUNK;
+	uint32_t run[6] = {0, 0, 0, 0, 0, 0};
+	int run_mx = -1;
+	for (uint32_t i0 = 0; i0 < nc; i0 += SCHUNK) {
+		const uint32_t i = i0 + threadIdx.x;
+		const bool ok = i < nc;
+		ChunkPart p;
+		if (ok) p = part[i];
+		else { for (int s = 0; s < 6; ++s) p.sum[s] = 0; p.mx = -1; p.mn = INT_MAX; }
+		uint32_t o[6];
+		for (int s = 0; s < 6; ++s) { uint32_t tot; o[s] = run[s] + block_excl_add<uint32_t>(p.sum[s], s_w, &tot); run[s] += tot; }
+		const int omx = max(run_mx, block_excl_max(p.mx, s_wi, -1));
+		run_mx = max(run_mx, block_all_max(p.mx, s_wi));
+		if (ok) { for (int s = 0; s < 6; ++s) part[i].sum[s] = o[s]; part[i].mx = omx; }   // mn is still the chunk's own
+	}
+	int run_mn = INT_MAX;
+	for (uint32_t k = (nc + SCHUNK - 1) / SCHUNK; k-- > 0; ) {
+		const uint32_t i = k * SCHUNK + threadIdx.x;
+		const bool ok = i < nc;
+		const int mn = ok ? part[i].mn : INT_MAX;
+		const int omn = min(run_mn, block_excl_min_down(mn, s_wi, INT_MAX));
+		run_mn = min(run_mn, -block_all_max(mn == INT_MAX ? INT_MIN + 1 : -mn, s_wi));
+		if (ok) part[i].mn = omn;
+	}
 }
 
 __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRec *trec, const ChunkPart *part, TileScan *tsc)
