@@ -9,6 +9,20 @@ REF, GEN = os.path.join(ROOT, "oracle", "_ref", "ropebwt2"), os.path.join(ROOT, 
 N, L, SEED = 10_000_000, 101, 42
 out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropebwt2 r187 (oracle/_ref)",
        "n_reads": N, "read_len": L, "seed": SEED, "fmd_md5": {}}
+if os.path.exists(os.path.join(HERE, "golden_large.json")):           # keep entries produced by other invocations
+    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1")})
+if "--configs1" in sys.argv:
+    # BASELINE.json configs[1] at full size: 100 M x 101 bp, RLO, -m4g (6.5 minutes of reference time, 6.0 GB of .fmd):
+    #   synth_reads 100000000 101 42 | ropebwt2 -LRds -m4g -   (run on the GPU box's host, where the test runs)
+    g = subprocess.Popen([GEN, "100000000", "101", "42"], stdout=subprocess.PIPE)
+    p = subprocess.Popen([REF, "-LRds", "-m4g", "-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h, n = hashlib.md5(), 0
+    for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+        h.update(chunk); n += len(chunk)
+    assert p.wait() == 0 and g.wait() == 0
+    out["configs1"] = {"n_reads": 100000000, "read_len": 101, "seed": 42, "flags": "-LRds -m4g", "fmd_bytes": n, "fmd_md5": h.hexdigest()}
+    json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
+    sys.exit(0)
 for flags in ("-LRds", "-LRd"):
     g = subprocess.Popen([GEN, str(N), str(L), str(SEED)], stdout=subprocess.PIPE)
     p = subprocess.Popen([REF, flags, "-m1g", "-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)

@@ -60,6 +60,22 @@ def test_fmd_golden_10M_streamed(flags):
     assert h.hexdigest() == g["fmd_md5"][flags]
 
 
+def test_fmd_golden_configs1_full_size():
+    """BASELINE.json configs[1] at full size -- 100 M x 101 bp, RLO, -m4g (three GPU batches, 10.2 G symbols) -- streamed
+    through the CLI: the 6.0 GB .fmd has the md5 the real reference produced for the same input on the same kind of box"""
+    import hashlib, json
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["configs1"]
+    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
+    assert os.path.exists(gen), "oracle/synth_reads not built"
+    pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
+    pc = subprocess.Popen([CLI] + g["flags"].split() + ["-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h, n = hashlib.md5(), 0
+    for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+        h.update(chunk); n += len(chunk)
+    assert pc.wait() == 0 and pg.wait() == 0
+    assert n == g["fmd_bytes"] and h.hexdigest() == g["fmd_md5"]
+
+
 @pytest.mark.parametrize("so_flag", ["", "s", "r"])
 def test_incremental_build(golden, so_flag, tmp_path):
     """config 5 shape: -b on the first half, then -i + second half == one-shot build"""
