@@ -734,7 +734,7 @@ template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *c
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		id2[h] = 0; w2[h] = 0; l2[h] = 0;
-		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; l2[h] = L[k]; }
+		if (k < t.segend) { id2[h] = ID[k]; w2[h] = send ? 0 : W[k]; l2[h] = L[k]; }   // sharded: W is rebuilt on arrival (k_unpack)
 	}
 	group_setup(G, t, A, tf, sym2, flag2);
 	uint32_t nz = 0;
@@ -760,7 +760,7 @@ template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *c
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
 		const uint32_t id = id2[h];
 		uint64_t wv = w2[h] >> 4;
-		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
+		if (!send && ((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id);
 		} else {
