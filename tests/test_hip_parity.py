@@ -4,6 +4,8 @@ the BWT the oracle / the reference returns -- bit-exact, every rope, every count
 Structure mirrors how one would test mr_insert_multi itself: build the batch buffer main.c would
 build (helpers.encode_batch*), call insert_multi, compare the six ropes.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -158,8 +160,8 @@ def test_sparse_inserts_into_large_index(hip, so):
 def test_fuzz_small_shapes(hip, so):
     """many random small jobs: string counts around the tile / window / leaf sizes, lengths 0..80 with a heavy tail,
     N's, duplicates, 1-3 batches, both strands now and then; every rope compared with the oracle"""
-    rng = np.random.RandomState(1000 + so)
-    for it in range(24):
+    rng = np.random.RandomState(1000 + so + 7919 * int(os.environ.get("RB2_FUZZ_SEED", "0")))
+    for it in range(int(os.environ.get("RB2_FUZZ_ITERS", "24"))):          # soak runs: RB2_FUZZ_ITERS=400 RB2_FUZZ_SEED=k
         nb = rng.randint(1, 4)
         batches = []
         for _ in range(nb):
@@ -216,6 +218,33 @@ def test_invalid_symbols_fail_loudly(hip, badval, pos):
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode != 0 and b"inserted" not in p.stdout
     assert b"not nt6 codes" in p.stderr
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fuzz_medium_jobs(hip, seed):
+    """medium-size random jobs (0.1-0.3 M reads of 30-150 bp in 2-4 batches, i.i.d. or cut from a genome at 5-80x, random
+    order / strands): long enough for many merge windows per sub-rope, tile-spanning groups and both interval regimes"""
+    rng = np.random.RandomState(500 + seed)
+    so, strand = int(rng.randint(3)), int(rng.randint(2))
+    L = int(rng.randint(30, 151))
+    nb = int(rng.randint(2, 5))
+    n = int(rng.randint(100000, 300001)) // nb
+    cov = float(rng.choice([0, 5, 20, 80]))
+    glen = int(max(L + 1, n * nb * L / cov)) if cov else 0
+    per = (L + 1) * (2 if strand else 1)
+    o, dev = H.Oracle(so), hip.HipBwt(so)
+    p = dev.dev_alloc(n * per + 64)
+    for b in range(nb):
+        dev.synth_reads(p, b * n, n, L, seed=100 + seed, strand=strand, genome_len=glen)
+        dev.sync()
+        host = np.empty(n * per, np.uint8)
+        dev.L.rb2_hip_memcpy(dev.h, host.ctypes.data, p, n * per, 1)
+        dev.insert_multi_dev(p, n * per)
+        o.insert_multi(host)
+        assert np.array_equal(dev.counts(), o.counts()), "counts after batch %d (so %d strand %d L %d cov %g)" % (b, so, strand, L, cov)
+    for r in range(6):
+        assert np.array_equal(dev.rope(r), o.rope(r)), "rope %d (so %d strand %d L %d cov %g)" % (r, so, strand, L, cov)
+    dev.dev_free(p)
 
 
 def test_single_long_string(hip):
