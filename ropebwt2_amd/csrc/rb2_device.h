@@ -23,9 +23,12 @@
 
 namespace rb2 {
 
-constexpr int LEAF   = 1024;          // symbols per leaf
+constexpr int SBITS  = 3;              // bits per symbol ($ACGTN = 0..5)
+constexpr int SPW    = 21;             // symbols per 64-bit word (bit 63 unused)
+constexpr int LEAFW  = 64;             // words per leaf: one per lane of a wave
+constexpr int LEAF   = SPW * LEAFW;    // 1344 symbols per leaf
 constexpr int SB     = 32;            // leaves per superblock
-constexpr int LEAFB  = LEAF / 2;       // bytes per leaf: 4 bits per symbol
+constexpr int LEAFB  = LEAFW * 8;      // bytes per leaf
 constexpr int WPL    = 4;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
 constexpr int WIN    = WPL * LEAF;     // symbols per window
 constexpr int STILE  = 512;           // strings per string tile
@@ -207,10 +210,12 @@ __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane ? (~0ull >> 
 // RLO / input order: $ A C G T N;  RCLO: $ T G C A N
 __device__ __forceinline__ int sym_ord(int a, int is_comp) { return (is_comp && a >= 1 && a <= 4) ? 5 - a : a; }
 
-// symbol counts of packed 4-bit symbols.  Valid symbols are 0..5 = 000..101, so with the bit planes
-// b0,b1,b2 (one bit per nibble): #3 = |b0&b1|, #2 = |b1|-#3, #5 = |b0&b2|, #4 = |b2|-#5, #1 = |b0|-#3-#5.
+// symbol counts of packed 3-bit symbols (21 per word, symbol i in bits 3i..3i+2).  Valid symbols are 0..5 = 000..101,
+// so with the bit planes b0,b1,b2 (one bit per symbol): #3 = |b0&b1|, #2 = |b1|-#3, #5 = |b0&b2|, #4 = |b2|-#5, #1 = |b0|-#3-#5.
+constexpr uint64_t MLOW = 0x1249249249249249ull;           // bit 3i for i = 0..20
+constexpr uint64_t MALL = 0x7fffffffffffffffull;           // the 63 payload bits
 struct NibAcc { uint32_t p0 = 0, p1 = 0, p2 = 0, p01 = 0, p02 = 0; };
-__device__ __forceinline__ void nib_acc(NibAcc &A, uint64_t x, uint64_t M /* 0x1111.. of the nibbles to count */)
+__device__ __forceinline__ void nib_acc(NibAcc &A, uint64_t x, uint64_t M /* bits 3i of the symbols to count */)
 {
 	const uint64_t b0 = x & M, b1 = (x >> 1) & M, b2 = (x >> 2) & M;
 	A.p0 += (uint32_t)__popcll(b0); A.p1 += (uint32_t)__popcll(b1); A.p2 += (uint32_t)__popcll(b2);
@@ -221,41 +226,35 @@ __device__ __forceinline__ void nib_finish(const NibAcc &A, uint32_t n, uint32_t
 	c[3] = A.p01; c[2] = A.p1 - A.p01; c[5] = A.p02; c[4] = A.p2 - A.p02; c[1] = A.p0 - A.p01 - A.p02;
 	c[0] = n - (c[1] + c[2] + c[3] + c[4] + c[5]);
 }
-__device__ __forceinline__ void nib_counts(uint64_t x, uint64_t VM, uint32_t n, uint32_t c[6])
-{
-	NibAcc A;
-	nib_acc(A, x, VM & 0x1111111111111111ull);
-	nib_finish(A, n, c);
-}
 
-// accumulate the symbols at [from, to) of one packed leaf (16-byte loads; edge chunks are masked)
-__device__ __forceinline__ uint64_t nib_below(uint32_t n) { return n >= 16 ? ~0ull : (1ull << (4 * n)) - 1ull; }
+// all bits of the first n symbols of a word
+__device__ __forceinline__ uint64_t nib_below(uint32_t n) { return n >= (uint32_t)SPW ? MALL : (1ull << (SBITS * n)) - 1ull; }
+// accumulate the symbols at [from, to) of one packed leaf (16-byte loads = two words; edge words are masked)
 __device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, NibAcc &A)
 {
 	if (from >= to) return;
-	const uint64_t M1 = 0x1111111111111111ull;
-	const uint32_t c0 = from >> 5, c1 = (to - 1) >> 5;
+	const uint32_t c0 = from / (2 * SPW), c1 = (to - 1) / (2 * SPW);
 	auto edge = [&](uint32_t c) {
 		const uint4 v = q[c];
 		const uint64_t x0 = (uint64_t)v.y << 32 | v.x, x1 = (uint64_t)v.w << 32 | v.z;
-		const uint32_t base = c * 32;
-		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, 32u);      // in-chunk range [lo, hi)
-		nib_acc(A, x0, M1 & nib_below(min(hi, 16u)) & ~nib_below(min(lo, 16u)));
-		nib_acc(A, x1, M1 & nib_below(hi > 16 ? hi - 16 : 0u) & ~nib_below(lo > 16 ? lo - 16 : 0u));
+		const uint32_t base = c * 2 * SPW;
+		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, (uint32_t)(2 * SPW));      // in-chunk range [lo, hi)
+		nib_acc(A, x0, MLOW & nib_below(min(hi, (uint32_t)SPW)) & ~nib_below(min(lo, (uint32_t)SPW)));
+		nib_acc(A, x1, MLOW & nib_below(hi > SPW ? hi - SPW : 0u) & ~nib_below(lo > SPW ? lo - SPW : 0u));
 	};
 	edge(c0);
 	if (c1 == c0) return;
 	uint32_t c = c0 + 1;
-	for (; c + 4 <= c1; c += 4) {                              // interior chunks, four loads in flight (the scan is latency-bound)
+	for (; c + 4 <= c1; c += 4) {                              // interior chunks, four loads in flight
 		const uint4 v0 = q[c], v1 = q[c + 1], v2 = q[c + 2], v3 = q[c + 3];
-		nib_acc(A, (uint64_t)v0.y << 32 | v0.x, M1); nib_acc(A, (uint64_t)v0.w << 32 | v0.z, M1);
-		nib_acc(A, (uint64_t)v1.y << 32 | v1.x, M1); nib_acc(A, (uint64_t)v1.w << 32 | v1.z, M1);
-		nib_acc(A, (uint64_t)v2.y << 32 | v2.x, M1); nib_acc(A, (uint64_t)v2.w << 32 | v2.z, M1);
-		nib_acc(A, (uint64_t)v3.y << 32 | v3.x, M1); nib_acc(A, (uint64_t)v3.w << 32 | v3.z, M1);
+		nib_acc(A, (uint64_t)v0.y << 32 | v0.x, MLOW); nib_acc(A, (uint64_t)v0.w << 32 | v0.z, MLOW);
+		nib_acc(A, (uint64_t)v1.y << 32 | v1.x, MLOW); nib_acc(A, (uint64_t)v1.w << 32 | v1.z, MLOW);
+		nib_acc(A, (uint64_t)v2.y << 32 | v2.x, MLOW); nib_acc(A, (uint64_t)v2.w << 32 | v2.z, MLOW);
+		nib_acc(A, (uint64_t)v3.y << 32 | v3.x, MLOW); nib_acc(A, (uint64_t)v3.w << 32 | v3.z, MLOW);
 	}
 	for (; c < c1; ++c) {
 		const uint4 v = q[c];
-		nib_acc(A, (uint64_t)v.y << 32 | v.x, M1); nib_acc(A, (uint64_t)v.w << 32 | v.z, M1);
+		nib_acc(A, (uint64_t)v.y << 32 | v.x, MLOW); nib_acc(A, (uint64_t)v.w << 32 | v.z, MLOW);
 	}
 	edge(c1);
 }

@@ -361,25 +361,26 @@ void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
  * buffer (slot stride LEAF) + the byte count of every leaf; dst == NULL only counts.  Returns the bytes. */
 static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb = nullptr, void *user = nullptr)
 {
-	const uint64_t CH = 32768;                       // leaves per staging chunk (32 MiB of run bytes)
+	const uint64_t CH = 32768;                       // export chunks (XCHUNK symbols each) per staging round: 32 MiB of run bytes
 	const RopeDesc &d = h->h_rope[r];
-	if (d.nleaves == 0) return 0;
-	const uint64_t ch = std::min<uint64_t>(CH, d.nleaves);
+	const uint64_t nchunks = (d.n + XCHUNK - 1) / XCHUNK;
+	if (nchunks == 0 || d.nleaves == 0) return 0;
+	const uint64_t ch = std::min<uint64_t>(CH, nchunks);
 	const bool want = dst || cb;
-	h->xstage.ensure(ch * LEAF); h->xnb.ensure(ch);
-	std::vector<uint8_t> stage(want ? ch * LEAF : 0);
+	h->xstage.ensure(ch * XCHUNK); h->xnb.ensure(ch);
+	std::vector<uint8_t> stage(want ? ch * XCHUNK : 0);
 	std::vector<uint16_t> nb(ch);
 	int64_t k = 0;
-	for (uint64_t l0 = 0; l0 < d.nleaves; l0 += CH) {
-		const uint64_t nl = std::min<uint64_t>(CH, d.nleaves - l0);
-		hipLaunchKernelGGL(k_export, dim3(cdiv(nl, MW)), dim3(256), 0, h->st, h->pool[h->side].view(), d.leaf0, d.n, l0, (uint32_t)nl, h->xstage.p, h->xnb.p);
+	for (uint64_t c0 = 0; c0 < nchunks; c0 += CH) {
+		const uint64_t nc = std::min<uint64_t>(CH, nchunks - c0);
+		hipLaunchKernelGGL(k_export, dim3(cdiv(nc, MW)), dim3(256), 0, h->st, h->pool[h->side].view(), d.leaf0, d.n, c0, (uint32_t)nc, h->xstage.p, h->xnb.p);
 		HIPCHK(hipGetLastError());
-		if (want) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nl * LEAF, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nl * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
+		if (want) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nc * XCHUNK, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nc * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
-		for (uint64_t i = 0; i < nl; ++i) {
-			if (dst) memcpy(dst + k, stage.data() + i * LEAF, nb[i]);
-			if (cb) cb(user, stage.data() + i * LEAF, nb[i]);
+		for (uint64_t i = 0; i < nc; ++i) {
+			if (dst) memcpy(dst + k, stage.data() + i * XCHUNK, nb[i]);
+			if (cb) cb(user, stage.data() + i * XCHUNK, nb[i]);
 			k += nb[i];
 		}
 	}
@@ -438,7 +439,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			tot[b][c] += l;
 		}
 	}
-	// pass 2: decode again into LEAF-symbol leaves of packed 4-bit symbols, cutting rope b into its pieces
+	// pass 2: decode again into LEAF-symbol leaves of packed 3-bit symbols, cutting rope b into its pieces
 	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
 	RopeDesc rp[NR];
 	uint64_t leaf = 0;
@@ -471,10 +472,8 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 				while (keep && part > 0) {
 					if (!slot) open_leaf();
 					const int64_t take = std::min<int64_t>(part, LEAF - fill);
-					int64_t t = take;
-					if (t && (fill & 1)) { slot[fill >> 1] |= (uint8_t)(c << 4); ++fill; --t; }
-					if (t >= 2) { memset(slot + (fill >> 1), c | c << 4, (size_t)(t >> 1)); fill += (uint32_t)(t & ~1ll); t &= 1; }
-					if (t) { slot[fill >> 1] |= (uint8_t)c; ++fill; }
+					for (int64_t t = 0; t < take; ++t, ++fill)      // 21 symbols per 64-bit word, 3 bits each
+						((uint64_t*)slot)[fill / SPW] |= (uint64_t)c << (SBITS * (fill % SPW));
 					cur.c[c] += (uint16_t)take; part -= take;
 					if (fill == LEAF) close_leaf();
 				}

@@ -32,39 +32,47 @@
 namespace rb2 {
 
 constexpr int MW = 4;                       // waves (= output windows) per block
+#ifndef RB2_KMAX
+#define RB2_KMAX 5
+#endif
 constexpr int NXW = 64 * WPL;               // words per window
 constexpr int LPW = 64 / WPL;               // lanes per leaf
 
-__device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 4i set: nibble i of w == a
+__device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 3i set: symbol i of w == a
 {
-	uint64_t x = w ^ (a * 0x1111111111111111ull);
-	x |= x >> 1; x |= x >> 2;
-	return ~x & 0x1111111111111111ull;
+	const uint64_t x = w ^ (a * MLOW);
+	return ~(x | x >> 1 | x >> 2) & MLOW;                       // the three bits of a field, not a bit of its neighbour
 }
 
 // FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid
-template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint64_t *LO, const int ln,
+template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint64_t *LF, uint64_t *LO, const int ln,
 		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
 	const int nvalid = FULL ? WIN : d.nvalid, ni = d.ni;
 	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
-	const uint32_t sh0 = (uint32_t)d.i0 & 15u;
-	const uint32_t nw = (sh0 + nold + 15) >> 4;                 // words of the old side they live in (<= NXW + 1)
+	const uint64_t w0i = d.i0 / SPW;                            // old word that holds the first of them
+	const uint32_t sh0 = (uint32_t)(d.i0 - w0i * SPW);          // ... and its place in that word
+	const uint32_t nw = (sh0 + nold + SPW - 1) / SPW;           // words of the old side they live in (<= NXW + 1)
 
-	// ---- 1. new symbols of this window, by output position; the old words it draws from
+	// ---- 1. new symbols of this window, by output position (symbol and "new here" flag); the old words it draws from
 #pragma unroll
-	for (int w = 0; w < WPL; ++w) LX[ln + 64 * w] = 0;
+	for (int w = 0; w < WPL; ++w) { LX[ln + 64 * w] = 0; LF[ln + 64 * w] = 0; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	const uint64_t *ob = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 * (LEAFB / 8) + (d.i0 >> 4));
+	const uint64_t *ob = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 * LEAFW + w0i);
 	uint64_t wa[WPL], wt = 0;
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) { wa[w] = 0; if ((uint32_t)(ln + 64 * w) < nw) wa[w] = ob[ln + 64 * w]; }
 	if (ln < 2 && (uint32_t)(NXW + ln) < nw) wt = ob[NXW + ln];
 	for (int jj = ln; jj < ni; jj += 64) {
 		const uint64_t e = INS_E[d.ins0 + jj];
-		const uint32_t a = INS_A[d.ins0 + jj];
+		const uint64_t a = INS_A[d.ins0 + jj];
 		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the window
-		atomicOr((uint32_t*)LX + (p >> 3), (8u | a) << ((p & 7) * 4));
+		const uint32_t pw = p / SPW, ps = (p - pw * SPW) * SBITS;
+		const uint64_t sv = a << ps;                              // 32-bit LDS atomics: a 3-bit field may straddle bit 32
+		uint32_t *x32 = (uint32_t*)LX + 2 * pw, *f32 = (uint32_t*)LF + 2 * pw;
+		if ((uint32_t)sv) atomicOr(x32, (uint32_t)sv);
+		if ((uint32_t)(sv >> 32)) atomicOr(x32 + 1, (uint32_t)(sv >> 32));
+		atomicOr(f32 + (ps >> 5), 1u << (ps & 31));
 	}
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) LO[ln + 64 * w] = wa[w];
@@ -74,13 +82,13 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	// ---- 2. what does each lane consume
 	uint64_t X[WPL], VM[WPL], F[WPL];
 	uint32_t kin[WPL], non[WPL], ntot = 0, ktot = 0, vtot = 0;
-	const int p0 = ln * 16 * WPL;
+	const int p0 = ln * SPW * WPL;
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) {
 		X[w] = LX[WPL * ln + w];
-		const int v = FULL ? 16 : min(16, max(0, nvalid - p0 - 16 * w));
-		VM[w] = FULL || v >= 16 ? ~0ull : ((1ull << (4 * v)) - 1ull);     // nibbles of valid positions
-		F[w] = X[w] & 0x8888888888888888ull;
+		F[w] = LF[WPL * ln + w];                                // bit 3i: position i holds a new symbol
+		const int v = FULL ? SPW : min(SPW, max(0, nvalid - p0 - SPW * w));
+		VM[w] = FULL ? MALL : nib_below((uint32_t)v);           // all bits of the valid positions
 		kin[w] = (uint32_t)__popcll(F[w]);
 		non[w] = (uint32_t)v - kin[w];
 		ntot += non[w]; ktot += kin[w]; vtot += (uint32_t)v;
@@ -88,12 +96,12 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	const uint32_t sc2 = dpp_incl_add(ntot | ktot << 16);       // both prefix sums in one scan (each <= WIN < 2^16)
 	uint64_t out[WPL];
 	{
-		uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);             // first old symbol of this lane, in nibbles of LO[]
+		uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);             // first old symbol of this lane, in symbols of LO[]
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			const uint32_t k = op >> 4, sh = (op & 15) * 4;
+			const uint32_t k = op / SPW, sh = (op - k * SPW) * SBITS;
 			const uint64_t w0 = LO[k], w1 = LO[k + 1];           // k + 1 <= NXW + 1
-			out[w] = (w0 >> sh) | ((w1 << 1) << (63 - sh));       // sh == 0: the second term shifts out
+			out[w] = ((w0 >> sh) | (w1 << (63 - sh))) & MALL;     // 63 payload bits per word; sh == 0: the second term lands on bit 63
 			op += non[w];
 		}
 	}
@@ -102,7 +110,7 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	uint32_t kmax = kin[0];
 #pragma unroll
 	for (int w = 1; w < WPL; ++w) kmax = max(kmax, kin[w]);
-	if (!__any(kmax > 5)) {
+	if (!__any(kmax > RB2_KMAX)) {
 		// steady state: few new symbols per word.  Open one gap per new symbol, in ascending position.
 		// One loop per word index: its trip count is the largest number of new symbols any lane has in THAT word.
 #pragma unroll
@@ -110,36 +118,33 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 			uint64_t f = F[w];
 			{	// first new symbol of the word, branch-free (most words have none or one)
 				const bool has = f != 0;
-				const uint64_t lm = (1ull << ((has ? __builtin_ctzll(f) : 3) - 3)) - 1ull;
-				const uint64_t g = (out[w] & lm) | ((out[w] & ~lm) << 4);
+				const uint64_t lm = (1ull << (has ? __builtin_ctzll(f) : 0)) - 1ull;
+				const uint64_t g = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
 				out[w] = has ? g : out[w];
 				f &= f - 1;
 			}
 			while (__any(f != 0)) {
 				if (f) {
-					const uint64_t lm = (1ull << (__builtin_ctzll(f) - 3)) - 1ull;   // nibbles below the new symbol
+					const uint64_t lm = (1ull << __builtin_ctzll(f)) - 1ull;   // bits below the new symbol
 					f &= f - 1;
-					out[w] = (out[w] & lm) | ((out[w] & ~lm) << 4);
+					out[w] = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
 				}
 			}
 		}
 #pragma unroll
-		for (int w = 0; w < WPL; ++w) out[w] = (out[w] & VM[w]) | (X[w] & 0x7777777777777777ull);
+		for (int w = 0; w < WPL; ++w) out[w] = (out[w] & VM[w]) | X[w];
 	} else {
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			const uint64_t G = ~X[w] & VM[w];                      // bit 4i+3: position i takes an old symbol
-			const uint32_t glo = (uint32_t)G, ghi = (uint32_t)(G >> 32);
-			uint32_t olo = 0, ohi = 0;
-			uint64_t old = out[w];
+			const uint64_t G = ~F[w] & VM[w] & MLOW;               // bit 3i: position i takes an old symbol
+			uint64_t o = 0, old = out[w];
 #pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				const int nm = __builtin_amdgcn_sbfe(i < 8 ? glo : ghi, 4 * (i & 7) + 3, 1);   // -1: old symbol here
-				const uint32_t nib = (uint32_t)old & (uint32_t)nm & 15u;
-				if (i < 8) olo |= nib << (4 * i); else ohi |= nib << (4 * (i - 8));
-				old >>= (nm & 4);
+			for (int i = 0; i < SPW; ++i) {
+				const uint64_t nm = 0ull - ((G >> (SBITS * i)) & 1ull);   // all ones: old symbol here
+				o |= (old & nm & 7ull) << (SBITS * i);
+				old >>= (nm & SBITS);
 			}
-			out[w] = ((uint64_t)ohi << 32 | olo) | (X[w] & 0x7777777777777777ull);
+			out[w] = o | X[w];
 		}
 	}
 
@@ -148,7 +153,7 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	{
 		NibAcc A;
 #pragma unroll
-		for (int w = 0; w < WPL; ++w) nib_acc(A, out[w], VM[w] & 0x1111111111111111ull);
+		for (int w = 0; w < WPL; ++w) nib_acc(A, out[w], VM[w] & MLOW);
 		nib_finish(A, vtot, c);
 	}
 	const uint32_t e01 = c[0] | c[1] << 16, e23 = c[2] | c[3] << 16, e45 = c[4] | c[5] << 16;
@@ -165,7 +170,7 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		const uint64_t e = INS_E[d.ins0 + jj];
 		const uint32_t a = INS_A[d.ins0 + jj];
 		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;
-		const uint32_t lo = p / (16 * WPL), wi = (p >> 4) % WPL, below = (p & 15) * 4;
+		const uint32_t pw = p / SPW, lo = pw / WPL, wi = pw - lo * WPL, below = (p - pw * SPW) * SBITS;
 		const uint32_t bl = (p / LEAF) * LPW;                    // first lane of its leaf
 		const uint32_t sh = (a & 1) * 16;
 		uint32_t r = ((LP[4 * lo + (a >> 1)] >> sh) & 0xffffu) - ((LP[4 * bl + (a >> 1)] >> sh) & 0xffffu);
@@ -195,50 +200,57 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8];
+	__shared__ __align__(16) uint64_t lds[MW][3 * NXW + 8];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
+	uint64_t *LX = lds[wv], *LF = lds[wv] + NXW, *LO = lds[wv] + 2 * NXW;   // LO: NXW + 2 words used
 	const int ln = lane_id();
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
 	if (gw >= ctl->wf0[NR]) return;
 	const LeafDesc d = LD[gw];
-	if (d.nvalid == WIN) merge_window<true>(d, LX, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
-	else merge_window<false>(d, LX, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
+	if (d.nvalid == WIN) merge_window<true>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
+	else merge_window<false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_export: leaves [l0, l0+nl) of one sub-rope -> run-length bytes of ropebwt2's 43+3 codec, one
-// byte per run of <= 15 symbols (rle_enc1's 1-byte form, rle.h:55-57), runs cut at leaf ends.
-// Output: slot i of `dst` (stride LEAF) holds nb[i] bytes.  Not on the hot path.
+// k_export: chunks [c0, c0+nc) of XCHUNK symbols of one sub-rope -> run-length bytes of ropebwt2's 43+3 codec, one
+// byte per run of <= 15 symbols (rle_enc1's 1-byte form, rle.h:55-57), runs cut at chunk ends.  A sub-rope is a flat
+// array of 3-bit symbols (every leaf but the last is full), so chunk boundaries need not respect leaves.
+// Output: slot i of `dst` (stride XCHUNK) holds nb[i] bytes.  Not on the hot path.
 // ---------------------------------------------------------------------------------------------
 
-struct ExportLds { uint8_t outb[LEAF + 16]; };
+constexpr int XCHUNK = 1024;                // symbols per export chunk: 16 per lane
+struct ExportLds { uint8_t outb[XCHUNK + 16]; };
 
 __device__ __forceinline__ uint32_t byte_of(const uint32_t w[4], int i) { return (w[i >> 2] >> ((i & 3) * 8)) & 0xffu; }
-__device__ __forceinline__ uint32_t nib8_to_bytes_lo(uint32_t h)   // nibbles 0..3 of h -> 4 bytes
+__device__ __forceinline__ uint32_t tri4_to_bytes(uint32_t t)      // four 3-bit symbols (12 bits) -> 4 bytes
 {
-	uint32_t t = h & 0xffffu;
-	t = (t | t << 8) & 0x00ff00ffu;
-	return (t | t << 4) & 0x0f0f0f0fu;
+	return (t & 7u) | (t & 0x38u) << 5 | (t & 0x1c0u) << 10 | (t & 0xe00u) << 15;
 }
 
-__global__ __launch_bounds__(256) void k_export(PoolView pv, uint64_t leaf0, uint64_t n_syms, uint64_t l0, uint32_t nl, uint8_t *dst, uint16_t *nb)
+__global__ __launch_bounds__(256) void k_export(PoolView pv, uint64_t leaf0, uint64_t n_syms, uint64_t c0, uint32_t nc, uint8_t *dst, uint16_t *nb)
 {
 	__shared__ __align__(16) ExportLds lds[MW];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	ExportLds &L = lds[wv];
 	const int ln = lane_id();
 	const uint32_t li = blockIdx.x * MW + wv;
-	if (li >= nl) return;
-	const uint64_t j = l0 + li;
-	const int nvalid = (int)min((uint64_t)LEAF, n_syms - j * LEAF);
+	if (li >= nc) return;
+	const uint64_t s0 = (c0 + li) * (uint64_t)XCHUNK;           // first symbol of the chunk
+	const int nvalid = (int)min((uint64_t)XCHUNK, n_syms - s0);
 	const int p0 = ln * 16;
 	const int myvalid = min(16, max(0, nvalid - p0));
 	const uint32_t vmask = (1u << myvalid) - 1u;
-	const uint64_t w = ((const uint64_t*)(pv.data + (leaf0 + j) * (uint64_t)LEAFB))[ln];
+	uint64_t bits = 0;                                          // my 16 symbols, 3 bits each
+	if (myvalid) {
+		const uint64_t s = s0 + p0, wi = s / SPW;
+		const uint32_t sh = (uint32_t)(s - wi * SPW) * SBITS;
+		const uint64_t *W = (const uint64_t*)(pv.data + leaf0 * (uint64_t)LEAFB) + wi;
+		bits = W[0] >> sh;
+		if (sh + 16 * SBITS > 63) bits |= W[1] << (63 - sh);      // the next word belongs to the piece's slots (padding at worst)
+	}
 	uint32_t pw[4];
-	pw[0] = nib8_to_bytes_lo((uint32_t)w); pw[1] = nib8_to_bytes_lo((uint32_t)w >> 16);
-	pw[2] = nib8_to_bytes_lo((uint32_t)(w >> 32)); pw[3] = nib8_to_bytes_lo((uint32_t)(w >> 48));
+#pragma unroll
+	for (int k = 0; k < 4; ++k) pw[k] = tri4_to_bytes((uint32_t)(bits >> (12 * k)) & 0xfffu);
 #pragma unroll
 	for (int i = 0; i < 16; ++i) if (i >= myvalid) pw[i >> 2] |= 0xffu << ((i & 3) * 8);      // past the end: never equal to a symbol
 	((uint4*)L.outb)[ln] = make_uint4(0, 0, 0, 0);
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256) void k_export(PoolView pv, uint64_t leaf0, uin
 		for (int i = 0; i < 16; ++i) {
 			const uint32_t t = hm >> (i + 1);
 			const uint32_t len = t ? (uint32_t)__builtin_ctz(t) + 1u : lastlen - (uint32_t)i;
-			const uint32_t idx = (hm >> i & 1u) ? hb + __popc(hm & ((1u << i) - 1u)) : (uint32_t)LEAF;   // non-heads go to the dump slot
+			const uint32_t idx = (hm >> i & 1u) ? hb + __popc(hm & ((1u << i) - 1u)) : (uint32_t)XCHUNK;   // non-heads go to the dump slot
 			L.outb[idx] = (uint8_t)(len << 3 | byte_of(pw, i));
 		}
 	} else {
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256) void k_export(PoolView pv, uint64_t leaf0, uin
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	if (ln == 0) nb[li] = (uint16_t)nbytes;
-	((uint4*)(dst + (uint64_t)li * LEAF))[ln] = ((const uint4*)L.outb)[ln];
+	((uint4*)(dst + (uint64_t)li * XCHUNK))[ln] = ((const uint4*)L.outb)[ln];
 }
 
 } // namespace rb2
