@@ -472,8 +472,13 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 				while (keep && part > 0) {
 					if (!slot) open_leaf();
 					const int64_t take = std::min<int64_t>(part, LEAF - fill);
-					for (int64_t t = 0; t < take; ++t, ++fill)      // 21 symbols per 64-bit word, 3 bits each
-						((uint64_t*)slot)[fill / SPW] |= (uint64_t)c << (SBITS * (fill % SPW));
+					for (int64_t t = take; t > 0; ) {                // 21 symbols per 64-bit word, 3 bits each: a run fills word by word
+						const uint32_t wi = fill / SPW, off = fill % SPW;
+						const uint32_t k = (uint32_t)std::min<int64_t>(t, SPW - off);
+						const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
+						((uint64_t*)slot)[wi] |= ((uint64_t)c * MLOW & field) << (SBITS * off);
+						fill += k; t -= k;
+					}
 					cur.c[c] += (uint16_t)take; part -= take;
 					if (fill == LEAF) close_leaf();
 				}

@@ -96,13 +96,14 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	const uint32_t sc2 = dpp_incl_add(ntot | ktot << 16);       // both prefix sums in one scan (each <= WIN < 2^16)
 	uint64_t out[WPL];
 	{
-		uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);             // first old symbol of this lane, in symbols of LO[]
+		const uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);       // first old symbol of this lane, in symbols of LO[]
+		uint32_t k = op / SPW, sh = (op - k * SPW) * SBITS;
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			const uint32_t k = op / SPW, sh = (op - k * SPW) * SBITS;
 			const uint64_t w0 = LO[k], w1 = LO[k + 1];           // k + 1 <= NXW + 1
 			out[w] = ((w0 >> sh) | (w1 << (63 - sh))) & MALL;     // 63 payload bits per word; sh == 0: the second term lands on bit 63
-			op += non[w];
+			sh += SBITS * non[w];                                  // non <= SPW: at most one word further
+			if (sh >= 63) { sh -= 63; ++k; }
 		}
 	}
 
