@@ -3,9 +3,9 @@
 // Layout in HBM (all sizes are compile-time constants below):
 //
 //   sub-rope      rope b is kept as six independent pieces (b,x), x = the symbol following b in the
-//                 row's suffix; NR = 31 pieces (see below).  A piece is a flat array of 4-bit symbols.
-//   leaf          LEAF symbols of one piece, 4 bits each (LEAFB bytes; symbol i in bits 4(i%16).. of
-//                 64-bit word i/16).  Every leaf of a piece holds exactly LEAF symbols except the
+//                 row's suffix; NR = 31 pieces (see below).  A piece is a flat array of 3-bit symbols.
+//   leaf          LEAF symbols of one piece, 3 bits each (LEAFB bytes; symbol i in bits 3(i%21).. of
+//                 64-bit word i/21, bit 63 unused).  Every leaf of a piece holds exactly LEAF symbols except the
 //                 last, so "which leaf holds position p" is p / LEAF -- no B+ tree descent (the
 //                 reference walks rpnode_t buckets, rope.c:119-134).  Run-length coding (rle.h:39-75)
 //                 only happens on export (k_export).

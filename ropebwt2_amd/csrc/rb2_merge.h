@@ -5,20 +5,20 @@
 // rl copies of symbol a in front of position x and return the number of a's before x.  The
 // reference does this one run at a time through a B+ tree of run-length leaves; here one launch
 // rewrites every sub-rope side -> side^1 as a merge of two sorted sequences (old symbols, new
-// symbols).  In HBM a sub-rope is a flat array of 4-bit symbols (a leaf = LEAF symbols = LEAFB
-// bytes, symbol i in bits 4(i%16).. of 64-bit word i/16), so the merge is a pure stream: no run
+// symbols).  In HBM a sub-rope is a flat array of 3-bit symbols (a leaf = LEAF symbols = LEAFB
+// bytes, symbol i in bits 3(i%21).. of 64-bit word i/21), so the merge is a pure stream: no run
 // decoding, no re-encoding, no length-dependent paths.  Run-length coding is applied once, by
 // k_export, when the host asks for the ropes (mr_sync_host -> .fmd/.fmr writers).
 //
 // k_merge work decomposition: ONE WAVE PER OUTPUT WINDOW of WPL consecutive leaves, four
 // independent waves per block, no block-level barrier anywhere.  Lane l owns output positions
-// [16*WPL*l, 16*WPL*(l+1)) = WPL consecutive 64-bit words (64/WPL lanes per leaf):
+// [SPW*WPL*l, SPW*WPL*(l+1)) = WPL consecutive 64-bit words (64/WPL lanes per leaf):
 //   1. the new symbols of the window are OR-ed into a position-indexed nibble array in LDS as 8|a
 //      (bit 3 doubles as the "this position is new" flag), one LDS atomic per new symbol; the old
 //      words the window draws from are loaded at the same time and staged in LDS
 //   2. one packed wave prefix sum (not-new count | new count) -> first old symbol each lane
 //      consumes; the old symbols of each of its words are an unaligned 64-bit window of the stage
-//   3. expand: open one nibble gap per new symbol (wave-uniform loop, 1-2 trips in steady state;
+//   3. expand: open one 3-bit gap per new symbol (wave-uniform loop, 1-2 trips in steady state;
 //      16-step branch-free deal when some lane has many); the new symbols are already in place
 //   4. symbol counts per lane from three bit planes + five popcounts, three packed scans -> new
 //      LeafMeta of each leaf of the window
