@@ -63,10 +63,12 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) { wa[w] = 0; if ((uint32_t)(ln + 64 * w) < nw) wa[w] = ob[ln + 64 * w]; }
 	if (ln < 2 && (uint32_t)(NXW + ln) < nw) wt = ob[NXW + ln];
+	uint32_t p_first = 0, a_first = 0;                          // my first new symbol, kept for step 5
 	for (int jj = ln; jj < ni; jj += 64) {
 		const uint64_t e = INS_E[d.ins0 + jj];
 		const uint64_t a = INS_A[d.ins0 + jj];
 		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the window
+		if (jj == ln) { p_first = p; a_first = (uint32_t)a; }
 		const uint32_t pw = p / SPW, ps = (p - pw * SPW) * SBITS;
 		const uint64_t sv = a << ps;                              // 32-bit LDS atomics: a 3-bit field may straddle bit 32
 		uint32_t *x32 = (uint32_t*)LX + 2 * pw, *f32 = (uint32_t*)LF + 2 * pw;
@@ -168,9 +170,11 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 
 	// ---- 5. leaf-relative rank of every new symbol, one per lane
 	for (int jj = ln; jj < ni; jj += 64) {
-		const uint64_t e = INS_E[d.ins0 + jj];
-		const uint32_t a = INS_A[d.ins0 + jj];
-		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;
+		uint32_t p = p_first, a = a_first;
+		if (jj != ln) {                                        // more than 64 new symbols in the window: read them again
+			a = INS_A[d.ins0 + jj];
+			p = (uint32_t)(INS_E[d.ins0 + jj] - d.i0) + (uint32_t)jj;
+		}
 		const uint32_t pw = p / SPW, lo = pw / WPL, wi = pw - lo * WPL, below = (p - pw * SPW) * SBITS;
 		const uint32_t bl = (p / LEAF) * LPW;                    // first lane of its leaf
 		const uint32_t sh = (a & 1) * 16;
