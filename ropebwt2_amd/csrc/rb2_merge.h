@@ -210,8 +210,8 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	uint64_t *LX = lds[wv], *LF = lds[wv] + NXW, *LO = lds[wv] + 2 * NXW;   // LO: NXW + 2 words used
 	const int ln = lane_id();
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	const LeafDesc d = LD[gw];                                  // LD holds an entry for every window of the grid: both loads issue together
 	if (gw >= ctl->wf0[NR]) return;
-	const LeafDesc d = LD[gw];
 	if (d.nvalid == WIN) merge_window<true>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
 	else merge_window<false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
 }
