@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? rn.fhpre[s] : 0u);
 	}
 	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + rl.lh) : 0u;
+	f.b = (uint32_t)b; f.lt = tile - t0; f.pad = 0;
+	f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
 	tf[tile] = f;
 }
 
@@ -448,7 +450,7 @@ struct GroupLds {
 __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint8_t *A, const TileFix *tf, int sym2[2], int flag2[2])
 {
 	const int ln = lane_id(), w = wave_id();
-	if (threadIdx.x < sizeof(TileFix) / 4) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[blockIdx.x])[threadIdx.x];
+	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[blockIdx.x])[threadIdx.x];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
@@ -469,6 +471,13 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 		G.cpre[8][s] = run;
 	}
 	__syncthreads();
+}
+
+// tile context from the TileFix record (one uniform load; the caller checks blockIdx.x against the tile count)
+__device__ __forceinline__ void tile_ctx_fix(const TileFix &f, TileCtx &t)
+{
+	t.b = (int)f.b; t.lt = f.lt; t.segstart = f.segstart; t.segend = f.segend;
+	t.base = t.segstart + t.lt * STILE;
 }
 
 struct Member { uint32_t pa, pga, slot; uint64_t F; int lead; };   // lead: first member of my group inside this tile
@@ -516,10 +525,12 @@ template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
 	__shared__ GroupLds G;
-	if ((ctl->ne[par] == 0) != AE) return;
-	TileCtx t;
+	const TileFix &tfx = tf[blockIdx.x];                        // issued together with the mode and tile-count loads
 	const SegDesc &sg = ctl->seg[side];
-	if (!tile_ctx(sg, blockIdx.x, t)) return;
+	if ((ctl->ne[par] == 0) != AE) return;
+	if (blockIdx.x >= sg.tile0[NR]) return;
+	TileCtx t;
+	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
 	uint64_t l2[2], u2[2];                                     // issued before the barriers of group_setup
 #pragma unroll
@@ -724,10 +735,12 @@ template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *c
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
 {
 	__shared__ GroupLds G;
-	if ((ctl->ne[round & 1] == 0) != AE) return;
-	TileCtx t;
+	const TileFix &tfx = tf[blockIdx.x];                        // issued together with the mode and tile-count loads
 	const SegDesc &sg = ctl->seg[side];
-	if (!tile_ctx(sg, blockIdx.x, t)) return;
+	if ((ctl->ne[round & 1] == 0) != AE) return;
+	if (blockIdx.x >= sg.tile0[NR]) return;
+	TileCtx t;
+	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
 	uint32_t id2[2]; uint64_t w2[2], l2[2];                    // issued before the barriers of group_setup
 #pragma unroll
