@@ -45,7 +45,7 @@ __device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 3i s
 }
 
 // FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid
-template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint64_t *LF, uint64_t *LO, const int ln,
+template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint32_t *LF, uint64_t *LO, const int ln,
 		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
 	const int nvalid = FULL ? WIN : d.nvalid, ni = d.ni;
@@ -71,10 +71,10 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		if (jj == ln) { p_first = p; a_first = (uint32_t)a; }
 		const uint32_t pw = p / SPW, ps = (p - pw * SPW) * SBITS;
 		const uint64_t sv = a << ps;                              // 32-bit LDS atomics: a 3-bit field may straddle bit 32
-		uint32_t *x32 = (uint32_t*)LX + 2 * pw, *f32 = (uint32_t*)LF + 2 * pw;
+		uint32_t *x32 = (uint32_t*)LX + 2 * pw;
 		if ((uint32_t)sv) atomicOr(x32, (uint32_t)sv);
 		if ((uint32_t)(sv >> 32)) atomicOr(x32 + 1, (uint32_t)(sv >> 32));
-		atomicOr(f32 + (ps >> 5), 1u << (ps & 31));
+		atomicOr(LF + pw, 1u << (p - pw * SPW));                   // flags: one bit per position, 21 per word
 	}
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) LO[ln + 64 * w] = wa[w];
@@ -82,16 +82,17 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 
 	// ---- 2. what does each lane consume
-	uint64_t X[WPL], VM[WPL], F[WPL];
+	uint64_t X[WPL], VM[WPL];
+	uint32_t F[WPL];
 	uint32_t kin[WPL], non[WPL], ntot = 0, ktot = 0, vtot = 0;
 	const int p0 = ln * SPW * WPL;
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) {
 		X[w] = LX[WPL * ln + w];
-		F[w] = LF[WPL * ln + w];                                // bit 3i: position i holds a new symbol
+		F[w] = LF[WPL * ln + w];                                // bit i: position i holds a new symbol
 		const int v = FULL ? SPW : min(SPW, max(0, nvalid - p0 - SPW * w));
 		VM[w] = FULL ? MALL : nib_below((uint32_t)v);           // all bits of the valid positions
-		kin[w] = (uint32_t)__popcll(F[w]);
+		kin[w] = (uint32_t)__popc(F[w]);
 		non[w] = (uint32_t)v - kin[w];
 		ntot += non[w]; ktot += kin[w]; vtot += (uint32_t)v;
 	}
@@ -118,17 +119,17 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		// One loop per word index: its trip count is the largest number of new symbols any lane has in THAT word.
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			uint64_t f = F[w];
+			uint32_t f = F[w];
 			{	// first new symbol of the word, branch-free (most words have none or one)
 				const bool has = f != 0;
-				const uint64_t lm = (1ull << (has ? __builtin_ctzll(f) : 0)) - 1ull;
+				const uint64_t lm = (1ull << (SBITS * (has ? __builtin_ctz(f) : 0))) - 1ull;
 				const uint64_t g = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
 				out[w] = has ? g : out[w];
 				f &= f - 1;
 			}
 			while (__any(f != 0)) {
 				if (f) {
-					const uint64_t lm = (1ull << __builtin_ctzll(f)) - 1ull;   // bits below the new symbol
+					const uint64_t lm = (1ull << (SBITS * __builtin_ctz(f))) - 1ull;   // bits below the new symbol
 					f &= f - 1;
 					out[w] = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
 				}
@@ -139,11 +140,12 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 	} else {
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			const uint64_t G = ~F[w] & VM[w] & MLOW;               // bit 3i: position i takes an old symbol
+			const int v = FULL ? SPW : min(SPW, max(0, nvalid - p0 - SPW * w));
+			const uint32_t G = ~F[w] & ((1u << v) - 1u);            // bit i: position i takes an old symbol
 			uint64_t o = 0, old = out[w];
 #pragma unroll
 			for (int i = 0; i < SPW; ++i) {
-				const uint64_t nm = 0ull - ((G >> (SBITS * i)) & 1ull);   // all ones: old symbol here
+				const uint64_t nm = 0ull - (uint64_t)((G >> i) & 1u);    // all ones: old symbol here
 				o |= (old & nm & 7ull) << (SBITS * i);
 				old >>= (nm & SBITS);
 			}
@@ -205,9 +207,10 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ __align__(16) uint64_t lds[MW][3 * NXW + 8];
+	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8 + NXW / 2];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LF = lds[wv] + NXW, *LO = lds[wv] + 2 * NXW;   // LO: NXW + 2 words used
+	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
+	uint32_t *LF = (uint32_t*)(lds[wv] + 2 * NXW + 8);          // NXW flag words of 32 bits
 	const int ln = lane_id();
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
 	const LeafDesc d = LD[gw];                                  // LD holds an entry for every window of the grid: both loads issue together
