@@ -247,6 +247,16 @@ def test_fuzz_medium_jobs(hip, seed):
     dev.dev_free(p)
 
 
+@pytest.mark.parametrize("so", [0, 1])
+def test_one_symbol_fills_several_superblocks(hip, so):
+    """a sub-rope that is one symbol over more than two superblocks (2 x 32 leaves): per-symbol counts reach the leaf and
+    superblock maxima in the packed 16-bit scans of k_merge / k_meta_sb; the export emits maximal runs"""
+    lay = hip.HipBwt.layout()
+    n_sym = lay["leaf_syms"] * 32 * 2 + 5000                         # > 2 superblocks of A's in piece (A,A)
+    reads = [[1] * 100] * (n_sym // 100 + 1) + [[2] * 7, [1, 2, 1, 2]]
+    run_both(hip, so, [H.encode_batch(reads[:len(reads) // 2]), H.encode_batch(reads[len(reads) // 2:])])
+
+
 def test_single_long_string(hip):
     codes = H.splitmix_bases(1, 50000, seed=77)
     for so in (0, 1):
