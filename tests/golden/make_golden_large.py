@@ -10,7 +10,21 @@ N, L, SEED = 10_000_000, 101, 42
 out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropebwt2 r187 (oracle/_ref)",
        "n_reads": N, "read_len": L, "seed": SEED, "fmd_md5": {}}
 if os.path.exists(os.path.join(HERE, "golden_large.json")):           # keep entries produced by other invocations
-    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1")})
+    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1") or k.startswith("coverage")})
+if "--coverage" in sys.argv:
+    # overlapping reads: 30 M x 101 bp windows of one random 100 Mb genome (30x), RLO forward and RCLO both strands
+    cov = {"n_reads": 30000000, "read_len": 101, "seed": 42, "genome_len": 100000000, "runs": {}}
+    for flags in ("-LRds -m1g", "-Lrd -m2g"):
+        g = subprocess.Popen([GEN, "30000000", "101", "42", "0", "100000000"], stdout=subprocess.PIPE)
+        p = subprocess.Popen([REF] + flags.split() + ["-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        h, n = hashlib.md5(), 0
+        for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+            h.update(chunk); n += len(chunk)
+        assert p.wait() == 0 and g.wait() == 0
+        cov["runs"][flags] = {"fmd_bytes": n, "fmd_md5": h.hexdigest()}
+    out["coverage30x"] = cov
+    json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
+    sys.exit(0)
 if "--configs1" in sys.argv:
     # BASELINE.json configs[1] at full size: 100 M x 101 bp, RLO, -m4g (6.5 minutes of reference time, 6.0 GB of .fmd):
     #   synth_reads 100000000 101 42 | ropebwt2 -LRds -m4g -   (run on the GPU box's host, where the test runs)

@@ -60,6 +60,23 @@ def test_fmd_golden_10M_streamed(flags):
     assert h.hexdigest() == g["fmd_md5"][flags]
 
 
+@pytest.mark.parametrize("flags", ["-LRds -m1g", "-Lrd -m2g"])
+def test_fmd_golden_coverage_reads(flags):
+    """30 M overlapping reads (windows of one random genome, 30x; 3-6 G symbols): non-empty intervals, large groups and a
+    compressible BWT in every round -- the regime of real data.  .fmd md5 as produced by the real reference."""
+    import hashlib, json
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["coverage30x"]
+    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
+    assert os.path.exists(gen), "oracle/synth_reads not built"
+    pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"]), "0", str(g["genome_len"])], stdout=subprocess.PIPE)
+    pc = subprocess.Popen([CLI] + flags.split() + ["-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h, n = hashlib.md5(), 0
+    for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+        h.update(chunk); n += len(chunk)
+    assert pc.wait() == 0 and pg.wait() == 0
+    assert n == g["runs"][flags]["fmd_bytes"] and h.hexdigest() == g["runs"][flags]["fmd_md5"]
+
+
 def test_fmd_golden_configs1_full_size():
     """BASELINE.json configs[1] at full size -- 100 M x 101 bp, RLO, -m4g (three GPU batches, 10.2 G symbols) -- streamed
     through the CLI: the 6.0 GB .fmd has the md5 the real reference produced for the same input on the same kind of box"""
