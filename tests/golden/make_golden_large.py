@@ -10,7 +10,18 @@ N, L, SEED = 10_000_000, 101, 42
 out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropebwt2 r187 (oracle/_ref)",
        "n_reads": N, "read_len": L, "seed": SEED, "fmd_md5": {}}
 if os.path.exists(os.path.join(HERE, "golden_large.json")):           # keep entries produced by other invocations
-    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1") or k.startswith("coverage")})
+    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1") or k.startswith("coverage") or k.startswith("longreads")})
+if "--longreads" in sys.argv:
+    # long-read path: 200 k x 5 kbp, input order, one batch of 5001 rounds
+    g = subprocess.Popen([GEN, "200000", "5000", "44"], stdout=subprocess.PIPE)
+    p = subprocess.Popen([REF, "-LRd", "-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h = hashlib.md5()
+    for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+        h.update(chunk)
+    assert p.wait() == 0 and g.wait() == 0
+    out["longreads"] = {"n_reads": 200000, "read_len": 5000, "seed": 44, "flags": "-LRd", "fmd_md5": h.hexdigest()}
+    json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
+    sys.exit(0)
 if "--coverage" in sys.argv:
     # overlapping reads: 30 M x 101 bp windows of one random 100 Mb genome (30x), RLO forward and RCLO both strands
     cov = {"n_reads": 30000000, "read_len": 101, "seed": 42, "genome_len": 100000000, "runs": {}}

@@ -77,6 +77,20 @@ def test_fmd_golden_coverage_reads(flags):
     assert n == g["runs"][flags]["fmd_bytes"] and h.hexdigest() == g["runs"][flags]["fmd_md5"]
 
 
+def test_fmd_golden_long_reads():
+    """200 k x 5 kbp in input order (1 G symbols, one batch of 5001 rounds): the long-string path against the real reference"""
+    import hashlib, json
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["longreads"]
+    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
+    pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
+    pc = subprocess.Popen([CLI, g["flags"], "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h = hashlib.md5()
+    for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+        h.update(chunk)
+    assert pc.wait() == 0 and pg.wait() == 0
+    assert h.hexdigest() == g["fmd_md5"]
+
+
 def test_fmd_golden_configs1_full_size():
     """BASELINE.json configs[1] at full size -- 100 M x 101 bp, RLO, -m4g (three GPU batches, 10.2 G symbols) -- streamed
     through the CLI: the 6.0 GB .fmd has the md5 the real reference produced for the same input on the same kind of box"""
