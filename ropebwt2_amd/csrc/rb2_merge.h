@@ -121,10 +121,8 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		for (int w = 0; w < WPL; ++w) {
 			uint32_t f = F[w];
 			{	// first new symbol of the word, branch-free (most words have none or one)
-				const bool has = f != 0;
-				const uint64_t lm = (1ull << (SBITS * (has ? __builtin_ctz(f) : 0))) - 1ull;
-				const uint64_t g = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
-				out[w] = has ? g : out[w];
+				const uint64_t lm = (1ull << (f ? SBITS * __builtin_ctz(f) : 63)) - 1ull;   // no new symbol: all 63 payload bits stay
+				out[w] = (out[w] & lm) | ((out[w] & ~lm) << SBITS);
 				f &= f - 1;
 			}
 			while (__any(f != 0)) {
