@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- Gsymbols/s inserted by the gfx950 BCR engine (BASELINE.json metric).
 
-One "step" = one pass of the hot path (mr_insert_multi, /root/reference/mrope.c:258-345) over one
-`-m4g` batch of synthetic reads: 40,844,298 x 101 bp (4,166,118,396 symbols incl. sentinels),
-inserted into the index left by the previous step.  The default run (--steps 3) is exactly
-BASELINE.json configs[1]: 100 M x 101 bp, `-bsR` (RLO, forward strand), `-m4g`, 1 x MI355X
-(the third batch holds the remaining 18,311,404 reads).
+Workload at N = 1: BASELINE.json configs[1] -- 100 M x 101 bp synthetic reads, `-bsR` (RLO, forward
+strand), `-m4g`, 1 x MI355X.  `-m4g` cuts the job into three batches (40,844,297 / 40,844,297 /
+18,311,406 reads; main.c:136, 238).  One "step" = one pass of the hot path (mr_insert_multi,
+/root/reference/mrope.c:258-345) over one of these batches, inserted into the index left by the previous
+step of the same job.  `--steps K` cycles through the three batches: step k is batch k % 3 of job k // 3,
+and every job starts on an EMPTY index (rb2_hip_reset) -- the job never grows beyond configs[1], whatever K
+is.  The default (--steps 3) is exactly one configs[1] job.
 
-Inputs are generated on the device (splitmix64 stream of SURVEY.md 8c) before the timed region,
-so `value` is whole-job symbols / wall time with inputs resident in HBM.
+Inputs are generated on the device (splitmix64 stream of SURVEY.md 8c, tools/synth_reads.c is the same
+stream as text) before the timed region, so `value` is whole-job symbols / wall time with inputs resident
+in HBM.  Beside it the line reports
+  value_host_api   the same job through rb2_hip_insert_multi on HOST buffers (what mr_insert_multi does:
+                   one PCIe crossing per batch, no capacity hint) -- PCIe-inclusive, never `value`
+  whole_process    the CLI end to end on the same reads (text in, 6.0 GB .fmd out): main.c:340's number
+  cpu_baseline     the real reference (oracle/_ref) on a bounded sample of the same stream
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -34,6 +41,11 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SYMBOL = 50.0        # compulsory HBM traffic per inserted symbol
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
+CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
+# the real reference on the FULL configs[1] job, same kind of box (profiles/r01_configs1_cli_vs_reference.json)
+CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5,
+                   "source": "profiles/r01_configs1_cli_vs_reference.json (oracle/_ref/ropebwt2 -LRds -m4g on all 100 M reads, MI355X box host)"}
 
 
 def batch_reads(mem_arg_bytes, read_len):
@@ -46,11 +58,10 @@ def cpu_baseline(read_len, so_flag, sample_reads, budget_s=120):
     """Time the reference CLI (oracle/_ref, built from /root/reference by oracle/Makefile) on a
     bounded sample of the same read stream; falls back to the plain-C port (oracle/liboracle.so)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ropebwt2")
-    gen = os.path.join(ROOT, "oracle", "synth_reads")
     ncpu = os.cpu_count() or 1
-    if os.path.exists(ref) and os.path.exists(gen):
+    if os.path.exists(ref) and os.path.exists(GEN):
         try:
-            g = subprocess.Popen([gen, str(sample_reads), str(read_len), "42"], stdout=subprocess.PIPE)
+            g = subprocess.Popen([GEN, str(sample_reads), str(read_len), "42"], stdout=subprocess.PIPE)
             cmd = [ref, "-L", "-R", "-b"] + ([so_flag] if so_flag else []) + ["-m4g", "-o", "/dev/null", "-"]
             p = subprocess.run(cmd, stdin=g.stdout,
                                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=budget_s * 4)
@@ -61,7 +72,8 @@ def cpu_baseline(read_len, so_flag, sample_reads, budget_s=120):
             if tot_t > 0:
                 return {"value": tot_s / tot_t / 1e9, "unit": "Gsymbols/s", "cores": min(5, ncpu), "kind": "reference",
                         "sample": "%d x %d bp reads of the same splitmix64 stream, ropebwt2 -L -R -b %s -m4g (5 threads: 4 workers + master, mrope.c:287-296); "
-                                  "%.1f s insert time; host has %d cores" % (sample_reads, read_len, so_flag, tot_t, ncpu)}
+                                  "%.1f s insert time; host has %d cores" % (sample_reads, read_len, so_flag, tot_t, ncpu),
+                        "full_config": CPU_FULL_CONFIG}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("[bench] reference baseline failed: %r\n" % (e,))
     # plain-C port (single thread)
@@ -73,7 +85,52 @@ def cpu_baseline(read_len, so_flag, sample_reads, budget_s=120):
     o = helpers.Oracle({"-s": 1, "-r": 2}.get(so_flag, 0))
     t = time.time(); o.insert_multi(buf); dt = time.time() - t
     return {"value": len(buf) / dt / 1e9, "unit": "Gsymbols/s", "cores": 1, "kind": "port",
-            "sample": "%d x %d bp reads, oracle/bcr_oracle.c orc_insert_multi, 1 thread" % (n, read_len)}
+            "sample": "%d x %d bp reads, oracle/bcr_oracle.c orc_insert_multi, 1 thread" % (n, read_len),
+            "full_config": CPU_FULL_CONFIG}
+
+
+def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
+    """the same job through the host-buffer entry point (rb2_hip_insert_multi): every batch crosses PCIe inside the
+    call and nothing is reserved up front -- what a caller of mr_insert_multi gets (mrope.c:258 takes a host buffer)"""
+    import numpy as np
+    b = HipBwt(so, dev)
+    host = []
+    for p, n in zip(bufs_dev, sizes):
+        a = np.empty(n, np.uint8)
+        b.L.rb2_hip_memcpy(b.h, a.ctypes.data, p, n, 1)
+        host.append(a)
+    b.sync()
+    t0 = time.perf_counter()
+    for a in host:
+        b.insert_multi(a)
+    b.sync()
+    dt = time.perf_counter() - t0
+    ok = int(b.counts().sum()) == sum(sizes)
+    b.close()
+    return {"value": sum(sizes) / dt / 1e9, "unit": "Gsymbols/s", "seconds": dt, "counts_ok": ok,
+            "what": "one configs[1] job through rb2_hip_insert_multi on pageable host buffers, no rb2_hip_reserve: PCIe-inclusive"}
+
+
+def whole_process(reads, read_len, so_flag, batch_gib):
+    """CLI wall-clock, text in -> .fmd out (main.c:340 'Real time'), plus the CLI's own per-batch insert lines (main.c:241)"""
+    if not (os.path.exists(GEN) and os.path.exists(CLI)):
+        return None
+    flags = ["-LRd" + so_flag.strip("-"), "-m%gg" % batch_gib]
+    t0 = time.perf_counter()
+    g = subprocess.Popen([GEN, str(reads), str(read_len), "42"], stdout=subprocess.PIPE)
+    p = subprocess.run([CLI] + flags + ["-o", "/dev/null", "-"], stdin=g.stdout, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
+    g.wait()
+    dt = time.perf_counter() - t0
+    err = p.stderr.decode()
+    ins = [(int(m.group(1)), float(m.group(2))) for m in re.finditer(r"inserted (\d+) symbols in ([0-9.]+) sec", err)]
+    syms = sum(s for s, _ in ins)
+    if p.returncode != 0 or syms == 0:
+        sys.stderr.write("[bench] whole-process leg failed (rc %d)\n%s" % (p.returncode, err[-400:]))
+        return None
+    m = re.search(r"Real time: ([0-9.]+) sec", err)
+    return {"value": syms / dt / 1e9, "unit": "Gsymbols/s", "real_s": dt, "cli_real_s": float(m.group(1)) if m else None,
+            "insert_s": sum(t for _, t in ins), "insert_gsym_per_s": syms / sum(t for _, t in ins) / 1e9,
+            "what": "synth_reads %d %d 42 | ropebwt2 %s -o /dev/null -  (text parse + PCIe + insert + .fmd encode; one process)" % (reads, read_len, " ".join(flags))}
 
 
 def main():
@@ -87,6 +144,7 @@ def main():
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "independent"], help="what N > 1 ranks do (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the value_host_api / whole_process legs (profiling runs)")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     args = ap.parse_args()
 
@@ -152,32 +210,36 @@ def main():
         w.dev_free(p)
         w.close()
 
-    # ---- the job: K consecutive -m batches (sharded: the same batches on every rank, one index;
-    # ---- independent: this rank's own slice of the read stream, its own index)
+    # ---- the job: its -m batches (sharded: the same batches on every rank, one index; independent: this rank's own
+    # ---- slice of the read stream, its own index).  Step k = batch k % nb of job k // nb; a job starts on an empty index.
     bwt, do_insert = make(so, dev)
     bwt.profile(True)
     first = 0 if sharded or world == 1 else rank * args.reads
-    steps = []
-    done = 0
-    for k in range(args.steps):
-        n = min(per_batch, args.reads - done) if done < args.reads else per_batch
-        steps.append((first + done, n))
+    job, done = [], 0
+    while done < args.reads:
+        n = min(per_batch, args.reads - done)
+        job.append((first + done, n))
         done += n
+    nb = len(job)
     bufs = []
-    for (f, n) in steps:                          # inputs resident in HBM before the clock starts
+    for (f, n) in job:                            # inputs resident in HBM before the clock starts
         p = bwt.dev_alloc(n * (L + 1))
         bwt.synth_reads(p, f, n, L, seed=42)
         bufs.append(p)
+    sizes = [n * (L + 1) for _, n in job]
     # capacity hint (rb2_hip_reserve): the job's size is known up front, as it is to `ropebwt2 -m`; without it
     # the engine grows its buffers batch by batch (hipMalloc + copy + hipFree inside the timed region)
-    tot_syms = sum(n for _, n in steps) * (L + 1)
-    bwt.reserve(max(n for _, n in steps) * (L + 1), max(n for _, n in steps), tot_syms if not sharded else int(tot_syms * 1.25 / world))
+    tot_syms = sum(sizes)
+    bwt.reserve(max(sizes), max(n for _, n in job), tot_syms if not sharded else int(tot_syms * 1.25 / world))
     bwt.sync()
     bwt.profile_get(reset=True)
     barrier()
     t0 = time.perf_counter()
-    for (f, n), p in zip(steps, bufs):
-        do_insert(p, n * (L + 1))
+    for k in range(args.steps):
+        j = k % nb
+        if j == 0 and k > 0:
+            bwt.reset()                           # next job: empty index, same buffers
+        do_insert(bufs[j], sizes[j])
     bwt.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -185,10 +247,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    symbols = sum(n * (L + 1) for (_, n) in steps)
+    symbols = sum(sizes[k % nb] for k in range(args.steps))
+    last = (args.steps - 1) % nb + 1 if args.steps else 0      # batches in the index at the end (last job, maybe partial)
     prof = bwt.profile_get()
     counts = bwt.counts()
-    ok_counts = int(counts.sum()) == symbols and int(counts[:, 0].sum()) == sum(n for _, n in steps)
+    ok_counts = int(counts.sum()) == sum(sizes[:last]) and int(counts[:, 0].sum()) == sum(n for _, n in job[:last])
+    host_api = None
+    if rank == 0 and n_gpus == 1 and not args.no_extras:
+        bwt.reset()
+        host_api = host_api_rate(HipBwt, so, dev, bufs, sizes)
     for p in bufs:
         bwt.dev_free(p)
     bwt.close()
@@ -206,6 +273,9 @@ def main():
     mk = prof["k_merge"]
     units = mk["units"] / (active if sharded else 1)
     ach = ALG_BYTES_PER_SYMBOL * units / (mk["ms"] * 1e-3) / 1e9 if mk["ms"] > 0 else 0.0
+    njobs = -(-args.steps // nb)
+    reads_job = sum(n for _, n in job)
+    name = "configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % world
     out = {
         "metric": "Gsymbols/s inserted (wall-clock), bit-identical .fmd",
         "value": total_symbols / dt / 1e9,
@@ -214,11 +284,12 @@ def main():
         "ms_per_step": dt * 1e3 / max(1, args.steps),
         "higher_is_better": True, "scaling": "strong" if (sharded and args.mode == "strong") else "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "%s: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch of %d reads"
-                               % ("configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % world,
-                                  sum(n for _, n in steps), L, so_flag.strip("-"), args.batch, n_gpus, per_batch),
-                   "reads": sum(n for _, n in steps) * (1 if sharded else n_gpus), "symbols": total_symbols,
-                   "reads_per_gpu": sum(n for _, n in steps) // (n_gpus if sharded else 1), "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
+        "config": {"workload": "%s: %d x %d bp synthetic reads (splitmix64 seed 42), -b%sR -m%gg, %d x MI355X; step = one -m batch "
+                               "(%s reads); %d steps = %d job(s) of %d batches, each job on an empty index%s"
+                               % (name, reads_job, L, so_flag.strip("-"), args.batch, n_gpus, "/".join(str(n) for _, n in job), args.steps, njobs, nb,
+                                  "" if args.steps % nb == 0 else " (the last job stops after batch %d)" % (args.steps % nb)),
+                   "reads_per_job": reads_job * (1 if sharded else n_gpus), "jobs": args.steps / nb,
+                   "symbols": total_symbols, "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
                    "parallelism": "1 GPU" if n_gpus == 1 else
                                   ("31 sub-ropes (b,x) sharded over %d of %d GPUs (owner map %s); per round all_reduce(31x6 counts) + all_to_all(16 B string records) over RCCL"
                                    % (active, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
@@ -227,15 +298,26 @@ def main():
                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_ms": mk["ms"] / max(1, mk["launches"]), "launches": mk["launches"],
                      "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL,
+                     "algorithmic_bytes_per_launch": ALG_BYTES_PER_SYMBOL * units / max(1, mk["launches"]),
                      "note": None if not sharded else "rank 0 only; units per launch approximated by strings / active ranks"},
         "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
     }
+    # HBM bytes per k_merge launch from the PMC passes of this same command (tools/collect_profiles.sh -> profiles/):
+    # the per-launch average does not depend on K because every job is the same configs[1] job
     traffic_file = os.path.join(ROOT, "profiles", "k_merge_traffic.json")
-    if os.path.exists(traffic_file) and n_gpus == 1 and args.reads == 100_000_000 and args.batch == 4.0 and args.order == "rlo" and args.steps == 3:
+    if os.path.exists(traffic_file) and n_gpus == 1 and args.reads == 100_000_000 and args.batch == 4.0 and args.order == "rlo":
         try:
-            out["roofline"]["traffic"] = json.load(open(traffic_file)).get("bytes_per_launch")
+            tf = json.load(open(traffic_file))
+            out["roofline"]["traffic"] = tf.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tf.get("source")
         except Exception:  # noqa: BLE001
             pass
+    if host_api is not None:
+        out["value_host_api"] = host_api
+    if n_gpus == 1 and not args.no_extras:
+        wp = whole_process(args.reads, L, so_flag, args.batch)
+        if wp is not None:
+            out["whole_process"] = wp
     if not args.no_cpu_baseline and n_gpus == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
     print(json.dumps(out))

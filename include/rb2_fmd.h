@@ -17,8 +17,10 @@ typedef struct rb2_fmd_s rb2_fmd_t;
 
 rb2_fmd_t *rb2_fmd_init(void);                                 /* rld_init(6,3) + rld_itr_init, main.c:274-276 */
 void rb2_fmd_push(rb2_fmd_t *f, int64_t len, int sym);         /* rld_enc, rld0.c:153-161 (adjacent equal symbols merge) */
+void rb2_fmd_push_runs(rb2_fmd_t *f, const uint8_t *runs, int64_t n_bytes);   /* the same for a chunk of 43+3 run bytes (rle.h:39-75) */
 void rb2_fmd_finish(rb2_fmd_t *f);                             /* rld_enc_finish + rld_rank_index, rld0.c:163-217 */
 int  rb2_fmd_write(const rb2_fmd_t *f, FILE *fp);              /* rld_dump, rld0.c:223-244 */
+int  rb2_fmd_write_path(const rb2_fmd_t *f, const char *path);
 void rb2_fmd_counts(const rb2_fmd_t *f, int64_t c[7]);         /* total, $, A, C, G, T, N */
 void rb2_fmd_destroy(rb2_fmd_t *f);
 

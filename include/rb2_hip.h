@@ -46,6 +46,8 @@ int rb2_hip_device_count(void);
 rb2_hip_t *rb2_hip_create(int device, int sorting_order);
 void rb2_hip_destroy(rb2_hip_t *h);
 int  rb2_hip_sorting_order(const rb2_hip_t *h);
+/* empty the index again (what mr_destroy + mr_init would do) but keep every buffer the handle has grown */
+void rb2_hip_reset(rb2_hip_t *h);
 
 /* mr_insert_multi (mrope.c:258): insert all strings of `s` (concatenated, each REVERSED and
  * 0-terminated, nt6 codes 0..5, s[len-1]==0).  `s` is a host buffer, borrowed for the call. */

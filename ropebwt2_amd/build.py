@@ -67,6 +67,10 @@ def build_host(force=False):
     if os.path.exists(main_c) and (force or not _newer(exe, [main_c, out] + hdrs)):
         _run(["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-I" + INC, "-I" + host, "-o", exe, main_c,
               "-L" + LIBDIR, "-lropebwt2", "-lrb2hip", "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"])
+    gen_c = os.path.join(ROOT, "tools", "synth_reads.c")      # synthetic read generator (SURVEY.md 8c stream) for tests / bench
+    gen = os.path.join(BINDIR, "synth_reads")
+    if os.path.exists(gen_c) and (force or not _newer(gen, [gen_c])):
+        _run(["gcc", "-O2", "-std=c99", "-Wall", "-o", gen, gen_c])
     return out
 
 

@@ -15,6 +15,7 @@
 #include <string.h>
 #include <assert.h>
 #include "rb2_fmd.h"
+#include "rle.h"
 
 #define BLK_WORDS   8                    /* 1 << sbits, sbits = 3 */
 #define SYM_BITS    3                    /* ilog2(asize) + 1 */
@@ -108,6 +109,17 @@ void rb2_fmd_push(rb2_fmd_t *f, int64_t len, int sym)
 	f->pend_c = sym; f->pend_l = len;
 }
 
+/* a chunk of 43+3 run bytes (any run width, rle.h:39-75): what the device exports and what rope leaves hold.  One-byte
+ * runs -- all the device ever emits -- take the short path. */
+void rb2_fmd_push_runs(rb2_fmd_t *f, const uint8_t *q, int64_t n)
+{
+	const uint8_t *end = q + n;
+	while (q < end) {
+		if ((*q & 0x80) == 0) { rb2_fmd_push(f, *q >> 3, *q & 7); ++q; }
+		else { int c; int64_t l; q += rle_dec1_fn(q, &c, &l); rb2_fmd_push(f, l, c); }
+	}
+}
+
 void rb2_fmd_finish(rb2_fmd_t *f)
 {
 	uint64_t n_blks, last, i, k, run[6] = { 0, 0, 0, 0, 0, 0 };
@@ -173,4 +185,14 @@ void rb2_fmd_destroy(rb2_fmd_t *f)
 {
 	if (!f) return;
 	free(f->w); free(f->frame); free(f);
+}
+
+int rb2_fmd_write_path(const rb2_fmd_t *f, const char *path)     /* rb2_fmd_write to a named file (bindings without FILE*) */
+{
+	FILE *fp = fopen(path, "wb");
+	int r;
+	if (!fp) return -1;
+	r = rb2_fmd_write(f, fp);
+	if (fclose(fp) != 0) r = -1;
+	return r;
 }

@@ -26,80 +26,86 @@ static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need 
 static void str_putc(str_t *s, int c) { str_reserve(s, s->l + 2); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
 static void str_append(str_t *s, const char *p, size_t n) { str_reserve(s, s->l + n + 1); memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0; }
 
-/* ---- buffered reader: FASTA / FASTQ records or plain lines ------------------------------------ */
-typedef struct { gzFile fp; unsigned char buf[1 << 16]; int beg, end, eof, last; str_t seq, qual; } reader_t;
+/* ---- buffered reader: FASTA / FASTQ records or plain lines ------------------------------------
+ * Behaviour follows kseq.h as the reference uses it (main.c:177-187), including what happens at the edges:
+ * the stream is refilled RD_BUF bytes at a time and "end of input" is only known once a refill comes back short
+ * (kseq.h:70-75, 96-105) -- so an input whose size is a multiple of RD_BUF (0 included) yields one extra empty line
+ * in -L mode; sequence lines are taken raw (embedded blanks become N), a trailing CR is dropped; a FASTQ record
+ * whose quality string is shorter than its sequence ends the input (kseq_read's -2). */
+#define RD_BUF 16384
+typedef struct { gzFile fp; unsigned char buf[RD_BUF]; int beg, end, eof, last; str_t seq, qual; } reader_t;
 
+static int rd_fill(reader_t *r)               /* 0: nothing more to read */
+{
+	r->beg = 0; r->end = gzread(r->fp, r->buf, RD_BUF);
+	if (r->end < 0) r->end = 0;
+	if (r->end < RD_BUF) r->eof = 1;
+	return r->end > 0;
+}
 static int rd_getc(reader_t *r)
 {
 	if (r->beg >= r->end) {
-		if (r->eof) return -1;
-		r->beg = 0; r->end = gzread(r->fp, r->buf, sizeof(r->buf));
-		if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
+		if (r->eof || !rd_fill(r)) return -1;
 	}
 	return r->buf[r->beg++];
 }
-/* append the rest of the line to s (s may be NULL); returns the terminating char or -1.
- * Works on whole buffer spans (memchr), not character by character. */
-static int rd_line(reader_t *r, str_t *s, int only_graph)
+/* bytes up to the next delimiter ('\n', or any white space when !line) are appended to s (NULL: skipped); *delim gets
+ * the delimiter found (0: input ended first).  Returns -1 only when the input was already known to be exhausted. */
+static int rd_until(reader_t *r, str_t *s, int line, int *delim)
 {
+	if (delim) *delim = 0;
+	if (r->beg >= r->end && r->eof) return -1;
 	for (;;) {
-		unsigned char *b, *nl;
-		int n;
+		unsigned char *b;
+		int i, n;
 		if (r->beg >= r->end) {
-			if (r->eof) return -1;
-			r->beg = 0; r->end = gzread(r->fp, r->buf, sizeof(r->buf));
-			if (r->end <= 0) { r->eof = 1; r->end = 0; return -1; }
+			if (r->eof || !rd_fill(r)) break;
 		}
-		b = r->buf + r->beg;
-		nl = (unsigned char*)memchr(b, '\n', r->end - r->beg);
-		n = nl ? (int)(nl - b) : r->end - r->beg;
-		if (s && n) {
-			if (!only_graph) {
-				int k = n;
-				if (b[k-1] == '\r') --k;                  /* CR of a CRLF line end */
-				str_append(s, (const char*)b, k);
-			} else {
-				int i;
-				str_reserve(s, s->l + n + 1);
-				for (i = 0; i < n; ++i) if (isgraph(b[i])) s->s[s->l++] = (char)b[i];
-				s->s[s->l] = 0;
-			}
-		}
-		r->beg += n + (nl ? 1 : 0);
-		if (nl) return '\n';
+		b = r->buf + r->beg; n = r->end - r->beg;
+		if (line) { unsigned char *nl = (unsigned char*)memchr(b, '\n', n); i = nl ? (int)(nl - b) : n; }
+		else for (i = 0; i < n && !isspace(b[i]); ++i);
+		if (s && i) str_append(s, (const char*)b, i);
+		r->beg += i + 1;
+		if (i < n) { if (delim) *delim = b[i]; break; }
 	}
+	if (s) {
+		str_reserve(s, s->l + 1);
+		if (line && s->l > 1 && s->s[s->l-1] == '\r') --s->l;      /* kseq.h:136 */
+		s->s[s->l] = 0;
+	}
+	return 0;
 }
 static int read_line_record(reader_t *r)
 {
 	r->seq.l = 0; r->qual.l = 0;
-	str_reserve(&r->seq, 1); r->seq.s[0] = 0;
-	if (rd_line(r, &r->seq, 0) < 0 && r->seq.l == 0) return -1;
+	if (rd_until(r, &r->seq, 1, 0) < 0) return -1;
 	return (int)r->seq.l;
 }
 static int read_fastx_record(reader_t *r)
 {
-	int c;
-	r->seq.l = r->qual.l = 0;
-	str_reserve(&r->seq, 1); r->seq.s[0] = 0;
+	int c, d;
 	if (r->last == 0) {                                  /* look for the next header */
 		while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@');
 		if (c < 0) return -1;
+		r->last = c;
 	}
-	r->last = 0;
-	if (rd_line(r, 0, 0) < 0) return (int)r->seq.l;      /* name line */
+	r->seq.l = r->qual.l = 0;
+	str_reserve(&r->seq, 1); r->seq.s[0] = 0;
+	if (rd_until(r, 0, 0, &d) < 0) return -1;            /* name; then the comment up to the end of the line */
+	if (d != '\n') rd_until(r, 0, 1, 0);
 	while ((c = rd_getc(r)) >= 0 && c != '>' && c != '@' && c != '+') {
 		if (c == '\n') continue;
 		str_putc(&r->seq, c);
-		rd_line(r, &r->seq, 1);
+		rd_until(r, &r->seq, 1, 0);
 	}
 	if (c == '>' || c == '@') r->last = c;
 	if (c != '+') return (int)r->seq.l;
-	rd_line(r, 0, 0);                                    /* '+' line */
-	while (r->qual.l < r->seq.l && (c = rd_getc(r)) >= 0) {
-		if (c == '\n') continue;
-		str_putc(&r->qual, c);
-		rd_line(r, &r->qual, 1);
-	}
+	while ((c = rd_getc(r)) >= 0 && c != '\n');          /* rest of the '+' line */
+	if (c < 0) return -2;
+	str_reserve(&r->qual, 1); r->qual.s[0] = 0;
+	while (rd_until(r, &r->qual, 1, 0) >= 0 && r->qual.l < r->seq.l);
+	r->last = 0;
+	if (r->qual.l != r->seq.l) return -2;                /* truncated quality: the reference stops reading here */
 	return (int)r->seq.l;
 }
 
@@ -109,11 +115,11 @@ static void emit_runs(void *user, const uint8_t *q, int64_t n)
 {
 	rb2_fmd_t *fmd = (rb2_fmd_t*)user;
 	const uint8_t *end = q + n;
+	if (fmd) { rb2_fmd_push_runs(fmd, q, n); return; }
 	while (q < end) {
 		int sym; int64_t len, k;
 		rle_dec1(q, sym, len);
-		if (fmd) rb2_fmd_push(fmd, len, sym);
-		else {                                                 /* plain text: one fwrite per 64 KiB instead of a putchar per symbol */
+		{                                                      /* plain text: one fwrite per 64 KiB instead of a putchar per symbol */
 			static char tbuf[1 << 16];
 			static size_t tl = 0;
 			for (k = len; k > 0; ) {
@@ -231,7 +237,7 @@ int main(int argc, char *argv[])
 			else if (*p == 'G' || *p == 'g') x *= 1024 * 1024 * 1024;
 			m = x ? (int64_t)(x * .97) + 1 : 0;              /* main.c:136 */
 			break; }
-		default: return usage(block_len, max_nodes);
+		default: break;                                      /* unknown options are ignored, as in the reference (main.c:100-137 has no default) */
 		}
 	}
 	if (optind == argc && isatty(fileno(stdin))) return usage(block_len, max_nodes);

@@ -66,22 +66,30 @@ void *mr_hip_handle(mrope_t *mr) { return X(mr)->dev; }
 
 /* ---- host <-> device ------------------------------------------------------------------------- */
 
-/* device -> host ropes: download each rope as a run stream and bulk-load a fresh B+ tree */
+/* device -> host ropes: stream each rope's run bytes off the device ONCE into a growing buffer (the size is only known
+ * after the export; asking for it first would run the export kernel twice) and bulk-load a fresh B+ tree */
+typedef struct { uint8_t *p; int64_t n, m; } runbuf_t;
+static void runbuf_add(void *user, const uint8_t *q, int64_t n)
+{
+	runbuf_t *b = (runbuf_t*)user;
+	if (b->n + n > b->m) { b->m = (b->n + n) + ((b->n + n) >> 1) + (1 << 20); b->p = (uint8_t*)realloc(b->p, b->m); }
+	memcpy(b->p + b->n, q, n); b->n += n;
+}
+
 void mr_sync_host(mrope_t *mr)
 {
 	mrx_t *x = X(mr);
+	runbuf_t rb = { 0, 0, 0 };
 	int a;
 	if (x->host_ok) return;
 	assert(x->dev && x->dev_ok);
 	for (a = 0; a < 6; ++a) {
-		const int64_t nb = rb2_hip_rope_bytes(x->dev, a);
-		uint8_t *buf = (uint8_t*)malloc(nb > 0 ? nb : 1);
-		const int64_t got = rb2_hip_download_rope(x->dev, a, buf);
-		assert(got == nb);
+		rb.n = 0;
+		rb2_hip_stream_rope(x->dev, a, runbuf_add, &rb);
 		if (!mr->r[a]) mr->r[a] = rope_init(x->max_nodes, x->block_len);
-		rope_load_runs(mr->r[a], buf, got);
-		free(buf);
+		rope_load_runs(mr->r[a], rb.p, rb.n);
 	}
+	free(rb.p);
 	x->host_ok = 1;
 }
 

@@ -62,7 +62,7 @@ static void rope_reset(rope_t *r)
 {
 	if (r->node) arena_free((arena_t*)r->node);
 	if (r->leaf) arena_free((arena_t*)r->leaf);
-	r->node = arena_new(sizeof(rpnode_t) * r->max_nodes);
+	r->node = arena_new(sizeof(rpnode_t) * (r->max_nodes + 1));
 	r->leaf = arena_new(r->block_len);
 	memset(r->c, 0, sizeof(r->c));
 	r->root = new_bucket(r);
@@ -141,12 +141,15 @@ int64_t rope_insert_run(rope_t *rope, int64_t x, int a, int64_t rl, rpcache_t *c
 		e->l -= nlen;
 		ne = bucket_open_slot(bucket, pidx[depth-1]);
 		ne->p = (rpnode_t*)nl; ne->l = nlen; memcpy(ne->c, nc, 48);
-		for (k = depth - 1; k >= 0 && (int)path[k]->n == rope->max_nodes; --k) {
+		/* a bucket is split as soon as it holds max_nodes entries.  Buckets restored from a reference-built .fmr may
+		 * already hold max_nodes at rest (the reference splits those on its next descent, rope.c:120-124): they reach
+		 * max_nodes + 1 here, which is why arena items have one spare entry (rope_reset / rope_restore) */
+		for (k = depth - 1; k >= 0 && (int)path[k]->n >= rope->max_nodes; --k) {
 			rpnode_t *full = path[k], *right = new_bucket(rope), *parent, *pe;
-			const int half = rope->max_nodes / 2, isb = full->is_bottom;
+			const int nfull = full->n, half = nfull / 2, rest = nfull - half, isb = full->is_bottom;
 			int64_t sc[6], sl;
-			memcpy(right, full + half, sizeof(rpnode_t) * half);
-			right->n = half; right->is_bottom = isb;
+			memcpy(right, full + half, sizeof(rpnode_t) * rest);
+			right->n = rest; right->is_bottom = isb;
 			full->n = half;
 			if (k == 0) {                            /* grow a new root */
 				parent = new_bucket(rope);
@@ -160,7 +163,7 @@ int64_t rope_insert_run(rope_t *rope, int64_t x, int a, int64_t rl, rpcache_t *c
 				pe = &parent[pidx[k-1]];
 			}
 			entry_sum(full, 0, half, sc, &sl);  memcpy(pe->c, sc, 48); pe->l = sl; pe->p = full;
-			entry_sum(right, 0, half, sc, &sl); memcpy(ne->c, sc, 48); ne->l = sl; ne->p = right;
+			entry_sum(right, 0, rest, sc, &sl); memcpy(ne->c, sc, 48); ne->l = sl; ne->p = right;
 			if (k == 0) break;
 		}
 	}
@@ -276,6 +279,7 @@ static rpnode_t *restore_bucket(rope_t *r, FILE *fp, int64_t c[6])
 	uint8_t isb; int16_t n; int i, a;
 	rpnode_t *p = new_bucket(r);
 	if (fread(&isb, 1, 1, fp) != 1 || fread(&n, 2, 1, fp) != 1) { fprintf(stderr, "[E::rope_restore] truncated file\n"); exit(1); }
+	if (n < 1 || n > r->max_nodes) { fprintf(stderr, "[E::rope_restore] bucket with %d entries (max_nodes %d)\n", (int)n, r->max_nodes); exit(1); }
 	p->is_bottom = isb; p->n = n;
 	memset(c, 0, 48);
 	for (i = 0; i < n; ++i) {
@@ -300,7 +304,7 @@ rope_t *rope_restore(FILE *fp)
 	if (fread(&r->max_nodes, 4, 1, fp) != 1 || fread(&r->block_len, 4, 1, fp) != 1 || r->max_nodes < 2 || r->block_len < 32) {
 		fprintf(stderr, "[E::rope_restore] not an FMR rope\n"); exit(1);
 	}
-	r->node = arena_new(sizeof(rpnode_t) * r->max_nodes);
+	r->node = arena_new(sizeof(rpnode_t) * (r->max_nodes + 1));
 	r->leaf = arena_new(r->block_len);
 	r->root = restore_bucket(r, fp, r->c);
 	return r;

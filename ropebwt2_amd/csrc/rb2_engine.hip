@@ -271,6 +271,15 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	batch_end(h);
 }
 
+// the batch must end with a sentinel (mrope.c:268): bytes after the last 0 would be sized for but never inserted
+void check_last_byte(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
+{
+	uint8_t last = 1;
+	HIPCHK(hipMemcpyAsync(&last, s_dev + len - 1, 1, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (last != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }
+}
+
 } // namespace
 
 // =============================================================================================
@@ -330,10 +339,21 @@ void rb2_hip_destroy(rb2_hip_t *h)
 
 int rb2_hip_sorting_order(const rb2_hip_t *h) { return h->so; }
 
+/* back to the empty index of rb2_hip_create; buffers, shard ownership and profiling state are kept */
+void rb2_hip_reset(rb2_hip_t *h)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	if (h->batch) { fprintf(stderr, "[rb2_hip] reset inside a sharded batch\n"); abort(); }
+	memset(h->h_rope, 0, sizeof(h->h_rope));
+	HIPCHK(hipMemsetAsync(&h->ctl->rope[0][0], 0, sizeof(RopeDesc) * 2 * NR, h->st));
+	HIPCHK(hipMemsetAsync(&h->ctl->nsb_total, 0, 8, h->st));
+}
+
 void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0) { fprintf(stderr, "[rb2_hip] insert_multi: len must be > 0\n"); abort(); }   // mrope.c:268
+	check_last_byte(h, len, s_dev);
 	if (((uintptr_t)s_dev & 15) != 0) {              // kernels use 16-byte loads
 		h->sbuf.ensure((size_t)len + 64);
 		HIPCHK(hipMemcpyAsync(h->sbuf.p, s_dev, (size_t)len, hipMemcpyDeviceToDevice, h->st));
@@ -527,6 +547,7 @@ int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || ((uintptr_t)s_dev & 15)) { fprintf(stderr, "[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); abort(); }
+	check_last_byte(h, len, s_dev);
 	BatchState *B = new BatchState();
 	batch_begin(h, *B, len, s_dev);
 	h->batch = B;
@@ -645,6 +666,7 @@ void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
 {
 	HIPCHK(hipSetDevice(h->dev));
+	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rank1a: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n"); abort(); }
 	for (int s = 0; s < 6; ++s) cx[s] = 0;
 	for (int r = 0; r < NR && x > 0; ++r) {              /* whole pieces in front of x, then a scan inside one piece */
 		if (rope_sym(r) != b) continue;

@@ -30,6 +30,7 @@ def load_hip_lib():
         "rb2_hip_create": (vp, [i32, i32]),
         "rb2_hip_destroy": (None, [vp]),
         "rb2_hip_sorting_order": (i32, [vp]),
+        "rb2_hip_reset": (None, [vp]),
         "rb2_hip_insert_multi": (None, [vp, i64, vp]),
         "rb2_hip_insert_multi_dev": (None, [vp, i64, vp]),
         "rb2_hip_get_counts": (None, [vp, vp]),
@@ -67,7 +68,7 @@ def load_hip_lib():
 
 
 ABI_SYMBOLS = [
-    "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order",
+    "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
@@ -126,6 +127,10 @@ class HipBwt:
             self.close()
         except Exception:
             pass
+
+    def reset(self):
+        """empty index again; grown buffers are kept"""
+        self.L.rb2_hip_reset(self.h)
 
     # -- the hot path ---------------------------------------------------------------------
     def insert_multi(self, buf):

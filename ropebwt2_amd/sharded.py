@@ -240,12 +240,15 @@ class VirtualCluster:
 
     def insert_multi(self, buf):
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        ptrs = []
-        for r in self.ranks:                       # every rank sees the whole batch
-            p = r.dev_alloc(len(buf) + 64)
-            r.L.rb2_hip_memcpy(r.h, p, buf.ctypes.data, len(buf), 0)
-            ptrs.append(p)
-        gens = [r.batch_protocol(ptrs[k], len(buf), lambda n, k=k: self._ptr(k, 0, n), lambda n, k=k: self._ptr(k, 1, n))
+        r0 = self.ranks[0]
+        p = r0.dev_alloc(len(buf) + 64)            # one copy of the batch text: the virtual ranks share a device
+        r0.L.rb2_hip_memcpy(r0.h, p, buf.ctypes.data, len(buf), 0)
+        self.insert_multi_dev(p, len(buf))
+        r0.dev_free(p)
+
+    def insert_multi_dev(self, dev_ptr, nbytes):
+        """the batch already sits in device memory (16-byte aligned); every virtual rank reads the same buffer"""
+        gens = [r.batch_protocol(dev_ptr, nbytes, lambda n, k=k: self._ptr(k, 0, n), lambda n, k=k: self._ptr(k, 1, n))
                 for k, r in enumerate(self.ranks)]
         msgs = [next(g) for g in gens]
         done = False
@@ -256,24 +259,16 @@ class VirtualCluster:
                 tot = np.sum([m[1] for m in msgs], axis=0)
                 msgs = [g.send(tot.copy()) for g in gens]
             else:
-                # all_to_all in numpy: rank d receives, in source order, the block every source cut for it
-                host = []
-                for k, m in enumerate(msgs):
-                    n = sum(m[1]) * REC_BYTES
-                    a = np.zeros(max(n, 1), np.uint8)
-                    if n:
-                        self.ranks[k].L.rb2_hip_memcpy(self.ranks[k].h, a.ctypes.data, self.bufs[k][0], n, 1)
-                    host.append(a)
+                # all_to_all as device-to-device copies: rank d receives, in source order, the block every source cut for it
                 for d in range(self.n):
-                    parts = []
+                    off_d = 0
                     for s in range(self.n):
                         sc = msgs[s][1]
-                        off = sum(sc[:d]) * REC_BYTES
-                        parts.append(host[s][off:off + sc[d] * REC_BYTES])
                         assert sc[d] == msgs[d][2][s], "send/recv plans disagree"
-                    r = np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0, np.uint8)
-                    if len(r):
-                        self.ranks[d].L.rb2_hip_memcpy(self.ranks[d].h, self.bufs[d][1], r.ctypes.data, len(r), 0)
+                        if sc[d]:
+                            src = self.bufs[s][0] + sum(sc[:d]) * REC_BYTES
+                            self.ranks[d].L.rb2_hip_memcpy(self.ranks[d].h, self.bufs[d][1] + off_d, src, sc[d] * REC_BYTES, 2)
+                        off_d += sc[d] * REC_BYTES
                 nxt = []
                 for g in gens:
                     try:
@@ -283,8 +278,6 @@ class VirtualCluster:
                 if all(x is None for x in nxt):
                     done = True
                 msgs = nxt
-        for k, r in enumerate(self.ranks):
-            r.dev_free(ptrs[k])
 
     def counts(self):
         return self.ranks[0].counts()

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Large golden vector, produced by the REAL reference (oracle/_ref/ropebwt2): md5 of the .fmd of
-10 M x 101 bp reads of the SURVEY.md 8c stream (1.02 G symbols), input streamed from oracle/synth_reads.
+10 M x 101 bp reads of the SURVEY.md 8c stream (1.02 G symbols), input streamed from ropebwt2_amd/bin/synth_reads (tools/synth_reads.c).
 Only digests are stored.  Run in the build container:  python tests/golden/make_golden_large.py"""
 import hashlib, json, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-REF, GEN = os.path.join(ROOT, "oracle", "_ref", "ropebwt2"), os.path.join(ROOT, "oracle", "synth_reads")
+REF, GEN = os.path.join(ROOT, "oracle", "_ref", "ropebwt2"), os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
 N, L, SEED = 10_000_000, 101, 42
 out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropebwt2 r187 (oracle/_ref)",
        "n_reads": N, "read_len": L, "seed": SEED, "fmd_md5": {}}

@@ -14,6 +14,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 REF_BIN = os.path.join(ORACLE_DIR, "_ref", "ropebwt2")
 REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libropebwt2_ref.so")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")      # tools/synth_reads.c, built by ropebwt2_amd/build.py
 
 NT6 = np.full(256, 5, dtype=np.uint8)          # seq_nt6_table, main.c:17-26
 NT6[0] = 0

@@ -2,6 +2,8 @@
 
 mode "gpu":  every rank drives a real HIP engine on cuda:0 (several processes share the one GPU of the
              test box), exchange over gloo with host staging; owned ropes are compared with the oracle.
+mode "nccl": the same check with one GPU per rank and the exchange on device tensors over RCCL (backend "nccl"); needs as many
+             GPUs as ranks -- tests/test_sharded.py runs it whenever torch.cuda.device_count() >= 2.
 mode "mock": no GPU: a toy engine emits tagged records following a random count matrix; checks that
              TorchComm delivers them exactly where rb2_hip_shard_finish's layout expects them.
 """
@@ -18,13 +20,20 @@ sys.path.insert(0, os.path.dirname(HERE))
 def main():
     import torch.distributed as dist
     mode = sys.argv[1]
-    dist.init_process_group("gloo")
+    dev = 0
+    if mode == "nccl":
+        import torch
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo")
     rank, n = dist.get_rank(), dist.get_world_size()
     from ropebwt2_amd import sharded
-    if mode == "gpu":
+    if mode in ("gpu", "nccl"):
         import helpers as H
         so = int(sys.argv[2])
-        bwt = sharded.ShardedBwt(so, rank, n, device=0)
+        bwt = sharded.ShardedBwt(so, rank, n, device=dev)
         comm = sharded.TorchComm(bwt)
         reads = H.repetitive_reads(2500, seed=90 + so, genome_len=700, max_len=90)
         codes = H.splitmix_bases(3000, 60, seed=5)
@@ -47,7 +56,7 @@ def main():
                 assert np.array_equal(bwt.piece(r), want), "rank %d: piece %d differs" % (rank, r)
             else:
                 assert len(bwt.piece(r)) == 0
-        print("rank %d/%d so %d owned %s ok" % (rank, n, so, bwt.owned()))
+        print("rank %d/%d so %d backend %s owned %s ok" % (rank, n, so, dist.get_backend(), bwt.owned()))
     else:
         owner = sharded.default_owners(n)
         NR, sym, prev = sharded.NR, sharded.rope_sym, sharded.rope_prev

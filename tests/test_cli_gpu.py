@@ -49,8 +49,8 @@ def test_fmd_golden_10M_streamed(flags):
     equals the one the real reference produced (tests/golden/golden_large.json, make_golden_large.py)"""
     import hashlib, json
     g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))
-    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
-    assert os.path.exists(gen), "oracle/synth_reads not built"
+    gen = H.GEN
+    assert os.path.exists(gen), "ropebwt2_amd/bin/synth_reads not built"
     pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
     pc = subprocess.Popen([CLI, flags, "-m400m", "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     h = hashlib.md5()
@@ -66,8 +66,8 @@ def test_fmd_golden_coverage_reads(flags):
     compressible BWT in every round -- the regime of real data.  .fmd md5 as produced by the real reference."""
     import hashlib, json
     g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["coverage30x"]
-    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
-    assert os.path.exists(gen), "oracle/synth_reads not built"
+    gen = H.GEN
+    assert os.path.exists(gen), "ropebwt2_amd/bin/synth_reads not built"
     pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"]), "0", str(g["genome_len"])], stdout=subprocess.PIPE)
     pc = subprocess.Popen([CLI] + flags.split() + ["-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     h, n = hashlib.md5(), 0
@@ -81,7 +81,7 @@ def test_fmd_golden_long_reads():
     """200 k x 5 kbp in input order (1 G symbols, one batch of 5001 rounds): the long-string path against the real reference"""
     import hashlib, json
     g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["longreads"]
-    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
+    gen = H.GEN
     pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
     pc = subprocess.Popen([CLI, g["flags"], "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     h = hashlib.md5()
@@ -96,8 +96,8 @@ def test_fmd_golden_configs1_full_size():
     through the CLI: the 6.0 GB .fmd has the md5 the real reference produced for the same input on the same kind of box"""
     import hashlib, json
     g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["configs1"]
-    gen = os.path.join(H.ROOT, "oracle", "synth_reads")
-    assert os.path.exists(gen), "oracle/synth_reads not built"
+    gen = H.GEN
+    assert os.path.exists(gen), "ropebwt2_amd/bin/synth_reads not built"
     pg = subprocess.Popen([gen, str(g["n_reads"]), str(g["read_len"]), str(g["seed"])], stdout=subprocess.PIPE)
     pc = subprocess.Popen([CLI] + g["flags"].split() + ["-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     h, n = hashlib.md5(), 0

@@ -184,3 +184,42 @@ def test_rle_rope_random_against_model(hostlib):
             assert list(cx) == [model[:x].count(s) for s in range(6)]
             assert list(cy) == [model[:y].count(s) for s in range(6)]
     L.rope_destroy(r)
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("l,n", [(32, 4), (32, 8), (64, 4)])
+def test_restore_reference_fmr_with_full_buckets(l, n, tmp_path):
+    """the reference leaves buckets with n == max_nodes at rest and dumps them (rope.c:120-124 splits them on the NEXT
+    descent); restoring such a file and inserting with -m0 must split them too (used to overflow the bucket)"""
+    rng = np.random.RandomState(l * 100 + n)
+    for it in range(6):
+        so = ["", "-s", "-r"][it % 3]
+        mk = lambda k: H.lines_from_codes([rng.randint(1, 5, size=rng.randint(1, 60)) for _ in range(k)])
+        a, b = mk(int(rng.randint(100, 700))), mk(int(rng.randint(100, 700)))
+        flags = [x for x in ["-L", "-m0", so, "-l%d" % l, "-n%d" % n] if x]
+        f = tmp_path / "ref.fmr"
+        f.write_bytes(H.run_ref(flags + ["-b"], a))
+        want = H.run_ref(["-L", "-m0", "-i", str(f)], b)
+        assert cli(["-L", "-m0", "-i", str(f)], b) == want
+        g = tmp_path / "our.fmr"                           # and our .fmr (same options) continues in the reference
+        g.write_bytes(cli(flags + ["-b"], a))
+        assert H.run_ref(["-L", "-m0", "-i", str(g)], b) == want
+
+
+@pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+def test_reader_edge_cases_match_reference():
+    """kseq-compatible reading (main.c:177-187, kseq.h): raw sequence lines (blanks become N), trailing CR, truncated
+    quality ends the input, header without newline, sizes that are multiples of kseq's 16 KiB buffer, unknown options"""
+    line = b"ACGTACGTACGTACG\n"
+    fa16k = b">r\n" + b"ACGT" * 4095 + b"\n"
+    cases = [b"", b"\n", b">", b">a", b">a\n", b"@a\nACG\n+\nII\n@b\nAC\n+\nII\n", b"@a\nACG\n+", b"@a\nACG\n+\n",
+             b"ACGT\r\nAC\r\n", b">x y\nAC GT\r\nA\tC\n>z\n\r\nAC\n", b">r c\n\tGT TG\t\n>s\n\n", fa16k, fa16k + b">", fa16k + b">q\nAC"]
+    for data in cases:
+        for flags in (["-m0", "-d"], ["-m0", "-q", "20"], ["-m0", "-N", "-r"], ["-m0", "-Z", "-R"]):
+            p = subprocess.run([H.REF_BIN] + flags + ["-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            assert p.returncode == 0
+            assert cli(flags, data) == p.stdout, (flags, data[:40])
+    for data in (b"", line * 1024, (line * 1024)[:-1], b"ACG", b"ACG\n\n"):   # -L: an input of k x 16384 bytes ends with one extra empty read
+        p = subprocess.run([H.REF_BIN, "-L", "-R", "-m0", "-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        assert p.returncode == 0
+        assert cli(["-L", "-R", "-m0"], data) == p.stdout, data[:20]

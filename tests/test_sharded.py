@@ -157,3 +157,24 @@ def test_two_processes_over_gloo(hip, so):
     out = p.stdout.decode()
     assert p.returncode == 0, out
     assert out.count(" ok") >= 2, out
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="the RCCL path needs >= 2 GPUs on the box (one process per GPU)")
+@pytest.mark.parametrize("so", [0, 2])
+def test_processes_over_rccl(hip, so):
+    """one process per GPU, backend nccl (= RCCL): all_reduce of the count matrix and all_to_all_single of the string
+    records on device tensors; every rank compares its owned pieces with the oracle"""
+    n = min(_gpu_count(), 8)
+    p = launch(n, ["nccl", so], 29700 + so)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert out.count("backend nccl") >= n and out.count(" ok") >= n, out

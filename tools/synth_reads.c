@@ -1,4 +1,4 @@
-/* oracle/synth_reads.c -- TEST INFRASTRUCTURE.
+/* tools/synth_reads.c -- input generator for tests and bench.py (built to ropebwt2_amd/bin/synth_reads).
  * Deterministic synthetic read generator: base j of read i is
  * "ACGT"[splitmix64_output(seed, i*L+j+1) >> 62], one read per line.
  *   usage: synth_reads <n_reads> <read_len> [seed=42] [first_read=0] [genome_len=0]  > reads.txt
