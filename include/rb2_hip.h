@@ -129,6 +129,10 @@ void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read,
 
 void rb2_hip_sync(rb2_hip_t *h);
 
+/* leaf-layout statistics since rb2_hip_create: out[0] re-layouts (dense <-> sparse), out[1] void sparse rounds (a leaf ran out
+ * of slack; the round was redone densely), out[2] rounds inserted in place, out[3] 1 when the index currently has the sparse layout */
+void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4]);
+
 /* per-kernel timing, measured with hipEvents on the engine's own stream when enabled */
 #define RB2_K_SYM      0
 #define RB2_K_TSCAN    1
@@ -138,7 +142,8 @@ void rb2_hip_sync(rb2_hip_t *h);
 #define RB2_K_META     5
 #define RB2_K_ADVANCE  6
 #define RB2_K_INIT     7
-#define RB2_K_COUNT    8
+#define RB2_K_RELAYOUT 8   /* change between the dense and the sparse (slack) leaf layout */
+#define RB2_K_COUNT    9
 void rb2_hip_profile(rb2_hip_t *h, int enable);
 /* launches[k], ms[k] (summed), units[k] (strings processed, summed) since the last reset */
 void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[RB2_K_COUNT],

@@ -10,7 +10,14 @@
 //                 reference walks rpnode_t buckets, rope.c:119-134).  Run-length coding (rle.h:39-75)
 //                 only happens on export (k_export).
 //   LeafMeta      16 B per leaf: per-symbol counts of the preceding leaves of the same superblock
-//                 (u16 x 6).
+//                 (u16 x 6), their total (npre) and the leaf's own fill (n).  A second array (`own`)
+//                 holds every leaf's own counts: the merge kernels write it, k_meta_sb turns it into
+//                 the prefixes.
+//   sparse layout the same arrays, but leaves carry SLACK (fill <= LEAF, only the first few slots of
+//                 a superblock in use): rounds that touch few leaves insert IN PLACE into the leaves
+//                 they hit (k_merge_leaf) instead of rewriting the piece, and position -> leaf becomes
+//                 a search over sbpos / npre (locate()) instead of a division -- the counterpart of
+//                 the reference's B+ tree descent (rope.c:119-134) with its half-full leaves.
 //   superblock    SB consecutive leaves; Cnt6 (6 x u64) exclusive prefix of symbol counts over
 //                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf scan  (rope_rank2a,
 //                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
@@ -32,6 +39,7 @@ constexpr int LEAFB  = LEAFW * 8;      // bytes per leaf
 constexpr int WPL    = 4;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
 constexpr int WIN    = WPL * LEAF;     // symbols per window
 constexpr int STILE  = 512;           // strings per string tile
+constexpr int MW     = 4;             // waves per block in the one-wave-per-leaf / per-window kernels
 constexpr int SCHUNK = 1024;          // items per block in the 3-kernel scans
 constexpr int ZBLOCK = 16384;         // bytes per block when locating sentinels
 
@@ -45,7 +53,9 @@ __host__ __device__ inline int rope_sym(int r)  { return r == 0 ? 0 : 1 + (r - 1
 __host__ __device__ inline int rope_prev(int r) { return r == 0 ? 0 : (r - 1) % 6; }       // x
 __host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (a - 1) * 6 + b; }
 
-struct LeafMeta { uint16_t c[6]; uint16_t nbytes; uint16_t pad; };
+struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: prefixes inside the superblock + own fill; own[]: own counts + own fill
+constexpr int SP_FILL = 1008;          // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 336 inserts)
+constexpr int SP_USED = 24;            // ... leaf slots in use per superblock (the other 8 stay empty)
 struct Cnt6 { uint64_t v[6]; };
 
 struct RopeDesc {
@@ -76,6 +86,10 @@ struct Ctl {
 	// ne[p] != 0: some string has a NON-EMPTY interval in the arrays read by rounds of parity p.  Zero (always in input
 	// order; on random reads from round ~14 of a batch on) selects the kernel variants that never touch U / SIZE.
 	uint32_t ne[2];
+	// ---- sparse (in-place) rounds
+	uint32_t nwork;         // work orders (touched leaves) appended by k_part_sparse this round
+	uint32_t overflow;      // some touched leaf cannot take its inserts: the round is void (every later kernel returns) and the host redoes it densely
+	RopeDesc relay_old[NR]; // k_relayout: the layout being read while rope[side] already describes the one being written
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
 	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
 	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
@@ -98,7 +112,7 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 	uint16_t ni, nvalid;    // new symbols / symbols in the window
 };
 
-struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; };
+struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; LeafMeta *own; uint64_t *sbpos; };   // sbpos[sb] = symbols in front of superblock sb (pool-wide)
 
 struct TileRec {            // per string tile, written by k_sym
 	uint32_t hist[6];
@@ -263,18 +277,47 @@ __device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, Ni
 	edge(c1);
 }
 
+// position -> leaf when leaves carry slack (sparse layout; also valid on the dense one): the last leaf of the piece that
+// starts at or before p -- superblock by binary search over sbpos, leaf by binary search over the in-superblock prefixes.
+// A position on a leaf boundary goes to the RIGHT leaf, p == n to the last leaf in use (the reference sends boundaries to
+// the left child, rope.c:130; the BWT does not depend on it).  This is the descent of rope.c:119-134.
+struct Loc { uint64_t gl, s; uint32_t n; };   // leaf slot (pool-wide), piece position of its first symbol, its fill
+__device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
+{
+	Loc r; r.gl = rp.leaf0; r.s = 0; r.n = 0;
+	if (rp.nleaves == 0) return r;
+	const uint64_t nsb = (rp.nleaves + SB - 1) / SB, base = pv.sbpos[rp.sb0];
+	uint64_t lo = 0, hi = nsb - 1;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi + 1) >> 1;
+		if (pv.sbpos[rp.sb0 + mid] - base <= p) lo = mid; else hi = mid - 1;
+	}
+	const uint64_t sbs = pv.sbpos[rp.sb0 + lo] - base, l0 = (rp.sb0 + lo) * SB;
+	const uint32_t rel = (uint32_t)(p - sbs);                  // < 2^16: a superblock holds at most SB * LEAF symbols
+	uint32_t klo = 0, khi = (uint32_t)min((uint64_t)(SB - 1), rp.leaf0 + rp.nleaves - 1 - l0);
+	while (klo < khi) {                                        // unused slots (n == 0) trail the used ones: the predicate is monotone
+		const uint32_t mid = (klo + khi + 1) >> 1;
+		const LeafMeta m = pv.meta[l0 + mid];
+		if (m.npre <= rel && m.n > 0) klo = mid; else khi = mid - 1;
+	}
+	const LeafMeta m = pv.meta[l0 + klo];
+	r.gl = l0 + klo; r.s = sbs + m.npre; r.n = m.n;
+	return r;
+}
+
 // counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
 // superblock prefix + leaf-relative prefix + a scan of the packed leaf up to p, 32 symbols per load
-// (the reference walks the runs of one leaf, rle.c:147-158).
-__device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
+// (the reference walks the runs of one leaf, rle.c:147-158).  SPARSE: leaves carry slack, the leaf is found by locate().
+template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
 {
 	if (p >= rp.n) {
 #pragma unroll
 		for (int s = 0; s < 6; ++s) out[s] = rp.cnt[s];
 		return;
 	}
-	const uint64_t lf = p / LEAF, gl = rp.leaf0 + lf;
-	const uint32_t off = (uint32_t)(p % LEAF);
+	uint64_t gl; uint32_t off;
+	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
+	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	const LeafMeta m = pv.meta[gl];
 	NibAcc A;
@@ -288,21 +331,23 @@ __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t
 // occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],
 // mrope.c:202-224).  When the interval lies in one leaf -- the common case: intervals are short -- this is a scan of the
 // interval itself, no directory and no prefix (rle_rank2a counts the same way, rle.c:134-191); else two full ranks.
-__device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
+template <bool SPARSE = false> __device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
 {
-	const uint64_t lf = l / LEAF;
-	if ((u - 1) / LEAF == lf) {
+	uint64_t gl; uint32_t ol; bool one;
+	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
+	else { const uint64_t lf = l / LEAF; gl = rp.leaf0 + lf; ol = (uint32_t)(l - lf * LEAF); one = (u - 1) / LEAF == lf; }
+	if (one) {
 		NibAcc A;
-		const uint32_t ol = (uint32_t)(l - lf * LEAF), ou = (uint32_t)(u - lf * LEAF);
-		leaf_count((const uint4*)(pv.data + (rp.leaf0 + lf) * (uint64_t)LEAFB), ol, ou, A);
+		const uint32_t ou = ol + (uint32_t)(u - l);
+		leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), ol, ou, A);
 		uint32_t c[6];
 		nib_finish(A, ou - ol, c);
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {
 		uint64_t cl[6], cu[6];
-		rank_all(pv, rp, l, cl);
-		rank_all(pv, rp, u, cu);
+		rank_all<SPARSE>(pv, rp, l, cl);
+		rank_all<SPARSE>(pv, rp, u, cu);
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = cu[s] - cl[s];
 	}

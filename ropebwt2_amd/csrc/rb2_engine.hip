@@ -35,17 +35,18 @@ template <typename T> struct DevBuf {
 };
 
 struct Pool {
-	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta; DevBuf<Cnt6> sbcum;
+	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta, own; DevBuf<Cnt6> sbcum; DevBuf<uint64_t> sbpos;
 	uint64_t cap_leaves = 0;
 	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
 		if (leaves <= cap_leaves) return;
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
-		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); sbcum.ensure(nl / SB + 1, keep, st);
+		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); own.ensure(nl, keep, st);
+		sbcum.ensure(nl / SB + 1, keep, st); sbpos.ensure(nl / SB + 1, keep, st);
 		cap_leaves = nl;
 	}
-	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p}; }
-	void release() { data.release(); meta.release(); sbcum.release(); cap_leaves = 0; }
+	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p, own.p, sbpos.p}; }
+	void release() { data.release(); meta.release(); own.release(); sbcum.release(); sbpos.release(); cap_leaves = 0; }
 };
 
 struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
@@ -56,12 +57,19 @@ struct rb2_hip_s {
 	int dev = 0, so = 0;
 	hipStream_t st = 0;
 	Pool pool[2];
-	int side = 0;                       // pool side holding the current BWT
+	int side = 0;                       // descriptor parity: ctl->rope[side] / ctl->seg[side] describe the current BWT (flips every round)
+	int pside = 0;                      // pool that physically holds it (flips with `side` in dense rounds, stays in sparse ones)
+	bool sparse = false;                // the pool is in the sparse layout (leaves with slack, in-place rounds)
+	double sp_lambda = 0.4;             // go sparse when (strings per round) / (leaves of the index) falls below this
+	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
+	int sp_maxpen = 12;
+	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
 	Ctl *ctl = nullptr;                 // device
 	RopeDesc h_rope[NR];                // host mirror of ctl->rope[side] (sub-ropes)
 	// per-string state
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
+	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
 	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
@@ -121,12 +129,12 @@ void drain_profile(rb2_hip_t *h)
 inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
-void build_directory(rb2_hip_t *h, int sd, uint64_t nsb_ub)
+void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub)
 {
 	if (nsb_ub == 0) return;
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
 	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
-	PoolView pv = h->pool[sd].view();
+	PoolView pv = h->pool[pool].view();
 	hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p);
 	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
@@ -153,7 +161,7 @@ struct BatchState {
 void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m);
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
 	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
@@ -188,9 +196,11 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	uint64_t n_tot = 0;
 	for (int b = 0; b < NR; ++b) n_tot += h->h_rope[b].n;     // symbols held by THIS rank
 	const uint64_t leaves_ub = (n_tot + len) / LEAF + NR * (SB + 1);
-	h->pool[h->side].ensure(leaves_ub, true, st);
-	h->pool[h->side ^ 1].ensure(leaves_ub, false, st);
-	h->LD.ensure(leaves_ub + NR + 16);
+	if (!h->sparse) {                                          // (the sparse layout sizes its pools in relayout())
+		h->pool[h->pside].ensure(leaves_ub, true, st);
+		h->pool[h->pside ^ 1].ensure(leaves_ub, false, st);
+	}
+	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 16));   // dense: one work order per output window; sparse: at most one per string
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
 	{
@@ -222,33 +232,102 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
 // send == nullptr: strings go straight to the next-round arrays; else they are written as ShardRec.
+// Dense round: every piece is rewritten pool[pside] -> pool[pside ^ 1] (k_merge).
 void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
-	PoolView oldp = h->pool[sd].view(), newp = h->pool[sd ^ 1].view();
+	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
+	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) hipLaunchKernelGGL(k_prep<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  hipLaunchKernelGGL(k_prep<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  hipLaunchKernelGGL((k_prep<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
 	{ Scope sc(h, RB2_K_META, units);
-	  build_directory(h, sd ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
+	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) hipLaunchKernelGGL(k_advance<false>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send);
-	  hipLaunchKernelGGL(k_advance<true>, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send); }
-	h->side ^= 1; B.cur ^= 1;
+	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
+	  hipLaunchKernelGGL((k_advance<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
+}
+
+// leaf slots the pools must hold for an index of n symbols in the given layout
+uint64_t slots_for(uint64_t n, bool sparse)
+{
+	if (!sparse) return n / LEAF + NR * (SB + 1);
+	return (n / ((uint64_t)SP_FILL * SP_USED) + NR + 1) * SB;
+}
+
+// copy the index pool[pside] -> pool[pside ^ 1] in the other layout (or the same one, re-spread); descriptors of
+// ctl->rope[side] are rewritten in place.  n_ub: upper bound of the symbols held now.
+// n_grow: what the index may grow to while it stays in the new layout's pools (dense rounds ping-pong between both pools
+// and grow them; sparse rounds never leave their slots).
+void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
+{
+	hipStream_t st = h->st;
+	const uint32_t F = to_sparse ? SP_FILL : LEAF, K = to_sparse ? SP_USED : SB;
+	const uint64_t slots = slots_for(n_ub, to_sparse), cap = to_sparse ? slots : slots_for(std::max(n_ub, n_grow), false);
+	if (h->pool[h->pside ^ 1].cap_leaves < cap) {              // kernels of earlier rounds may still read the buffers about to be replaced
+		HIPCHK(hipStreamSynchronize(st));
+		h->pool[h->pside ^ 1].ensure(cap, false, st);
+	}
+	{
+		Scope sc(h, RB2_K_RELAYOUT, 0);
+		hipLaunchKernelGGL(k_relayout_setup, dim3(1), dim3(64), 0, st, h->ctl, h->side, F, K);
+		hipLaunchKernelGGL(k_relayout, dim3(cdiv(slots, MW)), dim3(256), 0, st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), h->pool[h->pside ^ 1].view(), F, K);
+		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1);
+	}
+	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout;
+	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
+		HIPCHK(hipStreamSynchronize(st));
+		h->pool[h->pside ^ 1].ensure(cap, false, st);
+	}
+}
+
+// Sparse round: the strings of the batch touch few leaves, each touched leaf is rewritten where it lies (k_merge_leaf),
+// the rest of the index keeps its bytes.  Returns false when some leaf could not take its inserts: nothing was
+// changed (every kernel behind k_part_sparse saw ctl->overflow and returned) and the caller redoes the round densely.
+bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
+{
+	hipStream_t st = h->st;
+	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
+	const int64_t units = (int64_t)B.m;
+	PoolView pv = h->pool[h->pside].view();
+	{ Scope sc(h, RB2_K_TSCAN, 0);
+	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
+	{ Scope sc(h, RB2_K_PREP, units);
+	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
+	  hipLaunchKernelGGL((k_prep<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
+	{ Scope sc(h, RB2_K_PART, units);
+	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p); }
+	{ Scope sc(h, RB2_K_MERGE, units);
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p); }
+	{ Scope sc(h, RB2_K_META, units);
+	  build_directory(h, sd ^ 1, h->pside, h->pool[h->pside].cap_leaves / SB); }
+	{ Scope sc(h, RB2_K_ADVANCE, units);
+	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p);
+	  hipLaunchKernelGGL((k_advance<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p); }
+	uint32_t ovf = 0;
+	HIPCHK(hipMemcpyAsync(&ovf, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (ovf) return false;
+	h->side ^= 1; B.cur ^= 1; ++h->n_sparse_rounds;
+	return true;
 }
 
 void batch_end(rb2_hip_t *h)
@@ -259,16 +338,34 @@ void batch_end(rb2_hip_t *h)
 	drain_profile(h);
 }
 
+// Which regime is a round in?  lambda = strings of the batch / leaves of the index: the dense rewrite costs ~ the index, the
+// in-place round ~ the touched leaves (+ a search per string).  The host only knows upper bounds of both; that is enough.
 void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 {
 	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); abort(); }
 	BatchState B;
 	batch_begin(h, B, len64, s);
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
+		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
+		const double lambda = (double)B.m / ((double)n_ub / LEAF + 1.0);
+		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0;
+		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
+		if (h->sp_backoff > 0) --h->sp_backoff;
+		if (want != h->sparse) relayout(h, want, n_ub, B.n_tot + B.len);
 		round_counts(h, B, r);
+		if (h->sparse) {
+			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
+			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
+			++h->n_void;
+			relayout(h, false, n_ub, B.n_tot + B.len);
+			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
+			h->sp_backoff = 1 << h->sp_penalty;
+		}
 		round_merge(h, B, r, nullptr);
 	}
 	batch_end(h);
+	if (h->trace) fprintf(stderr, "[rb2_hip] batch done: layout %s, relayouts %lld, void sparse rounds %lld, sparse rounds %lld\n", h->sparse ? "sparse" : "dense",
+			(long long)h->n_relayout, (long long)h->n_void, (long long)h->n_sparse_rounds);
 }
 
 // the batch must end with a sentinel (mrope.c:268): bytes after the last 0 would be sized for but never inserted
@@ -308,6 +405,8 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	h->dev = device; h->so = sorting_order;
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
+	if (getenv("RB2_SPARSE_LAMBDA")) h->sp_lambda = atof(getenv("RB2_SPARSE_LAMBDA"));   // 0: never leave the dense layout
+	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
@@ -328,7 +427,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
@@ -345,6 +444,7 @@ void rb2_hip_reset(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->batch) { fprintf(stderr, "[rb2_hip] reset inside a sharded batch\n"); abort(); }
 	memset(h->h_rope, 0, sizeof(h->h_rope));
+	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;
 	HIPCHK(hipMemsetAsync(&h->ctl->rope[0][0], 0, sizeof(RopeDesc) * 2 * NR, h->st));
 	HIPCHK(hipMemsetAsync(&h->ctl->nsb_total, 0, 8, h->st));
 }
@@ -379,6 +479,15 @@ void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
 
 /* run-length export of sub-rope r in chunks of CH leaves: k_export writes one 43+3 byte per run into a staging
  * buffer (slot stride LEAF) + the byte count of every leaf; dst == NULL only counts.  Returns the bytes. */
+static void ensure_dense(rb2_hip_t *h)          /* k_export streams flat pieces: leave the sparse layout first */
+{
+	if (!h->sparse) return;
+	uint64_t n = 0;
+	for (int r = 0; r < NR; ++r) n += h->h_rope[r].n;
+	relayout(h, false, n, n);
+	fetch_ropes(h);
+}
+
 static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb = nullptr, void *user = nullptr)
 {
 	const uint64_t CH = 32768;                       // export chunks (XCHUNK symbols each) per staging round: 32 MiB of run bytes
@@ -393,7 +502,7 @@ static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb
 	int64_t k = 0;
 	for (uint64_t c0 = 0; c0 < nchunks; c0 += CH) {
 		const uint64_t nc = std::min<uint64_t>(CH, nchunks - c0);
-		hipLaunchKernelGGL(k_export, dim3(cdiv(nc, MW)), dim3(256), 0, h->st, h->pool[h->side].view(), d.leaf0, d.n, c0, (uint32_t)nc, h->xstage.p, h->xnb.p);
+		hipLaunchKernelGGL(k_export, dim3(cdiv(nc, MW)), dim3(256), 0, h->st, h->pool[h->pside].view(), d.leaf0, d.n, c0, (uint32_t)nc, h->xstage.p, h->xnb.p);
 		HIPCHK(hipGetLastError());
 		if (want) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nc * XCHUNK, hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nc * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
@@ -410,6 +519,7 @@ static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb
 int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user)
 {
 	HIPCHK(hipSetDevice(h->dev));
+	ensure_dense(h);
 	int64_t k = 0;
 	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) k += export_piece(h, r, nullptr, cb, user);
 	return k;
@@ -419,6 +529,7 @@ int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user)
 int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
 {
 	HIPCHK(hipSetDevice(h->dev));
+	ensure_dense(h);
 	int64_t t = 0;
 	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) t += export_piece(h, r, nullptr);
 	return t;
@@ -427,6 +538,7 @@ int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
 int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
 {
 	HIPCHK(hipSetDevice(h->dev));
+	ensure_dense(h);
 	int64_t k = 0;
 	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) k += export_piece(h, r, dst + k);
 	return k;
@@ -479,7 +591,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			LeafMeta cur; memset(&cur, 0, sizeof(cur));
 			uint32_t fill = 0; uint8_t *slot = nullptr;
 			auto open_leaf = [&]() { data.resize(data.size() + LEAFB); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAFB; memset(&cur, 0, sizeof(cur)); fill = 0; };
-			auto close_leaf = [&]() { meta.back() = cur; ++d.nleaves; slot = nullptr; };
+			auto close_leaf = [&]() { cur.n = (uint16_t)fill; meta.back() = cur; ++d.nleaves; slot = nullptr; };
 			while (quota > 0) {
 				if (l == 0) {
 					if (!(p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); abort(); }
@@ -510,16 +622,17 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		if (l != 0 || (p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
 	}
 	data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
-	const int sd = h->side;
-	h->pool[sd].ensure(leaf + SB, false, h->st);
+	const int sd = h->side, ps = h->pside;
+	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;      /* what is loaded is the dense layout */
+	h->pool[ps].ensure(leaf + SB, false, h->st);
 	if (leaf) {
-		HIPCHK(hipMemcpyAsync(h->pool[sd].data.p, data.data(), data.size(), hipMemcpyHostToDevice, h->st));
-		HIPCHK(hipMemcpyAsync(h->pool[sd].meta.p, meta.data(), meta.size() * sizeof(LeafMeta), hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipMemcpyAsync(h->pool[ps].data.p, data.data(), data.size(), hipMemcpyHostToDevice, h->st));
+		HIPCHK(hipMemcpyAsync(h->pool[ps].own.p, meta.data(), meta.size() * sizeof(LeafMeta), hipMemcpyHostToDevice, h->st));   /* own counts; build_directory derives the prefixes */
 	}
 	HIPCHK(hipMemcpyAsync(&h->ctl->rope[sd][0], rp, sizeof(rp), hipMemcpyHostToDevice, h->st));
 	const uint64_t nsb = leaf / SB;
 	HIPCHK(hipMemcpyAsync(&h->ctl->nsb_total, &nsb, 8, hipMemcpyHostToDevice, h->st));
-	build_directory(h, sd, nsb);
+	build_directory(h, sd, ps, nsb);
 	HIPCHK(hipStreamSynchronize(h->st));
 	memcpy(h->h_rope, rp, sizeof(rp));
 }
@@ -672,7 +785,7 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
 		if (rope_sym(r) != b) continue;
 		const RopeDesc &d = h->h_rope[r];
 		if ((uint64_t)x >= d.n) { for (int s = 0; s < 6; ++s) cx[s] += (int64_t)d.cnt[s]; x -= (int64_t)d.n; continue; }
-		hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->side].view(), r, (uint64_t)x, h->d_tmp);
+		hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->pside].view(), r, (uint64_t)x, h->d_tmp, (int)h->sparse);
 		uint64_t out[6];
 		HIPCHK(hipMemcpyAsync(out, h->d_tmp, 48, hipMemcpyDeviceToHost, h->st));
 		HIPCHK(hipStreamSynchronize(h->st));
@@ -714,10 +827,15 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 	if (batch_strings > 0) ensure_strings(h, (uint64_t)batch_strings);
 	if (total_symbols > 0) {
 		const uint64_t leaves = (uint64_t)total_symbols / LEAF + NR * (SB + 1);
-		h->pool[h->side].ensure(leaves, true, h->st);
-		h->pool[h->side ^ 1].ensure(leaves, false, h->st);
+		h->pool[h->pside].ensure(leaves, true, h->st);
+		h->pool[h->pside ^ 1].ensure(leaves, false, h->st);
 		h->LD.ensure(leaves + NR + 16);
 	}
+}
+
+void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4])
+{
+	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
 }
 
 void rb2_hip_sync(rb2_hip_t *h) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }
@@ -732,7 +850,7 @@ void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[
 
 const char *rb2_hip_kernel_name(int k)
 {
-	static const char *nm[RB2_K_COUNT] = {"k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init"};
+	static const char *nm[RB2_K_COUNT] = {"k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout"};
 	return (k >= 0 && k < RB2_K_COUNT) ? nm[k] : "?";
 }
 

@@ -380,11 +380,12 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.
-__global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
+// SPARSE: the round inserts in place -- every piece keeps its slots (leaf0, nleaves, sb0), only n and the counts move.
+template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
 {
 	if (blockIdx.x) return;
 	const int r = threadIdx.x;
-	if (r == 0) ctl->ne[par ^ 1] = 0;                          // k_advance / k_unpack of this round count into it
+	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; }   // ne: k_advance / k_unpack of this round count into it
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
@@ -403,12 +404,17 @@ __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t
 		const uint64_t exf = __shfl(ex, first);
 		if (ok) { ctl->count[r][a] = c; ctl->ac[r][a] = ex - exf; }   // #a in this rope in front of piece r, after the round (mrope.c:332-336)
 	}
-	n.nleaves = (n.n + LEAF - 1) / LEAF;
-	const uint64_t padded = (n.nleaves + SB - 1) / SB * SB, nwin = (n.nleaves + WPL - 1) / WPL;
-	const uint64_t pinc = wave_incl_add<uint64_t>(padded), winc = wave_incl_add<uint64_t>(nwin);
-	n.leaf0 = pinc - padded; n.sb0 = n.leaf0 / SB;
-	if (ok) { ctl->rope[side ^ 1][r] = n; ctl->wf0[r] = winc - nwin; }
-	if (r == 63) { ctl->wf0[NR] = winc; ctl->wf0[NR + 1] = winc; ctl->nsb_total = pinc / SB; }
+	if (SPARSE) {
+		n.nleaves = o.nleaves; n.leaf0 = o.leaf0; n.sb0 = o.sb0;
+		if (ok) ctl->rope[side ^ 1][r] = n;
+	} else {
+		n.nleaves = (n.n + LEAF - 1) / LEAF;
+		const uint64_t padded = (n.nleaves + SB - 1) / SB * SB, nwin = (n.nleaves + WPL - 1) / WPL;
+		const uint64_t pinc = wave_incl_add<uint64_t>(padded), winc = wave_incl_add<uint64_t>(nwin);
+		n.leaf0 = pinc - padded; n.sb0 = n.leaf0 / SB;
+		if (ok) { ctl->rope[side ^ 1][r] = n; ctl->wf0[r] = winc - nwin; }
+		if (r == 63) { ctl->wf0[NR] = winc; ctl->wf0[NR + 1] = winc; ctl->nsb_total = pinc / SB; }
+	}
 	// next round's buckets: bucket (a,b) = strings that sat in a piece of rope b and inserted a, in
 	// (piece, order) order -- the stable scatter of mrope.c:303-309; only buckets of pieces held here
 	// are laid out locally; strings that inserted $ are dropped (mrope.c:310)
@@ -520,7 +526,7 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	return m;
 }
 
-template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
+template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
@@ -570,7 +576,7 @@ template <bool AE> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl,
 		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
 			uint64_t d[6];
-			range_counts(oldp, rp, l0[h], u0[h], d);
+			range_counts<SPARSE>(oldp, rp, l0[h], u0[h], d);
 			for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
 		}
 	}
@@ -644,6 +650,166 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	LD[s_wf0[b] + j] = d;
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_part_sparse: the same split seen from the inserts' side, for rounds that touch few leaves (sparse layout).  Every
+// insert finds its leaf (locate() = the descent of rope_insert_run, rope.c:119-134); the first insert of a leaf -- its
+// slot neighbour sits in another leaf -- gallops forward over E to count the leaf's inserts and appends one work order
+// for k_merge_leaf.  Cost is proportional to the inserts, not to the index.  A leaf that cannot take its inserts
+// (fill + ni > LEAF) voids the round: ctl->overflow, the host falls back to the dense rewrite.
+// One block per string tile (slots and strings of a bucket share the index range).
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD)
+{
+	__shared__ uint64_t s_gl[STILE + 1];
+	const TileFix &tfx = tf[blockIdx.x];
+	if (blockIdx.x >= ctl->seg[side].tile0[NR]) return;
+	TileCtx t;
+	tile_ctx_fix(tfx, t);
+	const RopeDesc &rp = ctl->rope[side][t.b];
+	const uint64_t *E = INS_E;
+	Loc lc[2];
+	__shared__ uint32_t s_w[4], s_base;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int x = h * 256 + threadIdx.x;
+		const uint64_t g = t.base + x;
+		lc[h].gl = ~0ull; lc[h].s = 0; lc[h].n = 0;
+		if (g < t.segend) lc[h] = locate(oldp, rp, E[g]);
+		s_gl[x + 1] = lc[h].gl;
+	}
+	if (threadIdx.x == 0) s_gl[0] = t.base > t.segstart ? locate(oldp, rp, E[t.base - 1]).gl : ~0ull;
+	__syncthreads();
+	bool head[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int x = h * 256 + threadIdx.x;
+		head[h] = t.base + x < t.segend && s_gl[x + 1] != s_gl[x];   // first insert of its leaf
+	}
+	// one slot in the work list per head: block-aggregated, one atomic per tile
+	uint32_t tot;
+	const uint32_t mine = (uint32_t)head[0] + (uint32_t)head[1];
+	uint32_t off = block_excl_add<uint32_t>(mine, s_w, &tot);
+	if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctl->nwork, tot) : 0u;
+	__syncthreads();
+	off += s_base;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int x = h * 256 + threadIdx.x;
+		const uint64_t g = t.base + x;
+		if (!head[h]) continue;
+		const uint64_t send = lc[h].s + lc[h].n;                // piece position one past the leaf
+		uint64_t q1 = t.segend;
+		if (send < rp.n) {                                     // (the last leaf in use takes everything up to the end)
+			uint64_t step = 1, lo = g + 1;                     // gallop: first q > g with E[q] >= send
+			while (lo + step - 1 < t.segend && E[lo + step - 1] < send) { lo += step; step <<= 1; }
+			uint64_t hi = min(lo + step - 1, t.segend);        // E[hi] >= send or hi == segend; everything below lo is < send
+			while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (E[mid] >= send) hi = mid; else lo = mid + 1; }
+			q1 = lo;
+		}
+		const uint64_t ni = q1 - g;
+		LeafDesc d;
+		d.i0 = lc[h].s; d.ins0 = g; d.gl = lc[h].gl; d.oleaf0 = 0;
+		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)min(lc[h].n + ni, (uint64_t)LEAF);
+		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = 1;  // the leaf cannot take them: void round
+		LD[off++] = d;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// re-layout: copy every piece from one pool side to the other with a new slack policy.  Logical leaf t of a piece holds
+// its symbols [t*F, (t+1)*F); a superblock uses its first K slots.  F = LEAF, K = SB is the dense layout (flat array, no
+// slack: what k_merge streams); F = SP_FILL, K = SP_USED the sparse one.  Not on the per-round path: it runs when the
+// engine changes between the two regimes (touched leaves << leaves, or back) and when slack runs out.
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_relayout_setup(Ctl *ctl, int side, uint32_t F, uint32_t K)
+{
+	if (blockIdx.x) return;
+	const int r = threadIdx.x;
+	const bool ok = r < NR;
+	RopeDesc o = ctl->rope[side][ok ? r : 0];
+	if (ok) ctl->relay_old[r] = o;
+	const bool dense = F == (uint32_t)LEAF && K == (uint32_t)SB;
+	uint64_t slots = 0;
+	if (ok) {
+		if (dense) { o.nleaves = (o.n + LEAF - 1) / LEAF; slots = (o.nleaves + SB - 1) / SB * SB; }
+		else { const uint64_t per = (uint64_t)F * K, nsb = max((uint64_t)1, (o.n + per - 1) / per); slots = nsb * SB; o.nleaves = slots; }
+	}
+	const uint64_t inc = wave_incl_add<uint64_t>(slots);
+	o.leaf0 = inc - slots; o.sb0 = o.leaf0 / SB;
+	if (ok) ctl->rope[side][r] = o;
+	if (r == 63) ctl->nsb_total = inc / SB;
+}
+
+// one wave per output leaf slot: gathers its symbols from the (one to three) old leaves that hold them -- 3-bit fields ORed into
+// place with LDS atomics --, writes the leaf and its own counts.  Slots that stay empty get zeroed counts.
+__global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, PoolView oldp, PoolView newp, uint32_t F, uint32_t K)
+{
+	__shared__ __align__(16) uint64_t lds[MW][LEAFW + 2];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint64_t *LX = lds[wv];
+	const int ln = lane_id();
+	const uint64_t gl = (uint64_t)blockIdx.x * MW + wv;         // output slot
+	if (gl >= ctl->nsb_total * SB) return;
+	// the piece that owns the slot: last one with leaf0 <= gl among those that have slots
+	const uint64_t l0 = ctl->rope[side][ln < NR ? ln : NR - 1].leaf0;
+	const int r = max(0, (int)__popcll(__ballot(ln < NR && l0 <= gl)) - 1);
+	const RopeDesc &nrp = ctl->rope[side][r], &orp = ctl->relay_old[r];
+	const uint64_t rel = gl - nrp.leaf0, sbi = rel / SB, k = rel % SB;
+	const uint64_t t = sbi * K + k, p0 = t * F;                 // logical leaf, its first symbol
+	const bool used = k < K && p0 < nrp.n;
+	const uint32_t nvalid = used ? (uint32_t)min((uint64_t)F, nrp.n - p0) : 0u;
+	LX[ln] = 0; if (ln < 2) LX[LEAFW + ln] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+	if (nvalid) {
+		Loc lc = locate(oldp, orp, p0);                          // wave-uniform
+		uint32_t off = (uint32_t)(p0 - lc.s), taken = 0;
+		while (taken < nvalid) {
+			const uint32_t take = min(lc.n - off, nvalid - taken);
+			if (take) {
+				const uint64_t w = ((const uint64_t*)oldp.data)[lc.gl * LEAFW + ln];
+				const uint32_t a = max(off, (uint32_t)(ln * SPW)), b = min(off + take, (uint32_t)((ln + 1) * SPW));   // my symbols [a, b) of the old leaf
+				if (a < b) {
+					const uint64_t bits = (w >> (SBITS * (a - ln * SPW))) & nib_below(b - a);
+					const uint32_t op = taken + (a - off), ow = op / SPW, sh = (op - ow * SPW) * SBITS;
+					const uint64_t lo = (bits << sh) & MALL, hi = sh ? bits >> (63 - sh) : 0ull;   // 63 payload bits per word
+					uint32_t *x32 = (uint32_t*)LX + 2 * ow;
+					if ((uint32_t)lo) atomicOr(x32, (uint32_t)lo);
+					if ((uint32_t)(lo >> 32)) atomicOr(x32 + 1, (uint32_t)(lo >> 32));
+					if ((uint32_t)hi) atomicOr(x32 + 2, (uint32_t)hi);
+					if ((uint32_t)(hi >> 32)) atomicOr(x32 + 3, (uint32_t)(hi >> 32));
+				}
+			}
+			taken += take; off = 0;
+			if (taken < nvalid) {                                // next old leaf in use: the next slot, or the first of the next superblock
+				uint64_t g2 = lc.gl + 1;
+				uint32_t n2 = 0;
+				if (g2 % SB != 0 && g2 < orp.leaf0 + orp.nleaves) n2 = oldp.meta[g2].n;
+				if (n2 == 0) { g2 = (lc.gl / SB + 1) * SB; n2 = oldp.meta[g2].n; }
+				lc.gl = g2; lc.n = n2;
+				if (n2 == 0) break;                              // cannot happen on a consistent directory
+			}
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+	const uint64_t out = LX[ln];
+	const int v = min(SPW, max(0, (int)nvalid - ln * SPW));
+	NibAcc A;
+	nib_acc(A, out, nib_below((uint32_t)v) & MLOW);
+	uint32_t c[6];
+	nib_finish(A, (uint32_t)v, c);
+	const uint32_t s01 = wave_sum<uint32_t>(c[0] | c[1] << 16), s23 = wave_sum<uint32_t>(c[2] | c[3] << 16), s45 = wave_sum<uint32_t>(c[4] | c[5] << 16);
+	((uint64_t*)newp.data)[gl * LEAFW + ln] = out;
+	if (ln == 0) {
+		LeafMeta m;
+		m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
+		m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
+		m.npre = 0; m.n = (uint16_t)nvalid;
+		newp.own[gl] = m;
+	}
+}
+
 } // namespace rb2
 #include "rb2_merge.h"
 namespace rb2 {
@@ -672,7 +838,8 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
-	if (ok) m = newp.meta[gl];
+	m.npre = 0; m.n = 0;
+	if (ok) m = newp.own[gl];                                  // own counts + fill, written by the merge kernels / k_relayout / the loader
 	const uint32_t e01 = m.c[0] | (uint32_t)m.c[1] << 16, e23 = m.c[2] | (uint32_t)m.c[3] << 16, e45 = m.c[4] | (uint32_t)m.c[5] << 16;
 	uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
 	const uint32_t h01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 31), h23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 31), h45 = (uint32_t)__builtin_amdgcn_readlane((int)s45, 31);
@@ -681,6 +848,7 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 	if (ok) {
 		m.c[0] = (uint16_t)x01; m.c[1] = (uint16_t)(x01 >> 16); m.c[2] = (uint16_t)x23; m.c[3] = (uint16_t)(x23 >> 16);
 		m.c[4] = (uint16_t)x45; m.c[5] = (uint16_t)(x45 >> 16);
+		m.npre = (uint16_t)((x01 & 0xffffu) + (x01 >> 16) + (x23 & 0xffffu) + (x23 >> 16) + (x45 & 0xffffu) + (x45 >> 16));   // <= SB * LEAF < 2^16
 		newp.meta[gl] = m;
 	}
 	if ((ln & 31) == 31 && live) {                            // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
@@ -721,7 +889,7 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
 	Cnt6 o;
 	for (int s = 0; s < 6; ++s) o.v[s] = part[blockIdx.x].v[s] + block_excl_add<uint64_t>(i < n ? sbtot[i].v[s] : 0ull, s_w, (uint64_t*)0);
-	if (i < n) newp.sbcum[i] = o;
+	if (i < n) { newp.sbcum[i] = o; newp.sbpos[i] = o.v[0] + o.v[1] + o.v[2] + o.v[3] + o.v[4] + o.v[5]; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -729,15 +897,16 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
+template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send)
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[blockIdx.x];                        // issued together with the mode and tile-count loads
 	const SegDesc &sg = ctl->seg[side];
 	if ((ctl->ne[round & 1] == 0) != AE) return;
+	if (SPARSE && ctl->overflow) return;                       // void round: the host redoes it on the dense layout
 	if (blockIdx.x >= sg.tile0[NR]) return;
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
@@ -765,8 +934,12 @@ template <bool AE> __global__ __launch_bounds__(256) void k_advance(const Ctl *c
 		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
 		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
 		// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
-		const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
-		const uint64_t gl = nrp.leaf0 + f / LEAF;
+		uint64_t gl;
+		if (SPARSE) gl = RKLEAF[t.segstart + m.slot];          // where k_merge_leaf put my symbol
+		else {
+			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
+			gl = nrp.leaf0 + f / LEAF;
+		}
 		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
@@ -851,11 +1024,12 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uin
 	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed, genome_len);
 }
 
-__global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out)
+__global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out, int sparse)
 {
 	if (threadIdx.x || blockIdx.x) return;
 	uint64_t c[6];
-	rank_all(pv, ctl->rope[side][b], x, c);
+	if (sparse) rank_all<true>(pv, ctl->rope[side][b], x, c);
+	else rank_all<false>(pv, ctl->rope[side][b], x, c);
 	for (int s = 0; s < 6; ++s) out[s] = c[s];
 }
 

@@ -31,12 +31,10 @@
 
 namespace rb2 {
 
-constexpr int MW = 4;                       // waves (= output windows) per block
 #ifndef RB2_KMAX
 #define RB2_KMAX 5
 #endif
-constexpr int NXW = 64 * WPL;               // words per window
-constexpr int LPW = 64 / WPL;               // lanes per leaf
+constexpr int NXW = 64 * WPL;               // words per window (dense merge)
 
 __device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 3i set: symbol i of w == a
 {
@@ -44,21 +42,25 @@ __device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 3i s
 	return ~(x | x >> 1 | x >> 2) & MLOW;                       // the three bits of a field, not a bit of its neighbour
 }
 
-// FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid
-template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint32_t *LF, uint64_t *LO, const int ln,
-		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
+// FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid.
+// WPL_ = words per lane: the window is WPL_ consecutive leaves (dense merge: WPL; in-place leaf merge: 1).
+// INPLACE: the window IS one leaf with slack, rewritten where it lies (sparse rounds): its old symbols are its own
+// first words, d.i0 is the piece position of its first symbol, every new symbol also gets its leaf slot (RKLEAF).
+template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *LX, uint32_t *LF, uint64_t *LO, const int ln,
+		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
 {
+	constexpr int WPL = WPL_, NXW = 64 * WPL_, LPW = 64 / WPL_, WIN = WPL_ * LEAF;   // shadow the dense constants
 	const int nvalid = FULL ? WIN : d.nvalid, ni = d.ni;
 	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
-	const uint64_t w0i = d.i0 / SPW;                            // old word that holds the first of them
-	const uint32_t sh0 = (uint32_t)(d.i0 - w0i * SPW);          // ... and its place in that word
+	const uint64_t w0i = INPLACE ? 0 : d.i0 / SPW;              // old word that holds the first of them
+	const uint32_t sh0 = INPLACE ? 0u : (uint32_t)(d.i0 - w0i * SPW);   // ... and its place in that word
 	const uint32_t nw = (sh0 + nold + SPW - 1) / SPW;           // words of the old side they live in (<= NXW + 1)
 
 	// ---- 1. new symbols of this window, by output position (symbol and "new here" flag); the old words it draws from
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) { LX[ln + 64 * w] = 0; LF[ln + 64 * w] = 0; }
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	const uint64_t *ob = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 * LEAFW + w0i);
+	const uint64_t *ob = (const uint64_t*)oldp.data + (INPLACE ? d.gl * LEAFW : (uint64_t)d.oleaf0 * LEAFW + w0i);
 	uint64_t wa[WPL], wt = 0;
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) { wa[w] = 0; if ((uint32_t)(ln + 64 * w) < nw) wa[w] = ob[ln + 64 * w]; }
@@ -185,6 +187,7 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 			r += (uint32_t)__popcll(nib_eq(LX[WPL * lo + w], a) & m);
 		}
 		RKREL[d.ins0 + jj] = (uint16_t)r;
+		if (INPLACE) RKLEAF[d.ins0 + jj] = (uint32_t)d.gl;
 	}
 	if ((ln % LPW) == LPW - 1 && (ln / LPW) * LEAF < nvalid) {   // last lane of a leaf that exists
 		const uint32_t bl = (uint32_t)(ln / LPW) * LPW;
@@ -192,8 +195,9 @@ template <bool FULL> __device__ __forceinline__ void merge_window(const LeafDesc
 		LeafMeta m;
 		m.c[0] = (uint16_t)t01; m.c[1] = (uint16_t)(t01 >> 16); m.c[2] = (uint16_t)t23; m.c[3] = (uint16_t)(t23 >> 16);
 		m.c[4] = (uint16_t)t45; m.c[5] = (uint16_t)(t45 >> 16);
-		m.nbytes = 0; m.pad = 0;
-		newp.meta[d.gl + ln / LPW] = m;                         // own counts; k_meta_sb turns them into prefixes
+		m.npre = 0;
+		m.n = (uint16_t)((t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu) + (t23 >> 16) + (t45 & 0xffffu) + (t45 >> 16));
+		newp.own[d.gl + ln / LPW] = m;                          // own counts + fill; k_meta_sb turns them into prefixes
 	}
 	{
 		uint64_t *dst = (uint64_t*)(newp.data + d.gl * (uint64_t)LEAFB) + WPL * ln;
@@ -213,8 +217,25 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
 	const LeafDesc d = LD[gw];                                  // LD holds an entry for every window of the grid: both loads issue together
 	if (gw >= ctl->wf0[NR]) return;
-	if (d.nvalid == WIN) merge_window<true>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
-	else merge_window<false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL);
+	if (d.nvalid == WIN) merge_window<true, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+	else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+}
+
+// sparse rounds: one wave per TOUCHED leaf (work orders appended by k_part_sparse, any order), rewritten in place --
+// rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts the
+// leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
+__global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+{
+	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;                 // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
+	uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);             // 64 flag words of 32 bits
+	const int ln = lane_id();
+	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	if (ctl->overflow || gw >= ctl->nwork) return;
+	const LeafDesc d = LD[gw];
+	merge_window<false, 1, true>(d, LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 }
 
 // ---------------------------------------------------------------------------------------------

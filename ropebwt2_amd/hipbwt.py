@@ -11,7 +11,7 @@ import numpy as np
 
 from .build import lib_path
 
-K_NAMES = ["k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init"]
+K_NAMES = ["k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout"]
 _lib = None
 
 
@@ -54,6 +54,7 @@ def load_hip_lib():
         "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
         "rb2_hip_synth_reads_cov": (None, [vp, vp, i64, i64, i32, u64, i32, i64]),
         "rb2_hip_sync": (None, [vp]),
+        "rb2_hip_sparse_stats": (None, [vp, vp]),
         "rb2_hip_profile": (None, [vp, i32]),
         "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
         "rb2_hip_kernel_name": (C.c_char_p, [i32]),
@@ -73,7 +74,7 @@ ABI_SYMBOLS = [
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy",
-    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_profile",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
 ]
 
@@ -188,6 +189,11 @@ class HipBwt:
 
     def sync(self):
         self.L.rb2_hip_sync(self.h)
+
+    def sparse_stats(self):
+        a = np.zeros(4, np.int64)
+        self.L.rb2_hip_sparse_stats(self.h, a.ctypes.data)
+        return {"relayouts": int(a[0]), "void_rounds": int(a[1]), "sparse_rounds": int(a[2]), "sparse_now": bool(a[3])}
 
     def profile(self, on=True):
         self.L.rb2_hip_profile(self.h, 1 if on else 0)

@@ -368,3 +368,123 @@ def test_rlo_sortedness_property(hip):
     spelled = [_walk(dev, c, r) for r in rows]      # reversed reads
     assert all(len(s) == L for s in spelled)
     assert all(spelled[i] <= spelled[i + 1] for i in range(len(spelled) - 1))
+
+
+# ---- sparse layout (leaves with slack, in-place rounds): forced on for every round ----------------------------------
+
+class _ForcedSparse:
+    """RB2_SPARSE_LAMBDA is read by rb2_hip_create: a huge threshold puts every round of every batch on the sparse path
+    (k_part_sparse / k_merge_leaf / locate()), and RB2_SPARSE_MAXPEN=0 re-enters it right after each dense fallback, so
+    re-layouts in both directions and void rounds (leaf overflow) happen all the time."""
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in ("RB2_SPARSE_LAMBDA", "RB2_SPARSE_MAXPEN")}
+        os.environ["RB2_SPARSE_LAMBDA"] = "1e18"
+        os.environ["RB2_SPARSE_MAXPEN"] = "0"
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_sparse_forced_repetitive_multibatch(hip, so):
+    reads = H.repetitive_reads(1500, seed=11 + so)
+    with _ForcedSparse():
+        run_both(hip, so, [H.encode_batch(reads[:500]), H.encode_batch(reads[500:1000]), H.encode_batch(reads[1000:], True, True)])
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_sparse_forced_random_golden(hip, golden, so):
+    g = golden["sets"]["100k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    with _ForcedSparse():
+        dev = hip.HipBwt(so)
+        for i in range(0, 100000, 40000):
+            dev.insert_multi(H.encode_batch_fixed(codes[i:i + 40000]))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_sparse_forced_long_reads(hip, golden, so):
+    g = golden["sets"]["200_x_10k"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    with _ForcedSparse():
+        dev = hip.HipBwt(so)
+        dev.insert_multi(H.encode_batch_fixed(codes))
+    assert H.md5(H.bwt_text(dev.bwt()) + b"\n") == g["text_md5"][SO_FLAG[so]]
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_sparse_forced_edge_shapes(hip, so):
+    lay = hip.HipBwt.layout()
+    n = lay["leaf_syms"] * lay["tile_leaves"] + 37
+    homo = [[1] * 70] * 300 + [[4] * 33] * 200 + [[2] * 5 + [5] * 3] * 100 + [[3] * (n // 64)] * 70
+    with _ForcedSparse():
+        run_both(hip, so, [np.zeros(1, np.uint8), np.zeros(7, np.uint8), np.array([3, 0], np.uint8), H.encode_batch([[1], [], [1], [5], [4, 4], []])])
+        run_both(hip, so, [H.encode_batch(homo[:400]), H.encode_batch(homo[400:])])
+        base = H.splitmix_bases(30000, 101, seed=5)
+        small = H.splitmix_bases(700, 101, seed=6)
+        dense = [[1] * 90] * 400 + [[2, 2, 2, 3] * 20] * 300
+        run_both(hip, so, [H.encode_batch_fixed(base), H.encode_batch_fixed(small), H.encode_batch(dense)])
+
+
+@pytest.mark.parametrize("so,strand", [(0, 0), (1, 0), (2, 1)])
+def test_sparse_forced_coverage_reads(hip, so, strand):
+    """overlapping reads: non-empty intervals -> the search-based rank (locate) inside k_prep<false, sparse>"""
+    n, L, glen = 12000, 50, 10000
+    per = (L + 1) * (2 if strand else 1)
+    o = H.Oracle(so)
+    with _ForcedSparse():
+        dev = hip.HipBwt(so)
+    p = dev.dev_alloc(n * per + 64)
+    for first in (0, n):
+        dev.synth_reads(p, first, n, L, seed=11, strand=strand, genome_len=glen)
+        dev.sync()
+        host = np.empty(n * per, np.uint8)
+        dev.L.rb2_hip_memcpy(dev.h, host.ctypes.data, p, n * per, 1)
+        dev.insert_multi_dev(p, n * per)
+        o.insert_multi(host)
+        assert np.array_equal(dev.counts(), o.counts())
+        r = o.rope(1)                                        # rank queries answered on whatever layout the batch ended in
+        for x in (0, 1, len(r) // 3, len(r) - 1, len(r)):
+            assert np.array_equal(dev.rank1a(1, x), np.bincount(r[:x], minlength=6))
+    for b in range(6):
+        assert np.array_equal(dev.rope(b), o.rope(b)), "rope %d" % b
+    dev.dev_free(p)
+
+
+def test_sparse_forced_fuzz(hip):
+    rng = np.random.RandomState(4242)
+    with _ForcedSparse():
+        for it in range(12):
+            so = int(rng.randint(3))
+            batches = []
+            for _ in range(int(rng.randint(1, 4))):
+                n = int(rng.choice([1, 2, 63, 65, 300, 513, 1500, 4000]))
+                pool = [list(rng.randint(1, 5, size=rng.randint(1, 30))) for _ in range(5)]
+                reads = []
+                for _ in range(n):
+                    L = int(rng.choice([0, 1, 5, 17, 40, 120]))
+                    r = (pool[rng.randint(5)] * 8)[:L] if rng.rand() < 0.3 else list(rng.randint(1, 5, size=L))
+                    reads.append([int(x) for x in r])
+                batches.append(H.encode_batch(reads, True, rng.rand() < 0.25))
+            run_both(hip, so, batches)
+
+
+def test_sparse_engages_on_long_reads(hip):
+    """1000 x 2 kbp in input order with the threshold at lambda < 2: the first ~670 rounds rewrite the (small) index densely,
+    then the engine re-lays the index out with slack and inserts in place; equals the oracle, and the statistics say so"""
+    codes = H.splitmix_bases(1000, 2000, seed=91)
+    old = os.environ.get("RB2_SPARSE_LAMBDA")
+    os.environ["RB2_SPARSE_LAMBDA"] = "2.0"
+    try:
+        o, g = run_both(hip, 0, [H.encode_batch_fixed(codes)])
+    finally:
+        if old is None:
+            os.environ.pop("RB2_SPARSE_LAMBDA", None)
+        else:
+            os.environ["RB2_SPARSE_LAMBDA"] = old
+    st = g.sparse_stats()
+    assert st["sparse_rounds"] > 1000 and st["relayouts"] >= 1, st
