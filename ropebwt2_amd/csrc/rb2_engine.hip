@@ -63,6 +63,8 @@ struct rb2_hip_s {
 	double sp_lambda = 0.4;             // go sparse when (strings per round) / (leaves of the index) falls below this
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
 	int sp_maxpen = 12;
+	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round
+	hipEvent_t ev_flag = nullptr;
 	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
 	Ctl *ctl = nullptr;                 // device
 	RopeDesc h_rope[NR];                // host mirror of ctl->rope[side] (sub-ropes)
@@ -155,6 +157,7 @@ struct BatchState {
 	unsigned nst_ub = 0, nsc = 0;
 	int cur = 0;                            // string array side
 	bool known_ae = false;                  // the host can tell that every interval of the batch is empty: input order, or an empty index
+	uint64_t counted = (uint64_t)-1;        // round whose counting phase (round_counts) is already queued
 };
 
 // per-string arrays + tile tables for batches of up to m strings
@@ -222,6 +225,10 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	h->cur_round = (int)r;
 	{ Scope sc(h, RB2_K_SYM, units);
 	  hipLaunchKernelGGL(k_sym, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+	if (B.nst_ub <= 4 * SCHUNK) {                              // few tiles (long reads): one single-block launch instead of five
+	  Scope sc(h, RB2_K_TSCAN, units);
+	  hipLaunchKernelGGL(k_tscan_fused, dim3(1), dim3(SCHUNK), 0, st, (const Ctl*)h->ctl, sd, (const TileRec*)h->trec.p, h->tsc.p, h->tfix.p, h->gcnt);
+	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
@@ -322,11 +329,18 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p);
 	  hipLaunchKernelGGL((k_advance<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p); }
-	uint32_t ovf = 0;
-	HIPCHK(hipMemcpyAsync(&ovf, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
-	HIPCHK(hipStreamSynchronize(st));
-	if (ovf) return false;
-	h->side ^= 1; B.cur ^= 1; ++h->n_sparse_rounds;
+	// The verdict of the round (did every leaf fit?) travels to pinned host memory behind the last kernel.  While it is on its
+	// way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch, and a void round r is
+	// redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues the next merge.
+	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipEventRecord(h->ev_flag, st));
+	h->side ^= 1; B.cur ^= 1;
+	const bool spec = r + 1 <= B.max_len;
+	if (spec) round_counts(h, B, r + 1);
+	HIPCHK(hipEventSynchronize(h->ev_flag));
+	if (*h->h_flag) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
+	B.counted = spec ? r + 1 : (uint64_t)-1;
+	++h->n_sparse_rounds;
 	return true;
 }
 
@@ -352,7 +366,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 		if (h->sp_backoff > 0) --h->sp_backoff;
 		if (want != h->sparse) relayout(h, want, n_ub, B.n_tot + B.len);
-		round_counts(h, B, r);
+		if (B.counted != r) round_counts(h, B, r);
 		if (h->sparse) {
 			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
 			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
@@ -360,6 +374,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			relayout(h, false, n_ub, B.n_tot + B.len);
 			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
 			h->sp_backoff = 1 << h->sp_penalty;
+			round_counts(h, B, r);                                 // the scratch of this round's counting phase was reused by the look-ahead
 		}
 		round_merge(h, B, r, nullptr);
 	}
@@ -412,6 +427,8 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
 	HIPCHK(hipMalloc((void**)&h->gcnt, NR * 6 * 8));
+	HIPCHK(hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault));
+	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
@@ -431,6 +448,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
+	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();
 	HIPCHK(hipStreamDestroy(h->st));
 	delete h;

@@ -377,6 +377,68 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 	tf[tile] = f;
 }
 
+// k_tscan1-3 + k_tfix + k_counts_local in ONE single-block launch, for rounds with few string tiles (long reads: 10^4 rounds of
+// 10^3 tiles, where five 10-microsecond launches per round are a large share of the round).  Same results, same formulas.
+__global__ __launch_bounds__(SCHUNK) void k_tscan_fused(const Ctl *ctl, int side, const TileRec *trec, TileScan *tsc, TileFix *tf, uint64_t *gcnt)
+{
+	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
+	__shared__ uint32_t s_t0[NR + 1];
+	const SegDesc &sg = ctl->seg[side];
+	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
+	__syncthreads();
+	const uint32_t nt = s_t0[NR];
+	uint32_t run[6] = {0, 0, 0, 0, 0, 0};
+	int run_mx = -1;
+	for (uint32_t i0 = 0; i0 < nt; i0 += SCHUNK) {              // forwards: exclusive sums, last head-bearing tile before
+		const uint32_t i = i0 + threadIdx.x;
+		const bool ok = i < nt;
+		TileScan o;
+		for (int s = 0; s < 6; ++s) { uint32_t tot; o.pre[s] = run[s] + block_excl_add<uint32_t>(ok ? trec[i].hist[s] : 0u, s_w, &tot); run[s] += tot; }
+		const int hv = (ok && trec[i].fh >= 0) ? (int)i : -1;
+		o.lht = max(run_mx, block_excl_max(hv, s_wi, -1));
+		run_mx = max(run_mx, block_all_max(hv, s_wi));
+		o.nht = INT_MAX;
+		if (ok) tsc[i] = o;
+	}
+	if (threadIdx.x == 0) { TileScan e; for (int s = 0; s < 6; ++s) e.pre[s] = run[s]; e.lht = -1; e.nht = INT_MAX; tsc[nt] = e; }
+	int run_mn = INT_MAX;
+	for (uint32_t k = (nt + SCHUNK - 1) / SCHUNK; k-- > 0; ) {   // backwards: first head-bearing tile after
+		const uint32_t i = k * SCHUNK + threadIdx.x;
+		const bool ok = i < nt;
+		const int hv = (ok && trec[i].fh >= 0) ? (int)i : INT_MAX;
+		const int omn = min(run_mn, block_excl_min_down(hv, s_wi, INT_MAX));
+		run_mn = min(run_mn, -block_all_max(hv == INT_MAX ? INT_MIN + 1 : -hv, s_wi));
+		if (ok) tsc[i].nht = omn;
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (uint32_t tile = threadIdx.x; tile < nt; tile += SCHUNK) {   // k_tfix
+		int b = 0;
+		while (tile >= s_t0[b+1]) ++b;
+		const uint32_t t0 = s_t0[b], t1 = s_t0[b+1];
+		const TileScan me = tsc[tile], first = tsc[t0];
+		const int lt = me.lht, nx = me.nht;
+		TileFix f;
+		TileScan sl, sn; TileRec rl, rn;
+		const bool hl = lt >= (int)t0, hn = nx < (int)t1;
+		if (hl) { sl = tsc[lt]; rl = trec[lt]; }
+		if (hn) { sn = tsc[nx]; rn = trec[nx]; } else sn = tsc[t1];
+		for (int s = 0; s < 6; ++s) {
+			f.tpre[s] = me.pre[s] - first.pre[s];
+			f.popen[s] = hl ? sl.pre[s] - first.pre[s] + rl.lhpre[s] : 0u;
+			f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? rn.fhpre[s] : 0u);
+		}
+		f.fopen = hl ? (uint32_t)((lt - t0) * STILE + rl.lh) : 0u;
+		f.b = (uint32_t)b; f.lt = tile - t0; f.pad = 0;
+		f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
+		tf[tile] = f;
+	}
+	if (threadIdx.x < NR * 6) {                                 // k_counts_local
+		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
+		gcnt[threadIdx.x] = nt ? (uint64_t)(tsc[s_t0[b+1]].pre[a] - tsc[s_t0[b]].pre[a]) : 0ull;
+	}
+}
+
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.

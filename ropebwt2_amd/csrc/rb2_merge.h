@@ -221,6 +221,45 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
 }
 
+// A leaf that receives only a few symbols (the normal case of a sparse round: one or two) does not need the window machinery:
+// every lane keeps its word in a register; per new symbol (ascending position, so earlier ones are already in place) one
+// masked compare + wave sum gives its rank, one shift with a DPP carry from the lane below opens the gap.  No LDS, and only
+// the words from the first changed one on are stored.  (rle_insert_cached, rle.c:10-89, for <= LIGHT_NI inserts.)
+constexpr int LIGHT_NI = 8;
+__device__ __forceinline__ void leaf_insert_few(const LeafDesc &d, const int ln, const PoolView &pool,
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+{
+	uint64_t *leaf = (uint64_t*)pool.data + d.gl * LEAFW;
+	const int ni = d.ni;
+	uint64_t w = leaf[ln];
+	LeafMeta m = pool.own[d.gl];
+	uint32_t pj = 0, aj = 0, myrank = 0;
+	if (ln < ni) { aj = INS_A[d.ins0 + ln]; pj = (uint32_t)(INS_E[d.ins0 + ln] - d.i0) + (uint32_t)ln; }   // final position E[q] + q inside the leaf
+	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 0) / SPW;   // first word that changes
+	uint32_t add01 = 0, add23 = 0, add45 = 0;
+	for (int j = 0; j < ni; ++j) {
+		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)aj, j);
+		const uint32_t pw = p / SPW, po = (p - pw * SPW) * SBITS;
+		const uint64_t below = (1ull << po) - 1ull;
+		const uint64_t msk = (uint32_t)ln < pw ? MLOW : ((uint32_t)ln == pw ? (MLOW & below) : 0ull);
+		const uint32_t r = lane63(dpp_incl_add((uint32_t)__popcll(nib_eq(w, a) & msk)));   // a's in front of p, leaf as it is now
+		if (ln == j) myrank = r;
+		const uint32_t carry = dpp_prev_lane((uint32_t)(w >> (SBITS * (SPW - 1))) & 7u);    // top symbol of the lane below moves up
+		if ((uint32_t)ln > pw) w = ((w << SBITS) & MALL) | carry;
+		else if ((uint32_t)ln == pw) w = (w & below) | ((uint64_t)a << po) | (((w & ~below) << SBITS) & MALL);
+		const uint32_t one = 1u << (16 * (a & 1));
+		if ((a >> 1) == 0) add01 += one; else if ((a >> 1) == 1) add23 += one; else add45 += one;
+	}
+	if ((uint32_t)ln >= pw0) leaf[ln] = w;
+	if (ln < ni) { RKREL[d.ins0 + ln] = (uint16_t)myrank; RKLEAF[d.ins0 + ln] = (uint32_t)d.gl; }
+	if (ln == 0) {
+		m.c[0] += (uint16_t)add01; m.c[1] += (uint16_t)(add01 >> 16); m.c[2] += (uint16_t)add23; m.c[3] += (uint16_t)(add23 >> 16);
+		m.c[4] += (uint16_t)add45; m.c[5] += (uint16_t)(add45 >> 16);
+		m.n += (uint16_t)ni;
+		pool.own[d.gl] = m;
+	}
+}
+
 // sparse rounds: one wave per TOUCHED leaf (work orders appended by k_part_sparse, any order), rewritten in place --
 // rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts the
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
@@ -229,12 +268,13 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 {
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;                 // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
-	uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);             // 64 flag words of 32 bits
 	const int ln = lane_id();
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
 	if (ctl->overflow || gw >= ctl->nwork) return;
 	const LeafDesc d = LD[gw];
+	if (d.ni <= LIGHT_NI) { leaf_insert_few(d, ln, pool, INS_E, INS_A, RKREL, RKLEAF); return; }
+	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;                 // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
+	uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);             // 64 flag words of 32 bits
 	merge_window<false, 1, true>(d, LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 }
 

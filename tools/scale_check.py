@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
     ap.add_argument("--both-strands", action="store_true")
     ap.add_argument("--genome-len", type=int, default=0, help="> 0: reads are windows of one random genome of this many bases (coverage data)")
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--profile", action="store_true", help="per-kernel times (hipEvents) and leaf-layout statistics in the output")
     args = ap.parse_args()
     from ropebwt2_amd import HipBwt, build_all
     build_all()
@@ -28,13 +30,15 @@ def main():
     per_batch = -(-(int(args.batch * 1024 ** 3 * 0.97) + 1) // per_read)       # main.c:136, 238
     so = {"io": 0, "rlo": 1, "rclo": 2}[args.order]
     bwt = HipBwt(so, 0)
+    if args.profile:
+        bwt.profile(True)
     total = args.reads * per_read
     bwt.reserve(per_batch * per_read, per_batch * (2 if args.both_strands else 1), total)
     buf = bwt.dev_alloc(per_batch * per_read + 64)
     done, times = 0, []
     while done < args.reads:
         n = min(per_batch, args.reads - done)
-        bwt.synth_reads(buf, done, n, L, seed=42, strand=1 if args.both_strands else 0, genome_len=args.genome_len)
+        bwt.synth_reads(buf, done, n, L, seed=args.seed, strand=1 if args.both_strands else 0, genome_len=args.genome_len)
         bwt.sync()
         t0 = time.perf_counter()
         bwt.insert_multi_dev(buf, n * per_read)
@@ -60,9 +64,13 @@ def main():
             r = bwt.rank1a(b, int(x))
             ok_rank &= int(r.sum()) == int(x) and bool(np.all(r >= prev))
             prev = r
+    extra = {}
+    if args.profile:
+        extra = {"kernels_ms": {k: round(v["ms"], 2) for k, v in bwt.profile_get().items()}, "layout": bwt.sparse_stats(),
+                 "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default")}
     bwt.dev_free(buf)
     bwt.close()
-    print(json.dumps({"reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "genome_len": args.genome_len, "batch_gib": args.batch,
+    print(json.dumps({**extra, "reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "genome_len": args.genome_len, "batch_gib": args.batch,
                       "batches": len(times), "symbols": total, "insert_s": sum(times), "gsym_per_s": total / sum(times) / 1e9,
                       "batch_s": [round(t, 3) for t in times], "counts_ok": ok, "lf_ok": ok_lf, "rank_ok": ok_rank}))
 
