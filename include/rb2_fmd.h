@@ -24,6 +24,14 @@ int  rb2_fmd_write_path(const rb2_fmd_t *f, const char *path);
 void rb2_fmd_counts(const rb2_fmd_t *f, int64_t c[7]);         /* total, $, A, C, G, T, N */
 void rb2_fmd_destroy(rb2_fmd_t *f);
 
+/* The same file from several threads: runs are pushed as they come (any chunking, whole runs per call), worker threads encode
+ * segments of the stream speculatively and one thread stitches them into the exact sequential result (fmd.c).
+ * rb2_fmdp_finish() joins the workers and returns a FINISHED rb2_fmd_t (rb2_fmd_write / rb2_fmd_counts / rb2_fmd_destroy). */
+typedef struct rb2_fmdp_s rb2_fmdp_t;
+rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t segment_bytes /* 0: default */);
+void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n_bytes);
+rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p);
+
 #ifdef __cplusplus
 }
 #endif

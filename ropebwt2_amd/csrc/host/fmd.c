@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <assert.h>
+#include <pthread.h>
 #include "rb2_fmd.h"
 #include "rle.h"
 
@@ -30,6 +31,12 @@ struct rb2_fmd_s {
 	int pend_c; int64_t pend_l;          /* run waiting to be merged with its successor */
 	uint64_t n_bytes, n_frames, *frame;
 	int finished;
+	/* speculative encoding of one segment of the run stream (parallel writer, see rb2_fmdp_*): no chunk rule, and the
+	 * stream offset of the first run of every block is recorded */
+	int spec;
+	uint32_t *start; uint8_t *type; size_t nblk, cap_blk;   /* start[k], type[k] of block k; block nblk is the one being filled */
+	uint32_t run_pos;                                       /* offset of the run being encoded */
+	int64_t pend_seg;                                       /* true orbit of the parallel writer: segment in which the pending run starts */
 };
 
 static const int hdr_words[3] = { 2, 4, 7 };   /* (7*16+63)/64, (7*32+63)/64, 7 */
@@ -51,6 +58,7 @@ static size_t block_tail(size_t head)
 	const size_t end = head + BLK_WORDS;                      /* one past the block */
 	return end % CHUNK_WORDS == 0 ? end - 2 : end - 1;        /* last block of a chunk is one word shorter (rld0.h:75) */
 }
+static size_t block_tail_of(const rb2_fmd_t *f, size_t head) { return f->spec ? head + BLK_WORDS - 1 : block_tail(head); }
 
 rb2_fmd_t *rb2_fmd_init(void)
 {
@@ -77,9 +85,16 @@ static void open_next_block(rb2_fmd_t *f)
 	}
 	f->w[f->head] |= (uint64_t)type << 62;
 	f->p = f->head + hdr_words[type];
-	f->tail = block_tail(f->head);
+	f->tail = block_tail_of(f, f->head);
 	f->r = 64;
 	memcpy(f->mcnt, f->cnt, sizeof(f->cnt));
+	if (f->spec) {                                            /* block nblk is complete; the new one starts with the run at run_pos */
+		if (++f->nblk + 1 >= f->cap_blk) {
+			f->cap_blk = f->cap_blk ? f->cap_blk * 2 : 1024;
+			f->start = (uint32_t*)realloc(f->start, f->cap_blk * 4); f->type = (uint8_t*)realloc(f->type, f->cap_blk);
+		}
+		f->start[f->nblk] = f->run_pos; f->type[f->nblk] = (uint8_t)type;
+	}
 }
 
 static void encode_run(rb2_fmd_t *f, int64_t l, int c)
@@ -120,14 +135,22 @@ void rb2_fmd_push_runs(rb2_fmd_t *f, const uint8_t *q, int64_t n)
 	}
 }
 
+static void fmd_index(rb2_fmd_t *f);
+
 void rb2_fmd_finish(rb2_fmd_t *f)
 {
-	uint64_t n_blks, last, i, k, run[6] = { 0, 0, 0, 0, 0, 0 };
-	int ibits, j;
 	if (f->finished) return;
 	if (f->pend_l) encode_run(f, f->pend_l, f->pend_c);
 	f->pend_l = 0;
 	open_next_block(f);
+	fmd_index(f);
+}
+
+/* stream length + rank frames; f->mcnt holds the totals */
+static void fmd_index(rb2_fmd_t *f)
+{
+	uint64_t n_blks, last, i, k, run[6] = { 0, 0, 0, 0, 0, 0 };
+	int ibits, j;
 	f->n_bytes = (uint64_t)f->p * 8;
 	/* rank index (rld0.c:163-205) */
 	n_blks = f->n_bytes * 8 / 64 / BLK_WORDS + 1;
@@ -195,4 +218,300 @@ int rb2_fmd_write_path(const rb2_fmd_t *f, const char *path)     /* rb2_fmd_writ
 	r = rb2_fmd_write(f, fp);
 	if (fclose(fp) != 0) r = -1;
 	return r;
+}
+
+/* ===============================================================================================
+ * Parallel writer.  The greedy block packing of the format (a run goes into the current 8-word block if it fits, else opens
+ * the next one, rld0.c:137-151) is a sequential automaton, but its state is short-lived: two encoders that start on the same
+ * run stream at different points produce the same blocks as soon as they open a block at the same run -- which happens
+ * after a few thousand blocks (the offset between them performs a random walk of a few bits per block).  So:
+ *   - the run stream is cut into segments; worker threads encode every segment SPECULATIVELY, as if a block started at
+ *     its first run (no chunk rule), and record the stream offset at which each of their blocks starts;
+ *   - one thread follows the TRUE orbit: it encodes from where the valid output ends until it opens a block at an offset
+ *     where the speculative encoding of that segment also opens one (with the same header width); from there the
+ *     speculative blocks are the true ones and are copied wholesale (block contents do not depend on their position: headers
+ *     hold the counts of the previous block only), up to the segment's last complete block or the next block that the
+ *     chunk rule shortens (the last block of every 2^23-word chunk, rld0.h:75) -- then it encodes again, and so on.
+ * The output is byte-identical to the sequential writer's (tests/test_host_layer.py); the rank frames are built afterwards
+ * from the block headers as before.
+ * =============================================================================================== */
+
+typedef struct {
+	uint8_t *runs; int64_t n;        /* run bytes of the segment (whole runs) */
+	int prev_sym;                    /* symbol of the last run of the previous segment (-1: none) */
+	int prev_sym_out;                /* symbol of this segment's last run (taken before the bytes are freed) */
+	rb2_fmd_t *sp;                   /* speculative encoding */
+	int64_t sum[N_FIELDS];           /* symbols in the segment (total, then per symbol) */
+	int state;                       /* 0 filling, 1 queued, 2 being encoded, 3 encoded */
+} fseg_t;
+
+struct rb2_fmdp_s {
+	rb2_fmd_t *f;                    /* the true stream */
+	fseg_t **seg; int64_t nseg, cap_seg, seg_bytes;          /* segments are allocated one by one: workers keep pointers to them */
+	int64_t n_queued, next_work;     /* segments handed to the workers / next one a worker takes */
+	int64_t cur_seg, cur_pos;        /* input cursor of the true orbit */
+	int64_t tot[N_FIELDS];
+	int64_t n_copied_blocks, n_true_blocks;
+	pthread_t *thr; int nthr, closing;
+	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+};
+
+static inline int run_at(const uint8_t *q, int *c, int64_t *l)    /* one run of the 43+3 codec; returns its bytes */
+{
+	if ((*q & 0x80) == 0) { *c = *q & 7; *l = *q >> 3; return 1; }
+	return rle_dec1_fn(q, c, l);
+}
+
+static inline uint64_t run_code(int64_t l, int c, int *w)          /* Elias delta of l + 3 bits of c (rld0.c:45-51) */
+{
+	const int y = ilog2_u64((uint64_t)l), z = ilog2_u64((uint64_t)y + 1);
+	*w = 2 * z + 1 + y + SYM_BITS;
+	return ((((uint64_t)l ^ (1ull << y)) | (uint64_t)(y + 1) << y) << SYM_BITS) | (uint64_t)c;
+}
+
+static inline void place_bits(rb2_fmd_t *f, uint64_t x, int w)
+{
+	if (w > f->r) {
+		w -= f->r;
+		f->w[f->p++] |= x >> w;
+		f->r = 64 - w;
+		f->w[f->p] = x << f->r;
+	} else {
+		f->r -= w;
+		f->w[f->p] |= x << f->r;
+	}
+}
+
+static void spec_encode(fseg_t *sg)
+{
+	rb2_fmd_t *f = (rb2_fmd_t*)calloc(1, sizeof(rb2_fmd_t));
+	const uint8_t *q = sg->runs;
+	int64_t i = 0, n = sg->n, pl = 0, ppos = 0, l;
+	int c, pc = -1;
+	f->spec = 1;
+	reserve(f, (size_t)(n / 4 + 4 * BLK_WORDS));             /* ~5 bits per run byte on random reads; grows when needed */
+	f->cap_blk = (size_t)(n / 256 + 1024);
+	f->start = (uint32_t*)malloc(f->cap_blk * 4); f->type = (uint8_t*)malloc(f->cap_blk);
+	f->head = 0; f->p = hdr_words[0]; f->tail = block_tail_of(f, 0); f->r = 64;
+	memset(sg->sum, 0, sizeof(sg->sum));
+	while (i < n) {                                           /* the straddling run belongs to the true orbit: skip it (but count it) */
+		const int nb = run_at(q + i, &c, &l);
+		if (c != sg->prev_sym) break;
+		sg->sum[0] += l; sg->sum[c + 1] += l; i += nb;
+	}
+	f->start[0] = (uint32_t)i; f->type[0] = 0;
+	while (i < n) {
+		const int nb = run_at(q + i, &c, &l);
+		sg->sum[0] += l; sg->sum[c + 1] += l;
+		if (c == pc) pl += l;
+		else {
+			if (pl) { f->run_pos = (uint32_t)ppos; encode_run(f, pl, pc); }
+			pc = c; pl = l; ppos = i;
+		}
+		i += nb;
+	}
+	/* the last maximal run may continue in the next segment, and the block being filled is incomplete: both are left to the
+	 * true orbit, which resumes at start[nblk] */
+	sg->sp = f;
+}
+
+static void *fmdp_worker(void *arg)
+{
+	rb2_fmdp_t *p = (rb2_fmdp_t*)arg;
+	pthread_mutex_lock(&p->mu);
+	for (;;) {
+		while (p->next_work >= p->n_queued && !p->closing) pthread_cond_wait(&p->cv_work, &p->mu);
+		if (p->next_work >= p->n_queued) break;
+		fseg_t *sg = p->seg[p->next_work++];
+		sg->state = 2;
+		pthread_mutex_unlock(&p->mu);
+		spec_encode(sg);
+		pthread_mutex_lock(&p->mu);
+		sg->state = 3;
+		pthread_cond_broadcast(&p->cv_done);
+	}
+	pthread_mutex_unlock(&p->mu);
+	return 0;
+}
+
+rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t seg_bytes)
+{
+	rb2_fmdp_t *p = (rb2_fmdp_t*)calloc(1, sizeof(rb2_fmdp_t));
+	int i;
+	p->f = rb2_fmd_init();
+	p->seg_bytes = seg_bytes > 0 ? seg_bytes : 16 << 20;
+	if (p->seg_bytes > 0x7fffffff) p->seg_bytes = 0x7fffffff;     /* offsets inside a segment are 32 bit */
+	p->nthr = n_threads > 0 ? n_threads : 1;
+	pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv_work, 0); pthread_cond_init(&p->cv_done, 0);
+	p->thr = (pthread_t*)calloc(p->nthr, sizeof(pthread_t));
+	for (i = 0; i < p->nthr; ++i) pthread_create(&p->thr[i], 0, fmdp_worker, p);
+	return p;
+}
+
+static fseg_t *cur_fill(rb2_fmdp_t *p)                        /* the segment being filled (created on demand) */
+{
+	if (p->nseg == p->n_queued) {
+		fseg_t *sg = (fseg_t*)calloc(1, sizeof(fseg_t));
+		sg->prev_sym = -1;
+		if (p->nseg > 0) {                                     /* symbol of the last run before this segment */
+			const fseg_t *b = p->seg[p->nseg - 1];
+			sg->prev_sym = b->prev_sym_out;
+		}
+		sg->runs = (uint8_t*)malloc((size_t)p->seg_bytes + 2048);
+		pthread_mutex_lock(&p->mu);
+		if (p->nseg == p->cap_seg) {
+			p->cap_seg = p->cap_seg ? p->cap_seg * 2 : 256;
+			p->seg = (fseg_t**)realloc(p->seg, p->cap_seg * sizeof(fseg_t*));
+		}
+		p->seg[p->nseg++] = sg;
+		pthread_mutex_unlock(&p->mu);
+	}
+	return p->seg[p->nseg - 1];
+}
+
+static void queue_fill(rb2_fmdp_t *p)                          /* hand the segment being filled to the workers */
+{
+	if (p->nseg == p->n_queued) return;
+	{	/* symbol of the segment's last run: its head byte is the last byte that is not a continuation byte (rle.h:39-51) */
+		fseg_t *sg = p->seg[p->nseg - 1];
+		int64_t k = sg->n - 1;
+		while (k > 0 && (sg->runs[k] & 0xC0) == 0x80) --k;
+		sg->prev_sym_out = sg->n > 0 ? (sg->runs[k] & 7) : sg->prev_sym;
+	}
+	pthread_mutex_lock(&p->mu);
+	p->seg[p->nseg - 1]->state = 1;
+	p->n_queued = p->nseg;
+	pthread_cond_signal(&p->cv_work);
+	pthread_mutex_unlock(&p->mu);
+}
+
+/* ---- the true orbit ---- */
+
+static void hdr_counts(const uint64_t *h, int64_t v[N_FIELDS])   /* counts stored in a block header */
+{
+	const int type = (int)(h[0] >> 62);
+	int j;
+	for (j = 0; j < N_FIELDS; ++j) {
+		if (type == 0)      v[j] = (int64_t)((h[j / 4] >> (16 * (j % 4))) & 0xffffu);
+		else if (type == 1) v[j] = (int64_t)((h[j / 2] >> (32 * (j % 2))) & 0x3fffffffu);   /* every field < 2^30; the width tag shares word 0 */
+		else                v[j] = (int64_t)(j == 0 ? h[0] & 0x3fffffffffffffffull : h[j]);
+	}
+}
+
+/* the true orbit has just opened a block (header written) for the run at offset `pos` of segment sg: if the speculative encoding
+ * of the segment opened one there too, take its blocks.  Returns the offset at which the true orbit resumes, or -1. */
+static int64_t try_couple(rb2_fmdp_t *p, fseg_t *sg, int64_t pos)
+{
+	rb2_fmd_t *f = p->f, *sp = sg->sp;
+	size_t lo = 0, hi = sp->nblk, j, e, k;
+	int64_t prev[N_FIELDS];
+	int i;
+	if (sp->nblk == 0 || f->tail != f->head + BLK_WORDS - 1) return -1;
+	while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((int64_t)sp->start[mid] < pos) lo = mid + 1; else hi = mid; }
+	j = lo;
+	if (j >= sp->nblk || (int64_t)sp->start[j] != pos || (int)(f->w[f->head] >> 62) != sp->type[j]) return -1;
+	/* blocks j .. e-1 are copied; block e is opened by the true orbit again (it is the partial one, or the chunk rule shortens it) */
+	for (e = j + 1; e < sp->nblk; ++e) {
+		const size_t ah = f->head + (e - j) * BLK_WORDS;
+		if (block_tail(ah) != ah + BLK_WORDS - 1) break;
+	}
+	reserve(f, f->head + (e - j + 2) * BLK_WORDS);
+	k = hdr_words[sp->type[j]];
+	memcpy(f->w + f->head + k, sp->w + j * BLK_WORDS + k, (BLK_WORDS - k) * 8);      /* body of block j behind the true header */
+	if (e > j + 1) memcpy(f->w + f->head + BLK_WORDS, sp->w + (j + 1) * BLK_WORDS, (e - j - 1) * BLK_WORDS * 8);
+	p->n_copied_blocks += (int64_t)(e - j);
+	/* state: block e-1 is complete; its counts are in the speculative header of block e */
+	hdr_counts(sp->w + e * BLK_WORDS, prev);
+	f->head += (e - j - 1) * BLK_WORDS;
+	for (i = 0; i < N_FIELDS; ++i) f->cnt[i] = f->mcnt[i] + prev[i];
+	f->p = f->tail = f->head + BLK_WORDS - 1; f->r = 0;       /* full: the next run opens block e through open_next_block */
+	return (int64_t)sp->start[e];
+}
+
+/* advance the true orbit over everything that is encoded speculatively so far (final: over everything, waiting for the workers) */
+static void stitch(rb2_fmdp_t *p, int final)
+{
+	rb2_fmd_t *f = p->f;
+	for (;;) {
+		fseg_t *sg;
+		const uint8_t *q;
+		int64_t i, n;
+		pthread_mutex_lock(&p->mu);
+		if (p->cur_seg >= p->n_queued) { pthread_mutex_unlock(&p->mu); return; }
+		sg = p->seg[p->cur_seg];
+		while ((final || p->n_queued - p->cur_seg > 4 * p->nthr + 8) && sg->state != 3) pthread_cond_wait(&p->cv_done, &p->mu);   /* backlog: let the workers catch up */
+		if (sg->state != 3) { pthread_mutex_unlock(&p->mu); return; }
+		pthread_mutex_unlock(&p->mu);
+		q = sg->runs; n = sg->n; i = p->cur_pos;
+		if (i == 0) { int k; for (k = 0; k < N_FIELDS; ++k) p->tot[k] += sg->sum[k]; }
+		if (p->cur_seg == 0 && i == 0 && sg->sp->nblk > 0 && f->p == (size_t)hdr_words[0] && f->r == 64) {
+			/* the very first block of the stream is a block start for both by construction */
+			const int64_t r = try_couple(p, sg, (int64_t)sg->sp->start[0]);
+			if (r >= 0) i = r;
+		}
+		while (i < n) {
+			int c, w; int64_t l;
+			const int nb = run_at(q + i, &c, &l);
+			if (c == f->pend_c) { f->pend_l += l; i += nb; continue; }
+			if (f->pend_l) {                                   /* flush the pending maximal run: it started at f->run_pos of segment pend_seg */
+				const uint64_t x = run_code(f->pend_l, f->pend_c, &w);
+				if (w >= f->r && f->p == f->tail) {
+					open_next_block(f);
+					++p->n_true_blocks;
+					if (f->pend_seg == p->cur_seg) {             /* the pending run started in THIS segment: its offset can be looked up */
+						const int64_t r = try_couple(p, sg, (int64_t)f->run_pos);
+						if (r >= 0) { f->pend_c = -1; f->pend_l = 0; i = r; continue; }
+					}
+				}
+				place_bits(f, x, w);
+				f->cnt[0] += f->pend_l; f->cnt[f->pend_c + 1] += f->pend_l;
+			}
+			f->pend_c = c; f->pend_l = l; f->run_pos = (uint32_t)i; f->pend_seg = p->cur_seg;
+			i += nb;
+		}
+		free(sg->runs); sg->runs = 0;
+		free(sg->sp->w); free(sg->sp->start); free(sg->sp->type); free(sg->sp); sg->sp = 0;
+		++p->cur_seg; p->cur_pos = 0;                        /* (the fseg_t itself stays: the next segment reads prev_sym_out) */
+	}
+}
+
+void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n)
+{
+	while (n > 0) {
+		fseg_t *sg = cur_fill(p);
+		int64_t take = n;
+		if (take > p->seg_bytes + 1024 - sg->n) {              /* a chunk larger than a segment: cut at a run boundary */
+			take = p->seg_bytes + 1024 - sg->n;
+			while (take > 0 && (runs[take] & 0xC0) == 0x80) --take;
+			if (take == 0) { queue_fill(p); stitch(p, 0); continue; }
+		}
+		memcpy(sg->runs + sg->n, runs, (size_t)take); sg->n += take;
+		runs += take; n -= take;
+		if (sg->n >= p->seg_bytes) { queue_fill(p); stitch(p, 0); }
+	}
+}
+
+rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
+{
+	rb2_fmd_t *f = p->f;
+	int i;
+	queue_fill(p);
+	stitch(p, 1);
+	pthread_mutex_lock(&p->mu);
+	p->closing = 1;
+	pthread_cond_broadcast(&p->cv_work);
+	pthread_mutex_unlock(&p->mu);
+	for (i = 0; i < p->nthr; ++i) pthread_join(p->thr[i], 0);
+	/* tail of the stream, as rb2_fmd_finish does it -- but the running counts of the true orbit are only meaningful as
+	 * differences, the totals come from the segments */
+	if (f->pend_l) { encode_run(f, f->pend_l, f->pend_c); f->pend_l = 0; }
+	open_next_block(f);
+	memcpy(f->mcnt, p->tot, sizeof(p->tot)); memcpy(f->cnt, p->tot, sizeof(p->tot));
+	fmd_index(f);
+	if (getenv("RB2_FMD_STATS")) fprintf(stderr, "[rb2_fmdp] %lld segments, %lld blocks copied from the speculative encodings, %lld encoded by the true orbit\n",
+			(long long)p->nseg, (long long)p->n_copied_blocks, (long long)p->n_true_blocks);
+	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
+	{ int64_t k; for (k = 0; k < p->nseg; ++k) free(p->seg[k]); }
+	free(p->thr); free(p->seg); free(p);
+	return f;
 }

@@ -113,9 +113,8 @@ static int read_fastx_record(reader_t *r)
 /* output: one chunk of 43+3 run bytes -> .fmd encoder (user != 0) or plain text */
 static void emit_runs(void *user, const uint8_t *q, int64_t n)
 {
-	rb2_fmd_t *fmd = (rb2_fmd_t*)user;
 	const uint8_t *end = q + n;
-	if (fmd) { rb2_fmd_push_runs(fmd, q, n); return; }
+	if (user) { rb2_fmdp_push_runs((rb2_fmdp_t*)user, q, n); return; }
 	while (q < end) {
 		int sym; int64_t len, k;
 		rle_dec1(q, sym, len);
@@ -305,11 +304,18 @@ int main(int argc, char *argv[])
 	if (flag & F_BIN) mr_dump(mr, stdout);
 	else if (flag & F_TREE) mr_print_tree(mr);
 	else {
-		rb2_fmd_t *fmd = flag & F_RLD ? rb2_fmd_init() : 0;
-		mr_stream_runs(mr, emit_runs, fmd);                    /* the reference walks mr_itr_next_block here (main.c:288-305) */
-		if (fmd) {
+		/* .fmd: the Elias-delta coding of the run stream is spread over worker threads (fmd.c: speculative segments + one
+		 * stitching pass; RB2_FMD_THREADS=0 for the plain sequential writer path with one worker) */
+		rb2_fmdp_t *fmdp = 0;
+		if (flag & F_RLD) {
+			long nt = sysconf(_SC_NPROCESSORS_ONLN) - 1;
+			if (getenv("RB2_FMD_THREADS")) nt = atol(getenv("RB2_FMD_THREADS"));
+			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 24 ? 24 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
+		}
+		mr_stream_runs(mr, emit_runs, fmdp);                   /* the reference walks mr_itr_next_block here (main.c:288-305) */
+		if (fmdp) {
 			int64_t cc[7];
-			rb2_fmd_finish(fmd);
+			rb2_fmd_t *fmd = rb2_fmdp_finish(fmdp);
 			rb2_fmd_counts(fmd, cc);
 			fprintf(stderr, "[M::%s] rld: (tot, $, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
 					(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5], (long)cc[6]);

@@ -60,7 +60,7 @@ struct rb2_hip_s {
 	int side = 0;                       // descriptor parity: ctl->rope[side] / ctl->seg[side] describe the current BWT (flips every round)
 	int pside = 0;                      // pool that physically holds it (flips with `side` in dense rounds, stays in sparse ones)
 	bool sparse = false;                // the pool is in the sparse layout (leaves with slack, in-place rounds)
-	double sp_lambda = 0.4;             // go sparse when (strings per round) / (leaves of the index) falls below this
+	double sp_lambda = 0.6;             // go sparse when (strings per round) / (leaves of the index) falls below this
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
 	int sp_maxpen = 12;
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round

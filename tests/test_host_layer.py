@@ -223,3 +223,100 @@ def test_reader_edge_cases_match_reference():
         p = subprocess.run([H.REF_BIN, "-L", "-R", "-m0", "-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         assert p.returncode == 0
         assert cli(["-L", "-R", "-m0"], data) == p.stdout, data[:20]
+
+
+# ---- parallel .fmd writer (fmd.c: speculative segments + stitching) == sequential writer, byte for byte -------------------
+
+def _fmd_lib():
+    from ropebwt2_amd.build import lib_path
+    L = C.CDLL(lib_path("libropebwt2.so"))
+    L.rb2_fmd_init.restype = C.c_void_p
+    L.rb2_fmd_push_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.rb2_fmd_finish.argtypes = [C.c_void_p]
+    L.rb2_fmd_destroy.argtypes = [C.c_void_p]
+    L.rb2_fmd_write_path.argtypes = [C.c_void_p, C.c_char_p]
+    L.rb2_fmdp_init.restype = C.c_void_p
+    L.rb2_fmdp_init.argtypes = [C.c_int, C.c_int64]
+    L.rb2_fmdp_push_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.rb2_fmdp_finish.restype = C.c_void_p
+    L.rb2_fmdp_finish.argtypes = [C.c_void_p]
+    return L
+
+
+def _write_both(L, chunks, threads, seg, tmp_path):
+    """chunks: list of uint8 arrays holding whole runs; returns (sequential bytes, parallel bytes)"""
+    f = L.rb2_fmd_init()
+    for r in chunks:
+        L.rb2_fmd_push_runs(f, r.ctypes.data, len(r))
+    L.rb2_fmd_finish(f)
+    a = str(tmp_path / "seq.fmd").encode()
+    assert L.rb2_fmd_write_path(f, a) == 0
+    L.rb2_fmd_destroy(f)
+    p = L.rb2_fmdp_init(threads, seg)
+    for r in chunks:
+        L.rb2_fmdp_push_runs(p, r.ctypes.data, len(r))
+    f = L.rb2_fmdp_finish(p)
+    b = str(tmp_path / "par.fmd").encode()
+    assert L.rb2_fmd_write_path(f, b) == 0
+    L.rb2_fmd_destroy(f)
+    return open(a, "rb").read(), open(b, "rb").read()
+
+
+@pytest.mark.parametrize("n,chunk,threads,seg", [(0, 64, 2, 4096), (1, 64, 2, 4096), (5000, 100, 3, 256), (200000, 1000, 4, 4096),
+                                                 (3000000, 1024, 8, 65536), (3000000, 777, 5, 1 << 20)])
+def test_parallel_fmd_writer_one_byte_runs(n, chunk, threads, seg, tmp_path):
+    """device-style input: one-byte runs, equal symbols in adjacent bytes (cut runs) merge in the writer; segments from far
+    smaller than the coupling distance (the true orbit does nearly everything) to large (nearly everything is copied)"""
+    rng = np.random.RandomState(n % 97 + threads)
+    runs = (rng.choice([1, 1, 1, 2, 2, 3, 5, 15], size=n).astype(np.uint8) << 3 | rng.randint(0, 6, size=n).astype(np.uint8)).astype(np.uint8)
+    a, b = _write_both(_fmd_lib(), [runs[i:i + chunk] for i in range(0, n, chunk)], threads, seg, tmp_path)
+    assert a == b
+
+
+@pytest.mark.parametrize("threads,seg", [(3, 2048), (4, 50000), (6, 1 << 20)])
+def test_parallel_fmd_writer_wide_runs(threads, seg, tmp_path):
+    """2/4/8-byte runs up to 2^40 symbols: 32- and 64-bit block headers, runs that straddle segments"""
+    from ropebwt2_amd.hipbwt import encode_runs
+    rng = np.random.RandomState(7)
+    n = 120000
+    lens = np.where(rng.rand(n) < 0.7, rng.randint(1, 16, size=n), np.where(rng.rand(n) < 0.5, rng.randint(16, 5000, size=n), rng.randint(1 << 20, 1 << 40, size=n)))
+    syms = rng.randint(0, 6, size=n)
+    chunks, k = [], 0
+    while k < n:
+        k2 = min(n, k + int(rng.randint(1, 400)))
+        out = bytearray()
+        for c, l in zip(syms[k:k2].tolist(), lens[k:k2].tolist()):       # every run on its own: equal neighbours stay separate runs
+            out += encode_runs(np.full(1, c, np.uint8)).tobytes() if l == 1 else b""
+            if l > 1:
+                nb = 1 if l < 16 else 2 if l < 256 else 4 if l < (1 << 19) else 8
+                if nb == 1:
+                    out.append(l << 3 | c)
+                else:
+                    tail, ll = [], l
+                    for _ in range(nb - 1):
+                        tail.append(0x80 | (ll & 0x3f)); ll >>= 6
+                    out.append({2: 0xC0, 4: 0xE0, 8: 0xF0}[nb] | ll << 3 | c); out.extend(reversed(tail))
+        chunks.append(np.frombuffer(bytes(out), np.uint8))
+        k = k2
+    a, b = _write_both(_fmd_lib(), chunks, threads, seg, tmp_path)
+    assert a == b
+
+
+def test_parallel_fmd_writer_crosses_a_chunk_border(tmp_path):
+    """more than 64 MiB of output: the last block of a 2^23-word chunk is one word shorter (rld0.h:75), which the speculative
+    encodings cannot know -- the stitcher re-encodes from there until it couples again"""
+    rng = np.random.RandomState(3)
+    n = 70_000_000
+    runs = (rng.choice([1, 2, 3, 7], size=n).astype(np.uint8) << 3 | rng.randint(1, 5, size=n).astype(np.uint8)).astype(np.uint8)
+    a, b = _write_both(_fmd_lib(), [runs[i:i + (1 << 20)] for i in range(0, n, 1 << 20)], 6, 0, tmp_path)
+    assert len(a) > (1 << 26) + 4096 and a == b
+
+
+def test_cli_fmd_small_segments_m0(golden):
+    """the CLI's .fmd through the parallel writer with segments far smaller than a leaf chunk and with one thread"""
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    for seg, thr in (("700", "3"), ("50000", "1"), ("0", "0")):
+        env = dict(os.environ, RB2_FMD_SEGMENT=seg, RB2_FMD_THREADS=thr)
+        p = subprocess.run([CLI, "-LRsd", "-m0", "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0 and H.md5(p.stdout) == g["fmd_md5"]["-LRsd"]
