@@ -63,8 +63,8 @@ void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36]);
  * the exact size; download copies it to host memory `dst` and returns the byte count. */
 int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b);
 int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst);
-/* the same stream handed to a callback leaf by leaf (n_bytes <= 1024 per call), without a host copy of the whole
- * rope: what an .fmd / text writer needs (replaces the walk over mr_itr_next_block, mrope.c:114-131) */
+/* the same stream handed to a callback in pieces of whole runs (up to 32 MiB per call; the buffer is only valid during
+ * the call), without a host copy of the whole rope: what an .fmd / text writer needs (replaces the walk over mr_itr_next_block, mrope.c:114-131) */
 typedef void (*rb2_hip_run_cb)(void *user, const uint8_t *runs, int64_t n_bytes);
 int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user);
 

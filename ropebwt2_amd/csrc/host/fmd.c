@@ -146,42 +146,91 @@ void rb2_fmd_finish(rb2_fmd_t *f)
 	fmd_index(f);
 }
 
-/* stream length + rank frames; f->mcnt holds the totals */
-static void fmd_index(rb2_fmd_t *f)
+/* stream length + rank frames (rld0.c:163-205); f->mcnt holds the totals.  Frame k describes the LAST block whose cumulative
+ * symbol count S lies in [(k-1) 2^ibits, k 2^ibits): k(block) = (S >> ibits) + 1 is monotone, so ranges of blocks can be
+ * handled independently once the counts in front of each range are known (two passes over the headers, nthr threads). */
+typedef struct { rb2_fmd_t *f; uint64_t i0, i1, last; uint64_t sum[6], base[6]; int ibits, pass; } idx_job_t;
+
+static inline void hdr_add(const uint64_t *h, uint64_t run[6])
 {
-	uint64_t n_blks, last, i, k, run[6] = { 0, 0, 0, 0, 0, 0 };
-	int ibits, j;
+	const int type = (int)(h[0] >> 62);
+	int j;
+	for (j = 1; j < N_FIELDS; ++j) {
+		uint64_t v;
+		if (type == 0)      v = (h[j / 4] >> (16 * (j % 4))) & 0xffffu;
+		else if (type == 1) v = (h[j / 2] >> (32 * (j % 2))) & 0x3fffffffu;
+		else                v = h[j];
+		run[j - 1] += v;
+	}
+}
+
+static void *idx_worker(void *arg)
+{
+	idx_job_t *jb = (idx_job_t*)arg;
+	rb2_fmd_t *f = jb->f;
+	uint64_t i, run[6], kprev = 0, iprev = 0, rprev[6];
+	int j;
+	if (jb->pass == 0) {
+		memset(jb->sum, 0, sizeof(jb->sum));
+		for (i = jb->i0; i < jb->i1; i += BLK_WORDS) hdr_add(f->w + i, jb->sum);
+		return 0;
+	}
+	memcpy(run, jb->base, sizeof(run));
+	for (i = jb->i0; i <= jb->i1 && i <= jb->last; i += BLK_WORDS) {   /* one block past the range: is my last k also the next range's first? */
+		uint64_t sum = 0, k;
+		hdr_add(f->w + i, run);
+		for (j = 0; j < 6; ++j) sum += run[j];
+		k = (sum >> jb->ibits) + 1;
+		if (kprev && k != kprev && kprev < f->n_frames) {          /* block iprev was the last one with kprev */
+			f->frame[kprev * N_FIELDS] = iprev;
+			for (j = 0; j < 6; ++j) f->frame[kprev * N_FIELDS + 1 + j] = rprev[j];
+		}
+		if (i >= jb->i1) { kprev = 0; break; }                      /* the look-ahead block belongs to the next range */
+		kprev = k; iprev = i; memcpy(rprev, run, sizeof(run));
+	}
+	if (kprev && kprev < f->n_frames) {                            /* the very last block of the stream */
+		f->frame[kprev * N_FIELDS] = iprev;
+		for (j = 0; j < 6; ++j) f->frame[kprev * N_FIELDS + 1 + j] = rprev[j];
+	}
+	return 0;
+}
+
+static void fmd_index_mt(rb2_fmd_t *f, int nthr)
+{
+	uint64_t n_blks, last, k, nb, per, acc[6] = { 0, 0, 0, 0, 0, 0 };
+	int ibits, t, j, pass;
+	idx_job_t *jobs;
+	pthread_t *th;
 	f->n_bytes = (uint64_t)f->p * 8;
-	/* rank index (rld0.c:163-205) */
 	n_blks = f->n_bytes * 8 / 64 / BLK_WORDS + 1;
-	last = (f->n_bytes >> 3) / BLK_WORDS * BLK_WORDS;
+	last = (f->n_bytes >> 3) / BLK_WORDS * BLK_WORDS;          /* word offset of the last header */
 	ibits = ilog2_u64((uint64_t)f->mcnt[0] / n_blks) + 4;
 	f->n_frames = (((uint64_t)f->mcnt[0] + (1ull << ibits) - 1) >> ibits) + 1;
 	f->frame = (uint64_t*)calloc(f->n_frames * N_FIELDS, 8);
-	for (i = BLK_WORDS, k = 1; i <= last; i += BLK_WORDS) {
-		const uint64_t *h = f->w + i;
-		const int type = (int)(h[0] >> 62);
-		uint64_t sum = 0;
-		for (j = 1; j < N_FIELDS; ++j) {
-			uint64_t v;
-			if (type == 0)      v = (h[j / 4] >> (16 * (j % 4))) & 0xffffu;
-			else if (type == 1) v = (h[j / 2] >> (32 * (j % 2))) & 0x3fffffffu;
-			else                v = h[j];
-			run[j - 1] += v;
+	nb = last / BLK_WORDS;                                     /* headers at words 8, 16, ..., last */
+	if (nthr < 1) nthr = 1;
+	if (nb < 4096) nthr = 1;
+	per = (nb + nthr - 1) / nthr;
+	jobs = (idx_job_t*)calloc(nthr, sizeof(idx_job_t)); th = (pthread_t*)calloc(nthr, sizeof(pthread_t));
+	for (pass = 0; pass < 2; ++pass) {
+		for (t = 0; t < nthr; ++t) {
+			idx_job_t *jb = &jobs[t];
+			uint64_t b0 = (uint64_t)t * per, b1 = b0 + per < nb ? b0 + per : nb;
+			if (b0 > nb) b0 = nb;
+			jb->f = f; jb->i0 = (b0 + 1) * BLK_WORDS; jb->i1 = (b1 + 1) * BLK_WORDS; jb->last = last; jb->ibits = ibits; jb->pass = pass;
+			if (nthr == 1) idx_worker(jb); else pthread_create(&th[t], 0, idx_worker, jb);
 		}
-		for (j = 0; j < 6; ++j) sum += run[j];
-		while (sum >= k << ibits) ++k;
-		if (k < f->n_frames) {
-			f->frame[k * N_FIELDS] = i;
-			for (j = 0; j < 6; ++j) f->frame[k * N_FIELDS + 1 + j] = run[j];
-		}
+		if (nthr > 1) for (t = 0; t < nthr; ++t) pthread_join(th[t], 0);
+		if (pass == 0) for (t = 0; t < nthr; ++t) { memcpy(jobs[t].base, acc, sizeof(acc)); for (j = 0; j < 6; ++j) acc[j] += jobs[t].sum[j]; }
 	}
-	assert(k >= f->n_frames - 1);
+	free(jobs); free(th);
 	for (k = 1; k < f->n_frames; ++k)                          /* empty frames repeat their predecessor */
 		if (f->frame[k * N_FIELDS] == 0)
 			memcpy(&f->frame[k * N_FIELDS], &f->frame[(k - 1) * N_FIELDS], N_FIELDS * 8);
 	f->finished = 1;
 }
+
+static void fmd_index(rb2_fmd_t *f) { fmd_index_mt(f, 1); }
 
 int rb2_fmd_write(const rb2_fmd_t *f, FILE *fp)
 {
@@ -507,7 +556,7 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
 	if (f->pend_l) { encode_run(f, f->pend_l, f->pend_c); f->pend_l = 0; }
 	open_next_block(f);
 	memcpy(f->mcnt, p->tot, sizeof(p->tot)); memcpy(f->cnt, p->tot, sizeof(p->tot));
-	fmd_index(f);
+	fmd_index_mt(f, p->nthr);
 	if (getenv("RB2_FMD_STATS")) fprintf(stderr, "[rb2_fmdp] %lld segments, %lld blocks copied from the speculative encodings, %lld encoded by the true orbit\n",
 			(long long)p->nseg, (long long)p->n_copied_blocks, (long long)p->n_true_blocks);
 	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);

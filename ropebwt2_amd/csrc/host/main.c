@@ -312,10 +312,13 @@ int main(int argc, char *argv[])
 			if (getenv("RB2_FMD_THREADS")) nt = atol(getenv("RB2_FMD_THREADS"));
 			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 24 ? 24 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
 		}
+		const double ts0 = realtime();
 		mr_stream_runs(mr, emit_runs, fmdp);                   /* the reference walks mr_itr_next_block here (main.c:288-305) */
 		if (fmdp) {
 			int64_t cc[7];
+			const double ts1 = realtime();
 			rb2_fmd_t *fmd = rb2_fmdp_finish(fmdp);
+			if (verbose >= 3) fprintf(stderr, "[M::%s] BWT streamed off the device and run-length coded in %.3f sec (+ %.3f sec to finish and index)\n", "main_ropebwt2", ts1 - ts0, realtime() - ts1);
 			rb2_fmd_counts(fmd, cc);
 			fprintf(stderr, "[M::%s] rld: (tot, $, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
 					(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5], (long)cc[6]);

@@ -89,7 +89,8 @@ struct rb2_hip_s {
 	int rank = 0, nranks = 1; int owner[NR] = {0};
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;
-	DevBuf<uint8_t> xstage; DevBuf<uint16_t> xnb;   // k_export staging
+	DevBuf<uint8_t> xstage, xpack; DevBuf<uint16_t> xnb; DevBuf<uint64_t> xoff;   // k_export staging, packed bytes, chunk offsets
+	uint8_t *xhost[2] = {nullptr, nullptr}; uint64_t *xtot[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr};   // pinned double buffer
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
 
@@ -449,7 +450,8 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
-	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release();
+	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
+	for (int i = 0; i < 2; ++i) if (h->xhost[i]) { HIPCHK(hipHostFree(h->xhost[i])); HIPCHK(hipHostFree(h->xtot[i])); HIPCHK(hipEventDestroy(h->xev[i])); }
 	HIPCHK(hipStreamDestroy(h->st));
 	delete h;
 }
@@ -506,30 +508,48 @@ static void ensure_dense(rb2_hip_t *h)          /* k_export streams flat pieces:
 	fetch_ropes(h);
 }
 
+/* run-length export of sub-rope r: k_export writes one 43+3 byte per run into a staging buffer (slot stride XCHUNK) and the
+ * byte count of every chunk, k_xcompact packs the slots back to back, and the packed bytes travel to one of two pinned
+ * host buffers -- while the host consumes one (dst copy / one callback per staging round), the device fills the other. */
 static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb = nullptr, void *user = nullptr)
 {
-	const uint64_t CH = 32768;                       // export chunks (XCHUNK symbols each) per staging round: 32 MiB of run bytes
+	const uint64_t CH = 32768;                       // export chunks (XCHUNK symbols each) per staging round: at most 32 MiB of run bytes
 	const RopeDesc &d = h->h_rope[r];
 	const uint64_t nchunks = (d.n + XCHUNK - 1) / XCHUNK;
 	if (nchunks == 0 || d.nleaves == 0) return 0;
 	const uint64_t ch = std::min<uint64_t>(CH, nchunks);
 	const bool want = dst || cb;
-	h->xstage.ensure(ch * XCHUNK); h->xnb.ensure(ch);
-	std::vector<uint8_t> stage(want ? ch * XCHUNK : 0);
-	std::vector<uint16_t> nb(ch);
-	int64_t k = 0;
-	for (uint64_t c0 = 0; c0 < nchunks; c0 += CH) {
+	h->xstage.ensure(ch * XCHUNK); h->xnb.ensure(ch); h->xpack.ensure(ch * XCHUNK + 16); h->xoff.ensure(ch + 1);
+	if (!h->xhost[0]) {
+		for (int i = 0; i < 2; ++i) {
+			HIPCHK(hipHostMalloc((void**)&h->xhost[i], CH * XCHUNK + 64, hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->xtot[i], 64, hipHostMallocDefault));
+			HIPCHK(hipEventCreateWithFlags(&h->xev[i], hipEventDisableTiming));
+		}
+	}
+	auto launch = [&](uint64_t c0, int buf) {
 		const uint64_t nc = std::min<uint64_t>(CH, nchunks - c0);
 		hipLaunchKernelGGL(k_export, dim3(cdiv(nc, MW)), dim3(256), 0, h->st, h->pool[h->pside].view(), d.leaf0, d.n, c0, (uint32_t)nc, h->xstage.p, h->xnb.p);
-		HIPCHK(hipGetLastError());
-		if (want) HIPCHK(hipMemcpyAsync(stage.data(), h->xstage.p, nc * XCHUNK, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipMemcpyAsync(nb.data(), h->xnb.p, nc * sizeof(uint16_t), hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
-		for (uint64_t i = 0; i < nc; ++i) {
-			if (dst) memcpy(dst + k, stage.data() + i * XCHUNK, nb[i]);
-			if (cb) cb(user, stage.data() + i * XCHUNK, nb[i]);
-			k += nb[i];
+		hipLaunchKernelGGL(k_xscan, dim3(1), dim3(SCHUNK), 0, h->st, (const uint16_t*)h->xnb.p, (uint32_t)nc, h->xoff.p);
+		HIPCHK(hipMemcpyAsync(h->xtot[buf], h->xoff.p + nc, 8, hipMemcpyDeviceToHost, h->st));
+		if (want) {
+			hipLaunchKernelGGL(k_xcompact, dim3(cdiv(nc, MW)), dim3(256), 0, h->st, (const uint8_t*)h->xstage.p, (const uint16_t*)h->xnb.p, (const uint64_t*)h->xoff.p, (uint32_t)nc, h->xpack.p);
+			// the packed size is only known on the device: copy the upper bound the slots could hold, in one piece
+			HIPCHK(hipMemcpyAsync(h->xhost[buf], h->xpack.p, nc * XCHUNK, hipMemcpyDeviceToHost, h->st));
 		}
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(h->xev[buf], h->st));
+	};
+	int64_t k = 0;
+	int buf = 0;
+	launch(0, 0);
+	for (uint64_t c0 = 0; c0 < nchunks; c0 += CH, buf ^= 1) {
+		if (c0 + CH < nchunks) launch(c0 + CH, buf ^ 1);
+		HIPCHK(hipEventSynchronize(h->xev[buf]));
+		const int64_t n = (int64_t)*h->xtot[buf];
+		if (dst) memcpy(dst + k, h->xhost[buf], (size_t)n);
+		if (cb && n) cb(user, h->xhost[buf], n);
+		k += n;
 	}
 	return k;
 }

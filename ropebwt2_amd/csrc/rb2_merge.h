@@ -394,4 +394,30 @@ __global__ __launch_bounds__(256) void k_export(PoolView pv, uint64_t leaf0, uin
 	((uint4*)(dst + (uint64_t)li * XCHUNK))[ln] = ((const uint4*)L.outb)[ln];
 }
 
+// exclusive prefix of the chunks' byte counts (one block); off[n] = total
+__global__ __launch_bounds__(SCHUNK) void k_xscan(const uint16_t *nb, uint32_t n, uint64_t *off)
+{
+	__shared__ uint64_t s_w[16];
+	uint64_t run = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += SCHUNK) {
+		const uint32_t i = i0 + threadIdx.x;
+		uint64_t tot;
+		const uint64_t ex = block_excl_add<uint64_t>(i < n ? (uint64_t)nb[i] : 0ull, s_w, &tot);
+		if (i < n) off[i] = run + ex;
+		run += tot;
+	}
+	if (threadIdx.x == 0) off[n] = run;
+}
+
+// pack the chunks' run bytes back to back (one wave per chunk, byte-wise: the destinations are unaligned)
+__global__ __launch_bounds__(256) void k_xcompact(const uint8_t *stage, const uint16_t *nb, const uint64_t *off, uint32_t nc, uint8_t *dst)
+{
+	const uint32_t li = blockIdx.x * MW + (threadIdx.x >> 6);
+	if (li >= nc) return;
+	const uint32_t n = nb[li];
+	const uint8_t *src = stage + (uint64_t)li * XCHUNK;
+	uint8_t *o = dst + off[li];
+	for (uint32_t i = lane_id(); i < n; i += 64) o[i] = src[i];
+}
+
 } // namespace rb2
