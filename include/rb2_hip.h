@@ -19,6 +19,15 @@
  * the host can splice them straight into rope leaves.  The device itself only ever emits the
  * 1-byte form (run length < 16), which is a valid subset of that codec.
  *
+ * Limits of this build (checked; a violation prints a message and abort()s):
+ *   - fewer than 2^32 - 1024 strings per batch (string ids are 32 bit on the device; ropebwt2's default -m10g holds at most
+ *     ~10^10 one-symbol strings, so this only excludes batches of degenerate reads);
+ *   - positions inside one sub-rope below 2^48 (the sharded wire format packs l into 48 bits, rb2_device.h ShardRec);
+ *   - at most 64 ranks in the sharded protocol (31 sub-ropes exist; more than 16 ranks carry no additional load on DNA);
+ *   - symbols must be nt6 codes 0..5, the buffer must end with a sentinel (mrope.c:268);
+ *   - the index lives in HBM: 2 x 0.38 B per symbol (dense layout) plus ~100 B per string of the batch; running out of device
+ *     memory reports the size that was needed.
+ *
  * Error convention: like the reference (mrope.c has none), functions do not return error codes
  * for programming errors; any HIP failure or a missing GPU prints a message to stderr and
  * abort()s -- there is no CPU fallback behind this ABI.
@@ -80,6 +89,10 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 
 /* rank of all six symbols in [0,x) of rope b, computed on the device (rope_rank1a, rope.h:45) */
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
+/* the same for n positions at once: out[i*6 + a] = number of a's in [0, x[i]) of rope b.  One wave per query (a coalesced
+ * 512-byte leaf load, bit-plane popcounts per lane, DPP reduction): the query-side counterpart of rope_rank1a for workloads
+ * that ask millions of ranks (x, out: host memory). */
+void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_t *out);
 
 /* ---- rope sharding across GPUs ---------------------------------------------------------------
  * One handle per GPU (one process per GPU).  The unit of ownership is a SUB-ROPE: rope b is kept as

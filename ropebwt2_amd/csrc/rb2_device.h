@@ -381,4 +381,63 @@ __device__ __forceinline__ uint32_t dpp_prev_lane(uint32_t v) { return dpp0<0x13
 __device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return dpp0<0x130, 0xf>(v); }   // wave_shl:1, lane 63 reads 0
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 
+
+// ---------------------------------------------------------------------------------------------
+// wave-cooperative rank: a leaf is 64 words = one per lane.  One coalesced 512-byte load, per-lane bit-plane popcounts of
+// the lane's share of [from, to), three packed DPP reductions -> the six counts in every lane.  Cost is independent of the
+// interval length (the single-thread scan of leaf_count is linear in it): this is what serves long intervals and intervals
+// that span leaves in k_prep, and every query of k_rank_batch.  (rle_rank2a, rle.c:134-191; rope_rank2a, rope.c:179-194.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_leaf_counts(const uint64_t *leaf, uint32_t from, uint32_t to, uint32_t c[6])
+{
+	const uint32_t b = (uint32_t)lane_id() * SPW;
+	const uint64_t w = leaf[lane_id()];
+	const uint32_t lo = from > b ? min(from - b, (uint32_t)SPW) : 0u, hi = to > b ? min(to - b, (uint32_t)SPW) : 0u;   // my symbols [lo, hi)
+	NibAcc A;
+	nib_acc(A, w, MLOW & nib_below(hi) & ~nib_below(lo));
+	const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
+	NibAcc T;
+	T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
+	nib_finish(T, to > from ? to - from : 0u, c);
+}
+
+// all 64 lanes call it with the same p
+template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
+{
+	if (p >= rp.n) {
+#pragma unroll
+		for (int s = 0; s < 6; ++s) out[s] = rp.cnt[s];
+		return;
+	}
+	uint64_t gl; uint32_t off;
+	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
+	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
+	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
+	const LeafMeta m = pv.meta[gl];
+	uint32_t c[6];
+	wave_leaf_counts((const uint64_t*)pv.data + gl * LEAFW, 0, off, c);
+#pragma unroll
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
+}
+
+// occurrences of the six symbols inside [l, u), l < u, by one wave (what range_counts does with one thread)
+template <bool SPARSE> __device__ __forceinline__ void wave_range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
+{
+	uint64_t gl; uint32_t ol; bool one;
+	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
+	else { const uint64_t lf = l / LEAF; gl = rp.leaf0 + lf; ol = (uint32_t)(l - lf * LEAF); one = (u - 1) / LEAF == lf; }
+	if (one) {
+		uint32_t c[6];
+		wave_leaf_counts((const uint64_t*)pv.data + gl * LEAFW, ol, ol + (uint32_t)(u - l), c);
+#pragma unroll
+		for (int s = 0; s < 6; ++s) d[s] = c[s];
+	} else {
+		uint64_t cl[6], cu[6];
+		wave_rank_all<SPARSE>(pv, rp, l, cl);
+		wave_rank_all<SPARSE>(pv, rp, u, cu);
+#pragma unroll
+		for (int s = 0; s < 6; ++s) d[s] = cu[s] - cl[s];
+	}
+}
+
 } // namespace rb2

@@ -26,7 +26,15 @@ template <typename T> struct DevBuf {
 		if (n <= cap) return;
 		size_t ncap = std::max(n, cap + cap / 2);
 		T *q = nullptr;
-		HIPCHK(hipMalloc((void**)&q, ncap * sizeof(T)));
+		hipError_t e_ = hipMalloc((void**)&q, ncap * sizeof(T));
+		if (e_ != hipSuccess && ncap > n) { ncap = n; (void)hipGetLastError(); e_ = hipMalloc((void**)&q, ncap * sizeof(T)); }   // no room for the growth margin: take what is needed
+		if (e_ != hipSuccess) {                                    // tell the caller how much was needed (a 288 GB part can run out: both strands of 1.2 B reads)
+			size_t fr = 0, tot = 0;
+			(void)hipMemGetInfo(&fr, &tot);
+			fprintf(stderr, "[rb2_hip] out of device memory: a buffer of %.2f GB was needed (it held %.2f GB before), %.2f of %.2f GB are free; "
+					"use smaller batches (-m) or shard the index over more GPUs\n", ncap * sizeof(T) / 1e9, cap * sizeof(T) / 1e9, fr / 1e9, tot / 1e9);
+			abort();
+		}
 		if (keep && p && cap) { HIPCHK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
 		if (p) HIPCHK(hipFree(p));
 		p = q; cap = ncap;
@@ -72,6 +80,7 @@ struct rb2_hip_s {
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
 	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
+	DevBuf<uint64_t> qbuf;              // rank queries and their answers
 	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
@@ -445,7 +454,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
@@ -814,22 +823,26 @@ void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int
 	HIPCHK(hipStreamSynchronize(h->st));
 }
 
-void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
+/* n rank queries against rope b in one launch: one wave per query (k_rank_batch / wave_rank_all) */
+void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_t *out)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rank1a: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n"); abort(); }
-	for (int s = 0; s < 6; ++s) cx[s] = 0;
-	for (int r = 0; r < NR && x > 0; ++r) {              /* whole pieces in front of x, then a scan inside one piece */
-		if (rope_sym(r) != b) continue;
-		const RopeDesc &d = h->h_rope[r];
-		if ((uint64_t)x >= d.n) { for (int s = 0; s < 6; ++s) cx[s] += (int64_t)d.cnt[s]; x -= (int64_t)d.n; continue; }
-		hipLaunchKernelGGL(k_rank1, dim3(1), dim3(1), 0, h->st, h->ctl, h->side, h->pool[h->pside].view(), r, (uint64_t)x, h->d_tmp, (int)h->sparse);
-		uint64_t out[6];
-		HIPCHK(hipMemcpyAsync(out, h->d_tmp, 48, hipMemcpyDeviceToHost, h->st));
-		HIPCHK(hipStreamSynchronize(h->st));
-		for (int s = 0; s < 6; ++s) cx[s] += (int64_t)out[s];
-		x = 0;
-	}
+	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rank: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n"); abort(); }
+	if (n <= 0) return;
+	if (b < 0 || b > 5) { fprintf(stderr, "[rb2_hip] rank: bad rope %d\n", b); abort(); }
+	h->qbuf.ensure((size_t)n * 7);
+	HIPCHK(hipMemcpyAsync(h->qbuf.p, x, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
+	hipLaunchKernelGGL(k_rank_batch, dim3(cdiv((uint64_t)n, MW)), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), b,
+			(const uint64_t*)h->qbuf.p, (uint64_t)n, h->qbuf.p + n, (int)h->sparse);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, h->qbuf.p + n, (size_t)n * 48, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
+{
+	if (x < 0) x = 0;
+	rb2_hip_rank_batch(h, b, 1, &x, cx);
 }
 
 void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)

@@ -625,7 +625,16 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 	}
 	// Non-empty intervals: the members of a group share [l, u) (mrope.c:192-202), so rope_rank2a is evaluated once per
 	// group and tile -- by the group's first member inside the tile -- and handed to the others through LDS.
+	// Short intervals inside one leaf (the bulk: a handful of rows) are counted by the lead thread itself, scanning only the
+	// interval; long ones and those that span leaves are queued and served by whole WAVES (wave_range_counts: one coalesced
+	// 512-byte load per leaf, bit-plane popcounts per lane, packed DPP reductions) -- their cost does not grow with the interval.
 	__shared__ uint64_t s_d[AE ? 1 : STILE][6];                // #s in [l, u) of the group led by string x of the tile
+	constexpr int QCAP = 128;                                  // queue slots; a tile with more long queries counts the rest with single threads
+	__shared__ uint64_t s_ql[AE ? 1 : QCAP], s_qu[AE ? 1 : QCAP];
+	__shared__ uint16_t s_qx[AE ? 1 : QCAP];
+	__shared__ uint32_t s_nq;
+	if (threadIdx.x == 0) s_nq = 0;                            // (ordered before the appends by the barriers of group_setup... made explicit below)
+	__syncthreads();
 	Member mm[2];
 	uint64_t l0[2], u0[2];
 #pragma unroll
@@ -637,10 +646,22 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 		mm[h] = group_member(G, t, x, sym2[h], orda);
 		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
-			uint64_t d[6];
-			range_counts<SPARSE>(oldp, rp, l0[h], u0[h], d);
-			for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
+			const bool small = u0[h] - l0[h] <= 4 * 2 * SPW && (SPARSE || (u0[h] - 1) / LEAF == l0[h] / LEAF);
+			uint32_t q = QCAP;
+			if (!small) q = atomicAdd(&s_nq, 1u);
+			if (q < (uint32_t)QCAP) { s_ql[q] = l0[h]; s_qu[q] = u0[h]; s_qx[q] = (uint16_t)x; }
+			else {
+				uint64_t d[6];
+				range_counts<SPARSE>(oldp, rp, l0[h], u0[h], d);
+				for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
+			}
 		}
+	}
+	__syncthreads();
+	for (uint32_t q = wave_id(), nq = min(s_nq, (uint32_t)QCAP); q < nq; q += 4) {   // wave-uniform loop
+		uint64_t d[6];
+		wave_range_counts<SPARSE>(oldp, rp, s_ql[q], s_qu[q], d);
+		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[s_qx[q]][s] = d[s];
 	}
 	__syncthreads();
 #pragma unroll
@@ -1084,6 +1105,24 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uin
 		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed, genome_len) << ((k & 3) * 8);
 		*(uint4*)(dst + g0) = make_uint4(w[0], w[1], w[2], w[3]);
 	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed, genome_len);
+}
+
+// one wave per query: counts of the six symbols in [0, x[i]) of ROPE b (its pieces (b,$), (b,A), ... in order)
+__global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, PoolView pv, int b, const uint64_t *x, uint64_t n, uint64_t *out, int sparse)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * MW + (threadIdx.x >> 6);
+	if (i >= n) return;
+	uint64_t p = x[i], acc[6] = {0, 0, 0, 0, 0, 0};
+	for (int r = 0; r < NR && p > 0; ++r) {
+		if (rope_sym(r) != b) continue;
+		const RopeDesc &d = ctl->rope[side][r];
+		uint64_t c[6];
+		if (p >= d.n) { for (int s = 0; s < 6; ++s) acc[s] += d.cnt[s]; p -= d.n; continue; }
+		if (sparse) wave_rank_all<true>(pv, d, p, c); else wave_rank_all<false>(pv, d, p, c);
+		for (int s = 0; s < 6; ++s) acc[s] += c[s];
+		p = 0;
+	}
+	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
 __global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out, int sparse)

@@ -39,6 +39,7 @@ def load_hip_lib():
         "rb2_hip_stream_rope": (i64, [vp, i32, vp, vp]),
         "rb2_hip_load_ropes": (None, [vp, vp, vp]),
         "rb2_hip_rank1a": (None, [vp, i32, i64, vp]),
+        "rb2_hip_rank_batch": (None, [vp, i32, i64, vp, vp]),
         "rb2_hip_reserve": (None, [vp, i64, i64, i64]),
         "rb2_hip_num_subropes": (i32, []),
         "rb2_hip_shard_setup": (None, [vp, i32, i32, vp]),
@@ -71,7 +72,7 @@ def load_hip_lib():
 ABI_SYMBOLS = [
     "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
-    "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_reserve", "rb2_hip_dev_alloc",
+    "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy",
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_profile",
@@ -176,6 +177,14 @@ class HipBwt:
         c = np.zeros(6, np.int64)
         self.L.rb2_hip_rank1a(self.h, b, x, c.ctypes.data)
         return c
+
+    def rank_batch(self, b, xs):
+        """counts of the six symbols in [0, x) of rope b for every x in xs (one launch, one wave per query)"""
+        xs = np.ascontiguousarray(xs, dtype=np.int64)
+        out = np.zeros((len(xs), 6), np.int64)
+        if len(xs):
+            self.L.rb2_hip_rank_batch(self.h, b, len(xs), xs.ctypes.data, out.ctypes.data)
+        return out
 
     # -- measurement helpers ----------------------------------------------------------------
     def dev_alloc(self, nbytes):

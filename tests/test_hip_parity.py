@@ -488,3 +488,39 @@ def test_sparse_engages_on_long_reads(hip):
             os.environ["RB2_SPARSE_LAMBDA"] = old
     st = g.sparse_stats()
     assert st["sparse_rounds"] > 1000 and st["relayouts"] >= 1, st
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_rank_batch_matches_oracle(hip, sparse):
+    """rb2_hip_rank_batch (one wave per query, wave_rank_all) on both leaf layouts against a bincount of the oracle's ropes"""
+    reads = H.repetitive_reads(6000, seed=8, genome_len=900, max_len=120) + [[1] * 400] * 30
+    if sparse:
+        with _ForcedSparse():
+            o, dev = run_both(hip, 2, [H.encode_batch(reads[:3000]), H.encode_batch(reads[3000:], True, True)])
+    else:
+        o, dev = run_both(hip, 2, [H.encode_batch(reads[:3000]), H.encode_batch(reads[3000:], True, True)])
+    rng = np.random.RandomState(5)
+    for b in range(6):
+        r = o.rope(b)
+        xs = np.concatenate([[0, 1, len(r) - 1, len(r), len(r) + 5], rng.randint(0, len(r) + 1, size=300)]).clip(0, None)
+        got = dev.rank_batch(b, xs)
+        cum = np.zeros((len(r) + 1, 6), np.int64)
+        for s in range(6):
+            cum[1:, s] = np.cumsum(r == s)
+        assert np.array_equal(got, cum[np.minimum(xs, len(r))]), "rope %d" % b
+        assert np.array_equal(dev.rank1a(b, int(xs[7])), got[7])
+
+
+@pytest.mark.parametrize("so", [1, 2])
+def test_huge_groups_long_intervals(hip, so):
+    """amplicon-like input: thousands of identical and near-identical reads -> every round has intervals of thousands of rows,
+    most of them spanning leaves: the wave-cooperative interval counts of k_prep (wave_range_counts) do the work"""
+    rng = np.random.RandomState(12)
+    base = list(rng.randint(1, 5, size=150))
+    reads = []
+    for i in range(9000):
+        r = list(base)
+        if i % 3 == 0:
+            r[int(rng.randint(150))] = int(rng.randint(1, 5))
+        reads.append(r[int(rng.randint(0, 20)):])
+    run_both(hip, so, [H.encode_batch(reads[:4000]), H.encode_batch(reads[4000:], True, so == 2)])
