@@ -625,15 +625,16 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 	}
 	// Non-empty intervals: the members of a group share [l, u) (mrope.c:192-202), so rope_rank2a is evaluated once per
 	// group and tile -- by the group's first member inside the tile -- and handed to the others through LDS.
-	// Short intervals inside one leaf (the bulk: a handful of rows) are counted by the lead thread itself, scanning only the
-	// interval; long ones and those that span leaves are queued and served by whole WAVES (wave_range_counts: one coalesced
-	// 512-byte load per leaf, bit-plane popcounts per lane, packed DPP reductions) -- their cost does not grow with the interval.
-	__shared__ uint64_t s_d[AE ? 1 : STILE][6];                // #s in [l, u) of the group led by string x of the tile
-	constexpr int QCAP = 128;                                  // queue slots; a tile with more long queries counts the rest with single threads
-	__shared__ uint64_t s_ql[AE ? 1 : QCAP], s_qu[AE ? 1 : QCAP];
-	__shared__ uint16_t s_qx[AE ? 1 : QCAP];
-	__shared__ uint32_t s_nq;
-	if (threadIdx.x == 0) s_nq = 0;                            // (ordered before the appends by the barriers of group_setup... made explicit below)
+	// The lead threads only POST their query (l, u) in the group's LDS slot and append the slot to one of two lists; then
+	//   - short intervals inside one leaf (the bulk: a handful of rows) are counted by consecutive threads, one query each,
+	//     scanning only the interval (range_counts) -- the leads are scattered over all waves of the tile, the list is dense,
+	//     so one or two waves run the scan instead of all of them;
+	//   - long intervals and those that span leaves are served by whole WAVES (wave_range_counts: one coalesced 512-byte load
+	//     per leaf, bit-plane popcounts per lane, packed DPP reductions): their cost does not grow with the interval.
+	__shared__ uint64_t s_d[AE ? 1 : STILE][6];                // in: [0] = l, [1] = u; out: #s in [l, u) of the group led by string x of the tile
+	__shared__ uint16_t s_qs[AE ? 1 : STILE], s_qw[AE ? 1 : STILE];
+	__shared__ uint32_t s_ns, s_nw;
+	if (threadIdx.x == 0) { s_ns = 0; s_nw = 0; }
 	__syncthreads();
 	Member mm[2];
 	uint64_t l0[2], u0[2];
@@ -647,21 +648,23 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
 			const bool small = u0[h] - l0[h] <= 4 * 2 * SPW && (SPARSE || (u0[h] - 1) / LEAF == l0[h] / LEAF);
-			uint32_t q = QCAP;
-			if (!small) q = atomicAdd(&s_nq, 1u);
-			if (q < (uint32_t)QCAP) { s_ql[q] = l0[h]; s_qu[q] = u0[h]; s_qx[q] = (uint16_t)x; }
-			else {
-				uint64_t d[6];
-				range_counts<SPARSE>(oldp, rp, l0[h], u0[h], d);
-				for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
-			}
+			s_d[x][0] = l0[h]; s_d[x][1] = u0[h];
+			if (small) s_qs[atomicAdd(&s_ns, 1u)] = (uint16_t)x; else s_qw[atomicAdd(&s_nw, 1u)] = (uint16_t)x;
 		}
 	}
 	__syncthreads();
-	for (uint32_t q = wave_id(), nq = min(s_nq, (uint32_t)QCAP); q < nq; q += 4) {   // wave-uniform loop
+	for (uint32_t i = threadIdx.x; i < s_ns; i += 256) {
+		const int x = s_qs[i];
 		uint64_t d[6];
-		wave_range_counts<SPARSE>(oldp, rp, s_ql[q], s_qu[q], d);
-		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[s_qx[q]][s] = d[s];
+		range_counts<SPARSE>(oldp, rp, s_d[x][0], s_d[x][1], d);
+		for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
+	}
+	for (uint32_t q = wave_id(); q < s_nw; q += 4) {           // wave-uniform loop
+		const int x = s_qw[q];
+		uint64_t d[6];
+		wave_range_counts<SPARSE>(oldp, rp, s_d[x][0], s_d[x][1], d);
+		__builtin_amdgcn_wave_barrier();
+		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
 	}
 	__syncthreads();
 #pragma unroll
