@@ -906,13 +906,20 @@ namespace rb2 {
 
 // one wave per TWO superblocks (lanes 0-31 / 32-63): per-leaf counts -> exclusive prefix inside the superblock;
 // superblock totals.  Counts are <= LEAF per leaf, prefixes < 2^16: two symbols per packed DPP scan.
-__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot)
+// touch != nullptr (sparse rounds): only superblocks that k_merge_leaf stamped this round changed; the prefixes and the total
+// of every other one are still right (sbtot persists between rounds), so the wave returns after one 8-byte load.
+__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot, const uint32_t *touch, uint32_t stamp)
 {
 	const int ln = lane_id();
 	const uint64_t sb = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2 + (ln >> 5);
 	const uint64_t nsb = ctl->nsb_total;
 	if (sb - (ln >> 5) >= nsb) return;                        // wave-uniform
 	const bool live = sb < nsb;
+	if (touch) {
+		if (ctl->overflow) return;                             // void round
+		const uint64_t sbA0 = sb - (ln >> 5);
+		if (touch[sbA0] != stamp && (sbA0 + 1 >= nsb || touch[sbA0 + 1] != stamp)) return;   // wave-uniform
+	}
 	const uint64_t gl = sb * SB + (ln & 31);
 	// sub-ropes start on superblock boundaries, in ascending order: the one that owns a superblock is the
 	// last with sb0 <= sb (one strided load + ballot per half, see seg_of); its tail leaves may be padding

@@ -264,7 +264,7 @@ __device__ __forceinline__ void leaf_insert_few(const LeafDesc &d, const int ln,
 // rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts the
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
 __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF, uint32_t *touch, uint32_t stamp)
 {
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
 	if (ctl->overflow || gw >= ctl->nwork) return;
 	const LeafDesc d = LD[gw];
+	if (ln == 0) touch[d.gl / SB] = stamp;                     // this superblock's prefixes must be rebuilt (k_meta_sb)
 	if (d.ni <= LIGHT_NI) { leaf_insert_few(d, ln, pool, INS_E, INS_A, RKREL, RKLEAF); return; }
 	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;                 // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
 	uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);             // 64 flag words of 32 bits
