@@ -287,7 +287,22 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 	Loc r; r.gl = rp.leaf0; r.s = 0; r.n = 0;
 	if (rp.nleaves == 0) return r;
 	const uint64_t nsb = (rp.nleaves + SB - 1) / SB, base = pv.sbpos[rp.sb0];
-	uint64_t lo = 0, hi = nsb - 1;
+	// superblocks hold about the same number of symbols each (a re-layout fills them evenly, inserts land at random), so start
+	// from the interpolated guess and gallop: a handful of probes instead of log2(nsb); still O(log distance) on skewed pieces
+	uint64_t lo, hi;
+	{
+		uint64_t g = rp.n ? (uint64_t)((double)p / (double)rp.n * (double)nsb) : 0;
+		if (g >= nsb) g = nsb - 1;
+		if (pv.sbpos[rp.sb0 + g] - base <= p) {                  // answer in [g, nsb): gallop up
+			uint64_t step = 1; lo = g;
+			while (lo + step < nsb && pv.sbpos[rp.sb0 + lo + step] - base <= p) { lo += step; step <<= 1; }
+			hi = min(lo + step, nsb) - 1;                          // sbpos[lo] <= p; everything above hi is > p
+		} else {                                                   // answer in [0, g): gallop down
+			uint64_t step = 1; hi = g - 1;                         // g > 0 here: sbpos[sb0] - base == 0 <= p
+			while (hi >= step && pv.sbpos[rp.sb0 + hi - step + 1] - base > p) { hi -= step; step <<= 1; }
+			lo = hi >= step ? hi - step + 1 : 0;                   // sbpos[lo] <= p (lo == 0 at worst); everything above hi is > p
+		}
+	}
 	while (lo < hi) {
 		const uint64_t mid = (lo + hi + 1) >> 1;
 		if (pv.sbpos[rp.sb0 + mid] - base <= p) lo = mid; else hi = mid - 1;
