@@ -122,6 +122,12 @@ void    rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_c
 void    rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[]);
 void    rb2_hip_shard_end(rb2_hip_t *h);
 void    rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind);
+/* stream-ordered variant (no host synchronisation between kernels and collectives; one per round for the caller to read the
+ * reduced matrix): run on the caller's stream and keep the count matrix in a caller-owned device buffer that is all-reduced
+ * in place.  With it: shard_counts(h, r, NULL); all_reduce(gcnt_dev); copy gcnt_dev to the host; shard_merge(h, r, host copy,
+ * send, nsend); all_to_all; shard_finish(...) -- merge and finish return while the device is still working. */
+void    rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream);       /* e.g. torch.cuda.current_stream().cuda_stream */
+void    rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev);     /* NR*6 int64 on this device; NULL switches back */
 
 /* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */
 

@@ -96,6 +96,9 @@ struct rb2_hip_s {
 	int debug = 0;
 	int cur_round = -1;
 	uint64_t *gcnt = nullptr;           // device: NR x 6 count matrix of the current round
+	uint64_t *gcnt_own = nullptr;       // ... the engine's own buffer while a caller-owned one is bound (rb2_hip_shard_async)
+	int async_proto = 0; bool own_stream = true;
+	uint64_t *pin_sd = nullptr; ShardPiece *pin_pcs = nullptr;   // pinned staging of the per-round exchange layout (async protocol)
 	int rank = 0, nranks = 1; int owner[NR] = {0};
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;
@@ -467,9 +470,11 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
+	if (h->gcnt_own) h->gcnt = h->gcnt_own;
+	if (h->pin_sd) { HIPCHK(hipHostFree(h->pin_sd)); HIPCHK(hipHostFree(h->pin_pcs)); }
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
 	for (int i = 0; i < 2; ++i) if (h->xhost[i]) { HIPCHK(hipHostFree(h->xhost[i])); HIPCHK(hipHostFree(h->xtot[i])); HIPCHK(hipEventDestroy(h->xev[i])); }
-	HIPCHK(hipStreamDestroy(h->st));
+	if (h->own_stream) HIPCHK(hipStreamDestroy(h->st));
 	delete h;
 }
 
@@ -729,8 +734,41 @@ void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt)
 	HIPCHK(hipSetDevice(h->dev));
 	BatchState &B = *(BatchState*)h->batch;
 	round_counts(h, B, (uint64_t)round);
+	if (h->async_proto && !local_cnt) return;                  /* stream-ordered protocol: the caller reduces the bound device buffer in place */
 	HIPCHK(hipMemcpyAsync(local_cnt, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
+}
+
+/* ---- stream-ordered variant of the protocol ------------------------------------------------------------
+ * rb2_hip_use_stream: run everything on the caller's stream (e.g. torch's current stream, on which RCCL collectives are
+ * ordered), so that kernels and collectives need no host synchronisation between them.
+ * rb2_hip_shard_async: bind a caller-owned device buffer (NR*6 int64) as the count matrix: shard_counts(h, r, NULL) leaves
+ * this rank's rows there, the caller all-reduces it IN PLACE on the same stream, shard_merge then reads it from the device
+ * (its host copy is only used to lay out the exchange); shard_merge / shard_finish return without waiting for the device.
+ * One host synchronisation per round remains: the caller reading the reduced matrix to size the uneven all-to-all. */
+void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (h->own_stream) { HIPCHK(hipStreamDestroy(h->st)); h->own_stream = false; }
+	h->st = (hipStream_t)hip_stream;
+}
+
+void rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipStreamSynchronize(h->st));
+	if (gcnt_dev) {
+		if (!h->gcnt_own) h->gcnt_own = h->gcnt;
+		h->gcnt = (uint64_t*)gcnt_dev; h->async_proto = 1;
+		if (!h->pin_sd) {
+			HIPCHK(hipHostMalloc((void**)&h->pin_sd, 2 * NR * 6 * 8, hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void**)&h->pin_pcs, 2 * sizeof(ShardPiece) * 64 * NR * 6, hipHostMallocDefault));
+		}
+	} else {
+		if (h->gcnt_own) h->gcnt = h->gcnt_own;
+		h->async_proto = 0;
+	}
 }
 
 /* where the members of (piece r -> symbol a) sit in the send buffer of rank `src`: per destination rank d,
@@ -761,12 +799,13 @@ void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt,
 	memset(off, 0, sizeof(off));
 	if (h->nranks > 64) { fprintf(stderr, "[rb2_hip] too many ranks\n"); abort(); }
 	shard_layout(h->owner, h->nranks, h->rank, global_cnt, off, send_counts, start);
-	uint64_t sd[NR][6];
+	uint64_t sd_stack[NR][6];
+	uint64_t (*sd)[6] = h->async_proto ? (uint64_t (*)[6])(h->pin_sd + (round & 1) * NR * 6) : sd_stack;   /* async: the copy outlives this call */
 	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) sd[r][a] = (uint64_t)off[r][a];
-	HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, NR * 6 * 8, hipMemcpyHostToDevice, h->st));
-	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd), hipMemcpyHostToDevice, h->st));
+	if (!h->async_proto) HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, NR * 6 * 8, hipMemcpyHostToDevice, h->st));   /* async: already reduced in place on the device */
+	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd_stack), hipMemcpyHostToDevice, h->st));
 	round_merge(h, B, (uint64_t)round, (ShardRec*)send_dev);
-	HIPCHK(hipStreamSynchronize(h->st));                       /* the send buffer is complete (and sd / global_cnt consumed) when we return */
+	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));  /* the send buffer is complete (and sd / global_cnt consumed) when we return */
 }
 
 void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[])
@@ -805,13 +844,20 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 	}
 	if (base > 0) {
 		std::sort(pcs.begin(), pcs.end(), [](const ShardPiece &x, const ShardPiece &y) { return x.src < y.src; });
-		h->pieces.ensure(pcs.size() + 1);
-		HIPCHK(hipMemcpyAsync(h->pieces.p, pcs.data(), pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
+		const ShardPiece *src = pcs.data();
+		if (h->async_proto) {                                   /* the copy outlives this call: stage in pinned memory, and never reallocate the device list mid-batch */
+			if (pcs.size() > (size_t)64 * NR * 6) { fprintf(stderr, "[rb2_hip] shard_finish: too many exchange pieces\n"); abort(); }
+			ShardPiece *pin = h->pin_pcs + (round & 1) * 64 * NR * 6;
+			memcpy(pin, pcs.data(), pcs.size() * sizeof(ShardPiece));
+			src = pin;
+			if (h->pieces.cap < (size_t)64 * NR * 6 + 1) { HIPCHK(hipStreamSynchronize(h->st)); h->pieces.ensure((size_t)64 * NR * 6 + 1); }
+		} else h->pieces.ensure(pcs.size() + 1);
+		HIPCHK(hipMemcpyAsync(h->pieces.p, src, pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
 		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
 		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->START.p, (uint32_t)round,
 				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
 	}
-	HIPCHK(hipStreamSynchronize(h->st));
+	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));
 }
 
 void rb2_hip_shard_end(rb2_hip_t *h)

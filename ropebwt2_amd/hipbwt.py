@@ -50,6 +50,8 @@ def load_hip_lib():
         "rb2_hip_shard_finish": (None, [vp, i64, vp, vp, vp]),
         "rb2_hip_shard_end": (None, [vp]),
         "rb2_hip_memcpy": (None, [vp, vp, vp, i64, i32]),
+        "rb2_hip_use_stream": (None, [vp, vp]),
+        "rb2_hip_shard_async": (None, [vp, vp]),
         "rb2_hip_dev_alloc": (vp, [vp, i64]),
         "rb2_hip_dev_free": (None, [vp, vp]),
         "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
@@ -74,7 +76,7 @@ ABI_SYMBOLS = [
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
-    "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy",
+    "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
 ]

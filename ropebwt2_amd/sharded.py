@@ -19,6 +19,7 @@ tensors, or gloo with host staging) or by ``VirtualCluster`` (N engines in one p
 -- how the sharded path is validated bit-for-bit on a single-GPU box).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -185,6 +186,8 @@ class TorchComm:
         return self.recv_t.data_ptr() if self.on_device else self.recv_dev
 
     def insert_multi_dev(self, dev_ptr, nbytes):
+        if self.on_device and os.environ.get("RB2_SHARD_PROTOCOL", "async") != "sync" and hasattr(self.bwt, "h"):
+            return self._insert_stream_ordered(dev_ptr, nbytes)
         torch, dist, bwt = self.torch, self.dist, self.bwt
         gen = bwt.batch_protocol(dev_ptr, nbytes, self.send_ptr, self.recv_ptr)
         msg = next(gen)
@@ -209,6 +212,37 @@ class TorchComm:
                     msg = next(gen)
         except StopIteration:
             pass
+
+
+    def _insert_stream_ordered(self, dev_ptr, nbytes):
+        """RCCL path without host round trips between kernels and collectives (rb2_hip_use_stream / rb2_hip_shard_async):
+        the engine runs on torch's current stream, the count matrix lives in a device tensor that is all-reduced in place,
+        the merge kernels, the all_to_all and the unpack kernel are ordered by the stream.  The host synchronises ONCE per
+        round -- it needs the reduced matrix to size the uneven all_to_all."""
+        torch, dist, bwt = self.torch, self.dist, self.bwt
+        L, h = bwt.L, bwt.h
+        if getattr(self, "gc", None) is None:
+            self.gc = torch.zeros(NR * 6, dtype=torch.int64, device=self.dev)
+            L.rb2_hip_use_stream(h, torch.cuda.current_stream().cuda_stream)
+            L.rb2_hip_shard_async(h, self.gc.data_ptr())
+        rounds = L.rb2_hip_shard_begin(h, nbytes, dev_ptr)
+        cap = L.rb2_hip_shard_capacity(h)
+        send_ptr, recv_ptr = self.send_ptr(cap), self.recv_ptr(cap)
+        E = self.EPR
+        for r in range(rounds):
+            L.rb2_hip_shard_counts(h, r, None)
+            dist.all_reduce(self.gc)
+            g = np.ascontiguousarray(self.gc.cpu().numpy())           # the one synchronisation of the round
+            nsend = (C.c_int64 * bwt.nranks)()
+            L.rb2_hip_shard_merge(h, r, g.ctypes.data, send_ptr, nsend)
+            cnt = np.tensordot(bwt.xt, g.reshape(NR, 6), axes=([2, 3], [0, 1]))
+            sc, rc = [int(x) for x in cnt[bwt.rank]], [int(x) for x in cnt[:, bwt.rank]]
+            assert list(nsend) == sc
+            if int(cnt.sum()):
+                dist.all_to_all_single(self.recv_t[:sum(rc) * E], self.send_t[:sum(sc) * E], [c * E for c in rc], [c * E for c in sc])
+            nrecv = (C.c_int64 * bwt.nranks)(*rc)
+            L.rb2_hip_shard_finish(h, r, g.ctypes.data, recv_ptr, nrecv)
+        L.rb2_hip_shard_end(h)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -307,3 +341,59 @@ class VirtualCluster:
     def rope(self, b):
         from .hipbwt import expand_runs
         return expand_runs(self.rope_rle(b))
+
+
+class StreamOrderedCluster(VirtualCluster):
+    """N engines on one device driven through the STREAM-ORDERED protocol (rb2_hip_use_stream + rb2_hip_shard_async): every
+    engine runs on torch's current stream, the count matrices are device tensors, and the two collectives are plain torch
+    ops on that stream (a sum for the all_reduce, slice copies for the all_to_all).  Same engine calls, same absence of
+    host synchronisation as TorchComm over RCCL -- on a box with one GPU."""
+
+    def __init__(self, sorting_order, nranks, device=0, owners=None):
+        super().__init__(sorting_order, nranks, device, owners)
+        import torch
+        self.torch = torch
+        torch.cuda.set_device(device)
+        self.dev = torch.device("cuda", device)
+        st = torch.cuda.current_stream().cuda_stream
+        self.gc = [torch.zeros(NR * 6, dtype=torch.int64, device=self.dev) for _ in range(nranks)]
+        for r, g in zip(self.ranks, self.gc):
+            r.L.rb2_hip_use_stream(r.h, st)
+            r.L.rb2_hip_shard_async(r.h, g.data_ptr())
+        self.tx = self.rx = None
+
+    def insert_multi_dev(self, dev_ptr, nbytes):
+        torch, n = self.torch, self.n
+        L = self.ranks[0].L
+        rounds = [L.rb2_hip_shard_begin(r.h, nbytes, dev_ptr) for r in self.ranks]
+        assert len(set(rounds)) == 1
+        cap = max(L.rb2_hip_shard_capacity(r.h) for r in self.ranks)
+        if self.tx is None or self.tx[0].numel() < cap * 2:
+            self.tx = [torch.empty(max(1, cap) * 2, dtype=torch.int64, device=self.dev) for _ in range(n)]
+            self.rx = [torch.empty(max(1, cap) * 2, dtype=torch.int64, device=self.dev) for _ in range(n)]
+        xt = self.ranks[0].xt
+        for rd in range(rounds[0]):
+            for r in self.ranks:
+                L.rb2_hip_shard_counts(r.h, rd, None)
+            tot = torch.stack(self.gc).sum(0)                        # all_reduce, in place on every rank's tensor
+            for g in self.gc:
+                g.copy_(tot)
+            gh = np.ascontiguousarray(tot.cpu().numpy())             # the one synchronisation of the round
+            cnt = np.tensordot(xt, gh.reshape(NR, 6), axes=([2, 3], [0, 1]))      # [src, dst]
+            for k, r in enumerate(self.ranks):
+                nsend = (C.c_int64 * n)()
+                L.rb2_hip_shard_merge(r.h, rd, gh.ctypes.data, self.tx[k].data_ptr(), nsend)
+                assert list(nsend) == [int(x) for x in cnt[k]]
+            for d in range(n):                                       # all_to_all: slice copies on the same stream
+                off = 0
+                for s_ in range(n):
+                    c = int(cnt[s_, d])
+                    if c:
+                        so = int(cnt[s_, :d].sum())
+                        self.rx[d][off * 2:(off + c) * 2].copy_(self.tx[s_][so * 2:(so + c) * 2])
+                    off += c
+            for k, r in enumerate(self.ranks):
+                nrecv = (C.c_int64 * n)(*[int(x) for x in cnt[:, k]])
+                L.rb2_hip_shard_finish(r.h, rd, gh.ctypes.data, self.rx[k].data_ptr(), nrecv)
+        for r in self.ranks:
+            L.rb2_hip_shard_end(r.h)

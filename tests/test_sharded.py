@@ -178,3 +178,37 @@ def test_processes_over_rccl(hip, so):
     out = p.stdout.decode()
     assert p.returncode == 0, out
     assert out.count("backend nccl") >= n and out.count(" ok") >= n, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("so", [0, 1, 2])
+@pytest.mark.parametrize("n", [2, 8])
+def test_stream_ordered_protocol(hip, so, n):
+    """the protocol TorchComm uses over RCCL (engine on the caller's stream, count matrix reduced in place in a device tensor, no
+    host synchronisation around merge / exchange / unpack) with N engines on one device and torch ops as collectives"""
+    from ropebwt2_amd.sharded import StreamOrderedCluster
+    reads = H.repetitive_reads(3000, seed=160 + so, genome_len=800, max_len=100)
+    codes = H.splitmix_bases(4000, 75, seed=13)
+    batches = [H.encode_batch(reads[:1800]), H.encode_batch_fixed(codes), H.encode_batch(reads[1800:], True, True)]
+    o = H.Oracle(so)
+    vc = StreamOrderedCluster(so, n)
+    for buf in batches:
+        o.insert_multi(buf)
+        vc.insert_multi(buf)
+        assert np.array_equal(vc.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(vc.rope(b), o.rope(b)), "rope %d" % b
+    vc.close()
+
+
+@pytest.mark.gpu
+def test_stream_ordered_protocol_golden_1M(hip, golden):
+    from ropebwt2_amd.sharded import StreamOrderedCluster
+    g = golden["sets"]["1M_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    vc = StreamOrderedCluster(2, 8)
+    vc.insert_multi(H.encode_batch_fixed(codes[:600000], True, True))
+    vc.insert_multi(H.encode_batch_fixed(codes[600000:], True, True))
+    bwt = np.concatenate([vc.rope(b) for b in range(6)])
+    assert H.md5(H.bwt_text(bwt) + b"\n") == g["text_md5"]["-Lr"]
+    vc.close()
