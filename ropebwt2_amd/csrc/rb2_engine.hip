@@ -71,7 +71,8 @@ struct rb2_hip_s {
 	double sp_lambda = 0.6;             // go sparse when (strings per round) / (leaves of the index) falls below this
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
 	int sp_maxpen = 12;
-	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round
+	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
+	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
 	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
 	Ctl *ctl = nullptr;                 // device
@@ -230,6 +231,27 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	HIPCHK(hipStreamSynchronize(st));
 }
 
+// Once no string of the batch has a non-empty interval, none ever will again (u' = l' + 0): ctl->ne is monotone inside a batch.
+// Every round leaves a snapshot of it in a pinned ring WITHOUT synchronising; a snapshot that has landed and reads "the next
+// round sees only empty intervals" lets the host launch only the all-empty variants of k_prep / k_advance from then on
+// (a stale snapshot only delays that).  Before: both variants every round, the wrong one returning at once (2 x ~18 us).
+void ne_snapshot(rb2_hip_t *h, uint64_t r)
+{
+	uint32_t *slot = h->h_flag + 16 + 2 * (r % rb2_hip_s::NE_RING);
+	slot[0] = slot[1] = 0xffffffffu;                           // "not landed yet"
+	HIPCHK(hipMemcpyAsync(slot, &h->ctl->ne[0], 8, hipMemcpyDeviceToHost, h->st));
+}
+bool ne_all_empty_from(rb2_hip_t *h, uint64_t r)               // may round r (and all later ones) skip the non-AE variants?
+{
+	for (uint64_t q = r; q-- > 0 && r - q < (uint64_t)rb2_hip_s::NE_RING; ) {
+		const volatile uint32_t *slot = h->h_flag + 16 + 2 * (q % rb2_hip_s::NE_RING);
+		const uint32_t v = slot[(q & 1) ^ 1];                  // after round q: ne[(q&1)^1] is the flag of round q + 1
+		if (v == 0) return true;
+		if (v != 0xffffffffu) return false;                    // the newest snapshot that landed says "still non-empty intervals"
+	}
+	return false;
+}
+
 // phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
 void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 {
@@ -280,6 +302,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
 	  hipLaunchKernelGGL((k_advance<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+	if (!B.known_ae && !send) ne_snapshot(h, r);
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
 }
 
@@ -353,6 +376,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	// The verdict of the round (did every leaf fit?) travels to pinned host memory behind the last kernel.  While it is on its
 	// way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch, and a void round r is
 	// redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues the next merge.
+	if (!B.known_ae) ne_snapshot(h, r);
 	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipEventRecord(h->ev_flag, st));
 	h->side ^= 1; B.cur ^= 1;
@@ -381,6 +405,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	BatchState B;
 	batch_begin(h, B, len64, s);
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
+		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
 		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
 		const double lambda = (double)B.m / ((double)n_ub / LEAF + 1.0);
 		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0;
@@ -448,7 +473,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
 	HIPCHK(hipMalloc((void**)&h->gcnt, NR * 6 * 8));
-	HIPCHK(hipHostMalloc((void**)&h->h_flag, 64, hipHostMallocDefault));
+	HIPCHK(hipHostMalloc((void**)&h->h_flag, 64 + 8 * rb2_hip_s::NE_RING, hipHostMallocDefault));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));

@@ -1135,13 +1135,4 @@ __global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, Po
 	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
-__global__ void k_rank1(const Ctl *ctl, int side, PoolView pv, int b, uint64_t x, uint64_t *out, int sparse)
-{
-	if (threadIdx.x || blockIdx.x) return;
-	uint64_t c[6];
-	if (sparse) rank_all<true>(pv, ctl->rope[side][b], x, c);
-	else rank_all<false>(pv, ctl->rope[side][b], x, c);
-	for (int s = 0; s < 6; ++s) out[s] = c[s];
-}
-
 } // namespace rb2
