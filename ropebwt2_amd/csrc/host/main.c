@@ -14,6 +14,7 @@
 #include <unistd.h>
 #include <sys/resource.h>
 #include <sys/time.h>
+#include <pthread.h>
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_fmd.h"
@@ -155,6 +156,114 @@ static int is_own_revcomp(int l, const uint8_t *s)      /* even length and s == 
 
 enum { F_FOR = 1, F_REV = 2, F_ODD = 4, F_BIN = 8, F_TREE = 16, F_THR = 64, F_LINE = 256, F_RLD = 512, F_NON = 1024, F_CUTN = 4096 };
 
+/* ---- from a raw record to the strings handed to the index (main.c:184-237) --------------------- */
+typedef struct { int flag, min_q, min_cut, batch; } enc_cfg_t;
+
+/* everything between the reader and the strands: -L trimming, nt6 codes, quality masking, -N, reversal, -x / -C.  Works in
+ * place on s[0..l] (s[l] is writable).  Returns the new length, or -1 when the record is dropped. */
+static int prepare_record(const enc_cfg_t *c, uint8_t *s, int l, const char *qual, int qual_l)
+{
+	const int flag = c->flag;
+	int i;
+	if (flag & F_LINE) { for (i = 0; i < l && (((s[i] | 32) - 'a') < 26u); ++i); l = i; }   /* keep the leading letters (main.c:184-187) */
+	for (i = 0; i < l; ++i) s[i] = nt6_tab[s[i]];
+	if (!(flag & F_LINE) && qual_l && c->min_q > 0)
+		for (i = 0; i < l && i < qual_l; ++i) if (qual[i] - 33 < c->min_q) s[i] = 5;
+	if (flag & F_NON) { for (i = 0; i < l && s[i] != 5; ++i); if (i < l) return -1; }
+	for (i = 0; i < l / 2; ++i) { uint8_t t = s[i]; s[i] = s[l-1-i]; s[l-1-i] = t; }   /* the API wants reversed strings */
+	s[l] = 0;
+	if (flag & F_CUTN) {                                 /* split at N, drop short pieces (main.c:204-218) */
+		int k = 0, b = 0;
+		for (i = 0; i <= l; ++i) {
+			if (i == l || s[i] == 5) {
+				const int seg = i - b;
+				if (seg >= c->min_cut) {
+					if ((flag & F_ODD) && is_own_revcomp(seg, &s[k - seg])) --k;
+					s[k++] = 0;
+				} else k -= seg;
+				b = i + 1;
+			} else s[k++] = s[i];
+		}
+		if (--k <= 0) return -1;
+		l = k;
+	} else if ((flag & F_ODD) && is_own_revcomp(l, s)) {
+		if (l > 0) s[--l] = 0;
+		else if (c->batch) return -1;                    /* reference quirk (main.c:219-222): an empty read under -C vanishes in batch mode */
+	}
+	return l;
+}
+
+static void revcomp_in_place(uint8_t *s, int l)         /* reverse complement, again stored reversed: complement in place */
+{
+	int i;
+	for (i = 0; i < l / 2; ++i) { uint8_t t = (uint8_t)comp6(s[l-1-i]); s[l-1-i] = (uint8_t)comp6(s[i]); s[i] = t; }
+	if (l & 1) s[l/2] = (uint8_t)comp6(s[l/2]);
+}
+
+static void append_strands(const enc_cfg_t *c, uint8_t *s, int l, str_t *out)
+{
+	if (c->flag & F_FOR) str_append(out, (char*)s, l + 1);
+	if (c->flag & F_REV) { revcomp_in_place(s, l); str_append(out, (char*)s, l + 1); }
+}
+
+/* ---- -L input in batch mode: lines are independent, so blocks of whole lines are encoded by worker threads while the main
+ * thread reads ahead and appends the finished blocks, in order, to the batch buffer (same strings, same batch boundaries as
+ * the sequential loop; at GPU insert rates the text parser is the wall-clock of the whole program). ---- */
+typedef struct {
+	uint8_t *in; int64_t n_in, m_in; int extra_empty;    /* whole lines (the last one may lack its newline) + kseq's phantom empty line */
+	str_t out; uint32_t *rec_end; size_t n_rec, m_rec;   /* encoded strings; out offset after every record */
+	int state;                                           /* 0 free, 1 queued, 2 done */
+} pjob_t;
+typedef struct {
+	enc_cfg_t cfg; pjob_t *job; int njob;
+	int64_t next_work, n_queued; int closing;
+	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+} pparse_t;
+
+static void pjob_encode(const enc_cfg_t *cfg, pjob_t *jb)
+{
+	uint8_t *p = jb->in, *end = jb->in + jb->n_in;
+	jb->out.l = 0; jb->n_rec = 0;
+	str_reserve(&jb->out, (size_t)jb->n_in * (((cfg->flag & F_FOR) ? 1 : 0) + ((cfg->flag & F_REV) ? 1 : 0)) + 64);
+	while (p < end || jb->extra_empty) {
+		uint8_t *nl, *next;
+		int l;
+		if (p < end) {
+			nl = (uint8_t*)memchr(p, '\n', end - p);
+			next = nl ? nl + 1 : end;
+			if (!nl) nl = end;
+			l = (int)(nl - p);
+			if (l > 1 && p[l-1] == '\r') --l;               /* kseq.h:136 */
+		} else { jb->extra_empty = 0; next = end; l = 0; }    /* (in[n_in] is writable) */
+		l = prepare_record(cfg, p, l, 0, 0);
+		if (l >= 0) {
+			append_strands(cfg, p, l, &jb->out);
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
+		}
+		p = next;
+	}
+}
+
+static void *pparse_worker(void *arg)
+{
+	pparse_t *pp = (pparse_t*)arg;
+	pthread_mutex_lock(&pp->mu);
+	for (;;) {
+		pjob_t *jb;
+		while (pp->next_work >= pp->n_queued && !pp->closing) pthread_cond_wait(&pp->cv_work, &pp->mu);
+		if (pp->next_work >= pp->n_queued) break;
+		jb = &pp->job[pp->next_work++ % pp->njob];
+		pthread_mutex_unlock(&pp->mu);
+		pjob_encode(&pp->cfg, jb);
+		pthread_mutex_lock(&pp->mu);
+		jb->state = 2;
+		pthread_cond_broadcast(&pp->cv_done);
+	}
+	pthread_mutex_unlock(&pp->mu);
+	return 0;
+}
+
 static int usage(int block_len, int max_nodes)
 {
 	fprintf(stderr, "\nUsage:   ropebwt2-%s [options] <in.fq.gz>\n\n", RB2_VERSION);
@@ -183,6 +292,13 @@ static int usage(int block_len, int max_nodes)
 static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
 {
 	const double c0 = cputime(), r0 = realtime();
+	if (getenv("RB2_DUMP_BATCHES")) {                       /* debugging / tests of the readers without a GPU: the batches go to a file, nothing is inserted */
+		FILE *fp = fopen(getenv("RB2_DUMP_BATCHES"), "ab");
+		const int64_t n = (int64_t)buf->l;
+		if (fp) { fwrite(&n, 8, 1, fp); fwrite(buf->s, 1, buf->l, fp); fclose(fp); }
+		buf->l = 0;
+		return;
+	}
 	mr_insert_multi(mr, (int64_t)buf->l, (const uint8_t*)buf->s, flag & F_THR);
 	if (verbose >= 3) fprintf(stderr, "[M::%s] inserted %ld symbols in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", (long)buf->l, realtime() - r0, cputime() - c0);
 	buf->l = 0;
@@ -250,45 +366,95 @@ int main(int argc, char *argv[])
 	if (rd->fp == 0) { fprintf(stderr, "[E::%s] fail to open the input\n", __func__); return 1; }
 	ct = cputime(); rt = realtime();
 
+	{
+	enc_cfg_t cfg;
+	long pthr = sysconf(_SC_NPROCESSORS_ONLN) - 1;
+	cfg.flag = flag; cfg.min_q = min_q; cfg.min_cut = min_cut; cfg.batch = m != 0;
+	if (getenv("RB2_PARSE_THREADS")) pthr = atol(getenv("RB2_PARSE_THREADS"));
+	if (pthr > 16) pthr = 16;
+	if ((flag & F_LINE) && m && pthr > 1) {                 /* -L in batch mode: blocks of whole lines encoded by worker threads */
+		const int64_t CHUNK = getenv("RB2_PARSE_CHUNK") ? atol(getenv("RB2_PARSE_CHUNK")) : 16 << 20;
+		pparse_t pp;
+		pthread_t *th = (pthread_t*)calloc(pthr, sizeof(pthread_t));
+		uint8_t *carry = (uint8_t*)malloc(CHUNK + 16); int64_t n_carry = 0, m_carry = CHUNK + 16, total = 0, consumed = 0;
+		int k, last_byte = '\n', eof = 0;
+		memset(&pp, 0, sizeof(pp));
+		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
+		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0);
+		for (k = 0; k < pthr; ++k) pthread_create(&th[k], 0, pparse_worker, &pp);
+		while (!eof || consumed < pp.n_queued) {
+			/* 1. take over every finished block that is next in line (blocking only when there is nothing to read into) */
+			pthread_mutex_lock(&pp.mu);
+			while (consumed < pp.n_queued && (pp.job[consumed % pp.njob].state == 2 || eof || pp.n_queued - consumed >= pp.njob)) {
+				pjob_t *jb = &pp.job[consumed % pp.njob];
+				size_t done = 0, r0 = 0;
+				while (jb->state != 2) pthread_cond_wait(&pp.cv_done, &pp.mu);
+				pthread_mutex_unlock(&pp.mu);
+				while (done < jb->out.l) {                          /* same flush points as the sequential loop: after the record that fills the batch */
+					size_t lo = r0, hi = jb->n_rec;                 /* first record whose end reaches the threshold */
+					const int64_t need = m - (int64_t)buf.l;
+					while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((int64_t)(jb->rec_end[mid] - done) >= need) hi = mid; else lo = mid + 1; }
+					if (lo == jb->n_rec) { str_append(&buf, jb->out.s + done, jb->out.l - done); done = jb->out.l; }
+					else {
+						str_append(&buf, jb->out.s + done, jb->rec_end[lo] - done); done = jb->rec_end[lo]; r0 = lo + 1;
+						flush_batch(mr, &buf, flag, verbose);
+					}
+				}
+				pthread_mutex_lock(&pp.mu);
+				jb->state = 0; ++consumed;
+			}
+			pthread_mutex_unlock(&pp.mu);
+			if (eof) continue;
+			/* 2. read the next block, cut it behind its last newline, queue it */
+			{
+				pjob_t *jb = &pp.job[pp.n_queued % pp.njob];     /* free: the loop above keeps n_queued - consumed < njob */
+				int64_t got = 0, cut;
+				if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+				memcpy(jb->in, carry, n_carry);
+				while (got < CHUNK) {                             /* gzread may return short counts on pipes */
+					const int r = gzread(rd->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
+					if (r <= 0) { eof = 1; break; }
+					got += r;
+				}
+				total += got;
+				if (got) last_byte = jb->in[n_carry + got - 1];
+				jb->n_in = n_carry + got;
+				if (!eof) {                                       /* keep the unfinished last line for the next block */
+					for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
+					n_carry = jb->n_in - cut;                       /* (cut == 0: one line longer than a block -- everything is carried on) */
+					if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)realloc(carry, m_carry); }
+					memcpy(carry, jb->in + cut, n_carry);
+					jb->n_in = cut;
+				} else n_carry = 0;
+				/* kseq learns about the end of input only from a short refill (kseq.h:70-75, 96-105): an input of k x 16384 bytes
+				 * that ends with a newline (or is empty) yields one more, empty, line */
+				jb->extra_empty = eof && total % RD_BUF == 0 && last_byte == '\n';
+				if (jb->n_in > 0 || jb->extra_empty) {
+					pthread_mutex_lock(&pp.mu);
+					jb->state = 1; ++pp.n_queued;
+					pthread_cond_signal(&pp.cv_work);
+					pthread_mutex_unlock(&pp.mu);
+				}
+			}
+		}
+		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_mutex_unlock(&pp.mu);
+		for (k = 0; k < pthr; ++k) pthread_join(th[k], 0);
+		for (k = 0; k < pp.njob; ++k) { free(pp.job[k].in); free(pp.job[k].out.s); free(pp.job[k].rec_end); }
+		free(pp.job); free(th); free(carry);
+		pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done);
+	} else
 	while ((flag & F_LINE ? read_line_record(rd) : read_fastx_record(rd)) >= 0) {
 		uint8_t *s = (uint8_t*)rd->seq.s;
-		int l = (int)rd->seq.l;
-		if (flag & F_LINE) { for (i = 0; i < l && (((s[i] | 32) - 'a') < 26u); ++i); l = i; }   /* keep the leading letters (main.c:184-187) */
-		for (i = 0; i < l; ++i) s[i] = nt6_tab[s[i]];
-		if (!(flag & F_LINE) && rd->qual.l && min_q > 0)
-			for (i = 0; i < l && i < (int)rd->qual.l; ++i) if (rd->qual.s[i] - 33 < min_q) s[i] = 5;
-		if (flag & F_NON) { for (i = 0; i < l && s[i] != 5; ++i); if (i < l) continue; }
-		for (i = 0; i < l / 2; ++i) { uint8_t t = s[i]; s[i] = s[l-1-i]; s[l-1-i] = t; }   /* the API wants reversed strings */
-		s[l] = 0;
-		if (flag & F_CUTN) {                                 /* split at N, drop short pieces (main.c:204-218) */
-			int k = 0, b = 0;
-			for (i = 0; i <= l; ++i) {
-				if (i == l || s[i] == 5) {
-					const int seg = i - b;
-					if (seg >= min_cut) {
-						if ((flag & F_ODD) && is_own_revcomp(seg, &s[k - seg])) --k;
-						s[k++] = 0;
-					} else k -= seg;
-					b = i + 1;
-				} else s[k++] = s[i];
-			}
-			if (--k <= 0) continue;
-			l = k;
-		} else if ((flag & F_ODD) && is_own_revcomp(l, s)) {
-			if (l > 0) s[--l] = 0;
-			else if (m) continue;                            /* reference quirk (main.c:219-222): an empty read under -C vanishes in batch mode */
+		int l = prepare_record(&cfg, s, (int)rd->seq.l, rd->qual.s, (int)rd->qual.l);
+		if (l < 0) continue;
+		if (m) {
+			append_strands(&cfg, s, l, &buf);
+			if ((int64_t)buf.l >= m) flush_batch(mr, &buf, flag, verbose);
+		} else {
+			if (flag & F_FOR) mr_insert1(mr, s);
+			if (flag & F_REV) { revcomp_in_place(s, l); mr_insert1(mr, s); }
 		}
-		if (flag & F_FOR) {
-			if (m) str_append(&buf, (char*)s, l + 1);
-			else mr_insert1(mr, s);
-		}
-		if (flag & F_REV) {                                  /* reverse complement, again stored reversed: complement in place */
-			for (i = 0; i < l / 2; ++i) { uint8_t t = (uint8_t)comp6(s[l-1-i]); s[l-1-i] = (uint8_t)comp6(s[i]); s[i] = t; }
-			if (l & 1) s[l/2] = (uint8_t)comp6(s[l/2]);
-			if (m) str_append(&buf, (char*)s, l + 1);
-			else mr_insert1(mr, s);
-		}
-		if (m && (int64_t)buf.l >= m) flush_batch(mr, &buf, flag, verbose);
+	}
 	}
 	if (m && buf.l) flush_batch(mr, &buf, flag, verbose);
 	if (verbose >= 3) {

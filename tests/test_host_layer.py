@@ -320,3 +320,53 @@ def test_cli_fmd_small_segments_m0(golden):
         env = dict(os.environ, RB2_FMD_SEGMENT=seg, RB2_FMD_THREADS=thr)
         p = subprocess.run([CLI, "-LRsd", "-m0", "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert p.returncode == 0 and H.md5(p.stdout) == g["fmd_md5"]["-LRsd"]
+
+
+# ---- the -L reader in batch mode: worker threads encode blocks of whole lines; same strings, same batch boundaries ---------------
+
+def _dump_batches(flags, data, env, tmp_path, tag):
+    f = tmp_path / ("batches_%s.bin" % tag)
+    if f.exists():
+        f.unlink()
+    e = dict(os.environ, RB2_DUMP_BATCHES=str(f))
+    e.update(env)
+    p = subprocess.run([CLI] + flags + ["-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    return f.read_bytes() if f.exists() else b""
+
+
+@pytest.mark.parametrize("flags", [["-L", "-R"], ["-L"], ["-L", "-F"], ["-L", "-N"], ["-L", "-x", "5"], ["-L", "-x", "4", "-C"], ["-L", "-R", "-C"]])
+def test_parallel_line_reader_equals_sequential(flags, tmp_path):
+    """RB2_DUMP_BATCHES writes every batch (length + bytes) instead of inserting it: the threaded -L reader must produce the
+    same byte stream cut into the same batches as the sequential loop, for block sizes down to a few bytes (carry-over of
+    unfinished lines, lines longer than a block), CR line ends, empty lines, a last line without newline, N's and filters"""
+    rng = np.random.RandomState(len(" ".join(flags)))
+    lines = []
+    for i in range(4000):
+        L = int(rng.choice([0, 1, 3, 20, 101, 400], p=[.05, .05, .1, .3, .4, .1]))
+        s = "".join(rng.choice(list("ACGTNacgtn"), size=L, p=[.22, .22, .22, .22, .03, .02, .02, .02, .02, .01]))
+        if rng.rand() < 0.03:
+            s += " trailing words"
+        if rng.rand() < 0.05 and L >= 2 and L % 2 == 0:                 # its own reverse complement: -C trims it
+            h = s[:L // 2].upper().replace("N", "A")
+            s = h + h[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        lines.append(s + ("\r" if rng.rand() < 0.1 else ""))
+    for data in ("\n".join(lines) + "\n", "\n".join(lines), "", "\n", "ACGT", "ACGT\n" * 4096, ("A" * 15 + "\n") * 1024):
+        data = data.encode()
+        for m in ("-m20k", "-m3k", "-m1g"):
+            want = _dump_batches(flags + [m], data, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq")
+            for chunk, thr in (("64", "3"), ("1000", "2"), ("70000", "5"), ("0", "4")):
+                env = {"RB2_PARSE_THREADS": thr}
+                if chunk != "0":
+                    env["RB2_PARSE_CHUNK"] = chunk
+                got = _dump_batches(flags + [m], data, env, tmp_path, "par")
+                assert got == want, (flags, m, chunk, thr, len(data), len(got), len(want))
+
+
+def test_line_reader_batches_match_python_model(tmp_path):
+    """the dumped batch of the threaded reader is what helpers.encode_batch builds (main.c:200-237)"""
+    codes = H.splitmix_bases(3000, 50, seed=2)
+    text = H.reads_to_text(codes)
+    got = _dump_batches(["-L", "-m1g"], text, {"RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": "5000"}, tmp_path, "model")
+    want = H.encode_batch_fixed(codes, True, True).tobytes()
+    assert got[8:] == want and int.from_bytes(got[:8], "little") == len(want)

@@ -71,3 +71,14 @@ def test_sanitized_reader_and_filters(san_cli):
     for data in (fq, fa, b"", b">", b"@a\nACG\n+", b">x y\nAC GT\r\nA\tC\n>z\n\r\nAC\n", b"ACGT\r\n\r\nNNNN\n"):
         for flags in (["-m0", "-d"], ["-m0", "-q", "20"], ["-m0", "-N", "-r"], ["-m0", "-C", "-s"], ["-m0", "-F"]):
             run(san_cli, flags, data)
+
+
+def test_sanitized_parallel_line_reader(san_cli, tmp_path):
+    """the threaded -L reader (batches dumped to a file instead of being inserted) under ASan/UBSan"""
+    text = H.reads_to_text(H.splitmix_bases(5000, 101, 3)) + b"ACGTNNAC\r\n\nAC"
+    dump = tmp_path / "b.bin"
+    for chunk in ("100", "4096", "1000000"):
+        if dump.exists():
+            dump.unlink()
+        run(san_cli, ["-L", "-m50k", "-x", "3"], text, env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})
+        assert dump.stat().st_size > len(text)
