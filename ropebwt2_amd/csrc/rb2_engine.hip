@@ -365,7 +365,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtouch.p, h->sp_stamp); }
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtouch.p, h->sp_stamp); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, h->sbtouch.p, h->sp_stamp); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);

@@ -226,19 +226,29 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 // masked compare + wave sum gives its rank, one shift with a DPP carry from the lane below opens the gap.  No LDS, and only
 // the words from the first changed one on are stored.  (rle_insert_cached, rle.c:10-89, for <= LIGHT_NI inserts.)
 constexpr int LIGHT_NI = 8;
-__device__ __forceinline__ void leaf_insert_few(const LeafDesc &d, const int ln, const PoolView &pool,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+constexpr int LPWV = 2;                     // touched leaves per wave in k_merge_leaf: their loads are issued together (the kernel is
+                                            // bound by memory latency x occupancy, not by bandwidth or instructions)
+struct LeafJob { uint64_t w; LeafMeta m; uint32_t pj, aj; };
+
+__device__ __forceinline__ void leaf_job_load(const LeafDesc &d, const int ln, const PoolView &pool,
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, LeafJob &J)
+{
+	J.w = ((const uint64_t*)pool.data)[d.gl * LEAFW + ln];
+	J.m = pool.own[d.gl];
+	J.pj = 0; J.aj = 0;
+	if (ln < (int)d.ni) { J.aj = INS_A[d.ins0 + ln]; J.pj = (uint32_t)(INS_E[d.ins0 + ln] - d.i0) + (uint32_t)ln; }   // final position E[q] + q inside the leaf
+}
+
+__device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, const PoolView &pool, LeafJob &J, uint16_t *RKREL, uint32_t *RKLEAF)
 {
 	uint64_t *leaf = (uint64_t*)pool.data + d.gl * LEAFW;
 	const int ni = d.ni;
-	uint64_t w = leaf[ln];
-	LeafMeta m = pool.own[d.gl];
-	uint32_t pj = 0, aj = 0, myrank = 0;
-	if (ln < ni) { aj = INS_A[d.ins0 + ln]; pj = (uint32_t)(INS_E[d.ins0 + ln] - d.i0) + (uint32_t)ln; }   // final position E[q] + q inside the leaf
-	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)pj, 0) / SPW;   // first word that changes
+	uint64_t w = J.w;
+	uint32_t myrank = 0;
+	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, 0) / SPW;   // first word that changes
 	uint32_t add01 = 0, add23 = 0, add45 = 0;
 	for (int j = 0; j < ni; ++j) {
-		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)aj, j);
+		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)J.aj, j);
 		const uint32_t pw = p / SPW, po = (p - pw * SPW) * SBITS;
 		const uint64_t below = (1ull << po) - 1ull;
 		const uint64_t msk = (uint32_t)ln < pw ? MLOW : ((uint32_t)ln == pw ? (MLOW & below) : 0ull);
@@ -253,6 +263,7 @@ __device__ __forceinline__ void leaf_insert_few(const LeafDesc &d, const int ln,
 	if ((uint32_t)ln >= pw0) leaf[ln] = w;
 	if (ln < ni) { RKREL[d.ins0 + ln] = (uint16_t)myrank; RKLEAF[d.ins0 + ln] = (uint32_t)d.gl; }
 	if (ln == 0) {
+		LeafMeta m = J.m;
 		m.c[0] += (uint16_t)add01; m.c[1] += (uint16_t)(add01 >> 16); m.c[2] += (uint16_t)add23; m.c[3] += (uint16_t)(add23 >> 16);
 		m.c[4] += (uint16_t)add45; m.c[5] += (uint16_t)(add45 >> 16);
 		m.n += (uint16_t)ni;
@@ -260,8 +271,8 @@ __device__ __forceinline__ void leaf_insert_few(const LeafDesc &d, const int ln,
 	}
 }
 
-// sparse rounds: one wave per TOUCHED leaf (work orders appended by k_part_sparse, any order), rewritten in place --
-// rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts the
+// sparse rounds: one wave per LPWV TOUCHED leaves (work orders appended by k_part_sparse, any order), rewritten in place --
+// rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts a
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
 __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF, uint32_t *touch, uint32_t stamp)
@@ -269,14 +280,25 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
-	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
-	if (ctl->overflow || gw >= ctl->nwork) return;
-	const LeafDesc d = LD[gw];
-	if (ln == 0) touch[d.gl / SB] = stamp;                     // this superblock's prefixes must be rebuilt (k_meta_sb)
-	if (d.ni <= LIGHT_NI) { leaf_insert_few(d, ln, pool, INS_E, INS_A, RKREL, RKLEAF); return; }
-	uint64_t *LX = lds[wv], *LO = lds[wv] + 64;                 // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
-	uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);             // 64 flag words of 32 bits
-	merge_window<false, 1, true>(d, LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
+	const uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LPWV;
+	const uint32_t nwork = ctl->nwork;
+	if (ctl->overflow || g0 >= nwork) return;
+	LeafDesc d[LPWV];
+	LeafJob J[LPWV];
+#pragma unroll
+	for (int k = 0; k < LPWV; ++k) d[k] = LD[min(g0 + k, (uint64_t)nwork - 1)];    // (a duplicate of the last order is never run)
+#pragma unroll
+	for (int k = 0; k < LPWV; ++k) if (g0 + k < nwork && d[k].ni <= LIGHT_NI) leaf_job_load(d[k], ln, pool, INS_E, INS_A, J[k]);
+#pragma unroll
+	for (int k = 0; k < LPWV; ++k) {
+		if (g0 + k >= nwork) break;
+		if (ln == 0) touch[d[k].gl / SB] = stamp;               // this superblock's prefixes must be rebuilt (k_meta_sb)
+		if (d[k].ni <= LIGHT_NI) { leaf_job_run(d[k], ln, pool, J[k], RKREL, RKLEAF); continue; }
+		uint64_t *LX = lds[wv], *LO = lds[wv] + 64;             // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
+		uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);         // 64 flag words of 32 bits
+		merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
