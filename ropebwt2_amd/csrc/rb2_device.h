@@ -309,19 +309,12 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 	}
 	const uint64_t sbs = pv.sbpos[rp.sb0 + lo] - base, l0 = (rp.sb0 + lo) * SB;
 	const uint32_t rel = (uint32_t)(p - sbs);                  // < 2^16: a superblock holds at most SB * LEAF symbols
-	// the leaf inside the superblock: last slot k with npre[k] <= rel that is in use (unused slots trail the used ones, so the
-	// predicate is monotone).  Two rounds of independent loads -- quarter starts, then the seven slots inside the quarter -- instead
-	// of five dependent ones: the searches of a sparse round are bound by load latency.
-	const uint32_t khi = (uint32_t)min((uint64_t)(SB - 1), rp.leaf0 + rp.nleaves - 1 - l0);
-	auto pred = [&](uint32_t k) -> uint32_t {
-		if (k > khi) return 0u;
-		const LeafMeta mk = pv.meta[l0 + k];
-		return (mk.npre <= rel && mk.n > 0) ? 1u : 0u;
-	};
-	const uint32_t q = (pred(SB / 4) + pred(SB / 2) + pred(3 * SB / 4)) * (SB / 4);
-	uint32_t klo = q;
-#pragma unroll
-	for (uint32_t i = 1; i < SB / 4; ++i) klo += pred(q + i);
+	uint32_t klo = 0, khi = (uint32_t)min((uint64_t)(SB - 1), rp.leaf0 + rp.nleaves - 1 - l0);
+	while (klo < khi) {                                        // unused slots (n == 0) trail the used ones: the predicate is monotone
+		const uint32_t mid = (klo + khi + 1) >> 1;
+		const LeafMeta mk = pv.meta[l0 + mid];
+		if (mk.npre <= rel && mk.n > 0) klo = mid; else khi = mid - 1;
+	}
 	const LeafMeta m = pv.meta[l0 + klo];
 	r.gl = l0 + klo; r.s = sbs + m.npre; r.n = m.n;
 	return r;

@@ -381,34 +381,64 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 // 10^3 tiles, where five 10-microsecond launches per round are a large share of the round).  Same results, same formulas.
 __global__ __launch_bounds__(SCHUNK) void k_tscan_fused(const Ctl *ctl, int side, const TileRec *trec, TileScan *tsc, TileFix *tf, uint64_t *gcnt)
 {
-	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
+	__shared__ uint32_t s_p[7][16];                             // per-wave totals of the six histogram columns + the head marker
 	__shared__ uint32_t s_t0[NR + 1];
 	const SegDesc &sg = ctl->seg[side];
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
 	__syncthreads();
 	const uint32_t nt = s_t0[NR];
-	uint32_t run[6] = {0, 0, 0, 0, 0, 0};
-	int run_mx = -1;
+	// block scans: DPP inside the wave (VALU only), one LDS exchange of the 16 wave totals, a 16-lane DPP scan of those -- two
+	// barriers per 1024 tiles for all seven columns (the first version used seven LDS-shuffle scans: 43 us for 2000 tiles)
+	uint32_t run[6] = {0, 0, 0, 0, 0, 0}, run_mx = 0;           // carries between chunks; heads are tracked as tile + 1 (0: none)
 	for (uint32_t i0 = 0; i0 < nt; i0 += SCHUNK) {              // forwards: exclusive sums, last head-bearing tile before
 		const uint32_t i = i0 + threadIdx.x;
 		const bool ok = i < nt;
+		uint32_t v[7], inc[7];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { v[s] = ok ? trec[i].hist[s] : 0u; inc[s] = dpp_incl_add(v[s]); }
+		v[6] = (ok && trec[i].fh >= 0) ? i + 1 : 0u; inc[6] = dpp_incl_max(v[6]);
+		if (ln == 63) {
+#pragma unroll
+			for (int s = 0; s < 7; ++s) s_p[s][wv] = inc[s];
+		}
+		__syncthreads();
 		TileScan o;
-		for (int s = 0; s < 6; ++s) { uint32_t tot; o.pre[s] = run[s] + block_excl_add<uint32_t>(ok ? trec[i].hist[s] : 0u, s_w, &tot); run[s] += tot; }
-		const int hv = (ok && trec[i].fh >= 0) ? (int)i : -1;
-		o.lht = max(run_mx, block_excl_max(hv, s_wi, -1));
-		run_mx = max(run_mx, block_all_max(hv, s_wi));
+#pragma unroll
+		for (int s = 0; s < 7; ++s) {
+			const uint32_t p = ln < 16 ? s_p[s][ln] : 0u;
+			const uint32_t pin = s < 6 ? dpp_incl_add(p) : dpp_incl_max(p);
+			const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
+			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)pin, 15);
+			if (s < 6) { o.pre[s] = run[s] + off + inc[s] - v[s]; run[s] += tot; }
+			else {
+				const uint32_t prevl = dpp_prev_lane(inc[6]);       // inclusive max of the lanes below (0 for lane 0)
+				const uint32_t ex = max(max(run_mx, off), prevl);
+				o.lht = (int)ex - 1;
+				run_mx = max(run_mx, tot);
+			}
+		}
 		o.nht = INT_MAX;
 		if (ok) tsc[i] = o;
+		__syncthreads();
 	}
 	if (threadIdx.x == 0) { TileScan e; for (int s = 0; s < 6; ++s) e.pre[s] = run[s]; e.lht = -1; e.nht = INT_MAX; tsc[nt] = e; }
-	int run_mn = INT_MAX;
-	for (uint32_t k = (nt + SCHUNK - 1) / SCHUNK; k-- > 0; ) {   // backwards: first head-bearing tile after
-		const uint32_t i = k * SCHUNK + threadIdx.x;
+	uint32_t run_nx = 0;                                        // backwards: first head-bearing tile after, as a prefix max of (BIG - tile) over reversed threads
+	for (uint32_t k = (nt + SCHUNK - 1) / SCHUNK; k-- > 0; ) {
+		const uint32_t i = k * SCHUNK + (SCHUNK - 1 - threadIdx.x);
 		const bool ok = i < nt;
-		const int hv = (ok && trec[i].fh >= 0) ? (int)i : INT_MAX;
-		const int omn = min(run_mn, block_excl_min_down(hv, s_wi, INT_MAX));
-		run_mn = min(run_mn, -block_all_max(hv == INT_MAX ? INT_MIN + 1 : -hv, s_wi));
-		if (ok) tsc[i].nht = omn;
+		const uint32_t v = (ok && trec[i].fh >= 0) ? 0x7fffffffu - i : 0u;
+		const uint32_t inc = dpp_incl_max(v);
+		if (ln == 63) s_p[6][wv] = inc;
+		__syncthreads();
+		const uint32_t p = ln < 16 ? s_p[6][ln] : 0u;
+		const uint32_t pin = dpp_incl_max(p);
+		const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
+		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)pin, 15);
+		const uint32_t ex = max(max(run_nx, off), dpp_prev_lane(inc));
+		if (ok) tsc[i].nht = ex ? (int)(0x7fffffffu - ex) : INT_MAX;
+		run_nx = max(run_nx, tot);
+		__syncthreads();
 	}
 	__threadfence_block();
 	__syncthreads();
