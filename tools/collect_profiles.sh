@@ -22,7 +22,7 @@ timeout 1500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O -o write --output-f
 # 4. summaries
 cp $O/bench.json $S/${TAG}_bench.json
 DB=$(ls $O/*ktrace*results.db $O/*/*ktrace*results.db 2>/dev/null | head -1)
-[ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $S/${TAG}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras (MI355X)"
+[ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $S/${TAG}_bench_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras (MI355X)" $((STEPS * 102))
 F=$(ls $O/*fetch*counter_collection.csv $O/*/*fetch*counter_collection.csv 2>/dev/null | head -1)
 W=$(ls $O/*write*counter_collection.csv $O/*/*write*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python $R/tools/traffic_summary.py $F $W $S/${TAG}_hbm_traffic.csv $S/k_merge_traffic.json "python bench.py --steps $STEPS --warmup 0 --no-cpu-baseline --no-extras"
