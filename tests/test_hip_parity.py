@@ -524,3 +524,41 @@ def test_huge_groups_long_intervals(hip, so):
             r[int(rng.randint(150))] = int(rng.randint(1, 5))
         reads.append(r[int(rng.randint(0, 20)):])
     run_both(hip, so, [H.encode_batch(reads[:4000]), H.encode_batch(reads[4000:], True, so == 2)])
+
+
+@pytest.mark.parametrize("seed,lam", [(11, "3.0"), (12, "8.0"), (13, "1.5")])
+def test_fuzz_medium_jobs_with_layout_changes(hip, seed, lam):
+    """medium-size jobs (0.1-0.25 M reads in 3-4 batches, i.i.d. or overlapping, random order / strands) with the sparse threshold
+    raised so that the layout changes by itself a few times per job: thousands of leaves are re-laid out with slack, tens of
+    thousands of in-place rounds' worth of leaves are touched, void rounds send the index back to the dense layout"""
+    rng = np.random.RandomState(900 + seed)
+    so, strand = int(rng.randint(3)), int(rng.randint(2))
+    L = int(rng.randint(60, 200))
+    nb = int(rng.randint(3, 5))
+    n = int(rng.randint(100000, 250001)) // nb
+    cov = float(rng.choice([0, 10, 40]))
+    glen = int(max(L + 1, n * nb * L / cov)) if cov else 0
+    per = (L + 1) * (2 if strand else 1)
+    old = os.environ.get("RB2_SPARSE_LAMBDA")
+    os.environ["RB2_SPARSE_LAMBDA"] = lam
+    try:
+        o, dev = H.Oracle(so), hip.HipBwt(so)
+    finally:
+        if old is None:
+            os.environ.pop("RB2_SPARSE_LAMBDA", None)
+        else:
+            os.environ["RB2_SPARSE_LAMBDA"] = old
+    p = dev.dev_alloc(n * per + 64)
+    for b in range(nb):
+        dev.synth_reads(p, b * n, n, L, seed=300 + seed, strand=strand, genome_len=glen)
+        dev.sync()
+        host = np.empty(n * per, np.uint8)
+        dev.L.rb2_hip_memcpy(dev.h, host.ctypes.data, p, n * per, 1)
+        dev.insert_multi_dev(p, n * per)
+        o.insert_multi(host)
+        assert np.array_equal(dev.counts(), o.counts()), "counts after batch %d (so %d strand %d L %d cov %g)" % (b, so, strand, L, cov)
+    st = dev.sparse_stats()
+    for r in range(6):
+        assert np.array_equal(dev.rope(r), o.rope(r)), "rope %d (so %d strand %d L %d cov %g, %s)" % (r, so, strand, L, cov, st)
+    assert st["sparse_rounds"] > 0, st
+    dev.dev_free(p)
