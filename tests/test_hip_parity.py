@@ -526,7 +526,7 @@ def test_huge_groups_long_intervals(hip, so):
     run_both(hip, so, [H.encode_batch(reads[:4000]), H.encode_batch(reads[4000:], True, so == 2)])
 
 
-@pytest.mark.parametrize("seed,lam", [(11, "3.0"), (12, "8.0"), (13, "1.5")])
+@pytest.mark.parametrize("seed,lam", [(11, "3.0"), (12, "8.0"), (13, "5.0")])
 def test_fuzz_medium_jobs_with_layout_changes(hip, seed, lam):
     """medium-size jobs (0.1-0.25 M reads in 3-4 batches, i.i.d. or overlapping, random order / strands) with the sparse threshold
     raised so that the layout changes by itself a few times per job: thousands of leaves are re-laid out with slack, tens of
