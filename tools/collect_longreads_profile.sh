@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box: rocprofv3 kernel stats + HBM traffic counters of the long-read job (configs[3] at one tenth: 1 M x 10 kbp).
+#   usage: collect_longreads_profile.sh [tag] [reads]      summaries in gpurun_out/prof_<tag>/summary/
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02_long}
+READS=${2:-1000000}
+O=$R/gpurun_out/prof_$TAG
+S=$O/summary
+mkdir -p $O $S
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/tools/scale_check.py --reads $READS --read-len 10000 --order io --seed 44"
+timeout 900 rocprofv3 --kernel-trace --stats -d $O -o ktrace -- $CMD > $O/ktrace.log 2>&1
+timeout 1500 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O -o fetch --output-format csv -- $CMD > $O/fetch.log 2>&1
+timeout 1500 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O -o write --output-format csv -- $CMD > $O/write.log 2>&1
+DB=$(ls $O/*ktrace*results.db $O/*/*ktrace*results.db 2>/dev/null | head -1)
+[ -n "$DB" ] && python $R/tools/rocprof_summary.py $DB $S/${TAG}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python tools/scale_check.py --reads $READS --read-len 10000 --order io --seed 44 (MI355X)"
+F=$(ls $O/*fetch*counter_collection.csv $O/*/*fetch*counter_collection.csv 2>/dev/null | head -1)
+W=$(ls $O/*write*counter_collection.csv $O/*/*write*counter_collection.csv 2>/dev/null | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python $R/tools/traffic_summary.py $F $W $S/${TAG}_hbm_traffic.csv $S/${TAG}_k_merge_traffic.json "python tools/scale_check.py --reads $READS --read-len 10000 --order io --seed 44"
+tail -2 $O/ktrace.log | cut -c1-400
+head -14 $S/${TAG}_kernel_stats.csv
+head -12 $S/${TAG}_hbm_traffic.csv
