@@ -937,7 +937,9 @@ namespace rb2 {
 // one wave per TWO superblocks (lanes 0-31 / 32-63): per-leaf counts -> exclusive prefix inside the superblock;
 // superblock totals.  Counts are <= LEAF per leaf, prefixes < 2^16: two symbols per packed DPP scan.
 // touch != nullptr (sparse rounds): only superblocks that k_merge_leaf stamped this round changed; the prefixes and the total
-// of every other one are still right (sbtot persists between rounds), so the wave returns after one 8-byte load.
+// of every other one are still right (sbtot persists between rounds), so the wave returns after one 8-byte load.  The stamp also
+// carries the FIRST touched slot of the superblock (touch = stamp << 5 | 31 - slot, raised with atomicMax): the prefixes in front
+// of it are unchanged too, so only the slots from there to SP_USED - 1 are read and rewritten, on top of the old prefix of that slot.
 __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot, const uint32_t *touch, uint32_t stamp)
 {
 	const int ln = lane_id();
@@ -945,10 +947,16 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 	const uint64_t nsb = ctl->nsb_total;
 	if (sb - (ln >> 5) >= nsb) return;                        // wave-uniform
 	const bool live = sb < nsb;
+	int first = 0, last = SB;                                  // slots [first, last) of my superblock are recomputed
 	if (touch) {
 		if (ctl->overflow) return;                             // void round
 		const uint64_t sbA0 = sb - (ln >> 5);
-		if (touch[sbA0] != stamp && (sbA0 + 1 >= nsb || touch[sbA0 + 1] != stamp)) return;   // wave-uniform
+		const uint32_t vA = touch[sbA0], vB = sbA0 + 1 < nsb ? touch[sbA0 + 1] : 0u;
+		const bool tA = (vA >> 5) == stamp, tB = (vB >> 5) == stamp;
+		if (!tA && !tB) return;                                // wave-uniform
+		const uint32_t vme = (ln >> 5) ? vB : vA;
+		first = ((ln >> 5) ? tB : tA) ? 31 - (int)(vme & 31u) : SB;   // an untouched neighbour: nothing to do in that half
+		last = SP_USED;                                        // the sparse layout never uses the other slots (their n stays 0)
 	}
 	const uint64_t gl = sb * SB + (ln & 31);
 	// sub-ropes start on superblock boundaries, in ascending order: the one that owns a superblock is the
@@ -958,15 +966,23 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 	const int rA = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA)) - 1);
 	const int rB = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA + 1)) - 1);
 	const RopeDesc &rp = ctl->rope[nside][(ln >> 5) ? rB : rA];
-	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
+	const int k = ln & 31;
+	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves && k >= first && k < last;
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
 	m.npre = 0; m.n = 0;
 	if (ok) m = newp.own[gl];                                  // own counts + fill, written by the merge kernels / k_relayout / the loader
+	uint32_t b01 = 0, b23 = 0, b45 = 0;                        // prefix in front of slot `first`: zero for a full rebuild, else what meta[] holds there
+	if (touch) {
+		if (ok && k == first) { const LeafMeta o = newp.meta[gl]; b01 = o.c[0] | (uint32_t)o.c[1] << 16; b23 = o.c[2] | (uint32_t)o.c[3] << 16; b45 = o.c[4] | (uint32_t)o.c[5] << 16; }
+		const int src = (ln & 32) + min(first, SB - 1);
+		b01 = __shfl(b01, src); b23 = __shfl(b23, src); b45 = __shfl(b45, src);
+	}
 	const uint32_t e01 = m.c[0] | (uint32_t)m.c[1] << 16, e23 = m.c[2] | (uint32_t)m.c[3] << 16, e45 = m.c[4] | (uint32_t)m.c[5] << 16;
 	uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
 	const uint32_t h01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 31), h23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 31), h45 = (uint32_t)__builtin_amdgcn_readlane((int)s45, 31);
 	if (ln >> 5) { s01 -= h01; s23 -= h23; s45 -= h45; }      // second superblock: prefix relative to its own first leaf
+	s01 += b01; s23 += b23; s45 += b45;
 	const uint32_t x01 = s01 - e01, x23 = s23 - e23, x45 = s45 - e45;
 	if (ok) {
 		m.c[0] = (uint16_t)x01; m.c[1] = (uint16_t)(x01 >> 16); m.c[2] = (uint16_t)x23; m.c[3] = (uint16_t)(x23 >> 16);
@@ -974,7 +990,7 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 		m.npre = (uint16_t)((x01 & 0xffffu) + (x01 >> 16) + (x23 & 0xffffu) + (x23 >> 16) + (x45 & 0xffffu) + (x45 >> 16));   // <= SB * LEAF < 2^16
 		newp.meta[gl] = m;
 	}
-	if ((ln & 31) == 31 && live) {                            // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
+	if (k == 31 && live && first < SB) {                      // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
 		Cnt6 c;
 		c.v[0] = s01 & 0xffffu; c.v[1] = s01 >> 16; c.v[2] = s23 & 0xffffu; c.v[3] = s23 >> 16; c.v[4] = s45 & 0xffffu; c.v[5] = s45 >> 16;
 		sbtot[sb] = c;

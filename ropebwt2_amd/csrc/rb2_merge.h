@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 #pragma unroll
 	for (int k = 0; k < LPWV; ++k) {
 		if (g0 + k >= nwork) break;
-		if (ln == 0) touch[d[k].gl / SB] = stamp;               // this superblock's prefixes must be rebuilt (k_meta_sb)
+		if (ln == 0) atomicMax(&touch[d[k].gl / SB], stamp << 5 | (31u - (uint32_t)(d[k].gl % SB)));   // this superblock's prefixes must be rebuilt from this slot on (k_meta_sb)
 		if (d[k].ni <= LIGHT_NI) { leaf_job_run(d[k], ln, pool, J[k], RKREL, RKLEAF); continue; }
 		uint64_t *LX = lds[wv], *LO = lds[wv] + 64;             // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
 		uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);         // 64 flag words of 32 bits
