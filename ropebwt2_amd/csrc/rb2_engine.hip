@@ -411,6 +411,15 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0;
 		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 		if (h->sp_backoff > 0) --h->sp_backoff;
+		if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
+			const uint64_t need = slots_for(n_ub, true), have = h->pool[h->pside ^ 1].cap_leaves;
+			size_t fr = 0, tot = 0;
+			const double bytes = (double)need * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);   // (the old buffers are freed only after the new ones exist)
+			if (need > have && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
+				want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
+				if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
+			}
+		}
 		if (want != h->sparse) relayout(h, want, n_ub, B.n_tot + B.len);
 		if (B.counted != r) round_counts(h, B, r);
 		if (h->sparse) {
