@@ -467,6 +467,7 @@ int main(int argc, char *argv[])
 	free(buf.s); gzclose(rd->fp); free(rd->seq.s); free(rd->qual.s); free(rd);
 
 	if (out != stdout) { fflush(stdout); if (dup2(fileno(out), fileno(stdout)) < 0) return 1; }   /* mr_print_tree writes to stdout */
+	{ static char obuf[4 << 20]; fflush(stdout); setvbuf(stdout, obuf, _IOFBF, sizeof(obuf)); }   /* .fmr dumps are millions of small fwrites */
 	if (flag & F_BIN) mr_dump(mr, stdout);
 	else if (flag & F_TREE) mr_print_tree(mr);
 	else {

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <assert.h>
+#include <pthread.h>
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_hip.h"
@@ -76,20 +77,33 @@ static void runbuf_add(void *user, const uint8_t *q, int64_t n)
 	memcpy(b->p + b->n, q, n); b->n += n;
 }
 
+typedef struct { rope_t *r; runbuf_t rb; } load_job_t;
+static void *load_worker(void *arg)
+{
+	load_job_t *j = (load_job_t*)arg;
+	rope_load_runs(j->r, j->rb.p, j->rb.n);
+	free(j->rb.p); j->rb.p = 0;
+	return 0;
+}
+
 void mr_sync_host(mrope_t *mr)
 {
 	mrx_t *x = X(mr);
-	runbuf_t rb = { 0, 0, 0 };
+	load_job_t job[6];
+	pthread_t th[6];
 	int a;
 	if (x->host_ok) return;
 	assert(x->dev && x->dev_ok);
+	/* the six ropes are independent trees: each is bulk-loaded by its own thread as soon as its run bytes have arrived, while
+	 * the next rope is still streaming off the device (the reference has nothing to do here: its ropes were built on the host) */
 	for (a = 0; a < 6; ++a) {
-		rb.n = 0;
-		rb2_hip_stream_rope(x->dev, a, runbuf_add, &rb);
+		memset(&job[a], 0, sizeof(job[a]));
+		rb2_hip_stream_rope(x->dev, a, runbuf_add, &job[a].rb);
 		if (!mr->r[a]) mr->r[a] = rope_init(x->max_nodes, x->block_len);
-		rope_load_runs(mr->r[a], rb.p, rb.n);
+		job[a].r = mr->r[a];
+		pthread_create(&th[a], 0, load_worker, &job[a]);
 	}
-	free(rb.p);
+	for (a = 0; a < 6; ++a) pthread_join(th[a], 0);
 	x->host_ok = 1;
 }
 
