@@ -284,6 +284,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
+	if ((uint64_t)nlf * 64 >= (1ull << 32)) { fprintf(stderr, "[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); abort(); }
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -303,6 +304,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  hipLaunchKernelGGL((k_advance<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
 	if (!B.known_ae && !send) ne_snapshot(h, r);
+	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
 }
 
@@ -329,8 +331,9 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 	{
 		Scope sc(h, RB2_K_RELAYOUT, 0);
 		hipLaunchKernelGGL(k_relayout_setup, dim3(1), dim3(64), 0, st, h->ctl, h->side, F, K);
-		hipLaunchKernelGGL(k_relayout, dim3(cdiv(slots, MW)), dim3(256), 0, st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), h->pool[h->pside ^ 1].view(), F, K);
+		hipLaunchKernelGGL(k_relayout, dim3(std::min<uint64_t>(cdiv(slots, MW), 1u << 20)), dim3(256), 0, st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), h->pool[h->pside ^ 1].view(), F, K);
 		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1);
+		HIPCHK(hipGetLastError());                              // a refused launch here would leave descriptors without data
 	}
 	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout;
 	if (to_sparse) {                                           // stamps of touched superblocks: none yet; sbtot now describes this layout
@@ -377,6 +380,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	// way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch, and a void round r is
 	// redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues the next merge.
 	if (!B.known_ae) ne_snapshot(h, r);
+	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipEventRecord(h->ev_flag, st));
 	h->side ^= 1; B.cur ^= 1;
@@ -408,7 +412,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
 		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
 		const double lambda = (double)B.m / ((double)n_ub / LEAF + 1.0);
-		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0;
+		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 26);   // (k_merge_leaf: one wave per two work orders, 2^32 threads per launch)
 		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 		if (h->sp_backoff > 0) --h->sp_backoff;
 		if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
@@ -918,13 +922,17 @@ void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_
 	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rank: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n"); abort(); }
 	if (n <= 0) return;
 	if (b < 0 || b > 5) { fprintf(stderr, "[rb2_hip] rank: bad rope %d\n", b); abort(); }
-	h->qbuf.ensure((size_t)n * 7);
-	HIPCHK(hipMemcpyAsync(h->qbuf.p, x, (size_t)n * 8, hipMemcpyHostToDevice, h->st));
-	hipLaunchKernelGGL(k_rank_batch, dim3(cdiv((uint64_t)n, MW)), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), b,
-			(const uint64_t*)h->qbuf.p, (uint64_t)n, h->qbuf.p + n, (int)h->sparse);
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(out, h->qbuf.p + n, (size_t)n * 48, hipMemcpyDeviceToHost, h->st));
-	HIPCHK(hipStreamSynchronize(h->st));
+	const int64_t CH = 1 << 24;                                  // queries per launch (one wave each; a launch is capped at 2^32 threads)
+	h->qbuf.ensure((size_t)std::min(n, CH) * 7);
+	for (int64_t i0 = 0; i0 < n; i0 += CH) {
+		const int64_t nc = std::min(CH, n - i0);
+		HIPCHK(hipMemcpyAsync(h->qbuf.p, x + i0, (size_t)nc * 8, hipMemcpyHostToDevice, h->st));
+		hipLaunchKernelGGL(k_rank_batch, dim3(cdiv((uint64_t)nc, MW)), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), b,
+				(const uint64_t*)h->qbuf.p, (uint64_t)nc, h->qbuf.p + nc, (int)h->sparse);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(out + i0 * 6, h->qbuf.p + nc, (size_t)nc * 48, hipMemcpyDeviceToHost, h->st));
+		HIPCHK(hipStreamSynchronize(h->st));
+	}
 }
 
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])

@@ -866,8 +866,9 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	uint64_t *LX = lds[wv];
 	const int ln = lane_id();
-	const uint64_t gl = (uint64_t)blockIdx.x * MW + wv;         // output slot
-	if (gl >= ctl->nsb_total * SB) return;
+	// grid-stride over the output slots: a launch is capped at 2^32 threads, i.e. 2^26 one-wave slots = 52 G symbols of sparse
+	// layout (found at full configs[3] size: the capped launch was refused and the re-layout silently did nothing)
+	for (uint64_t gl = (uint64_t)blockIdx.x * MW + wv; gl < ctl->nsb_total * SB; gl += (uint64_t)gridDim.x * MW) {
 	// the piece that owns the slot: last one with leaf0 <= gl among those that have slots
 	const uint64_t l0 = ctl->rope[side][ln < NR ? ln : NR - 1].leaf0;
 	const int r = max(0, (int)__popcll(__ballot(ln < NR && l0 <= gl)) - 1);
@@ -923,6 +924,8 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 		m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
 		m.npre = 0; m.n = (uint16_t)nvalid;
 		newp.own[gl] = m;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // LX is reused by the next slot
 	}
 }
 
