@@ -57,6 +57,7 @@ struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: pref
 constexpr int SP_FILL = 1008;          // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 336 inserts)
 constexpr int SP_USED = 24;            // ... leaf slots in use per superblock (the other 8 stay empty)
 struct Cnt6 { uint64_t v[6]; };
+struct SbTot { uint32_t p01, p23, p45, pad; };             // symbol counts of one superblock, six 16-bit fields (<= SB * LEAF each)
 
 struct RopeDesc {
 	uint64_t n;         // symbols

@@ -87,7 +87,7 @@ struct rb2_hip_s {
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<TileFix> tfix; DevBuf<ChunkPart> cpart;
-	DevBuf<Cnt6> sbtot, sbpart;
+	DevBuf<SbTot> sbtot; DevBuf<Cnt6> sbpart;
 	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
 	// profiling
 	int prof = 0;

@@ -943,7 +943,7 @@ namespace rb2 {
 // of every other one are still right (sbtot persists between rounds), so the wave returns after one 8-byte load.  The stamp also
 // carries the FIRST touched slot of the superblock (touch = stamp << 5 | 31 - slot, raised with atomicMax): the prefixes in front
 // of it are unchanged too, so only the slots from there to SP_USED - 1 are read and rewritten, on top of the old prefix of that slot.
-__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, Cnt6 *sbtot, const uint32_t *touch, uint32_t stamp)
+__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, const uint32_t *touch, uint32_t stamp)
 {
 	const int ln = lane_id();
 	const uint64_t sb = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2 + (ln >> 5);
@@ -994,20 +994,33 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 		newp.meta[gl] = m;
 	}
 	if (k == 31 && live && first < SB) {                      // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
-		Cnt6 c;
-		c.v[0] = s01 & 0xffffu; c.v[1] = s01 >> 16; c.v[2] = s23 & 0xffffu; c.v[3] = s23 >> 16; c.v[4] = s45 & 0xffffu; c.v[5] = s45 >> 16;
+		SbTot c;
+		c.p01 = s01; c.p23 = s23; c.p45 = s45; c.pad = 0;
 		sbtot[sb] = c;
 	}
 }
 
-__global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const Cnt6 *sbtot, Cnt6 *part)
+// the three-kernel prefix over the superblock totals.  A total is six 16-bit counts (<= SB * LEAF = 43008 each) in 16 bytes; inside
+// a chunk of 1024 superblocks sums stay below 2^26, so the chunk-level work is 32-bit DPP scans with one LDS exchange (the first
+// version scanned 64-bit values through LDS shuffles, six times two barriers per chunk -- at 100 G symbols of sparse layout,
+// 4 M superblocks, that was a third of a round); only the chunk bases are 64 bit.
+__global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const SbTot *sbtot, Cnt6 *part)
 {
-	__shared__ uint64_t s_w[16];
+	__shared__ uint32_t s_p[6][16];
 	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
 	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
-	Cnt6 o;
-	for (int s = 0; s < 6; ++s) { uint64_t tot; block_excl_add<uint64_t>(i < n ? sbtot[i].v[s] : 0ull, s_w, &tot); o.v[s] = tot; }
-	if (threadIdx.x == 0) part[blockIdx.x] = o;
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
+	if (i < n) t = sbtot[i];
+	const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+#pragma unroll
+	for (int s = 0; s < 6; ++s) { const uint32_t w = lane63(dpp_incl_add(v[s])); if (ln == 0) s_p[s][wv] = w; }
+	__syncthreads();
+	if (threadIdx.x < 6) {
+		uint64_t tot = 0;
+		for (int k = 0; k < SCHUNK / 64; ++k) tot += s_p[threadIdx.x][k];
+		part[blockIdx.x].v[threadIdx.x] = tot;
+	}
 }
 __global__ __launch_bounds__(SCHUNK) void k_sbscan2(const Ctl *ctl, Cnt6 *part)
 {
@@ -1024,13 +1037,28 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan2(const Ctl *ctl, Cnt6 *part)
 		if (ok) part[i] = o;
 	}
 }
-__global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const Cnt6 *sbtot, const Cnt6 *part, PoolView newp)
+__global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, const Cnt6 *part, PoolView newp)
 {
-	__shared__ uint64_t s_w[16];
+	__shared__ uint32_t s_p[6][16];
 	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
 	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
+	if (i < n) t = sbtot[i];
+	const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+	uint32_t inc[6];
+#pragma unroll
+	for (int s = 0; s < 6; ++s) { inc[s] = dpp_incl_add(v[s]); if (ln == 63) s_p[s][wv] = inc[s]; }
+	__syncthreads();
+	const Cnt6 base = part[blockIdx.x];
 	Cnt6 o;
-	for (int s = 0; s < 6; ++s) o.v[s] = part[blockIdx.x].v[s] + block_excl_add<uint64_t>(i < n ? sbtot[i].v[s] : 0ull, s_w, (uint64_t*)0);
+#pragma unroll
+	for (int s = 0; s < 6; ++s) {
+		const uint32_t p = ln < 16 ? s_p[s][ln] : 0u;
+		const uint32_t pin = dpp_incl_add(p);
+		const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
+		o.v[s] = base.v[s] + off + inc[s] - v[s];
+	}
 	if (i < n) { newp.sbcum[i] = o; newp.sbpos[i] = o.v[0] + o.v[1] + o.v[2] + o.v[3] + o.v[4] + o.v[5]; }
 }
 
