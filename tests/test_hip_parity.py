@@ -456,9 +456,10 @@ def test_sparse_forced_coverage_reads(hip, so, strand):
 
 
 def test_sparse_forced_fuzz(hip):
-    rng = np.random.RandomState(4242)
+    """soak runs: RB2_FUZZ_ITERS=400 RB2_FUZZ_SEED=k"""
+    rng = np.random.RandomState(4242 + 7919 * int(os.environ.get("RB2_FUZZ_SEED", "0")))
     with _ForcedSparse():
-        for it in range(12):
+        for it in range(int(os.environ.get("RB2_FUZZ_ITERS", "12"))):
             so = int(rng.randint(3))
             batches = []
             for _ in range(int(rng.randint(1, 4))):
