@@ -70,7 +70,7 @@ struct rb2_hip_s {
 	bool sparse = false;                // the pool is in the sparse layout (leaves with slack, in-place rounds)
 	double sp_lambda = 0.6;             // go sparse when (strings per round) / (leaves of the index) falls below this
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
-	int sp_maxpen = 12;
+	int sp_maxpen = 6;                  // at most 64 dense rounds between two attempts (a failed attempt costs about four dense rounds)
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
@@ -416,10 +416,11 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 		if (h->sp_backoff > 0) --h->sp_backoff;
 		if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
-			const uint64_t need = slots_for(n_ub, true), have = h->pool[h->pside ^ 1].cap_leaves;
+			const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
+			const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
 			size_t fr = 0, tot = 0;
-			const double bytes = (double)need * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);   // (the old buffers are freed only after the new ones exist)
-			if (need > have && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
+			const double bytes = grow * (double)need * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);   // (the old buffers are freed only after the new ones exist)
+			if (grow && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
 				want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
 				if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
 			}
