@@ -70,6 +70,7 @@ struct rb2_hip_s {
 	bool sparse = false;                // the pool is in the sparse layout (leaves with slack, in-place rounds)
 	double sp_lambda = 0.6;             // go sparse when (strings per round) / (leaves of the index) falls below this
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
+	int sp_head = 8;                    // dense rounds at the start of a batch while the index is sparse (see insert_dev)
 	int sp_maxpen = 6;                  // at most 64 dense rounds between two attempts (a failed attempt costs about four dense rounds)
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
 	static constexpr int NE_RING = 32;
@@ -408,6 +409,10 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); abort(); }
 	BatchState B;
 	batch_begin(h, B, len64, s);
+	// The first rounds of a batch are hot spots by construction: round 0 puts every string into rope $ (at its end in input order,
+	// at a handful of positions in the sorted orders), round k touches ~4^k places.  A sparse index would void each of them (a
+	// re-layout there and back per round); one dense phase of eight rounds costs two re-layouts for all of them.
+	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
 		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
@@ -431,6 +436,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
 			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
 			++h->n_void;
+			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
 			relayout(h, false, n_ub, B.n_tot + B.len);
 			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
 			h->sp_backoff = 1 << h->sp_penalty;
@@ -481,6 +487,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	h->debug = getenv("RB2_HIP_DEBUG") ? atoi(getenv("RB2_HIP_DEBUG")) : 0;
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	if (getenv("RB2_SPARSE_LAMBDA")) h->sp_lambda = atof(getenv("RB2_SPARSE_LAMBDA"));   // 0: never leave the dense layout
+	if (getenv("RB2_SPARSE_HEAD")) h->sp_head = atoi(getenv("RB2_SPARSE_HEAD"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));

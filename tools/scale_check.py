@@ -64,10 +64,9 @@ def main():
             r = bwt.rank1a(b, int(x))
             ok_rank &= int(r.sum()) == int(x) and bool(np.all(r >= prev))
             prev = r
-    extra = {}
+    extra = {"layout": bwt.sparse_stats(), "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default")}
     if args.profile:
-        extra = {"kernels_ms": {k: round(v["ms"], 2) for k, v in bwt.profile_get().items()}, "layout": bwt.sparse_stats(),
-                 "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default")}
+        extra["kernels_ms"] = {k: round(v["ms"], 2) for k, v in bwt.profile_get().items()}
     bwt.dev_free(buf)
     bwt.close()
     print(json.dumps({**extra, "reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "genome_len": args.genome_len, "batch_gib": args.batch,
