@@ -278,6 +278,31 @@ __device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, Ni
 	edge(c1);
 }
 
+// ---- sparse layout: the directory of a superblock ---------------------------------------------
+// In the sparse layout the 512 bytes that hold the 32 LeafMeta prefixes of a superblock in the dense one (PoolView::meta) are
+// eight rows of 32 16-bit values, one per leaf slot: row 0 = fill, rows 1-6 = OWN counts of the six symbols (row 7 unused).
+// An in-place insert changes the entries of its own leaf and nothing else -- there is no prefix behind it to move, which is
+// what keeps a round's cost proportional to the leaves it touches (the reference updates the counts along one root-to-leaf
+// path, rope.c:139-146); a query sums the row in front of its slot, one 48-byte read per symbol.
+constexpr int DIRW = 8 * SB;            // 16-bit values per superblock
+__device__ __forceinline__ uint16_t *dir_row(const PoolView &pv, uint64_t sb, int row) { return (uint16_t*)pv.meta + sb * DIRW + row * SB; }
+__device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, int row, uint32_t k)   // sum of slots [0, k) of a row, k <= SP_USED
+{
+	const uint4 *q = (const uint4*)dir_row(pv, sb, row);
+	uint32_t acc = 0;                                          // two 16-bit sums side by side (<= 12 * LEAF each)
+#pragma unroll
+	for (int i = 0; i < SP_USED / 8; ++i) {
+		const uint4 v = q[i];
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t s0 = (uint32_t)(8 * i + 2 * j);      // the word holds slots s0, s0 + 1
+			acc += w[j] & (k > s0 + 1 ? 0xffffffffu : (k == s0 + 1 ? 0xffffu : 0u));
+		}
+	}
+	return (acc & 0xffffu) + (acc >> 16);
+}
+
 // position -> leaf when leaves carry slack (sparse layout; also valid on the dense one): the last leaf of the piece that
 // starts at or before p -- superblock by binary search over sbpos, leaf by binary search over the in-superblock prefixes.
 // A position on a leaf boundary goes to the RIGHT leaf, p == n to the last leaf in use (the reference sends boundaries to
@@ -310,14 +335,30 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 	}
 	const uint64_t sbs = pv.sbpos[rp.sb0 + lo] - base, l0 = (rp.sb0 + lo) * SB;
 	const uint32_t rel = (uint32_t)(p - sbs);                  // < 2^16: a superblock holds at most SB * LEAF symbols
-	uint32_t klo = 0, khi = (uint32_t)min((uint64_t)(SB - 1), rp.leaf0 + rp.nleaves - 1 - l0);
-	while (klo < khi) {                                        // unused slots (n == 0) trail the used ones: the predicate is monotone
-		const uint32_t mid = (klo + khi + 1) >> 1;
-		const LeafMeta mk = pv.meta[l0 + mid];
-		if (mk.npre <= rel && mk.n > 0) klo = mid; else khi = mid - 1;
+	// inside the superblock: the fills of its slots are one 48-byte read (dir_row 0); unused slots (n == 0) trail the used ones
+	const uint4 *q = (const uint4*)dir_row(pv, rp.sb0 + lo, 0);
+	uint32_t run = 0, klo = 0, pre = 0, nk = 0;
+#pragma unroll
+	for (int i = 0; i < SP_USED / 8; ++i) {
+		const uint4 v = q[i];
+		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const uint32_t n = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
+			if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = n; }
+			run += n;
+		}
 	}
-	const LeafMeta m = pv.meta[l0 + klo];
-	r.gl = l0 + klo; r.s = sbs + m.npre; r.n = m.n;
+	r.gl = l0 + klo; r.s = sbs + pre; r.n = nk;
+	return r;
+}
+
+// the dense layout needs no search: every leaf of a piece but the last is full
+__device__ __forceinline__ Loc locate_dense(const RopeDesc &rp, uint64_t p)
+{
+	Loc r;
+	const uint64_t lf = rp.nleaves ? min(p / LEAF, rp.nleaves - 1) : 0;
+	r.gl = rp.leaf0 + lf; r.s = lf * LEAF; r.n = (uint32_t)min((uint64_t)LEAF, rp.n - r.s);
 	return r;
 }
 
@@ -335,13 +376,21 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
 	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
-	const LeafMeta m = pv.meta[gl];
+	uint32_t pc[6];                                            // symbols of the superblock in front of the leaf
+	if (SPARSE) {
+#pragma unroll
+		for (int s = 0; s < 6; ++s) pc[s] = dir_prefix(pv, gl / SB, 1 + s, (uint32_t)(gl % SB));
+	} else {
+		const LeafMeta m = pv.meta[gl];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
+	}
 	NibAcc A;
 	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), 0, off, A);
 	uint32_t c[6];
 	nib_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
 }
 
 // occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],
@@ -429,11 +478,23 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
 	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
-	const LeafMeta m = pv.meta[gl];
+	uint32_t pc[6];
+	if (SPARSE) {                                              // lane j < k holds the counts of slot j: three packed wave sums
+		const uint32_t k = (uint32_t)(gl % SB), ln = (uint32_t)lane_id();
+		uint32_t v[6];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) v[s] = ln < k ? dir_row(pv, gl / SB, 1 + s)[ln] : 0u;
+		const uint32_t t01 = lane63(dpp_incl_add(v[0] | v[1] << 16)), t23 = lane63(dpp_incl_add(v[2] | v[3] << 16)), t45 = lane63(dpp_incl_add(v[4] | v[5] << 16));
+		pc[0] = t01 & 0xffffu; pc[1] = t01 >> 16; pc[2] = t23 & 0xffffu; pc[3] = t23 >> 16; pc[4] = t45 & 0xffffu; pc[5] = t45 >> 16;
+	} else {
+		const LeafMeta m = pv.meta[gl];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
+	}
 	uint32_t c[6];
 	wave_leaf_counts((const uint64_t*)pv.data + gl * LEAFW, 0, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + m.c[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
 }
 
 // occurrences of the six symbols inside [l, u), l < u, by one wave (what range_counts does with one thread)

@@ -83,7 +83,7 @@ struct rb2_hip_s {
 	DevBuf<uint16_t> RKREL;
 	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
 	DevBuf<uint64_t> qbuf;              // rank queries and their answers
-	DevBuf<uint32_t> sbtouch; uint32_t sp_stamp = 0; uint64_t sp_nsb = 0;   // sparse rounds: stamp of the last round that touched a superblock
+	uint64_t sp_nsb = 0;                // superblocks of the sparse pool (upper bound)
 	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
@@ -147,13 +147,15 @@ void drain_profile(rb2_hip_t *h)
 inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
-void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, const uint32_t *touch = nullptr, uint32_t stamp = 0)
+void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false)
 {
 	if (nsb_ub == 0) return;
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
 	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
 	PoolView pv = h->pool[pool].view();
-	hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, touch, stamp);
+	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
+	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
+	if (!leaves_done) hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
 	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);
@@ -332,17 +334,12 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 	{
 		Scope sc(h, RB2_K_RELAYOUT, 0);
 		hipLaunchKernelGGL(k_relayout_setup, dim3(1), dim3(64), 0, st, h->ctl, h->side, F, K);
-		hipLaunchKernelGGL(k_relayout, dim3(std::min<uint64_t>(cdiv(slots, MW), 1u << 20)), dim3(256), 0, st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), h->pool[h->pside ^ 1].view(), F, K);
-		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1);
+		hipLaunchKernelGGL(k_relayout, dim3(std::min<uint64_t>(cdiv(slots, MW), 1u << 20)), dim3(256), 0, st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), h->pool[h->pside ^ 1].view(), F, K, (int)h->sparse);
+		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1, to_sparse);
 		HIPCHK(hipGetLastError());                              // a refused launch here would leave descriptors without data
 	}
 	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout;
-	if (to_sparse) {                                           // stamps of touched superblocks: none yet; sbtot now describes this layout
-		h->sp_nsb = slots / SB + 1;
-		h->sbtouch.ensure(h->sp_nsb + 2);
-		HIPCHK(hipMemsetAsync(h->sbtouch.p, 0, (h->sp_nsb + 2) * 4, st));
-		h->sp_stamp = 0;
-	}
+	if (to_sparse) h->sp_nsb = slots / SB + 1;                // (h->sbtot now describes this layout; the in-place rounds keep it current)
 	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
 		HIPCHK(hipStreamSynchronize(st));
 		h->pool[h->pside ^ 1].ensure(cap, false, st);
@@ -358,7 +355,6 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView pv = h->pool[h->pside].view();
-	++h->sp_stamp;
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -369,9 +365,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	{ Scope sc(h, RB2_K_PART, units);
 	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtouch.p, h->sp_stamp); }
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
-	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, h->sbtouch.p, h->sp_stamp); }
+	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p);
@@ -436,6 +432,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
 			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
 			++h->n_void;
+			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
 			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
 			relayout(h, false, n_ub, B.n_tot + B.len);
 			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
@@ -511,7 +508,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipStreamSynchronize(h->st));
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->qbuf.release(); h->sbtouch.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(64) void k_relayout_setup(Ctl *ctl, int side, uint3
 
 // one wave per output leaf slot: gathers its symbols from the (one to three) old leaves that hold them -- 3-bit fields ORed into
 // place with LDS atomics --, writes the leaf and its own counts.  Slots that stay empty get zeroed counts.
-__global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, PoolView oldp, PoolView newp, uint32_t F, uint32_t K)
+__global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, PoolView oldp, PoolView newp, uint32_t F, uint32_t K, int old_sparse)
 {
 	__shared__ __align__(16) uint64_t lds[MW][LEAFW + 2];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 	LX[ln] = 0; if (ln < 2) LX[LEAFW + ln] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	if (nvalid) {
-		Loc lc = locate(oldp, orp, p0);                          // wave-uniform
+		Loc lc = old_sparse ? locate(oldp, orp, p0) : locate_dense(orp, p0);   // wave-uniform
 		uint32_t off = (uint32_t)(p0 - lc.s), taken = 0;
 		while (taken < nvalid) {
 			const uint32_t take = min(lc.n - off, nvalid - taken);
@@ -902,8 +902,11 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 			if (taken < nvalid) {                                // next old leaf in use: the next slot, or the first of the next superblock
 				uint64_t g2 = lc.gl + 1;
 				uint32_t n2 = 0;
-				if (g2 % SB != 0 && g2 < orp.leaf0 + orp.nleaves) n2 = oldp.meta[g2].n;
-				if (n2 == 0) { g2 = (lc.gl / SB + 1) * SB; n2 = oldp.meta[g2].n; }
+				if (!old_sparse) n2 = g2 < orp.leaf0 + orp.nleaves ? (uint32_t)min((uint64_t)LEAF, orp.n - (g2 - orp.leaf0) * LEAF) : 0u;
+				else {
+					if (g2 % SB != 0) n2 = dir_row(oldp, g2 / SB, 0)[g2 % SB];
+					if (n2 == 0) { g2 = (lc.gl / SB + 1) * SB; n2 = g2 < orp.leaf0 + orp.nleaves ? dir_row(oldp, g2 / SB, 0)[0] : 0u; }
+				}
 				lc.gl = g2; lc.n = n2;
 				if (n2 == 0) break;                              // cannot happen on a consistent directory
 			}
@@ -939,28 +942,16 @@ namespace rb2 {
 
 // one wave per TWO superblocks (lanes 0-31 / 32-63): per-leaf counts -> exclusive prefix inside the superblock;
 // superblock totals.  Counts are <= LEAF per leaf, prefixes < 2^16: two symbols per packed DPP scan.
-// touch != nullptr (sparse rounds): only superblocks that k_merge_leaf stamped this round changed; the prefixes and the total
-// of every other one are still right (sbtot persists between rounds), so the wave returns after one 8-byte load.  The stamp also
-// carries the FIRST touched slot of the superblock (touch = stamp << 5 | 31 - slot, raised with atomicMax): the prefixes in front
-// of it are unchanged too, so only the slots from there to SP_USED - 1 are read and rewritten, on top of the old prefix of that slot.
-__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, const uint32_t *touch, uint32_t stamp)
+// Runs after every kernel that rewrites whole pieces (k_merge, k_relayout, the loader).  sparse: the pool is in the sparse layout --
+// its directory holds own counts by rows (dir_row, rb2_device.h), so this is a transposition of own[]; the in-place rounds
+// that follow keep rows and totals current themselves (dir_put, rb2_merge.h).
+__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, int sparse)
 {
 	const int ln = lane_id();
 	const uint64_t sb = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2 + (ln >> 5);
 	const uint64_t nsb = ctl->nsb_total;
 	if (sb - (ln >> 5) >= nsb) return;                        // wave-uniform
 	const bool live = sb < nsb;
-	int first = 0, last = SB;                                  // slots [first, last) of my superblock are recomputed
-	if (touch) {
-		if (ctl->overflow) return;                             // void round
-		const uint64_t sbA0 = sb - (ln >> 5);
-		const uint32_t vA = touch[sbA0], vB = sbA0 + 1 < nsb ? touch[sbA0 + 1] : 0u;
-		const bool tA = (vA >> 5) == stamp, tB = (vB >> 5) == stamp;
-		if (!tA && !tB) return;                                // wave-uniform
-		const uint32_t vme = (ln >> 5) ? vB : vA;
-		first = ((ln >> 5) ? tB : tA) ? 31 - (int)(vme & 31u) : SB;   // an untouched neighbour: nothing to do in that half
-		last = SP_USED;                                        // the sparse layout never uses the other slots (their n stays 0)
-	}
 	const uint64_t gl = sb * SB + (ln & 31);
 	// sub-ropes start on superblock boundaries, in ascending order: the one that owns a superblock is the
 	// last with sb0 <= sb (one strided load + ballot per half, see seg_of); its tail leaves may be padding
@@ -969,31 +960,30 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 	const int rA = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA)) - 1);
 	const int rB = max(0, (int)__popcll(__ballot(ln < NR && sb0 <= sbA + 1)) - 1);
 	const RopeDesc &rp = ctl->rope[nside][(ln >> 5) ? rB : rA];
-	const int k = ln & 31;
-	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves && k >= first && k < last;
+	const bool ok = live && gl >= rp.leaf0 && gl < rp.leaf0 + rp.nleaves;
 	LeafMeta m;
 	for (int s = 0; s < 6; ++s) m.c[s] = 0;
 	m.npre = 0; m.n = 0;
 	if (ok) m = newp.own[gl];                                  // own counts + fill, written by the merge kernels / k_relayout / the loader
-	uint32_t b01 = 0, b23 = 0, b45 = 0;                        // prefix in front of slot `first`: zero for a full rebuild, else what meta[] holds there
-	if (touch) {
-		if (ok && k == first) { const LeafMeta o = newp.meta[gl]; b01 = o.c[0] | (uint32_t)o.c[1] << 16; b23 = o.c[2] | (uint32_t)o.c[3] << 16; b45 = o.c[4] | (uint32_t)o.c[5] << 16; }
-		const int src = (ln & 32) + min(first, SB - 1);
-		b01 = __shfl(b01, src); b23 = __shfl(b23, src); b45 = __shfl(b45, src);
-	}
 	const uint32_t e01 = m.c[0] | (uint32_t)m.c[1] << 16, e23 = m.c[2] | (uint32_t)m.c[3] << 16, e45 = m.c[4] | (uint32_t)m.c[5] << 16;
 	uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
 	const uint32_t h01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 31), h23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 31), h45 = (uint32_t)__builtin_amdgcn_readlane((int)s45, 31);
 	if (ln >> 5) { s01 -= h01; s23 -= h23; s45 -= h45; }      // second superblock: prefix relative to its own first leaf
-	s01 += b01; s23 += b23; s45 += b45;
 	const uint32_t x01 = s01 - e01, x23 = s23 - e23, x45 = s45 - e45;
-	if (ok) {
+	if (sparse) {
+		if (live) {                                            // all 32 slots: an unused one must read as empty
+			uint16_t *dr = dir_row(newp, sb, 0) + (ln & 31);
+			dr[0] = m.n;
+#pragma unroll
+			for (int s = 0; s < 6; ++s) dr[(1 + s) * SB] = m.c[s];
+		}
+	} else if (ok) {
 		m.c[0] = (uint16_t)x01; m.c[1] = (uint16_t)(x01 >> 16); m.c[2] = (uint16_t)x23; m.c[3] = (uint16_t)(x23 >> 16);
 		m.c[4] = (uint16_t)x45; m.c[5] = (uint16_t)(x45 >> 16);
 		m.npre = (uint16_t)((x01 & 0xffffu) + (x01 >> 16) + (x23 & 0xffffu) + (x23 >> 16) + (x45 & 0xffffu) + (x45 >> 16));   // <= SB * LEAF < 2^16
 		newp.meta[gl] = m;
 	}
-	if (k == 31 && live && first < SB) {                      // inclusive prefix of the last leaf = superblock total (<= 32768 per symbol)
+	if ((ln & 31) == 31 && live) {                             // inclusive prefix of the last leaf = superblock total (<= 43008 per symbol)
 		SbTot c;
 		c.p01 = s01; c.p23 = s23; c.p45 = s45; c.pad = 0;
 		sbtot[sb] = c;
@@ -1110,7 +1100,7 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
 			gl = nrp.leaf0 + f / LEAF;
 		}
-		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + newp.meta[gl].c[a] + RKREL[t.segstart + m.slot];
+		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;

@@ -189,7 +189,7 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 		RKREL[d.ins0 + jj] = (uint16_t)r;
 		if (INPLACE) RKLEAF[d.ins0 + jj] = (uint32_t)d.gl;
 	}
-	if ((ln % LPW) == LPW - 1 && (ln / LPW) * LEAF < nvalid) {   // last lane of a leaf that exists
+	if (!INPLACE && (ln % LPW) == LPW - 1 && (ln / LPW) * LEAF < nvalid) {   // last lane of a leaf that exists (in place: the directory is kept by dir_add)
 		const uint32_t bl = (uint32_t)(ln / LPW) * LPW;
 		const uint32_t t01 = s01 - LP[4 * bl + 0], t23 = s23 - LP[4 * bl + 1], t45 = s45 - LP[4 * bl + 2];
 		LeafMeta m;
@@ -225,28 +225,56 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 // every lane keeps its word in a register; per new symbol (ascending position, so earlier ones are already in place) one
 // masked compare + wave sum gives its rank, one shift with a DPP carry from the lane below opens the gap.  No LDS, and only
 // the words from the first changed one on are stored.  (rle_insert_cached, rle.c:10-89, for <= LIGHT_NI inserts.)
+// Sparse rounds keep the rank directory current themselves (the dense rounds rebuild it, k_meta_sb): the directory of a
+// superblock holds OWN counts by rows (dir_row, rb2_device.h), so a leaf that received symbols adds them to its own entries and
+// to the superblock total, and nothing behind it moves.  What a round costs is then proportional to the leaves it touches; only
+// the prefix over the superblock totals (k_sbscan*) still reads every superblock.  (rope.c:139-146: the counts along the path.)
+// Atomics although a row entry has one writer (the total has several): a 2-byte store is a partial write the memory side has to
+// merge, and measured slower (1 M touched leaves per round: k_merge_leaf 0.42 ms with stores, 0.32 ms with atomics).  The kernel
+// is bound by the latency of a wave's chain of memory operations, not by bytes (reading only the changed tail of a leaf gains
+// nothing): the atomics are issued as ONE instruction, and before the wave starts shifting words -- at its end they cost 0.05 ms
+// more, as three instructions another 0.04.  d01 | d23 | d45: symbols received, packed like LeafMeta::c; same values in all lanes.
+__device__ __forceinline__ void dir_add(const PoolView &pool, SbTot *sbtot, uint64_t gl, int ln, uint32_t d01, uint32_t d23, uint32_t d45)
+{
+	const uint32_t k = (uint32_t)(gl % SB), hs = (k & 1) * 16;
+	uint32_t *dw32 = (uint32_t*)dir_row(pool, gl / SB, 0) + (k >> 1);
+	const int s = ln - 1;                                      // lanes 1-6: one symbol each
+	const uint32_t dw = s < 2 ? d01 : (s < 4 ? d23 : d45), dv = (dw >> ((uint32_t)(s & 1) * 16)) & 0xffffu;
+	// one atomic instruction: lane 0 the fill, lanes 1-6 the symbols that changed, lanes 7-9 the three words of the total
+	uint32_t *ptr = dw32 + ln * (SB / 2);
+	uint32_t val = (ln == 0 ? (d01 & 0xffffu) + (d01 >> 16) + (d23 & 0xffffu) + (d23 >> 16) + (d45 & 0xffffu) + (d45 >> 16) : dv) << hs;
+	if (ln >= 7) { ptr = (uint32_t*)&sbtot[gl / SB] + (ln - 7); val = ln == 7 ? d01 : (ln == 8 ? d23 : d45); }
+	if (ln <= 9 && val) atomicAdd(ptr, val);
+}
+
 constexpr int LIGHT_NI = 8;
 constexpr int LPWV = 2;                     // touched leaves per wave in k_merge_leaf: their loads are issued together (the kernel is
                                             // bound by memory latency x occupancy, not by bandwidth or instructions)
-struct LeafJob { uint64_t w; LeafMeta m; uint32_t pj, aj; };
+struct LeafJob { uint64_t w; uint32_t pj, aj; };
 
 __device__ __forceinline__ void leaf_job_load(const LeafDesc &d, const int ln, const PoolView &pool,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, LeafJob &J)
 {
 	J.w = ((const uint64_t*)pool.data)[d.gl * LEAFW + ln];
-	J.m = pool.own[d.gl];
 	J.pj = 0; J.aj = 0;
 	if (ln < (int)d.ni) { J.aj = INS_A[d.ins0 + ln]; J.pj = (uint32_t)(INS_E[d.ins0 + ln] - d.i0) + (uint32_t)ln; }   // final position E[q] + q inside the leaf
 }
 
-__device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, const PoolView &pool, LeafJob &J, uint16_t *RKREL, uint32_t *RKLEAF)
+__device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, const PoolView &pool, LeafJob &J, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
 	uint64_t *leaf = (uint64_t*)pool.data + d.gl * LEAFW;
 	const int ni = d.ni;
 	uint64_t w = J.w;
 	uint32_t myrank = 0;
 	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, 0) / SPW;   // first word that changes
-	uint32_t add01 = 0, add23 = 0, add45 = 0;
+	{	// what the leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
+		// while the wave shifts words
+		uint32_t dd[3] = {0, 0, 0};
+#pragma unroll
+		for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(ln < ni && J.aj == (uint32_t)sy)) << (16 * (sy & 1));
+		dir_add(pool, sbtot, d.gl, ln, dd[0], dd[1], dd[2]);
+		if (ln < ni) RKLEAF[d.ins0 + ln] = (uint32_t)d.gl;
+	}
 	for (int j = 0; j < ni; ++j) {
 		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)J.aj, j);
 		const uint32_t pw = p / SPW, po = (p - pw * SPW) * SBITS;
@@ -257,45 +285,42 @@ __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, co
 		const uint32_t carry = dpp_prev_lane((uint32_t)(w >> (SBITS * (SPW - 1))) & 7u);    // top symbol of the lane below moves up
 		if ((uint32_t)ln > pw) w = ((w << SBITS) & MALL) | carry;
 		else if ((uint32_t)ln == pw) w = (w & below) | ((uint64_t)a << po) | (((w & ~below) << SBITS) & MALL);
-		const uint32_t one = 1u << (16 * (a & 1));
-		if ((a >> 1) == 0) add01 += one; else if ((a >> 1) == 1) add23 += one; else add45 += one;
 	}
-	if ((uint32_t)ln >= pw0) leaf[ln] = w;
-	if (ln < ni) { RKREL[d.ins0 + ln] = (uint16_t)myrank; RKLEAF[d.ins0 + ln] = (uint32_t)d.gl; }
-	if (ln == 0) {
-		LeafMeta m = J.m;
-		m.c[0] += (uint16_t)add01; m.c[1] += (uint16_t)(add01 >> 16); m.c[2] += (uint16_t)add23; m.c[3] += (uint16_t)(add23 >> 16);
-		m.c[4] += (uint16_t)add45; m.c[5] += (uint16_t)(add45 >> 16);
-		m.n += (uint16_t)ni;
-		pool.own[d.gl] = m;
-	}
+	if ((uint32_t)ln >= pw0) leaf[ln] = w;                     // (the line is in L2: the leaf was just read)
+	if (ln < ni) RKREL[d.ins0 + ln] = (uint16_t)myrank;
 }
 
 // sparse rounds: one wave per LPWV TOUCHED leaves (work orders appended by k_part_sparse, any order), rewritten in place --
 // rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts a
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
 __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF, uint32_t *touch, uint32_t stamp)
+		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
 	const uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LPWV;
-	const uint32_t nwork = ctl->nwork;
-	if (ctl->overflow || g0 >= nwork) return;
 	LeafDesc d[LPWV];
 	LeafJob J[LPWV];
 #pragma unroll
-	for (int k = 0; k < LPWV; ++k) d[k] = LD[min(g0 + k, (uint64_t)nwork - 1)];    // (a duplicate of the last order is never run)
+	for (int k = 0; k < LPWV; ++k) d[k] = LD[g0 + k];          // LD has a slot for every order the grid could run: issued together with the counters
+	const uint32_t nwork = ctl->nwork;                        // (the kernel is bound by the latency of its chain of loads: every link counts)
+	if (ctl->overflow || g0 >= nwork) return;
 #pragma unroll
 	for (int k = 0; k < LPWV; ++k) if (g0 + k < nwork && d[k].ni <= LIGHT_NI) leaf_job_load(d[k], ln, pool, INS_E, INS_A, J[k]);
 #pragma unroll
 	for (int k = 0; k < LPWV; ++k) {
 		if (g0 + k >= nwork) break;
-		if (ln == 0) atomicMax(&touch[d[k].gl / SB], stamp << 5 | (31u - (uint32_t)(d[k].gl % SB)));   // this superblock's prefixes must be rebuilt from this slot on (k_meta_sb)
-		if (d[k].ni <= LIGHT_NI) { leaf_job_run(d[k], ln, pool, J[k], RKREL, RKLEAF); continue; }
+		if (d[k].ni <= LIGHT_NI) { leaf_job_run(d[k], ln, pool, J[k], RKREL, RKLEAF, sbtot); continue; }
 		uint64_t *LX = lds[wv], *LO = lds[wv] + 64;             // LO: 64 + 2 old words, later the 64 x 4 packed prefixes (128 words)
 		uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);         // 64 flag words of 32 bits
+		uint32_t dd[3] = {0, 0, 0};                              // what the leaf receives, per symbol
+		for (int j0 = 0; j0 < (int)d[k].ni; j0 += 64) {
+			const uint32_t a = j0 + ln < (int)d[k].ni ? (uint32_t)INS_A[d[k].ins0 + j0 + ln] : 7u;
+#pragma unroll
+			for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(a == (uint32_t)sy)) << (16 * (sy & 1));
+		}
+		dir_add(pool, sbtot, d[k].gl, ln, dd[0], dd[1], dd[2]);
 		merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
 	}
