@@ -221,7 +221,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		h->pool[h->pside].ensure(leaves_ub, true, st);
 		h->pool[h->pside ^ 1].ensure(leaves_ub, false, st);
 	}
-	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 16));   // dense: one work order per output window; sparse: at most one per string
+	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
 	{
@@ -339,7 +339,7 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 		HIPCHK(hipGetLastError());                              // a refused launch here would leave descriptors without data
 	}
 	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout;
-	if (to_sparse) h->sp_nsb = slots / SB + 1;                // (h->sbtot now describes this layout; the in-place rounds keep it current)
+	if (to_sparse) h->sp_nsb = slots / SB + 1;
 	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
 		HIPCHK(hipStreamSynchronize(st));
 		h->pool[h->pside ^ 1].ensure(cap, false, st);

@@ -221,43 +221,71 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
 }
 
-// A leaf that receives only a few symbols (the normal case of a sparse round: one or two) does not need the window machinery:
-// every lane keeps its word in a register; per new symbol (ascending position, so earlier ones are already in place) one
-// masked compare + wave sum gives its rank, one shift with a DPP carry from the lane below opens the gap.  No LDS, and only
-// the words from the first changed one on are stored.  (rle_insert_cached, rle.c:10-89, for <= LIGHT_NI inserts.)
 // Sparse rounds keep the rank directory current themselves (the dense rounds rebuild it, k_meta_sb): the directory of a
 // superblock holds OWN counts by rows (dir_row, rb2_device.h), so a leaf that received symbols adds them to its own entries and
 // to the superblock total, and nothing behind it moves.  What a round costs is then proportional to the leaves it touches; only
 // the prefix over the superblock totals (k_sbscan*) still reads every superblock.  (rope.c:139-146: the counts along the path.)
 // Atomics although a row entry has one writer (the total has several): a 2-byte store is a partial write the memory side has to
-// merge, and measured slower (1 M touched leaves per round: k_merge_leaf 0.42 ms with stores, 0.32 ms with atomics).  The kernel
-// is bound by the latency of a wave's chain of memory operations, not by bytes (reading only the changed tail of a leaf gains
-// nothing): the atomics are issued as ONE instruction, and before the wave starts shifting words -- at its end they cost 0.05 ms
-// more, as three instructions another 0.04.  d01 | d23 | d45: symbols received, packed like LeafMeta::c; same values in all lanes.
-__device__ __forceinline__ void dir_add(const PoolView &pool, SbTot *sbtot, uint64_t gl, int ln, uint32_t d01, uint32_t d23, uint32_t d45)
+// merge, and measured slower (1 M touched leaves per round: k_merge_leaf 0.42 ms with stores, 0.32 ms with atomics).  They are
+// issued as ONE instruction, and before the wave starts shifting words: at its end they cost 0.05 ms more, as three
+// instructions another 0.04.
+// Lane roles: 0 = the fill, 1-6 = the own count of symbol ln - 1, 7-9 = the three packed words of the superblock total (its own
+// small array: 16 bytes per superblock stay in cache, the directory blocks do not -- with the total in the spare row of the block
+// k_merge_leaf took 0.06 ms longer and the scan kernels twice as long).  cnt = what the lane adds.
+__device__ __forceinline__ void dir_commit(const PoolView &pool, SbTot *sbtot, uint64_t gl, int ln, uint32_t cnt)
 {
-	const uint32_t k = (uint32_t)(gl % SB), hs = (k & 1) * 16;
-	uint32_t *dw32 = (uint32_t*)dir_row(pool, gl / SB, 0) + (k >> 1);
-	const int s = ln - 1;                                      // lanes 1-6: one symbol each
-	const uint32_t dw = s < 2 ? d01 : (s < 4 ? d23 : d45), dv = (dw >> ((uint32_t)(s & 1) * 16)) & 0xffffu;
-	// one atomic instruction: lane 0 the fill, lanes 1-6 the symbols that changed, lanes 7-9 the three words of the total
-	uint32_t *ptr = dw32 + ln * (SB / 2);
-	uint32_t val = (ln == 0 ? (d01 & 0xffffu) + (d01 >> 16) + (d23 & 0xffffu) + (d23 >> 16) + (d45 & 0xffffu) + (d45 >> 16) : dv) << hs;
-	if (ln >= 7) { ptr = (uint32_t*)&sbtot[gl / SB] + (ln - 7); val = ln == 7 ? d01 : (ln == 8 ? d23 : d45); }
-	if (ln <= 9 && val) atomicAdd(ptr, val);
+	const uint32_t k = (uint32_t)(gl % SB);
+	uint32_t *ptr = (uint32_t*)dir_row(pool, gl / SB, 0) + (uint32_t)ln * (SB / 2) + (k >> 1);
+	if (ln >= 7) ptr = (uint32_t*)&sbtot[gl / SB] + (ln - 7);
+	const uint32_t val = ln < 7 ? cnt << ((k & 1) * 16) : cnt;
+	if (ln < 10 && val) atomicAdd(ptr, val);
+}
+// a leaf that receives ni <= 64 symbols, lane j holding the j-th (light path: ni <= LIGHT_NI, a handful of instructions per symbol)
+__device__ __forceinline__ void dir_add(const PoolView &pool, SbTot *sbtot, uint64_t gl, int ln, int ni, uint32_t aj)
+{
+	const uint32_t keyA = (uint32_t)ln - 1u, keyW = (uint32_t)ln - 7u;   // lanes without that role never match: a <= 5, a >> 1 <= 2
+	uint32_t cnt = ln == 0 ? (uint32_t)ni : 0u;
+	auto tally = [&](int j) {
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)aj, j);
+		cnt += (a == keyA ? 1u : 0u) + ((a >> 1) == keyW ? 1u << (16 * (a & 1)) : 0u);
+	};
+	// first symbol outside the loop (ni >= 1): in straight-line code the compiler waits for exactly the load that brings aj; at a
+	// loop head it waits for every load in flight -- also the other leaf's words, whose latency this leaf's work is meant to hide
+	tally(0);
+	for (int j = 1; j < ni; ++j) tally(j);
+	dir_commit(pool, sbtot, gl, ln, cnt);
+}
+// ... any number, already counted: d01 | d23 | d45 packed like LeafMeta::c, same values in all lanes
+__device__ __forceinline__ void dir_add_packed(const PoolView &pool, SbTot *sbtot, uint64_t gl, int ln, uint32_t d01, uint32_t d23, uint32_t d45)
+{
+	const int s = ln - 1;
+	const uint32_t dw = s < 2 ? d01 : (s < 4 ? d23 : d45);
+	uint32_t cnt = (dw >> ((uint32_t)(s & 1) * 16)) & 0xffffu;
+	if (ln == 0) cnt = (d01 & 0xffffu) + (d01 >> 16) + (d23 & 0xffffu) + (d23 >> 16) + (d45 & 0xffffu) + (d45 >> 16);
+	if (ln >= 7) cnt = ln == 7 ? d01 : (ln == 8 ? d23 : d45);
+	dir_commit(pool, sbtot, gl, ln, cnt);
 }
 
+// A leaf that receives only a few symbols (the normal case of a sparse round: one or two) does not need the window machinery:
+// every lane keeps its word in a register; per new symbol (ascending position, so earlier ones are already in place) one
+// masked compare + wave sum gives its rank, one shift with a DPP carry from the lane below opens the gap.  No LDS, and only
+// the words from the first changed one on are stored.  (rle_insert_cached, rle.c:10-89, for <= LIGHT_NI inserts.)
 constexpr int LIGHT_NI = 8;
-constexpr int LPWV = 2;                     // touched leaves per wave in k_merge_leaf: their loads are issued together (the kernel is
-                                            // bound by memory latency x occupancy, not by bandwidth or instructions)
+constexpr int LPWV = 4;                     // touched leaves per wave in k_merge_leaf.  The kernel is bound by instruction issue (PMC: 225
+                                            // VALU + 184 SALU per two leaves at first) and by the latency of each wave's loads: all loads of
+                                            // the wave's leaves are issued first, back to back (see the barrier in k_merge_leaf; while the
+                                            // compiler still waited inside leaf_job_load, or sank loads into the branches, two leaves per
+                                            // wave were the optimum and the kernel took 0.31 ms; now 0.26 with two, 0.24 with four)
 struct LeafJob { uint64_t w; uint32_t pj, aj; };
 
 __device__ __forceinline__ void leaf_job_load(const LeafDesc &d, const int ln, const PoolView &pool,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, LeafJob &J)
+		const uint64_t *INS_E, const uint8_t *INS_A, LeafJob &J)
 {
 	J.w = ((const uint64_t*)pool.data)[d.gl * LEAFW + ln];
-	J.pj = 0; J.aj = 0;
-	if (ln < (int)d.ni) { J.aj = INS_A[d.ins0 + ln]; J.pj = (uint32_t)(INS_E[d.ins0 + ln] - d.i0) + (uint32_t)ln; }   // final position E[q] + q inside the leaf
+	// No branch and no use of a loaded value in here: the loads of all the wave's leaves are to be in flight together, and the
+	// compiler's wait counts stay exact only in straight-line code (lanes >= ni load the last insert again; they never use it).
+	const uint32_t q = (uint32_t)d.ins0 + (uint32_t)min(ln, (int)d.ni - 1);
+	J.aj = INS_A[q]; J.pj = ((const uint32_t*)INS_E)[2 * (uint64_t)q];   // low half: positions inside a leaf need no more
 }
 
 __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, const PoolView &pool, LeafJob &J, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
@@ -266,15 +294,12 @@ __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, co
 	const int ni = d.ni;
 	uint64_t w = J.w;
 	uint32_t myrank = 0;
+	J.pj = J.pj - (uint32_t)d.i0 + (uint32_t)ln;                 // final position E[q] + q inside the leaf (lanes >= ni: unused)
 	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, 0) / SPW;   // first word that changes
-	{	// what the leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
-		// while the wave shifts words
-		uint32_t dd[3] = {0, 0, 0};
-#pragma unroll
-		for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(ln < ni && J.aj == (uint32_t)sy)) << (16 * (sy & 1));
-		dir_add(pool, sbtot, d.gl, ln, dd[0], dd[1], dd[2]);
-		if (ln < ni) RKLEAF[d.ins0 + ln] = (uint32_t)d.gl;
-	}
+	// what the leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
+	// while the wave shifts words
+	dir_add(pool, sbtot, d.gl, ln, ni, J.aj);
+	if (ln < ni) RKLEAF[d.ins0 + ln] = (uint32_t)d.gl;
 	for (int j = 0; j < ni; ++j) {
 		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)J.aj, j);
 		const uint32_t pw = p / SPW, po = (p - pw * SPW) * SBITS;
@@ -294,7 +319,7 @@ __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, co
 // rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts a
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
 __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
+		const uint64_t *INS_E, const uint8_t *INS_A /* not __restrict__: see the barrier below */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -307,7 +332,11 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 	const uint32_t nwork = ctl->nwork;                        // (the kernel is bound by the latency of its chain of loads: every link counts)
 	if (ctl->overflow || g0 >= nwork) return;
 #pragma unroll
-	for (int k = 0; k < LPWV; ++k) if (g0 + k < nwork && d[k].ni <= LIGHT_NI) leaf_job_load(d[k], ln, pool, INS_E, INS_A, J[k]);
+	for (int k = 1; k < LPWV; ++k) if (g0 + k >= nwork) d[k] = d[0];   // (a duplicate of the first order is loaded but never run)
+#pragma unroll
+	for (int k = 0; k < LPWV; ++k) leaf_job_load(d[k], ln, pool, INS_E, INS_A, J[k]);
+	asm volatile("" ::: "memory");                            // the loads stay here, all of them, in this order: the compiler would sink each into the branch that uses
+	                                                          // it (and does, across this barrier, for pointers it knows to be read-only and unaliased)
 #pragma unroll
 	for (int k = 0; k < LPWV; ++k) {
 		if (g0 + k >= nwork) break;
@@ -320,7 +349,7 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 #pragma unroll
 			for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(a == (uint32_t)sy)) << (16 * (sy & 1));
 		}
-		dir_add(pool, sbtot, d[k].gl, ln, dd[0], dd[1], dd[2]);
+		dir_add_packed(pool, sbtot, d[k].gl, ln, dd[0], dd[1], dd[2]);
 		merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
 	}
