@@ -10,6 +10,7 @@
 #include <climits>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #include "rb2_hip.h"
 #include "rb2_kernels.h"
 
@@ -325,6 +326,8 @@ uint64_t slots_for(uint64_t n, bool sparse)
 void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 {
 	hipStream_t st = h->st;
+	const auto t_host0 = std::chrono::steady_clock::now();
+	const uint64_t cap_before[2] = { h->pool[0].cap_leaves, h->pool[1].cap_leaves };
 	const uint32_t F = to_sparse ? SP_FILL : LEAF, K = to_sparse ? SP_USED : SB;
 	const uint64_t slots = slots_for(n_ub, to_sparse), cap = to_sparse ? slots : slots_for(std::max(n_ub, n_grow), false);
 	if (h->pool[h->pside ^ 1].cap_leaves < cap) {              // kernels of earlier rounds may still read the buffers about to be replaced
@@ -343,6 +346,11 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
 		HIPCHK(hipStreamSynchronize(st));
 		h->pool[h->pside ^ 1].ensure(cap, false, st);
+	}
+	if (h->trace) {
+		HIPCHK(hipStreamSynchronize(st));
+		fprintf(stderr, "[rb2_hip] re-layout to %s: %.1f G symbols, %.3f s on the host clock, pools %.1f / %.1f -> %.1f / %.1f M leaf slots\n", to_sparse ? "sparse" : "dense", n_ub / 1e9,
+				std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host0).count(), cap_before[0] / 1e6, cap_before[1] / 1e6, h->pool[0].cap_leaves / 1e6, h->pool[1].cap_leaves / 1e6);
 	}
 }
 
@@ -432,7 +440,6 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
 			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
 			++h->n_void;
-			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
 			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
 			relayout(h, false, n_ub, B.n_tot + B.len);
 			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
