@@ -421,7 +421,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
 		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
 		const double lambda = (double)B.m / ((double)n_ub / LEAF + 1.0);
-		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 26);   // (k_merge_leaf: one wave per two work orders, 2^32 threads per launch)
+		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LPWV work orders, 2^32 threads per launch)
 		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 		if (h->sp_backoff > 0) --h->sp_backoff;
 		if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
