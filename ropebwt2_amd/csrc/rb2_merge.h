@@ -295,14 +295,16 @@ __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, co
 	uint64_t w = J.w;
 	uint32_t myrank = 0;
 	J.pj = J.pj - (uint32_t)d.i0 + (uint32_t)ln;                 // final position E[q] + q inside the leaf (lanes >= ni: unused)
-	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, 0) / SPW;   // first word that changes
+	const uint32_t pwl = J.pj / SPW, pol = (J.pj - pwl * SPW) * SBITS;   // word and bit offset of every insert, by its lane, once (a scalar
+	                                                                     // division by 21 per insert in the loop is eight SALU instructions)
+	const uint32_t pw0 = (uint32_t)__builtin_amdgcn_readlane((int)pwl, 0);   // first word that changes
 	// what the leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
 	// while the wave shifts words
 	dir_add(pool, sbtot, d.gl, ln, ni, J.aj);
 	if (ln < ni) RKLEAF[d.ins0 + ln] = (uint32_t)d.gl;
 	for (int j = 0; j < ni; ++j) {
-		const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)J.pj, j), a = (uint32_t)__builtin_amdgcn_readlane((int)J.aj, j);
-		const uint32_t pw = p / SPW, po = (p - pw * SPW) * SBITS;
+		const uint32_t pw = (uint32_t)__builtin_amdgcn_readlane((int)pwl, j), po = (uint32_t)__builtin_amdgcn_readlane((int)pol, j);
+		const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)J.aj, j);
 		const uint64_t below = (1ull << po) - 1ull;
 		const uint64_t msk = (uint32_t)ln < pw ? MLOW : ((uint32_t)ln == pw ? (MLOW & below) : 0ull);
 		const uint32_t r = lane63(dpp_incl_add((uint32_t)__popcll(nib_eq(w, a) & msk)));   // a's in front of p, leaf as it is now
