@@ -654,97 +654,105 @@ int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
 	return k;
 }
 
-static inline const uint8_t *dec43(const uint8_t *p, int *c, int64_t *l)   /* one run of the 43+3 codec (rle.h:39-51) */
-{
-	*c = *p & 7;
-	if ((*p & 0x80) == 0) { *l = *p >> 3; return p + 1; }
-	if ((*p >> 5) == 6) { *l = ((int64_t)(*p & 0x18) << 3) | (p[1] & 0x3f); return p + 2; }
-	const int nb = (*p & 0x10) ? 8 : 4;
-	int64_t v = (*p >> 3) & 1;
-	for (int i = 1; i < nb; ++i) v = (v << 6) | (p[i] & 0x3f);
-	*l = v;
-	return p + nb;
-}
-
 void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6])
 {
 	HIPCHK(hipSetDevice(h->dev));
-	// pass 1: symbol counts of the six ropes.  Piece (b,x) of rope b has as many rows as rope x has b's.
-	int64_t tot[6][6];
-	memset(tot, 0, sizeof(tot));
+	hipStream_t st = h->st;
+	// The run bytes go to the device as they are and are decoded there (k_ld_*, rb2_kernels.h): at configs[4] size -- an index of
+	// 500 M reads, 35 GB of runs -- a host loop over the runs is minutes of one core (the first version: 17 s for 5 G symbols).
+	DevBuf<uint8_t> dr[6]; DevBuf<uint64_t> blk[6];
+	DevBuf<unsigned long long> cnt;                            // [0, 36): symbol totals of the six ropes; [36, 36 + NR * 6): per piece
+	DevBuf<uint32_t> flag;                                     // [0] bad input, [1] long runs
+	const uint32_t long_cap = 1u << 20;
+	DevBuf<LdLong> longs;
+	cnt.ensure(36 + NR * 6); flag.ensure(2); longs.ensure(long_cap);
+	HIPCHK(hipMemsetAsync(cnt.p, 0, (36 + NR * 6) * 8, st));
+	HIPCHK(hipMemsetAsync(flag.p, 0, 8, st));
+	uint64_t nblk[6];
 	for (int b = 0; b < 6; ++b) {
-		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
-		while (p && p < end) {
-			int c; int64_t l;
-			p = dec43(p, &c, &l);
-			if (c > 5) { fprintf(stderr, "[rb2_hip] load_ropes: bad symbol %d\n", c); abort(); }
-			tot[b][c] += l;
-		}
+		const uint64_t nb = rle[b] && n_bytes[b] > 0 ? (uint64_t)n_bytes[b] : 0;
+		nblk[b] = cdiv(nb, LDB);
+		if (nb == 0) continue;
+		dr[b].ensure(nb + 16); blk[b].ensure(nblk[b] + 1);
+		HIPCHK(hipMemcpyAsync(dr[b].p, rle[b], nb, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_ld_count, dim3((unsigned)nblk[b]), dim3(256), 0, st, (const uint8_t*)dr[b].p, nb, blk[b].p, cnt.p + b * 6, flag.p);
 	}
-	// pass 2: decode again into LEAF-symbol leaves of packed 3-bit symbols, cutting rope b into its pieces
-	std::vector<uint8_t> data; std::vector<LeafMeta> meta;
+	unsigned long long tot_h[36]; uint32_t flag_h[2];
+	HIPCHK(hipMemcpyAsync(tot_h, cnt.p, sizeof(tot_h), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(flag_h, flag.p, 8, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (flag_h[0]) { fprintf(stderr, "[rb2_hip] load_ropes: not run-length bytes of ropebwt2's codec (bad symbol or truncated run)\n"); abort(); }
+	// piece (b,x) of rope b has as many rows as rope x has b's; rope $ is one piece
+	uint64_t tot[6][6];
+	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) tot[b][a] = tot_h[b * 6 + a];
 	RopeDesc rp[NR];
+	LdPieces tab[6];
 	uint64_t leaf = 0;
 	for (int r = 0; r < NR; ++r) memset(&rp[r], 0, sizeof(RopeDesc));
 	for (int b = 0; b < 6; ++b) {
-		const uint8_t *p = rle[b], *end = p + (n_bytes[b] > 0 ? n_bytes[b] : 0);
-		int c = 0; int64_t l = 0;                     // run being consumed
-		for (int x = 0; x < (b == 0 ? 1 : 6); ++x) {
+		LdPieces &t = tab[b];
+		memset(&t, 0, sizeof(t));
+		t.np = b == 0 ? 1 : 6;
+		uint64_t have = 0, want = 0;
+		for (int a = 0; a < 6; ++a) have += tot[b][a];
+		for (int x = 0; x < t.np; ++x) {
 			const int r = b == 0 ? 0 : rope_of(b, x);
-			int64_t quota = 0;
-			if (b == 0) { for (int a = 0; a < 6; ++a) quota += tot[0][a]; }
-			else quota = tot[x][b];
+			uint64_t quota = 0;
+			if (b == 0) quota = have; else quota = tot[x][b];
 			const bool keep = h->nranks == 1 || h->owner[r] == h->rank;   // sharded: other ranks' pieces are only counted
 			RopeDesc &d = rp[r];
 			d.leaf0 = leaf; d.sb0 = leaf / SB;
-			data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
-			LeafMeta cur; memset(&cur, 0, sizeof(cur));
-			uint32_t fill = 0; uint8_t *slot = nullptr;
-			auto open_leaf = [&]() { data.resize(data.size() + LEAFB); meta.resize(meta.size() + 1); slot = data.data() + data.size() - LEAFB; memset(&cur, 0, sizeof(cur)); fill = 0; };
-			auto close_leaf = [&]() { cur.n = (uint16_t)fill; meta.back() = cur; ++d.nleaves; slot = nullptr; };
-			while (quota > 0) {
-				if (l == 0) {
-					if (!(p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); abort(); }
-					p = dec43(p, &c, &l);
-					continue;
-				}
-				int64_t part = std::min<int64_t>(l, quota);
-				l -= part; quota -= part;
-				d.cnt[c] += part; d.n += part;
-				while (keep && part > 0) {
-					if (!slot) open_leaf();
-					const int64_t take = std::min<int64_t>(part, LEAF - fill);
-					for (int64_t t = take; t > 0; ) {                // 21 symbols per 64-bit word, 3 bits each: a run fills word by word
-						const uint32_t wi = fill / SPW, off = fill % SPW;
-						const uint32_t k = (uint32_t)std::min<int64_t>(t, SPW - off);
-						const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
-						((uint64_t*)slot)[wi] |= ((uint64_t)c * MLOW & field) << (SBITS * off);
-						fill += k; t -= k;
-					}
-					cur.c[c] += (uint16_t)take; part -= take;
-					if (fill == LEAF) close_leaf();
-				}
-			}
-			if (slot) close_leaf();
-			if (!keep) d.n = 0;
+			d.n = keep ? quota : 0;
+			d.nleaves = keep ? (quota + LEAF - 1) / LEAF : 0;
+			t.q[x] = want; t.word0[x] = leaf * LEAFW; t.keep[x] = keep; t.r[x] = r;
+			want += quota;
 			leaf += (d.nleaves + SB - 1) / SB * SB;
 		}
-		if (l != 0 || (p && p < end)) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
+		t.q[t.np] = want;
+		if (have < want) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); abort(); }
+		if (have > want) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
 	}
-	data.resize((size_t)leaf * LEAFB); meta.resize((size_t)leaf);
 	const int sd = h->side, ps = h->pside;
 	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;      /* what is loaded is the dense layout */
-	h->pool[ps].ensure(leaf + SB, false, h->st);
+	h->pool[ps].ensure(leaf + SB, false, st);
+	PoolView pv = h->pool[ps].view();
 	if (leaf) {
-		HIPCHK(hipMemcpyAsync(h->pool[ps].data.p, data.data(), data.size(), hipMemcpyHostToDevice, h->st));
-		HIPCHK(hipMemcpyAsync(h->pool[ps].own.p, meta.data(), meta.size() * sizeof(LeafMeta), hipMemcpyHostToDevice, h->st));   /* own counts; build_directory derives the prefixes */
+		HIPCHK(hipMemsetAsync(pv.data, 0, leaf * (uint64_t)LEAFB, st));
+		HIPCHK(hipMemsetAsync(pv.own, 0, leaf * sizeof(LeafMeta), st));
 	}
-	HIPCHK(hipMemcpyAsync(&h->ctl->rope[sd][0], rp, sizeof(rp), hipMemcpyHostToDevice, h->st));
+	std::vector<uint64_t> off;
+	for (int b = 0; b < 6; ++b) {
+		if (nblk[b] == 0) continue;
+		off.resize(nblk[b] + 1);
+		HIPCHK(hipMemcpyAsync(off.data(), blk[b].p, nblk[b] * 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		uint64_t run = 0;
+		for (uint64_t i = 0; i < nblk[b]; ++i) { const uint64_t v = off[i]; off[i] = run; run += v; }
+		HIPCHK(hipMemcpyAsync(blk[b].p, off.data(), nblk[b] * 8, hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_ld_expand, dim3((unsigned)nblk[b]), dim3(256), 0, st, (const uint8_t*)dr[b].p, (uint64_t)n_bytes[b], (const uint64_t*)blk[b].p, tab[b],
+				(uint64_t*)pv.data, cnt.p + 36, longs.p, flag.p + 1, long_cap, flag.p);
+		hipLaunchKernelGGL(k_ld_long, dim3(1024), dim3(256), 0, st, (const LdLong*)longs.p, (const uint32_t*)(flag.p + 1), long_cap, (uint64_t*)pv.data);
+		HIPCHK(hipMemcpyAsync(flag_h, flag.p, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));                      // (off is reused; the long-run list is per rope)
+		if (flag_h[0]) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d does not match the symbol counts of the other ropes\n", b); abort(); }
+		if (flag_h[1] > long_cap) { fprintf(stderr, "[rb2_hip] load_ropes: more than %u runs longer than %u symbols in rope %d\n", long_cap, LD_LONG, b); abort(); }
+		HIPCHK(hipMemsetAsync(flag.p + 1, 0, 4, st));
+	}
+	unsigned long long pc_h[NR * 6];
+	HIPCHK(hipMemcpyAsync(pc_h, cnt.p + 36, sizeof(pc_h), hipMemcpyDeviceToHost, st));
+	for (int r = 0; r < NR; ++r)
+		if (rp[r].nleaves) hipLaunchKernelGGL(k_ld_own, dim3((unsigned)cdiv(rp[r].nleaves, MW)), dim3(256), 0, st, pv, rp[r].leaf0, rp[r].nleaves, rp[r].n);
+	HIPCHK(hipStreamSynchronize(st));
+	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) rp[r].cnt[a] = pc_h[r * 6 + a];
+	HIPCHK(hipMemcpyAsync(&h->ctl->rope[sd][0], rp, sizeof(rp), hipMemcpyHostToDevice, st));
 	const uint64_t nsb = leaf / SB;
-	HIPCHK(hipMemcpyAsync(&h->ctl->nsb_total, &nsb, 8, hipMemcpyHostToDevice, h->st));
+	HIPCHK(hipMemcpyAsync(&h->ctl->nsb_total, &nsb, 8, hipMemcpyHostToDevice, st));
 	build_directory(h, sd, ps, nsb);
-	HIPCHK(hipStreamSynchronize(h->st));
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(st));
 	memcpy(h->h_rope, rp, sizeof(rp));
+	for (int b = 0; b < 6; ++b) { dr[b].release(); blk[b].release(); }
+	cnt.release(); flag.release(); longs.release();
 }
 
 /* ---- rope sharding across GPUs ------------------------------------------- */

@@ -1202,4 +1202,161 @@ __global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, Po
 	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// loader: ropebwt2's run-length bytes (43+3 codec, rle.h:39-75) -> packed leaves of the dense layout, for an index that
+// arrives from the host (mr_restore / -i old.fmr, rope_load_runs' counterpart).  The codec resynchronises on any byte --
+// continuation bytes are 10xxxxxx, everything else starts a run -- so the byte stream of a rope is cut into blocks of LDB
+// bytes that are decoded independently:
+//   k_ld_count   symbols of the runs that start in each block (+ the rope's six symbol totals)
+//   (host)       exclusive prefix over the blocks = the rope position of each block's first run
+//   k_ld_expand  every thread re-decodes its 32 bytes, a block scan gives it the rope position of its first run, and it ORs
+//                the symbols into the (zeroed) pieces of the rope: a piece is a flat array of 21-symbol words, consecutive
+//                runs share words, so a thread collects one word's bits and issues one atomicOr per word it touches;
+//                the symbol counts per piece (RopeDesc::cnt) are tallied in LDS and flushed once per block
+//   k_ld_long    runs of more than LD_LONG symbols inside one piece, one block each
+//   k_ld_own     own counts + fill of every leaf (k_meta_sb and the scans follow, as after any rewrite)
+// ---------------------------------------------------------------------------------------------
+constexpr int LDT = 32;                     // bytes per thread
+constexpr int LDB = 256 * LDT;              // bytes per block
+constexpr uint32_t LD_LONG = 4096;          // longer (parts of) runs are left to k_ld_long
+struct LdPieces {                           // the pieces of one rope, in rope order
+	uint64_t q[7];                          // rope position of the first symbol of piece i (q[np] = symbols of the rope)
+	uint64_t word0[6];                      // first 64-bit word of the piece in the pool
+	uint32_t keep[6];                       // 0: a piece held by another rank -- counted, not stored
+	int32_t  r[6];                          // sub-rope index
+	int32_t  np, pad;
+};
+struct LdLong { uint64_t word0, o, n; uint32_t c, pad; };   // n symbols c at symbol offset o of the piece that starts at word0
+
+__device__ __forceinline__ int ld_dec43(const uint8_t *p, const uint8_t *end, uint32_t &c, uint64_t &l)   // bytes of the run, 0: truncated
+{
+	const uint32_t b0 = p[0];
+	c = b0 & 7u;
+	if ((b0 & 0x80u) == 0) { l = b0 >> 3; return 1; }
+	if ((b0 >> 5) == 6u) { if (p + 2 > end) return 0; l = ((uint64_t)(b0 & 0x18u) << 3) | (p[1] & 0x3fu); return 2; }
+	const int nb = (b0 & 0x10u) ? 8 : 4;
+	if (p + nb > end) return 0;
+	uint64_t v = (b0 >> 3) & 1u;
+	for (int i = 1; i < nb; ++i) v = (v << 6) | (p[i] & 0x3fu);
+	l = v;
+	return nb;
+}
+// the runs that start in [o0, o0 + LDT): f(c, l) for each, in order
+template <typename F> __device__ __forceinline__ void ld_runs(const uint8_t *rle, uint64_t nbytes, uint64_t o0, uint32_t *bad, F f)
+{
+	const uint64_t o1 = min(o0 + LDT, nbytes);
+	for (uint64_t i = o0; i < o1; ++i) {
+		if ((rle[i] & 0xc0u) == 0x80u) continue;
+		uint32_t c; uint64_t l;
+		const int nb = ld_dec43(rle + i, rle + nbytes, c, l);
+		if (nb == 0 || c > 5u) { *bad = 1; continue; }
+		f(c, l);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ld_count(const uint8_t *rle, uint64_t nbytes, uint64_t *blk_n, unsigned long long *tot6, uint32_t *bad)
+{
+	__shared__ uint64_t s_w[4];
+	__shared__ unsigned long long s_c[6];
+	if (threadIdx.x < 6) s_c[threadIdx.x] = 0;
+	__syncthreads();
+	uint64_t n = 0, cnt[6] = {0, 0, 0, 0, 0, 0};
+	ld_runs(rle, nbytes, ((uint64_t)blockIdx.x * 256 + threadIdx.x) * LDT, bad, [&](uint32_t c, uint64_t l) {
+		n += l;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) cnt[s] += c == (uint32_t)s ? l : 0ull;     // (no dynamic register indexing)
+	});
+#pragma unroll
+	for (int c = 0; c < 6; ++c) { const uint64_t w = wave_sum<uint64_t>(cnt[c]); if (lane_id() == 0 && w) atomicAdd(&s_c[c], (unsigned long long)w); }
+	uint64_t tot;
+	block_excl_add<uint64_t>(n, s_w, &tot);                    // (its barriers also cover s_c)
+	if (threadIdx.x == 0) blk_n[blockIdx.x] = tot;
+	if (threadIdx.x < 6 && s_c[threadIdx.x]) atomicAdd(&tot6[threadIdx.x], s_c[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_ld_expand(const uint8_t *rle, uint64_t nbytes, const uint64_t *blk_off, LdPieces tab_arg, uint64_t *data,
+		unsigned long long *pcnt /* [NR][6] */, LdLong *longs, uint32_t *nlong, uint32_t long_cap, uint32_t *bad)
+{
+	__shared__ uint64_t s_w[4];
+	__shared__ unsigned long long s_pc[6][6];
+	__shared__ LdPieces tab;                                   // indexed by the thread's piece cursor
+	if (threadIdx.x == 0) tab = tab_arg;
+	if (threadIdx.x < 36) s_pc[threadIdx.x / 6][threadIdx.x % 6] = 0;
+	const uint64_t o0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * LDT;
+	uint64_t n = 0;
+	ld_runs(rle, nbytes, o0, bad, [&](uint32_t, uint64_t l) { n += l; });
+	uint64_t S = blk_off[blockIdx.x] + block_excl_add<uint64_t>(n, s_w, (uint64_t*)0);   // rope position of my first run
+	int x = 0;                                                 // piece of S (monotone)
+	uint64_t lc[6] = {0, 0, 0, 0, 0, 0};                       // symbols this thread put into piece x so far
+	auto tally_out = [&]() {
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { if (lc[s]) atomicAdd(&s_pc[x][s], (unsigned long long)lc[s]); lc[s] = 0; }
+	};
+	uint64_t cur_w = ~0ull, cur_v = 0;                         // the word being collected
+	auto flush = [&]() { if (cur_w != ~0ull && cur_v) atomicOr((unsigned long long*)&data[cur_w], (unsigned long long)cur_v); cur_v = 0; };
+	ld_runs(rle, nbytes, o0, bad, [&](uint32_t c, uint64_t l) {
+		while (l > 0) {
+			if (x < tab.np && S >= tab.q[x + 1]) { tally_out(); while (x < tab.np && S >= tab.q[x + 1]) ++x; }
+			if (x >= tab.np) { *bad = 2; return; }              // the rope is longer than the symbol counts of the other ropes imply
+			const uint64_t part = min(l, tab.q[x + 1] - S), o = S - tab.q[x];
+#pragma unroll
+			for (int s = 0; s < 6; ++s) lc[s] += c == (uint32_t)s ? part : 0ull;
+			if (tab.keep[x] && c != 0) {                       // $ = 0: the pool is zeroed
+				if (part > LD_LONG) {
+					const uint32_t k = atomicAdd(nlong, 1u);
+					if (k < long_cap) { LdLong e; e.word0 = tab.word0[x]; e.o = o; e.n = part; e.c = c; e.pad = 0; longs[k] = e; }
+				} else {
+					uint64_t wd = tab.word0[x] + o / SPW; uint32_t off = (uint32_t)(o % SPW), t = (uint32_t)part;
+					while (t > 0) {
+						const uint32_t k = min(t, (uint32_t)SPW - off);
+						const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
+						if (wd != cur_w) { flush(); cur_w = wd; }
+						cur_v |= ((uint64_t)c * MLOW & field) << (SBITS * off);
+						t -= k; off = 0; ++wd;
+					}
+				}
+			}
+			S += part; l -= part;
+		}
+	});
+	flush();
+	if (x < tab.np) tally_out();
+	__syncthreads();
+	if (threadIdx.x < 36) {
+		const int px = threadIdx.x / 6, c = threadIdx.x % 6;
+		if (px < tab.np && s_pc[px][c]) atomicAdd(&pcnt[tab.r[px] * 6 + c], s_pc[px][c]);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_ld_long(const LdLong *longs, const uint32_t *nlong, uint32_t long_cap, uint64_t *data)
+{
+	const uint32_t n = min(*nlong, long_cap);
+	for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+		const LdLong L = longs[e];
+		const uint64_t w0 = L.o / SPW, w1 = (L.o + L.n - 1) / SPW;      // words [w0, w1] of the piece
+		for (uint64_t w = w0 + threadIdx.x; w <= w1; w += 256) {
+			const uint64_t lo = max(L.o, w * SPW), hi = min(L.o + L.n, (w + 1) * SPW);   // symbols [lo, hi) of this word
+			const uint32_t off = (uint32_t)(lo - w * SPW), k = (uint32_t)(hi - lo);
+			const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
+			atomicOr((unsigned long long*)&data[L.word0 + w], (unsigned long long)(((uint64_t)L.c * MLOW & field) << (SBITS * off)));
+		}
+	}
+}
+
+// one wave per leaf of the piece [leaf0, leaf0 + nleaves) holding n symbols: own counts + fill
+__global__ __launch_bounds__(256) void k_ld_own(PoolView pv, uint64_t leaf0, uint64_t nleaves, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * MW + wave_id();
+	if (i >= nleaves) return;
+	const uint32_t fill = (uint32_t)min((uint64_t)LEAF, n - i * LEAF);
+	uint32_t c[6];
+	wave_leaf_counts((const uint64_t*)pv.data + (leaf0 + i) * LEAFW, 0, fill, c);
+	if (lane_id() == 0) {
+		LeafMeta m;
+		for (int s = 0; s < 6; ++s) m.c[s] = (uint16_t)c[s];
+		m.npre = 0; m.n = (uint16_t)fill;
+		pv.own[leaf0 + i] = m;
+	}
+}
+
 } // namespace rb2

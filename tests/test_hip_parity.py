@@ -284,6 +284,26 @@ def test_incremental_on_loaded_index(hip, so):
         assert np.array_equal(dev.rope(b), o.rope(b))
 
 
+def test_load_index_with_very_long_runs(hip):
+    """the device-side loader (k_ld_*): runs of tens of thousands of symbols (4-byte codes, spread over many words and leaves by
+    k_ld_long), runs cut by piece and leaf borders, then more inserts on top; ropes equal the oracle's before and after"""
+    from ropebwt2_amd.hipbwt import encode_runs
+    reads = [[1] * 3000] * 20 + [[2] * 2500] * 12 + [[1, 2] * 700] * 5 + H.repetitive_reads(500, seed=9, genome_len=300, max_len=50)
+    for so in (0, 1):
+        o = H.Oracle(so)
+        o.insert_multi(H.encode_batch(reads))
+        dev = hip.HipBwt(so)
+        dev.load_ropes([encode_runs(o.rope(b)) for b in range(6)])
+        assert np.array_equal(dev.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(dev.rope(b), o.rope(b)), "rope %d after load (so %d)" % (b, so)
+        more = H.encode_batch([[1] * 900, [3, 1, 1, 1, 2] * 40] + H.repetitive_reads(200, seed=10, genome_len=300, max_len=50))
+        o.insert_multi(more); dev.insert_multi(more)
+        for b in range(6):
+            assert np.array_equal(dev.rope(b), o.rope(b)), "rope %d after insert (so %d)" % (b, so)
+        dev.close()
+
+
 def test_rank1a_matches_oracle(hip):
     reads = H.repetitive_reads(4000, seed=3, genome_len=500, max_len=80)
     o, dev = run_both(hip, 1, [H.encode_batch(reads)])

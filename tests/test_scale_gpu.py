@@ -5,6 +5,7 @@
                                                   and the 100 M-read golden .fmd md5 (real reference) through the sharded path
   configs[3]  10 M x 10 kbp, input order       -> 1 M x 10 kbp (one -m10g batch of 10,001 rounds): size-independent properties
   configs[4]  -bi old.fmr + new reads          -> 5 M (reference-built .fmr) + 5 M through the CLI against the 10 M golden
+                                                  and 50 M + 50 M (our .fmr, decoded on the device) against the 100 M golden
 
 Everything is bit-exact: ropes byte for byte, .fmd by md5 of the reference's own output (tests/golden/golden_large.json)."""
 import ctypes as C
@@ -172,3 +173,28 @@ def test_configs4_incremental_5M_plus_5M(tmp_path):
         our = subprocess.run([CLI, "-LRd", "-i", str(ours), "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         pg.wait()
         assert ref.returncode == 0 and our.returncode == 0 and H.md5(ref.stdout) == H.md5(our.stdout)
+
+
+def test_configs4_incremental_50M_plus_50M(tmp_path):
+    """configs[4] at one tenth: an existing .fmr of 50 M reads (5.1 G symbols, 3.8 GB of run-length leaves, written by `-b`)
+    restored with `-i`, decoded into packed leaves ON THE DEVICE (k_ld_*), 50 M more reads inserted in two -m4g batches; in
+    RLO the incremental build equals the one-shot build, so the .fmd must have the md5 the real reference
+    produced for configs[1]."""
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["configs1"]
+    half, L, seed = g["n_reads"] // 2, g["read_len"], g["seed"]
+    work = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    old = os.path.join(work, "rb2_test_old_%d.fmr" % os.getpid())
+    try:
+        pg = subprocess.Popen([H.GEN, str(half), str(L), str(seed)], stdout=subprocess.PIPE)
+        pb = subprocess.run([CLI, "-LRbs", "-m4g", "-o", old, "-"], stdin=pg.stdout, stderr=subprocess.DEVNULL)
+        assert pb.returncode == 0 and pg.wait() == 0
+        pg = subprocess.Popen([H.GEN, str(half), str(L), str(seed), str(half)], stdout=subprocess.PIPE)
+        pc = subprocess.Popen([CLI, "-LRds", "-m4g", "-i", old, "-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        h, n = hashlib.md5(), 0
+        for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+            h.update(chunk); n += len(chunk)
+        assert pc.wait() == 0 and pg.wait() == 0
+        assert n == g["fmd_bytes"] and h.hexdigest() == g["fmd_md5"]
+    finally:
+        if os.path.exists(old):
+            os.remove(old)
