@@ -47,6 +47,7 @@ const uint8_t *mr_itr_next_block(mritr_t *i);                                   
 void     mr_print_tree(const mrope_t *mr);                                         /* mrope.c:162-168 */
 void     mr_dump(mrope_t *mr, FILE *fp);                                           /* mrope.c:136-143 */
 mrope_t *mr_restore(FILE *fp);                                                     /* mrope.c:145-160 */
+mrope_t *mr_restore_runs(FILE *fp);                                                /* rb2 extension: the same file, kept as run bytes until the device (mr_insert_multi) or a host operation needs it */
 
 /* ---- additions ------------------------------------------------------------------------------ */
 /* make the host ropes reflect the device BWT now (otherwise done on demand) */

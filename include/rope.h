@@ -60,6 +60,8 @@ const uint8_t *rope_itr_next_block(rpitr_t *i);                                 
 
 void    rope_print_node(const rpnode_t *p);                                        /* rope.c:225-251 */
 void    rope_dump(const rope_t *r, FILE *fp);                                      /* rope.c:270-275 */
+int64_t rope_dump_size(const rope_t *r);                                           /* rb2 extension: bytes rope_dump() writes */
+int     rope_dump_at(const rope_t *r, int fd, int64_t off);                         /* rb2 extension: the same bytes at offset off of a regular file (pwrite); 0 = ok */
 rope_t *rope_restore(FILE *fp);                                                    /* rope.c:308-318 */
 
 /* ---- additions (not in the reference) ---------------------------------------------------- */

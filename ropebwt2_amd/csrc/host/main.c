@@ -307,6 +307,7 @@ static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
 int main(int argc, char *argv[])
 {
 	mrope_t *mr = 0;
+	FILE *fp_restore = 0;
 	reader_t *rd;
 	int64_t m = (int64_t)(.97 * 10 * 1024 * 1024 * 1024) + 1;   /* main.c:94 */
 	int c, i, block_len = ROPE_DEF_BLOCK_LEN, max_nodes = ROPE_DEF_MAX_NODES, verbose = 3, so = MR_SO_IO, min_q = 0, thr_min = -1, min_cut = 0;
@@ -338,12 +339,10 @@ int main(int argc, char *argv[])
 		case 'M': thr_min = atoi(optarg); break;
 		case 'x': min_cut = atoi(optarg); flag |= F_CUTN; break;
 		case 'i': {
-			FILE *fp = fopen(optarg, "rb");
+			FILE *fp = fopen(optarg, "rb");                  /* (main.c:123-127 restores here; the file is read below, once -m is known) */
 			if (fp == 0) { fprintf(stderr, "[E::%s] fail to open file '%s'\n", __func__, optarg); return 1; }
-			if (mr) mr_destroy(mr);
-			mr = mr_restore(fp);
-			fclose(fp);
-			if (mr == 0) return 1;
+			if (fp_restore) fclose(fp_restore);
+			fp_restore = fp;
 			break; }
 		case 'm': {
 			char *p; double x = strtod(optarg, &p);
@@ -354,6 +353,11 @@ int main(int argc, char *argv[])
 			break; }
 		default: break;                                      /* unknown options are ignored, as in the reference (main.c:100-137 has no default) */
 		}
+	}
+	if (fp_restore) {                                        /* batch mode builds on the GPU: the run bytes are all it needs (mr_restore_runs) */
+		mr = m ? mr_restore_runs(fp_restore) : mr_restore(fp_restore);
+		fclose(fp_restore);
+		if (mr == 0) return 1;
 	}
 	if (optind == argc && isatty(fileno(stdin))) return usage(block_len, max_nodes);
 	if ((flag & F_CUTN) && m == 0) { fprintf(stderr, "[E::%s] option '-x' cannot be used with '-m0'\n", __func__); return 1; }
@@ -468,7 +472,15 @@ int main(int argc, char *argv[])
 
 	if (out != stdout) { fflush(stdout); if (dup2(fileno(out), fileno(stdout)) < 0) return 1; }   /* mr_print_tree writes to stdout */
 	{ static char obuf[4 << 20]; fflush(stdout); setvbuf(stdout, obuf, _IOFBF, sizeof(obuf)); }   /* .fmr dumps are millions of small fwrites */
-	if (flag & F_BIN) mr_dump(mr, stdout);
+	if (flag & F_BIN) {
+		const double td0 = realtime();
+		double td1;
+		mr_sync_host(mr);                                       /* device -> six host ropes (one loader thread per rope) */
+		td1 = realtime();
+		mr_dump(mr, stdout);
+		fflush(stdout);
+		if (verbose >= 3) fprintf(stderr, "[M::%s] BWT moved into host ropes in %.3f sec, .fmr written in %.3f sec\n", "main_ropebwt2", td1 - td0, realtime() - td1);
+	}
 	else if (flag & F_TREE) mr_print_tree(mr);
 	else {
 		/* .fmd: the Elias-delta coding of the run stream is spread over worker threads (fmd.c: speculative segments + one

@@ -8,13 +8,17 @@
  * State: the BWT lives either in the host ropes, in HBM, or both.
  *   host_ok  the six host ropes hold the current BWT (leaves + tree)
  *   dev_ok   the device holds the current BWT
+ *   raw_ok   neither yet: the run bytes of a restored .fmr wait in host arrays (mr_restore_runs) for whoever needs them first --
+ *            the device (the first mr_insert_multi: decoded there) or a host operation (trees bulk-loaded by mr_sync_host)
  * r[a]->c[] (read directly by the inline helpers of mrope.h) is kept current in both states.
  */
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <stdio.h>
 #include <assert.h>
 #include <pthread.h>
+#include <time.h>
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_hip.h"
@@ -23,6 +27,7 @@ typedef struct {
 	mrope_t pub;            /* must stay first: callers hold mrope_t* */
 	rb2_hip_t *dev;
 	int host_ok, dev_ok;
+	uint8_t *raw[6]; int64_t raw_n[6]; int raw_ok;          /* mr_restore_runs: the run bytes of the six ropes, no trees yet */
 	int max_nodes, block_len;
 } mrx_t;
 
@@ -54,6 +59,7 @@ void mr_destroy(mrope_t *mr)
 	if (!mr) return;
 	for (a = 0; a < 6; ++a) if (mr->r[a]) rope_destroy(mr->r[a]);   /* r[a] may be NULL after a freeing iteration */
 	if (X(mr)->dev) rb2_hip_destroy(X(mr)->dev);
+	for (a = 0; a < 6; ++a) free(X(mr)->raw[a]);
 	free(mr);
 }
 
@@ -93,17 +99,39 @@ void mr_sync_host(mrope_t *mr)
 	pthread_t th[6];
 	int a;
 	if (x->host_ok) return;
+	if (x->raw_ok && !(x->dev && x->dev_ok)) {                  /* restored run bytes nobody has used yet: bulk-load the six trees */
+		for (a = 0; a < 6; ++a) {
+			memset(&job[a], 0, sizeof(job[a]));
+			job[a].rb.p = x->raw[a]; job[a].rb.n = x->raw_n[a]; x->raw[a] = 0;
+			rope_destroy(mr->r[a]); mr->r[a] = rope_init(x->max_nodes, x->block_len);
+			job[a].r = mr->r[a];
+			pthread_create(&th[a], 0, load_worker, &job[a]);
+		}
+		for (a = 0; a < 6; ++a) pthread_join(th[a], 0);
+		x->raw_ok = 0; x->host_ok = 1;
+		return;
+	}
 	assert(x->dev && x->dev_ok);
 	/* the six ropes are independent trees: each is bulk-loaded by its own thread as soon as its run bytes have arrived, while
 	 * the next rope is still streaming off the device (the reference has nothing to do here: its ropes were built on the host) */
+	{
+	const int trace = getenv("RB2_SYNC_TRACE") != 0;
+	struct timespec t0, t1;
 	for (a = 0; a < 6; ++a) {
 		memset(&job[a], 0, sizeof(job[a]));
+		clock_gettime(CLOCK_MONOTONIC, &t0);
 		rb2_hip_stream_rope(x->dev, a, runbuf_add, &job[a].rb);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		if (trace) fprintf(stderr, "[mr_sync_host] rope %d: %.2f GB of runs off the device in %.3f s\n", a, job[a].rb.n / 1e9, (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9);
 		if (!mr->r[a]) mr->r[a] = rope_init(x->max_nodes, x->block_len);
 		job[a].r = mr->r[a];
 		pthread_create(&th[a], 0, load_worker, &job[a]);
 	}
+	clock_gettime(CLOCK_MONOTONIC, &t0);
 	for (a = 0; a < 6; ++a) pthread_join(th[a], 0);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if (trace) fprintf(stderr, "[mr_sync_host] waited %.3f s for the tree builders\n", (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9);
+	}
 	x->host_ok = 1;
 }
 
@@ -129,6 +157,12 @@ static void sync_dev(mrope_t *mr)
 	uint8_t *rle[6]; int64_t nb[6]; int a;
 	if (!x->dev) x->dev = rb2_hip_create(device_id(), mr->so);
 	if (x->dev_ok) return;
+	if (x->raw_ok) {                                            /* straight from the restored file to the device: no host trees */
+		rb2_hip_load_ropes(x->dev, (const uint8_t *const*)x->raw, x->raw_n);
+		for (a = 0; a < 6; ++a) { free(x->raw[a]); x->raw[a] = 0; }
+		x->raw_ok = 0; x->dev_ok = 1;
+		return;
+	}
 	assert(x->host_ok);
 	for (a = 0; a < 6; ++a) nb[a] = rope_export_runs(mr->r[a], &rle[a]);
 	rb2_hip_load_ropes(x->dev, (const uint8_t *const*)rle, nb);
@@ -193,6 +227,7 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
 	int a, b, pass;
 	const mrx_t *xx = X(mr);
 	const int on_dev = !xx->host_ok && xx->dev && xx->dev_ok;
+	if (!xx->host_ok && !on_dev) mr_sync_host((mrope_t*)mr);   /* restored run bytes: the trees are built on first use */
 	for (pass = 0; pass < 2; ++pass) {
 		int64_t pos = pass == 0 ? x : y, *out = pass == 0 ? cx : cy, z = 0, acc[6] = { 0, 0, 0, 0, 0, 0 };
 		if (pass == 1 && (cy == 0 || y < 0)) break;
@@ -237,12 +272,32 @@ void mr_print_tree(const mrope_t *mr)
 	putchar('\n');
 }
 
+typedef struct { const rope_t *r; int fd; int64_t off, size; int err; } dump_job_t;
+static void *dump_size_worker(void *p) { dump_job_t *j = (dump_job_t*)p; j->size = rope_dump_size(j->r); return 0; }
+static void *dump_write_worker(void *p) { dump_job_t *j = (dump_job_t*)p; j->err = rope_dump_at(j->r, j->fd, j->off); return 0; }
+
 void mr_dump(mrope_t *mr, FILE *fp)
 {
 	int a;
+	struct stat st;
 	mr_sync_host(mr);
 	fwrite("RB\2", 1, 3, fp);                                    /* magic; byte 3 = sorting order (mrope.c:139-140) */
 	fwrite(&mr->so, 1, 1, fp);
+	/* a regular file: the six ropes are written by six threads, each at its own offset (the bytes are those of rope_dump,
+	 * mrope.c:141; the reference writes them one fwrite after the other).  Pipes and terminals take the sequential path. */
+	if (fflush(fp) == 0 && fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && !getenv("RB2_DUMP_SEQUENTIAL")) {
+		dump_job_t job[6];
+		pthread_t th[6];
+		int64_t off = (int64_t)ftello(fp);
+		int bad = off < 0;
+		for (a = 0; a < 6 && !bad; ++a) { job[a].r = mr->r[a]; job[a].fd = fileno(fp); job[a].err = 0; pthread_create(&th[a], 0, dump_size_worker, &job[a]); }
+		for (a = 0; a < 6 && !bad; ++a) pthread_join(th[a], 0);
+		for (a = 0; a < 6 && !bad; ++a) { job[a].off = off; off += job[a].size; }
+		for (a = 0; a < 6 && !bad; ++a) pthread_create(&th[a], 0, dump_write_worker, &job[a]);
+		for (a = 0; a < 6 && !bad; ++a) { pthread_join(th[a], 0); if (job[a].err) bad = 2; }
+		if (!bad) { fseeko(fp, (off_t)off, SEEK_SET); return; }
+		if (bad == 2) { fprintf(stderr, "[E::%s] write error\n", __func__); exit(1); }
+	}
 	for (a = 0; a < 6; ++a) rope_dump(mr->r[a], fp);
 }
 
@@ -263,6 +318,88 @@ mrope_t *mr_restore(FILE *fp)
 	x->host_ok = 1; x->dev_ok = 0;
 	mr_get_c(&x->pub, c);
 	fprintf(stderr, "[M::%s] ($, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld)\n", __func__,
+			(long)c[0], (long)c[1], (long)c[2], (long)c[3], (long)c[4], (long)c[5]);
+	return &x->pub;
+}
+
+/* rb2 extension: mr_restore for an index that is going to the GPU.  The .fmr is a depth-first dump of six B+ trees
+ * (rope_dump, rope.c:270-275); a device build needs none of the tree, only the run bytes of the leaves in order, so they are
+ * gathered into one array per rope while the file streams by -- no nodes, no 512-byte blocks: at configs[4] size (37 GB)
+ * that is the difference between ~40 s (trees + export) and a sequential read.  The marginal counts (mr_get_c) come from
+ * the leaf records.  Host operations still work: mr_sync_host builds the trees from the run bytes on demand. */
+typedef struct {
+	FILE *fp; uint8_t *io; int64_t io_n, io_at, io_cap;         /* read window over the file */
+	uint8_t *p; int64_t n, m;                                    /* run bytes of the rope being read */
+	int max_nodes, block_len, err;
+} rawld_t;
+
+static const uint8_t *raw_take(rawld_t *w, int64_t k)          /* the next k bytes of the file (k <= 64 KiB), 0 at a premature end */
+{
+	if (w->io_n - w->io_at < k) {
+		memmove(w->io, w->io + w->io_at, (size_t)(w->io_n - w->io_at));
+		w->io_n -= w->io_at; w->io_at = 0;
+		w->io_n += (int64_t)fread(w->io + w->io_n, 1, (size_t)(w->io_cap - w->io_n), w->fp);
+		if (w->io_n < k) { w->err = 1; return 0; }
+	}
+	w->io_at += k;
+	return w->io + w->io_at - k;
+}
+
+static void raw_bucket(rawld_t *w, int64_t c[6])
+{
+	const uint8_t *q;
+	int i, a, n, isb;
+	if (w->err || (q = raw_take(w, 3)) == 0) return;
+	isb = q[0]; n = (int16_t)(q[1] | q[2] << 8);
+	if (n < 1 || n > w->max_nodes) { w->err = 1; return; }
+	for (i = 0; i < n && !w->err; ++i) {
+		if (isb) {
+			int64_t lc[6]; int nb;
+			if ((q = raw_take(w, 50)) == 0) return;
+			memcpy(lc, q, 48);
+			nb = q[48] | q[49] << 8;
+			if (nb + 2 > w->block_len || (q = raw_take(w, nb)) == 0) { w->err = 1; return; }
+			if (w->n + nb > w->m) { w->m = (w->n + nb) + ((w->n + nb) >> 1) + (1 << 20); w->p = (uint8_t*)realloc(w->p, (size_t)w->m); }
+			memcpy(w->p + w->n, q, (size_t)nb);
+			w->n += nb;
+			for (a = 0; a < 6; ++a) c[a] += lc[a];
+		} else raw_bucket(w, c);
+	}
+}
+
+mrope_t *mr_restore_runs(FILE *fp)
+{
+	uint8_t magic[4];
+	mrx_t *x;
+	rawld_t w;
+	int64_t c[6];
+	int a;
+	if (fread(magic, 1, 4, fp) != 4 || memcmp(magic, "RB\2", 3) != 0 || magic[3] > 2) {
+		fprintf(stderr, "[E::%s] not an FMR file\n", __func__);
+		return 0;
+	}
+	x = (mrx_t*)calloc(1, sizeof(mrx_t));
+	x->pub.so = magic[3];
+	x->pub.thr_min = 1000;
+	memset(&w, 0, sizeof(w));
+	w.fp = fp; w.io_cap = 64 << 20; w.io = (uint8_t*)malloc((size_t)w.io_cap);
+	for (a = 0; a < 6; ++a) {
+		const uint8_t *q = raw_take(&w, 8);
+		int32_t hdr[2];
+		if (q == 0) { fprintf(stderr, "[E::%s] not an FMR rope\n", __func__); exit(1); }
+		memcpy(hdr, q, 8);
+		if (hdr[0] < 2 || hdr[1] < 32) { fprintf(stderr, "[E::%s] not an FMR rope\n", __func__); exit(1); }
+		w.max_nodes = hdr[0]; w.block_len = hdr[1]; w.p = 0; w.n = w.m = 0;
+		x->pub.r[a] = rope_init(hdr[0], hdr[1]);
+		raw_bucket(&w, x->pub.r[a]->c);
+		if (w.err) { fprintf(stderr, "[E::%s] corrupt or truncated file\n", __func__); exit(1); }
+		x->raw[a] = w.p; x->raw_n[a] = w.n;
+		if (a == 0) { x->max_nodes = hdr[0]; x->block_len = hdr[1]; }
+	}
+	free(w.io);
+	x->host_ok = 0; x->dev_ok = 0; x->raw_ok = 1;
+	mr_get_c(&x->pub, c);
+	fprintf(stderr, "[M::%s] ($, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld)\n", "mr_restore",
 			(long)c[0], (long)c[1], (long)c[2], (long)c[3], (long)c[4], (long)c[5]);
 	return &x->pub;
 }

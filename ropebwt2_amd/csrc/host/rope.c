@@ -11,6 +11,8 @@
  */
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
+#include <emmintrin.h>
 #include <assert.h>
 #include <stdio.h>
 #include "rle.h"
@@ -274,6 +276,66 @@ void rope_dump(const rope_t *r, FILE *fp)
 	dump_bucket(r->root, fp);
 }
 
+/* The same bytes, written at a known offset of a regular file (rb2 extension, used by mr_dump to write the six ropes from six
+ * threads: at configs[4] size the .fmr is 73 GB and fwrite of one small piece after the other was 90 s of the run). */
+static int64_t bucket_dump_size(const rpnode_t *p)
+{
+	int64_t sz = 3;
+	int i;
+	for (i = 0; i < (int)p->n; ++i) sz += p->is_bottom ? 48 + 2 + *rle_nptr(p[i].p) : bucket_dump_size(p[i].p);
+	return sz;
+}
+
+int64_t rope_dump_size(const rope_t *r) { return 8 + bucket_dump_size(r->root); }
+
+typedef struct { int fd; int64_t off; uint8_t *buf; int64_t n, cap; int err; } dumpw_t;
+
+static void dumpw_flush(dumpw_t *w)
+{
+	int64_t done = 0;
+	while (done < w->n && !w->err) {
+		const ssize_t k = pwrite(w->fd, w->buf + done, (size_t)(w->n - done), (off_t)(w->off + done));
+		if (k <= 0) { w->err = 1; break; }
+		done += k;
+	}
+	w->off += w->n; w->n = 0;
+}
+
+static inline void dumpw_put(dumpw_t *w, const void *src, int64_t len)
+{
+	if (w->n + len > w->cap) dumpw_flush(w);
+	memcpy(w->buf + w->n, src, (size_t)len);
+	w->n += len;
+}
+
+static void dump_bucket_w(const rpnode_t *p, dumpw_t *w)
+{
+	const uint8_t isb = p->is_bottom;
+	const int16_t n = (int16_t)p->n;
+	int i;
+	dumpw_put(w, &isb, 1);
+	dumpw_put(w, &n, 2);
+	for (i = 0; i < n; ++i) {
+		if (isb) {
+			dumpw_put(w, p[i].c, 48);
+			dumpw_put(w, p[i].p, 2 + *rle_nptr(p[i].p));
+		} else dump_bucket_w(p[i].p, w);
+	}
+}
+
+int rope_dump_at(const rope_t *r, int fd, int64_t off)
+{
+	dumpw_t w;
+	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.buf = (uint8_t*)malloc((size_t)w.cap);
+	dumpw_put(&w, &r->max_nodes, 4);
+	dumpw_put(&w, &r->block_len, 4);
+	dump_bucket_w(r->root, &w);
+	dumpw_flush(&w);
+	free(w.buf);
+	return w.err ? -1 : 0;
+}
+
 static rpnode_t *restore_bucket(rope_t *r, FILE *fp, int64_t c[6])
 {
 	uint8_t isb; int16_t n; int i, a;
@@ -323,6 +385,47 @@ static rpnode_t *ent_push(entvec_t *e)
 	return &e->v[e->n++];
 }
 
+/* symbols of k one-byte runs (0 llll ccc, rle.h:55-57), per symbol: SSE2 (x86-64 baseline), 16 runs per step */
+static void count_plain_runs(const uint8_t *b, int64_t k, int64_t c[6])
+{
+	const __m128i zero = _mm_setzero_si128(), m7 = _mm_set1_epi8(7), m15 = _mm_set1_epi8(15);
+	__m128i acc[6];
+	int64_t i = 0;
+	int s;
+	for (s = 0; s < 6; ++s) acc[s] = zero;
+	for (; i + 16 <= k; i += 16) {
+		const __m128i v = _mm_loadu_si128((const __m128i*)(b + i));
+		const __m128i sym = _mm_and_si128(v, m7), len = _mm_and_si128(_mm_srli_epi16(v, 3), m15);
+		for (s = 0; s < 6; ++s)
+			acc[s] = _mm_add_epi64(acc[s], _mm_sad_epu8(_mm_and_si128(len, _mm_cmpeq_epi8(sym, _mm_set1_epi8((char)s))), zero));
+	}
+	for (s = 0; s < 6; ++s) {
+		int64_t t[2];
+		_mm_storeu_si128((__m128i*)t, acc[s]);
+		c[s] += t[0] + t[1];
+	}
+	for (; i < k; ++i) if ((b[i] & 7) < 6) c[b[i] & 7] += b[i] >> 3;
+}
+
+/* first i in [q, end - 1) where byte i cannot be taken as it is: it (or its successor) is not a one-byte run of length >= 1,
+ * or both carry the same symbol (they merge); end - 1 if there is none (the last byte always waits for what follows) */
+static const uint8_t *plain_span_end(const uint8_t *q, const uint8_t *end)
+{
+	const uint8_t *i = q;
+	for (; i + 17 <= end; i += 16) {                           /* 16 positions per step */
+		const __m128i x = _mm_loadu_si128((const __m128i*)i), y = _mm_loadu_si128((const __m128i*)(i + 1));
+		const __m128i m7 = _mm_set1_epi8(7), m78 = _mm_set1_epi8(0x78), zero = _mm_setzero_si128();
+		const __m128i same = _mm_cmpeq_epi8(_mm_and_si128(_mm_xor_si128(x, y), m7), zero);
+		const __m128i wide = _mm_or_si128(x, y);                /* top bit: a multi-byte run */
+		const __m128i empty = _mm_or_si128(_mm_cmpeq_epi8(_mm_and_si128(x, m78), zero), _mm_cmpeq_epi8(_mm_and_si128(y, m78), zero));
+		const int mask = _mm_movemask_epi8(_mm_or_si128(_mm_or_si128(same, empty), wide));
+		if (mask) return i + __builtin_ctz((unsigned)mask);
+	}
+	for (; i + 1 < end; ++i)
+		if (((i[0] | i[1]) & 0x80) || (i[0] & 0x78) == 0 || (i[1] & 0x78) == 0 || ((i[0] ^ i[1]) & 7) == 0) return i;
+	return end > q ? end - 1 : q;
+}
+
 void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
 {
 	const uint8_t *q = rle, *end = rle + (n_bytes > 0 ? n_bytes : 0);
@@ -337,6 +440,43 @@ void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
 	/* leaves: merge adjacent equal symbols, re-encode with the widest run form needed */
 	for (;;) {
 		int c = -1; int64_t l = 0;
+		/* the stream off the device is almost only one-byte runs that neither merge nor need re-encoding: such stretches are
+		 * copied into the leaves as they are and counted 16 runs at a time (one run at a time, this loop was 4.5 s per 1.7 GB
+		 * rope at configs[1] size and the whole of mr_sync_host's 5.3 s) */
+		if (end - q >= 64 && !(q[0] & 0x80) && (q[0] & 0x78) && (pc < 0 || (q[0] & 7) != pc)) {
+			const uint8_t *m = plain_span_end(q, end);
+			if (m - q >= 32) {
+				if (pc >= 0) {                                     /* the pending run is final: nothing after it carries its symbol */
+					uint8_t tmp[8];
+					const int nb = rle_enc1(tmp, pc, pl);
+					if (!cur || *rle_nptr(blk) + nb > fill) {
+						cur = ent_push(&lv);
+						blk = lv.n == 1 ? (uint8_t*)rope->root->p : new_leaf(rope);
+						cur->p = (rpnode_t*)blk;
+					}
+					memcpy(blk + 2 + *rle_nptr(blk), tmp, nb);
+					*rle_nptr(blk) += nb;
+					cur->c[pc] += pl; cur->l += pl; rope->c[pc] += pl;
+					pc = -1;
+				}
+				while (q < m) {
+					int64_t cc[6] = { 0, 0, 0, 0, 0, 0 }, t;
+					if (!cur || *rle_nptr(blk) >= fill) {
+						cur = ent_push(&lv);
+						blk = lv.n == 1 ? (uint8_t*)rope->root->p : new_leaf(rope);
+						cur->p = (rpnode_t*)blk;
+					}
+					t = fill - *rle_nptr(blk);
+					if (t > m - q) t = m - q;
+					memcpy(blk + 2 + *rle_nptr(blk), q, (size_t)t);
+					*rle_nptr(blk) += (uint16_t)t;
+					count_plain_runs(q, t, cc);
+					for (a = 0; a < 6; ++a) { cur->c[a] += cc[a]; cur->l += cc[a]; rope->c[a] += cc[a]; }
+					q += t;
+				}
+				continue;
+			}
+		}
 		if (q < end) { q += rle_dec1_fn(q, &c, &l); if (l == 0) continue; }
 		if (c == pc && c >= 0) { pl += l; continue; }
 		if (pc >= 0) {                                         /* flush the pending run */

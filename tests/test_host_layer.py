@@ -370,3 +370,56 @@ def test_line_reader_batches_match_python_model(tmp_path):
     got = _dump_batches(["-L", "-m1g"], text, {"RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": "5000"}, tmp_path, "model")
     want = H.encode_batch_fixed(codes, True, True).tobytes()
     assert got[8:] == want and int.from_bytes(got[:8], "little") == len(want)
+
+
+def test_fmr_dump_to_a_file_equals_dump_to_a_pipe(golden, tmp_path):
+    """mr_dump writes the six ropes of a regular file from six threads (pwrite at known offsets); a pipe -- and
+    RB2_DUMP_SEQUENTIAL=1 -- takes the reference's sequential fwrite path.  Same bytes, and the reference restores them."""
+    text = H.reads_to_text(H.splitmix_bases(3000, 101, 42))
+    for so in ("", "s", "r"):
+        piped = cli(["-LRb" + so, "-m0"], text)
+        f = tmp_path / ("par%s.fmr" % so)
+        assert subprocess.run([CLI, "-LRb" + so, "-m0", "-o", str(f), "-"], input=text, stderr=subprocess.DEVNULL).returncode == 0
+        assert f.read_bytes() == piped
+        g = tmp_path / ("seq%s.fmr" % so)
+        env = dict(os.environ, RB2_DUMP_SEQUENTIAL="1")
+        assert subprocess.run([CLI, "-LRb" + so, "-m0", "-o", str(g), "-"], input=text, stderr=subprocess.DEVNULL, env=env).returncode == 0
+        assert g.read_bytes() == piped
+
+
+def test_restore_runs_then_host_operations(hostlib, tmp_path):
+    """mr_restore_runs keeps a restored .fmr as run bytes (what a GPU build needs); a host operation that comes first --
+    a rank query, a dump -- makes mr_sync_host bulk-load the trees from them.  Ranks and the BWT equal mr_restore's."""
+    L = hostlib
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    for fn in ("mr_restore", "mr_restore_runs"):
+        getattr(L, fn).restype = C.c_void_p; getattr(L, fn).argtypes = [C.c_void_p]
+    L.mr_rank2a.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.mr_dump.argtypes = [C.c_void_p, C.c_void_p]
+    L.mr_destroy.argtypes = [C.c_void_p]
+    text = H.reads_to_text(H.splitmix_bases(2500, 101, 7)) + b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n" * 40
+    for so in ("", "s"):
+        f = tmp_path / ("in%s.fmr" % so)
+        f.write_bytes(cli(["-LRb" + so, "-m0"], text))
+        want_bwt = cli(["-m0", "-i", str(f)], b"")
+        ranks = {}
+        for fn in ("mr_restore", "mr_restore_runs"):
+            fp = libc.fopen(str(f).encode(), b"rb")
+            mr = getattr(L, fn)(fp)
+            libc.fclose(fp)
+            assert mr
+            out = []
+            for x in (0, 1, 1000, 123456, 2500 * 102 + 40 * 90):
+                cx = (C.c_int64 * 6)()
+                L.mr_rank2a(mr, x, -1, cx, None)
+                out.append(list(cx))
+            ranks[fn] = out
+            g = tmp_path / ("%s%s.fmr" % (fn, so))
+            fo = libc.fopen(str(g).encode(), b"wb")
+            L.mr_dump(mr, fo)
+            libc.fclose(fo)
+            L.mr_destroy(mr)
+            assert cli(["-m0", "-i", str(g)], b"") == want_bwt
+        assert ranks["mr_restore"] == ranks["mr_restore_runs"]
