@@ -121,6 +121,7 @@ def whole_process(reads, read_len, so_flag, batch_gib):
     flags = ["-LRd" + so_flag.strip("-"), "-m%gg" % batch_gib]
     txt, out = "/dev/shm/rb2_bench_%d.txt" % os.getpid(), "/dev/shm/rb2_bench_%d.fmd" % os.getpid()
     mode = "file"
+    fmr = None
     try:
         st = os.statvfs("/dev/shm")
         if st.f_bavail * st.f_frsize < reads * (read_len + 1) * 1.8 + (4 << 30):
@@ -131,6 +132,18 @@ def whole_process(reads, read_len, so_flag, batch_gib):
         p = subprocess.run([CLI] + flags + ["-o", out, txt], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
         dt = time.perf_counter() - t0
         fmd_bytes = os.path.getsize(out) if os.path.exists(out) else 0
+        os.unlink(out)
+        # the config's literal flags: -b = the .fmr (ropebwt2's own binary dump: device -> six host B+ trees -> file)
+        fflags = ["-LRb" + so_flag.strip("-"), "-m%gg" % batch_gib]
+        t1 = time.perf_counter()
+        pf = subprocess.run([CLI] + fflags + ["-o", out, txt], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
+        dtf = time.perf_counter() - t1
+        ef = pf.stderr.decode()
+        mh = re.search(r"moved into host ropes in ([0-9.]+) sec, \.fmr written in ([0-9.]+) sec", ef)
+        mcf = re.search(r"constructed FM-index in ([0-9.]+) sec", ef)
+        if pf.returncode == 0 and os.path.exists(out):
+            fmr = {"real_s": dtf, "read_parse_insert_s": float(mcf.group(1)) if mcf else None, "to_host_ropes_s": float(mh.group(1)) if mh else None,
+                   "write_s": float(mh.group(2)) if mh else None, "fmr_bytes": os.path.getsize(out), "flags": " ".join(fflags)}
     except Exception as e:  # noqa: BLE001
         sys.stderr.write("[bench] whole-process leg: %r; using a pipe from the generator\n" % (e,))
         mode, fmd_bytes = "pipe", None
@@ -156,6 +169,7 @@ def whole_process(reads, read_len, so_flag, batch_gib):
             "read_parse_insert_s": float(mc.group(1)) if mc else None, "insert_s": sum(t for _, t in ins),
             "insert_gsym_per_s": syms / sum(t for _, t in ins) / 1e9,
             "export_and_encode_s": float(ms.group(1)) + float(ms.group(2)) if ms else None, "fmd_bytes": fmd_bytes, "input": mode,
+            "fmr_output": fmr,
             "reference_same_job_real_s": CPU_FULL_CONFIG["real_s"],
             "what": "ropebwt2 %s -o out.fmd reads.txt (%d x %d bp text, %s; text parse + PCIe + insert + export + parallel .fmd encode + write; one process)"
                     % (" ".join(flags), reads, read_len, "both in /dev/shm" if mode == "file" else "piped from synth_reads, output to /dev/null")}
