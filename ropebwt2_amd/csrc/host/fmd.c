@@ -302,7 +302,8 @@ struct rb2_fmdp_s {
 	int64_t tot[N_FIELDS];
 	int64_t n_copied_blocks, n_true_blocks;
 	pthread_t *thr; int nthr, closing;
-	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+	pthread_t stitcher; int no_more;   /* the true orbit has a thread of its own: it copies every coupled block (6 GB at configs[1]) while the producer copies run bytes into segments */
+	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
 };
 
 static inline int run_at(const uint8_t *q, int *c, int64_t *l)    /* one run of the 43+3 codec; returns its bytes */
@@ -383,6 +384,8 @@ static void *fmdp_worker(void *arg)
 	return 0;
 }
 
+static void *fmdp_stitcher(void *arg);
+
 rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t seg_bytes)
 {
 	rb2_fmdp_t *p = (rb2_fmdp_t*)calloc(1, sizeof(rb2_fmdp_t));
@@ -394,6 +397,8 @@ rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t seg_bytes)
 	pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv_work, 0); pthread_cond_init(&p->cv_done, 0);
 	p->thr = (pthread_t*)calloc(p->nthr, sizeof(pthread_t));
 	for (i = 0; i < p->nthr; ++i) pthread_create(&p->thr[i], 0, fmdp_worker, p);
+	pthread_cond_init(&p->cv_space, 0);
+	pthread_create(&p->stitcher, 0, fmdp_stitcher, p);
 	return p;
 }
 
@@ -431,6 +436,8 @@ static void queue_fill(rb2_fmdp_t *p)                          /* hand the segme
 	p->seg[p->nseg - 1]->state = 1;
 	p->n_queued = p->nseg;
 	pthread_cond_signal(&p->cv_work);
+	pthread_cond_broadcast(&p->cv_done);                       /* (the stitcher also waits for segments to exist) */
+	while (p->n_queued - p->cur_seg > 4 * p->nthr + 8) pthread_cond_wait(&p->cv_space, &p->mu);   /* backlog: let workers and stitcher catch up */
 	pthread_mutex_unlock(&p->mu);
 }
 
@@ -478,7 +485,7 @@ static int64_t try_couple(rb2_fmdp_t *p, fseg_t *sg, int64_t pos)
 }
 
 /* advance the true orbit over everything that is encoded speculatively so far (final: over everything, waiting for the workers) */
-static void stitch(rb2_fmdp_t *p, int final)
+static void stitch(rb2_fmdp_t *p)                             /* body of the stitcher thread: segment after segment until the stream ends */
 {
 	rb2_fmd_t *f = p->f;
 	for (;;) {
@@ -486,10 +493,10 @@ static void stitch(rb2_fmdp_t *p, int final)
 		const uint8_t *q;
 		int64_t i, n;
 		pthread_mutex_lock(&p->mu);
+		while (p->cur_seg >= p->n_queued && !p->no_more) pthread_cond_wait(&p->cv_done, &p->mu);
 		if (p->cur_seg >= p->n_queued) { pthread_mutex_unlock(&p->mu); return; }
 		sg = p->seg[p->cur_seg];
-		while ((final || p->n_queued - p->cur_seg > 4 * p->nthr + 8) && sg->state != 3) pthread_cond_wait(&p->cv_done, &p->mu);   /* backlog: let the workers catch up */
-		if (sg->state != 3) { pthread_mutex_unlock(&p->mu); return; }
+		while (sg->state != 3) pthread_cond_wait(&p->cv_done, &p->mu);
 		pthread_mutex_unlock(&p->mu);
 		q = sg->runs; n = sg->n; i = p->cur_pos;
 		if (i == 0) { int k; for (k = 0; k < N_FIELDS; ++k) p->tot[k] += sg->sum[k]; }
@@ -520,9 +527,14 @@ static void stitch(rb2_fmdp_t *p, int final)
 		}
 		free(sg->runs); sg->runs = 0;
 		free(sg->sp->w); free(sg->sp->start); free(sg->sp->type); free(sg->sp); sg->sp = 0;
+		pthread_mutex_lock(&p->mu);
 		++p->cur_seg; p->cur_pos = 0;                        /* (the fseg_t itself stays: the next segment reads prev_sym_out) */
+		pthread_cond_broadcast(&p->cv_space);
+		pthread_mutex_unlock(&p->mu);
 	}
 }
+
+static void *fmdp_stitcher(void *arg) { stitch((rb2_fmdp_t*)arg); return 0; }
 
 void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n)
 {
@@ -532,11 +544,11 @@ void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n)
 		if (take > p->seg_bytes + 1024 - sg->n) {              /* a chunk larger than a segment: cut at a run boundary */
 			take = p->seg_bytes + 1024 - sg->n;
 			while (take > 0 && (runs[take] & 0xC0) == 0x80) --take;
-			if (take == 0) { queue_fill(p); stitch(p, 0); continue; }
+			if (take == 0) { queue_fill(p); continue; }
 		}
 		memcpy(sg->runs + sg->n, runs, (size_t)take); sg->n += take;
 		runs += take; n -= take;
-		if (sg->n >= p->seg_bytes) { queue_fill(p); stitch(p, 0); }
+		if (sg->n >= p->seg_bytes) queue_fill(p);
 	}
 }
 
@@ -545,7 +557,11 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
 	rb2_fmd_t *f = p->f;
 	int i;
 	queue_fill(p);
-	stitch(p, 1);
+	pthread_mutex_lock(&p->mu);
+	p->no_more = 1;
+	pthread_cond_broadcast(&p->cv_done);
+	pthread_mutex_unlock(&p->mu);
+	pthread_join(p->stitcher, 0);
 	pthread_mutex_lock(&p->mu);
 	p->closing = 1;
 	pthread_cond_broadcast(&p->cv_work);
@@ -559,7 +575,7 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
 	fmd_index_mt(f, p->nthr);
 	if (getenv("RB2_FMD_STATS")) fprintf(stderr, "[rb2_fmdp] %lld segments, %lld blocks copied from the speculative encodings, %lld encoded by the true orbit\n",
 			(long long)p->nseg, (long long)p->n_copied_blocks, (long long)p->n_true_blocks);
-	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done);
+	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done); pthread_cond_destroy(&p->cv_space);
 	{ int64_t k; for (k = 0; k < p->nseg; ++k) free(p->seg[k]); }
 	free(p->thr); free(p->seg); free(p);
 	return f;
