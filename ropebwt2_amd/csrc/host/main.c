@@ -289,7 +289,7 @@ static int usage(int block_len, int max_nodes)
 	return 1;
 }
 
-static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
+static void flush_batch_now(mrope_t *mr, str_t *buf, int flag, int verbose)
 {
 	const double c0 = cputime(), r0 = realtime();
 	if (getenv("RB2_DUMP_BATCHES")) {                       /* debugging / tests of the readers without a GPU: the batches go to a file, nothing is inserted */
@@ -302,6 +302,66 @@ static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
 	mr_insert_multi(mr, (int64_t)buf->l, (const uint8_t*)buf->s, flag & F_THR);
 	if (verbose >= 3) fprintf(stderr, "[M::%s] inserted %ld symbols in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", (long)buf->l, realtime() - r0, cputime() - c0);
 	buf->l = 0;
+}
+
+/* A full batch goes to an inserter thread and the reader gets the other buffer: the GPU inserts batch k while batch k + 1 is
+ * read and encoded (the reference inserts where it reads, main.c:238-242; same batches, same order, same calls).
+ * RB2_SYNC_INSERT=1 (and RB2_DUMP_BATCHES) keep everything in the caller's thread. */
+static struct {
+	pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+	mrope_t *mr; str_t job; int flag, verbose, busy, quit, started;
+} AF = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER };
+
+static void *aflush_worker(void *arg)
+{
+	(void)arg;
+	pthread_mutex_lock(&AF.mu);
+	for (;;) {
+		while (!AF.busy && !AF.quit) pthread_cond_wait(&AF.cv, &AF.mu);
+		if (!AF.busy) break;
+		pthread_mutex_unlock(&AF.mu);
+		flush_batch_now(AF.mr, &AF.job, AF.flag, AF.verbose);
+		pthread_mutex_lock(&AF.mu);
+		AF.busy = 0;
+		pthread_cond_broadcast(&AF.cv);
+	}
+	pthread_mutex_unlock(&AF.mu);
+	return 0;
+}
+
+static void flush_wait(void)                                /* every batch handed over so far is in the index */
+{
+	if (!AF.started) return;
+	pthread_mutex_lock(&AF.mu);
+	while (AF.busy) pthread_cond_wait(&AF.cv, &AF.mu);
+	pthread_mutex_unlock(&AF.mu);
+}
+
+static void flush_done(void)
+{
+	if (!AF.started) return;
+	flush_wait();
+	pthread_mutex_lock(&AF.mu);
+	AF.quit = 1;
+	pthread_cond_broadcast(&AF.cv);
+	pthread_mutex_unlock(&AF.mu);
+	pthread_join(AF.th, 0);
+	free(AF.job.s); AF.job.s = 0; AF.job.l = AF.job.m = 0;
+	AF.started = 0; AF.quit = 0;
+}
+
+static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
+{
+	str_t t;
+	if (getenv("RB2_DUMP_BATCHES") || getenv("RB2_SYNC_INSERT")) { flush_batch_now(mr, buf, flag, verbose); return; }
+	if (!AF.started) { AF.started = 1; pthread_create(&AF.th, 0, aflush_worker, 0); }
+	pthread_mutex_lock(&AF.mu);
+	while (AF.busy) pthread_cond_wait(&AF.cv, &AF.mu);       /* the batch before this one */
+	t = AF.job; AF.job = *buf; *buf = t;                       /* the reader goes on in the buffer the inserter is done with */
+	buf->l = 0;
+	AF.mr = mr; AF.flag = flag; AF.verbose = verbose; AF.busy = 1;
+	pthread_cond_broadcast(&AF.cv);
+	pthread_mutex_unlock(&AF.mu);
 }
 
 int main(int argc, char *argv[])
@@ -461,6 +521,7 @@ int main(int argc, char *argv[])
 	}
 	}
 	if (m && buf.l) flush_batch(mr, &buf, flag, verbose);
+	flush_done();
 	if (verbose >= 3) {
 		int64_t cc[6];
 		fprintf(stderr, "[M::%s] constructed FM-index in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", realtime() - rt, cputime() - ct);
