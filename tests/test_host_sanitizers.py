@@ -82,3 +82,13 @@ def test_sanitized_parallel_line_reader(san_cli, tmp_path):
             dump.unlink()
         run(san_cli, ["-L", "-m50k", "-x", "3"], text, env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})
         assert dump.stat().st_size > len(text)
+
+
+def test_sanitized_fmr_written_by_six_threads(san_cli, tmp_path):
+    """mr_dump to a regular file (six pwrite threads, rope_dump_size / rope_dump_at) under ASan/UBSan, against the piped bytes"""
+    text = H.reads_to_text(H.splitmix_bases(2000, 80, 5))
+    for extra in ([], ["-l", "64", "-n", "6"]):
+        piped = run(san_cli, ["-LRsb", "-m0"] + extra, text)
+        f = tmp_path / "p.fmr"
+        run(san_cli, ["-LRsb", "-m0", "-o", str(f)] + extra, text)
+        assert f.read_bytes() == piped
