@@ -62,6 +62,9 @@ void    rope_print_node(const rpnode_t *p);                                     
 void    rope_dump(const rope_t *r, FILE *fp);                                      /* rope.c:270-275 */
 int64_t rope_dump_size(const rope_t *r);                                           /* rb2 extension: bytes rope_dump() writes */
 int     rope_dump_at(const rope_t *r, int fd, int64_t off);                         /* rb2 extension: the same bytes at offset off of a regular file (pwrite); 0 = ok */
+int     rope_dump_nparts(const rope_t *r);                                          /* rb2 extension: the dump as independently sized and written parts (root header; one per child of the root) */
+int64_t rope_dump_part_size(const rope_t *r, int part);
+int     rope_dump_part_at(const rope_t *r, int part, int fd, int64_t off);
 rope_t *rope_restore(FILE *fp);                                                    /* rope.c:308-318 */
 
 /* ---- additions (not in the reference) ---------------------------------------------------- */

@@ -272,9 +272,25 @@ void mr_print_tree(const mrope_t *mr)
 	putchar('\n');
 }
 
-typedef struct { const rope_t *r; int fd; int64_t off, size; int err; } dump_job_t;
-static void *dump_size_worker(void *p) { dump_job_t *j = (dump_job_t*)p; j->size = rope_dump_size(j->r); return 0; }
-static void *dump_write_worker(void *p) { dump_job_t *j = (dump_job_t*)p; j->err = rope_dump_at(j->r, j->fd, j->off); return 0; }
+typedef struct { const rope_t *r; int part; int64_t off, size; } dump_part_t;
+typedef struct { dump_part_t *job; int njob, next, fd, pass, err; pthread_mutex_t mu; } dump_pool_t;
+
+static void *dump_pool_worker(void *arg)
+{
+	dump_pool_t *dp = (dump_pool_t*)arg;
+	for (;;) {
+		int k;
+		pthread_mutex_lock(&dp->mu);
+		k = dp->next < dp->njob ? dp->next++ : -1;
+		pthread_mutex_unlock(&dp->mu);
+		if (k < 0) break;
+		if (dp->pass == 0) dp->job[k].size = rope_dump_part_size(dp->job[k].r, dp->job[k].part);
+		else if (rope_dump_part_at(dp->job[k].r, dp->job[k].part, dp->fd, dp->job[k].off) != 0) {
+			pthread_mutex_lock(&dp->mu); dp->err = 1; pthread_mutex_unlock(&dp->mu);
+		}
+	}
+	return 0;
+}
 
 void mr_dump(mrope_t *mr, FILE *fp)
 {
@@ -283,20 +299,45 @@ void mr_dump(mrope_t *mr, FILE *fp)
 	mr_sync_host(mr);
 	fwrite("RB\2", 1, 3, fp);                                    /* magic; byte 3 = sorting order (mrope.c:139-140) */
 	fwrite(&mr->so, 1, 1, fp);
-	/* a regular file: the six ropes are written by six threads, each at its own offset (the bytes are those of rope_dump,
-	 * mrope.c:141; the reference writes them one fwrite after the other).  Pipes and terminals take the sequential path. */
-	if (fflush(fp) == 0 && fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && !getenv("RB2_DUMP_SEQUENTIAL")) {
-		dump_job_t job[6];
-		pthread_t th[6];
+	/* a regular file: the dump is cut into parts -- per rope the header and one part per subtree of the root -- that are sized,
+	 * given their offsets, and written with pwrite by a pool of threads (the bytes are those of rope_dump, mrope.c:141; the
+	 * reference writes them one fwrite after the other).  Pipes and terminals take the sequential path. */
+	/* Measured on tmpfs: at 7.5 GB (configs[1]) one thread of fwrite is the fastest (1.2 s; 4 / 16 / 32 threads: 2.3 / 2.1 / 1.7 s,
+	 * the sizing pass included), at 73 GB the threads win (8.7 s): they are used for large indexes, or when RB2_DUMP_THREADS asks. */
+	{
+		int64_t c[6], tot = 0;
+		mr_get_c(mr, c);
+		for (a = 0; a < 6; ++a) tot += c[a];
+		if (tot < ((int64_t)1 << 35) && !getenv("RB2_DUMP_THREADS")) st.st_mode = 0;
+		else if (fflush(fp) != 0 || fstat(fileno(fp), &st) != 0) st.st_mode = 0;
+	}
+	if (S_ISREG(st.st_mode) && !getenv("RB2_DUMP_SEQUENTIAL")) {
+		dump_pool_t dp;
+		pthread_t th[32];
+		int nthr = getenv("RB2_DUMP_THREADS") ? atoi(getenv("RB2_DUMP_THREADS")) : 16, k, p;
 		int64_t off = (int64_t)ftello(fp);
-		int bad = off < 0;
-		for (a = 0; a < 6 && !bad; ++a) { job[a].r = mr->r[a]; job[a].fd = fileno(fp); job[a].err = 0; pthread_create(&th[a], 0, dump_size_worker, &job[a]); }
-		for (a = 0; a < 6 && !bad; ++a) pthread_join(th[a], 0);
-		for (a = 0; a < 6 && !bad; ++a) { job[a].off = off; off += job[a].size; }
-		for (a = 0; a < 6 && !bad; ++a) pthread_create(&th[a], 0, dump_write_worker, &job[a]);
-		for (a = 0; a < 6 && !bad; ++a) { pthread_join(th[a], 0); if (job[a].err) bad = 2; }
-		if (!bad) { fseeko(fp, (off_t)off, SEEK_SET); return; }
-		if (bad == 2) { fprintf(stderr, "[E::%s] write error\n", __func__); exit(1); }
+		if (off >= 0) {
+			if (nthr < 1) nthr = 1;
+			if (nthr > 32) nthr = 32;
+			memset(&dp, 0, sizeof(dp));
+			pthread_mutex_init(&dp.mu, 0);
+			for (a = 0; a < 6; ++a) dp.njob += rope_dump_nparts(mr->r[a]);
+			dp.job = (dump_part_t*)calloc(dp.njob, sizeof(dump_part_t));
+			for (a = 0, k = 0; a < 6; ++a)
+				for (p = 0; p < rope_dump_nparts(mr->r[a]); ++p, ++k) { dp.job[k].r = mr->r[a]; dp.job[k].part = p; }
+			dp.fd = fileno(fp);
+			for (dp.pass = 0; dp.pass < 2; ++dp.pass) {           /* sizes, then bytes */
+				dp.next = 0;
+				for (k = 0; k < nthr; ++k) pthread_create(&th[k], 0, dump_pool_worker, &dp);
+				for (k = 0; k < nthr; ++k) pthread_join(th[k], 0);
+				if (dp.pass == 0) for (k = 0; k < dp.njob; ++k) { dp.job[k].off = off; off += dp.job[k].size; }
+			}
+			free(dp.job);
+			pthread_mutex_destroy(&dp.mu);
+			if (dp.err) { fprintf(stderr, "[E::%s] write error\n", __func__); exit(1); }
+			fseeko(fp, (off_t)off, SEEK_SET);
+			return;
+		}
 	}
 	for (a = 0; a < 6; ++a) rope_dump(mr->r[a], fp);
 }

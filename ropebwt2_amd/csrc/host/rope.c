@@ -323,6 +323,36 @@ static void dump_bucket_w(const rpnode_t *p, dumpw_t *w)
 	}
 }
 
+/* The dump in parts that can be sized and written independently: part 0 = the rope header and the root bucket's header (and,
+ * when the root is a bottom bucket, its leaves); parts 1..n = the subtrees of the root's n children, in order.  Concatenated
+ * they are rope_dump's bytes. */
+int rope_dump_nparts(const rope_t *r) { return r->root->is_bottom ? 1 : 1 + (int)r->root->n; }
+
+int64_t rope_dump_part_size(const rope_t *r, int part)
+{
+	if (part == 0) return r->root->is_bottom ? rope_dump_size(r) : 8 + 3;
+	return bucket_dump_size(r->root[part - 1].p);
+}
+
+static int dumpw_finish(dumpw_t *w) { dumpw_flush(w); free(w->buf); return w->err ? -1 : 0; }
+
+int rope_dump_part_at(const rope_t *r, int part, int fd, int64_t off)
+{
+	dumpw_t w;
+	if (part == 0 && r->root->is_bottom) return rope_dump_at(r, fd, off);
+	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.buf = (uint8_t*)malloc((size_t)w.cap);
+	if (part == 0) {
+		const uint8_t isb = 0;
+		const int16_t n = (int16_t)r->root->n;
+		dumpw_put(&w, &r->max_nodes, 4);
+		dumpw_put(&w, &r->block_len, 4);
+		dumpw_put(&w, &isb, 1);
+		dumpw_put(&w, &n, 2);
+	} else dump_bucket_w(r->root[part - 1].p, &w);
+	return dumpw_finish(&w);
+}
+
 int rope_dump_at(const rope_t *r, int fd, int64_t off)
 {
 	dumpw_t w;

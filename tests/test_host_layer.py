@@ -379,8 +379,10 @@ def test_fmr_dump_to_a_file_equals_dump_to_a_pipe(golden, tmp_path):
     for so in ("", "s", "r"):
         piped = cli(["-LRb" + so, "-m0"], text)
         f = tmp_path / ("par%s.fmr" % so)
-        assert subprocess.run([CLI, "-LRb" + so, "-m0", "-o", str(f), "-"], input=text, stderr=subprocess.DEVNULL).returncode == 0
-        assert f.read_bytes() == piped
+        for thr in ("1", "6", "16"):                         # (small indexes take the sequential path unless asked)
+            env = dict(os.environ, RB2_DUMP_THREADS=thr)
+            assert subprocess.run([CLI, "-LRb" + so, "-m0", "-o", str(f), "-"], input=text, stderr=subprocess.DEVNULL, env=env).returncode == 0
+            assert f.read_bytes() == piped
         g = tmp_path / ("seq%s.fmr" % so)
         env = dict(os.environ, RB2_DUMP_SEQUENTIAL="1")
         assert subprocess.run([CLI, "-LRb" + so, "-m0", "-o", str(g), "-"], input=text, stderr=subprocess.DEVNULL, env=env).returncode == 0

@@ -90,5 +90,5 @@ def test_sanitized_fmr_written_by_six_threads(san_cli, tmp_path):
     for extra in ([], ["-l", "64", "-n", "6"]):
         piped = run(san_cli, ["-LRsb", "-m0"] + extra, text)
         f = tmp_path / "p.fmr"
-        run(san_cli, ["-LRsb", "-m0", "-o", str(f)] + extra, text)
+        run(san_cli, ["-LRsb", "-m0", "-o", str(f)] + extra, text, env={"RB2_DUMP_THREADS": "5"})
         assert f.read_bytes() == piped
