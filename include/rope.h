@@ -70,6 +70,7 @@ rope_t *rope_restore(FILE *fp);                                                 
 /* ---- additions (not in the reference) ---------------------------------------------------- */
 /* replace the content of an EMPTY rope by the symbols of a 43+3 run stream (bulk load) */
 void    rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes);
+void    rope_load_runs_mt(rope_t *rope, const uint8_t *rle, int64_t n_bytes, int n_threads);   /* rb2 extension: the same tree, byte for byte, built by several threads */
 /* append all run bytes of the rope to a malloc'ed buffer; returns the byte count */
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out);
 

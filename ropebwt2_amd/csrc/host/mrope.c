@@ -87,7 +87,7 @@ typedef struct { rope_t *r; runbuf_t rb; } load_job_t;
 static void *load_worker(void *arg)
 {
 	load_job_t *j = (load_job_t*)arg;
-	rope_load_runs(j->r, j->rb.p, j->rb.n);
+	rope_load_runs_mt(j->r, j->rb.p, j->rb.n, getenv("RB2_LOAD_THREADS") ? atoi(getenv("RB2_LOAD_THREADS")) : 8);
 	free(j->rb.p); j->rb.p = 0;
 	return 0;
 }
@@ -119,6 +119,14 @@ void mr_sync_host(mrope_t *mr)
 	struct timespec t0, t1;
 	for (a = 0; a < 6; ++a) {
 		memset(&job[a], 0, sizeof(job[a]));
+		{	/* a run holds at least one symbol: the symbols of the rope bound its run bytes -- one allocation, no growing copies
+			 * (pages that are never written are never backed) */
+			int64_t c[36], ub = 1 << 20; int b;
+			rb2_hip_get_counts(x->dev, c);
+			for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
+			job[a].rb.p = (uint8_t*)malloc((size_t)ub);
+			job[a].rb.m = job[a].rb.p ? ub : 0;
+		}
 		clock_gettime(CLOCK_MONOTONIC, &t0);
 		rb2_hip_stream_rope(x->dev, a, runbuf_add, &job[a].rb);
 		clock_gettime(CLOCK_MONOTONIC, &t1);

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <unistd.h>
 #include <emmintrin.h>
+#include <pthread.h>
 #include <assert.h>
 #include <stdio.h>
 #include "rle.h"
@@ -456,16 +457,16 @@ static const uint8_t *plain_span_end(const uint8_t *q, const uint8_t *end)
 	return end > q ? end - 1 : q;
 }
 
+static void build_upper_levels(rope_t *rope, entvec_t *plv);
+
 void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
 {
 	const uint8_t *q = rle, *end = rle + (n_bytes > 0 ? n_bytes : 0);
 	const int fill = rope->block_len - RLE_MIN_SPACE - 2;      /* bytes of runs per leaf: leaves room for one insertion */
-	const int fan = rope->max_nodes > 4 ? rope->max_nodes - 2 : rope->max_nodes / 2;
-	entvec_t lv = { 0, 0, 0 }, up = { 0, 0, 0 };
+	entvec_t lv = { 0, 0, 0 };
 	rpnode_t *cur = 0;
 	uint8_t *blk = 0;
 	int pc = -1, a; int64_t pl = 0;
-	size_t i;
 	rope_reset(rope);
 	/* leaves: merge adjacent equal symbols, re-encode with the widest run form needed */
 	for (;;) {
@@ -525,7 +526,16 @@ void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
 		pc = c; pl = l;
 	}
 	if (lv.n == 0) { free(lv.v); return; }                     /* empty stream: the reset rope is the answer */
-	/* levels above: pack `fan` entries per bucket until a single bucket (the root) remains */
+	build_upper_levels(rope, &lv);
+}
+
+/* levels above the leaves: pack `fan` entries per bucket until a single bucket (the root) remains; frees lv */
+static void build_upper_levels(rope_t *rope, entvec_t *plv)
+{
+	const int fan = rope->max_nodes > 4 ? rope->max_nodes - 2 : rope->max_nodes / 2;
+	entvec_t lv = *plv, up = { 0, 0, 0 };
+	size_t i;
+	int a;
 	{
 		int bottom = 1;
 		for (;;) {
@@ -546,6 +556,151 @@ void rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes)
 		}
 	}
 	free(lv.v); free(up.v);
+}
+
+/* ---- the same tree from several threads (rb2 extension; mr_sync_host at configs[3]/[4] size spends half a minute here) -------
+ * rope_load_runs is a sequential automaton twice over: adjacent runs of one symbol merge, and a leaf takes runs until the next
+ * does not fit.  Both can be cut open without changing a byte of the result:
+ *   1. the stream is cut where two one-byte runs of different symbols meet (nothing merges across such a point); every segment
+ *      is brought into canonical form -- merged, re-encoded, empty runs dropped -- by its own thread, into its own buffer;
+ *   2. leaf k starts at the last run head <= start(k-1) + fill of the concatenated canonical stream: one pass over the leaves,
+ *      a few bytes each (the codec marks continuation bytes, rle.h:39-51);
+ *   3. the leaves are filled (copy + symbol counts) by the threads, each a contiguous range; the levels above as before. */
+typedef struct { const uint8_t *in; int64_t n; uint8_t *out; int64_t out_n; } canon_job_t;
+
+static int64_t canon_segment(const uint8_t *q, const uint8_t *end, uint8_t *out)
+{
+	uint8_t *o = out;
+	int pc = -1; int64_t pl = 0;
+	for (;;) {
+		int c = -1; int64_t l = 0;
+		if (end - q >= 64 && !(q[0] & 0x80) && (q[0] & 0x78) && (pc < 0 || (q[0] & 7) != pc)) {
+			const uint8_t *m = plain_span_end(q, end);
+			if (m - q >= 32) {
+				if (pc >= 0) { o += rle_enc1(o, pc, pl); pc = -1; }
+				memcpy(o, q, (size_t)(m - q)); o += m - q; q = m;
+				continue;
+			}
+		}
+		if (q < end) { q += rle_dec1_fn(q, &c, &l); if (l == 0) continue; }
+		if (c == pc && c >= 0) { pl += l; continue; }
+		if (pc >= 0) o += rle_enc1(o, pc, pl);
+		if (c < 0) break;
+		pc = c; pl = l;
+	}
+	return o - out;
+}
+
+static void *canon_worker(void *arg)
+{
+	canon_job_t *j = (canon_job_t*)arg;
+	j->out = (uint8_t*)malloc((size_t)j->n + 16);
+	j->out_n = canon_segment(j->in, j->in + j->n, j->out);
+	return 0;
+}
+
+typedef struct {
+	const canon_job_t *seg; const int64_t *pre; int nseg;       /* the canonical stream: segments and their start offsets */
+	const int64_t *start; int64_t nl, total;                    /* leaf starts */
+	rpnode_t *ent; int64_t k0, k1;                              /* my leaves */
+	int64_t c[6];
+} fill_job_t;
+
+static inline int vseg(const int64_t *pre, int nseg, int64_t x) { int t = 0; while (t + 1 < nseg && pre[t + 1] <= x) ++t; return t; }
+
+static void vcopy(const fill_job_t *f, uint8_t *dst, int64_t x, int64_t n)
+{
+	int t = vseg(f->pre, f->nseg, x);
+	while (n > 0) {
+		const int64_t o = x - f->pre[t], k = n < f->seg[t].out_n - o ? n : f->seg[t].out_n - o;
+		memcpy(dst, f->seg[t].out + o, (size_t)k);
+		dst += k; x += k; n -= k; ++t;
+	}
+}
+
+static void *fill_worker(void *arg)
+{
+	fill_job_t *f = (fill_job_t*)arg;
+	int64_t k;
+	int a;
+	for (k = f->k0; k < f->k1; ++k) {
+		const int64_t s = f->start[k], e = k + 1 < f->nl ? f->start[k + 1] : f->total, nb = e - s;
+		rpnode_t *en = &f->ent[k];
+		uint8_t *blk = (uint8_t*)en->p, *b = blk + 2;
+		int64_t cc[6] = { 0, 0, 0, 0, 0, 0 }, i, tot = 0;
+		int wide = 0;
+		vcopy(f, b, s, nb);
+		*rle_nptr(blk) = (uint16_t)nb;
+		for (i = 0; i < nb; ++i) wide |= b[i];
+		if (!(wide & 0x80)) count_plain_runs(b, nb, cc);
+		else {
+			const uint8_t *q = b, *end = b + nb;
+			while (q < end) { int c; int64_t l; q += rle_dec1_fn(q, &c, &l); if (c < 6) cc[c] += l; }
+		}
+		for (a = 0; a < 6; ++a) { en->c[a] = cc[a]; tot += cc[a]; f->c[a] += cc[a]; }
+		en->l = tot;
+	}
+	return 0;
+}
+
+void rope_load_runs_mt(rope_t *rope, const uint8_t *rle, int64_t n_bytes, int nthr)
+{
+	const int fill = rope->block_len - RLE_MIN_SPACE - 2;
+	canon_job_t seg[16];
+	fill_job_t fj[16];
+	pthread_t th[16];
+	int64_t pre[17], *start = 0, nl = 0, ml = 0, total, pos;
+	entvec_t lv = { 0, 0, 0 };
+	int t, nseg = 0, a;
+	if (nthr > 16) nthr = 16;
+	if (nthr < 2 || n_bytes < (int64_t)nthr * (getenv("RB2_LOAD_MIN_SEG") ? atol(getenv("RB2_LOAD_MIN_SEG")) : 8 << 20)) { rope_load_runs(rope, rle, n_bytes); return; }
+	/* 1. cut points: the first place at or behind k * n / nthr where two one-byte runs of different symbols meet */
+	{
+		int64_t from = 0;
+		for (t = 1; t <= nthr; ++t) {
+			int64_t cut = t == nthr ? n_bytes : n_bytes / nthr * t;
+			if (t < nthr) {
+				if (cut <= from) continue;
+				while (cut < n_bytes && !(!(rle[cut - 1] & 0x80) && (rle[cut - 1] & 0x78) && !(rle[cut] & 0x80) && (rle[cut] & 0x78) && ((rle[cut - 1] ^ rle[cut]) & 7))) ++cut;
+				if (cut >= n_bytes) continue;                     /* no such place in this stretch: it joins the next one */
+			}
+			seg[nseg].in = rle + from; seg[nseg].n = cut - from; seg[nseg].out = 0; seg[nseg].out_n = 0;
+			++nseg; from = cut;
+		}
+	}
+	for (t = 0; t < nseg; ++t) pthread_create(&th[t], 0, canon_worker, &seg[t]);
+	for (t = 0; t < nseg; ++t) pthread_join(th[t], 0);
+	for (t = 0, pre[0] = 0; t < nseg; ++t) pre[t + 1] = pre[t] + seg[t].out_n;
+	total = pre[nseg];
+	rope_reset(rope);
+	if (total == 0) { for (t = 0; t < nseg; ++t) free(seg[t].out); return; }
+	/* 2. leaf starts */
+	for (pos = 0; pos < total; ) {
+		int64_t nxt = pos + fill;
+		if (nl == ml) { ml = ml ? ml * 2 : 1 << 16; start = (int64_t*)realloc(start, (size_t)ml * sizeof(int64_t)); }
+		start[nl++] = pos;
+		if (nxt >= total) break;
+		for (;;) {                                             /* back to the head of the run that does not fit any more */
+			const int sg = vseg(pre, nseg, nxt);
+			if ((seg[sg].out[nxt - pre[sg]] & 0xC0) != 0x80) break;
+			--nxt;
+		}
+		pos = nxt;
+	}
+	/* 3. leaves: allocated here (the arena is not shared), filled by the threads */
+	lv.n = lv.m = (size_t)nl;
+	lv.v = (rpnode_t*)calloc((size_t)nl, sizeof(rpnode_t));
+	for (pos = 0; pos < nl; ++pos) lv.v[pos].p = (rpnode_t*)(pos == 0 ? (uint8_t*)rope->root->p : new_leaf(rope));
+	for (t = 0; t < nthr; ++t) {
+		memset(&fj[t], 0, sizeof(fj[t]));
+		fj[t].seg = seg; fj[t].pre = pre; fj[t].nseg = nseg; fj[t].start = start; fj[t].nl = nl; fj[t].total = total;
+		fj[t].ent = lv.v; fj[t].k0 = nl / nthr * t; fj[t].k1 = t == nthr - 1 ? nl : nl / nthr * (t + 1);
+		pthread_create(&th[t], 0, fill_worker, &fj[t]);
+	}
+	for (t = 0; t < nthr; ++t) { pthread_join(th[t], 0); for (a = 0; a < 6; ++a) rope->c[a] += fj[t].c[a]; }
+	for (t = 0; t < nseg; ++t) free(seg[t].out);
+	free(start);
+	build_upper_levels(rope, &lv);
 }
 
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out)

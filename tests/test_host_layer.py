@@ -425,3 +425,59 @@ def test_restore_runs_then_host_operations(hostlib, tmp_path):
             L.mr_destroy(mr)
             assert cli(["-m0", "-i", str(g)], b"") == want_bwt
         assert ranks["mr_restore"] == ranks["mr_restore_runs"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bulk_loader_threads_build_the_same_tree(hostlib, tmp_path, seed):
+    """rope_load_runs_mt cuts the run stream where nothing merges, brings the segments into canonical form in parallel, derives
+    the leaf starts from the codec's continuation marks and fills the leaves in parallel: the dump must equal rope_load_runs'
+    byte for byte -- on streams with runs that merge, empty runs, 2/4/8-byte runs and long stretches of one-byte runs."""
+    from ropebwt2_amd.hipbwt import encode_runs
+    L = hostlib
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.rope_init.restype = C.c_void_p; L.rope_init.argtypes = [C.c_int, C.c_int]
+    L.rope_load_runs.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.rope_load_runs_mt.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int]
+    L.rope_dump.argtypes = [C.c_void_p, C.c_void_p]
+    L.rope_destroy.argtypes = [C.c_void_p]
+    rng = np.random.RandomState(seed)
+    n = 600_000
+    sym = rng.randint(0, 6, size=n).astype(np.uint8)
+    ln = rng.randint(1, 16, size=n).astype(np.uint8)
+    same = rng.rand(n) < 0.02                                 # neighbours that merge
+    sym[1:][same[1:]] = sym[:-1][same[1:]]
+    ln[rng.rand(n) < 0.003] = 0                               # empty runs
+    plain = (ln << 3 | sym).astype(np.uint8)
+    parts, at = [], 0
+    for cut in sorted(rng.randint(0, n, size=40)):            # wide runs in between (2, 4 and 8 byte codes)
+        parts.append(plain[at:cut].tobytes())
+        wide = np.repeat(np.uint8(rng.randint(0, 6)), int(rng.choice([20, 300, 70_000, 600_000])))
+        parts.append(encode_runs(wide))
+        at = cut
+    parts.append(plain[at:].tobytes())
+    stream = b"".join(parts)
+    os.environ["RB2_LOAD_MIN_SEG"] = "4096"
+    try:
+        outs = []
+        for thr in (0, 2, 5, 16):
+            r = L.rope_init(64, 512) if thr != 5 else L.rope_init(6, 64)
+            if thr == 0:
+                L.rope_load_runs(r, stream, len(stream))
+            else:
+                L.rope_load_runs_mt(r, stream, len(stream), thr)
+            f = tmp_path / ("t%d.bin" % thr)
+            fp = libc.fopen(str(f).encode(), b"wb")
+            L.rope_dump(r, fp)
+            libc.fclose(fp)
+            L.rope_destroy(r)
+            outs.append(f.read_bytes())
+        assert outs[0] == outs[1] == outs[3]
+        r = L.rope_init(6, 64)                                 # small leaves and buckets: many levels
+        L.rope_load_runs(r, stream, len(stream))
+        f = tmp_path / "small.bin"
+        fp = libc.fopen(str(f).encode(), b"wb"); L.rope_dump(r, fp); libc.fclose(fp); L.rope_destroy(r)
+        assert f.read_bytes() == outs[2]
+    finally:
+        del os.environ["RB2_LOAD_MIN_SEG"]
