@@ -212,3 +212,30 @@ def test_stream_ordered_protocol_golden_1M(hip, golden):
     bwt = np.concatenate([vc.rope(b) for b in range(6)])
     assert H.md5(H.bwt_text(bwt) + b"\n") == g["text_md5"]["-Lr"]
     vc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_virtual_ranks_continue_a_loaded_index(hip, n):
+    """configs[4] on a sharded index: every rank is handed the run bytes of all six ropes (what mr_restore_runs holds), the device
+    loader keeps the pieces the rank owns and only counts the others; more batches through the sharded protocol; ropes = oracle"""
+    from ropebwt2_amd.sharded import VirtualCluster
+    from ropebwt2_amd.hipbwt import encode_runs
+    reads = H.repetitive_reads(2400, seed=71, genome_len=600, max_len=90) + [[1] * 400] * 30
+    for so in (0, 2):
+        o = H.Oracle(so)
+        o.insert_multi(H.encode_batch(reads[:1300]))
+        vc = VirtualCluster(so, n)
+        rles = [encode_runs(o.rope(b)) for b in range(6)]
+        for r in vc.ranks:
+            r.load_ropes(rles)
+        assert np.array_equal(vc.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(vc.rope(b), o.rope(b)), "rope %d after load (so %d)" % (b, so)
+        for buf in (H.encode_batch(reads[1300:2000]), H.encode_batch(reads[2000:], True, so == 2)):
+            o.insert_multi(buf)
+            vc.insert_multi(buf)
+            assert np.array_equal(vc.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(vc.rope(b), o.rope(b)), "rope %d (so %d)" % (b, so)
+        vc.close()
