@@ -217,7 +217,9 @@ typedef struct {
 typedef struct {
 	enc_cfg_t cfg; pjob_t *job; int njob;
 	int64_t next_work, n_queued; int closing;
-	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done;
+	int64_t consumed; int eof;                                  /* blocks the main thread has taken over; the reader thread saw the end of the input */
+	gzFile fp; int64_t chunk;                                   /* the reader thread's input */
+	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
 } pparse_t;
 
 static void pjob_encode(const enc_cfg_t *cfg, pjob_t *jb)
@@ -261,6 +263,55 @@ static void *pparse_worker(void *arg)
 		pthread_cond_broadcast(&pp->cv_done);
 	}
 	pthread_mutex_unlock(&pp->mu);
+	return 0;
+}
+
+/* The reader of the parallel -L path, a thread of its own: reads the next block, cuts it behind its last newline (the unfinished
+ * line is carried into the next block) and queues it for the encoders.  The main thread only takes the encoded blocks over, in
+ * order -- with both in one thread, reading 10 GB and appending 10 GB were 3+ s of configs[1]'s whole process. */
+static void *pparse_reader(void *arg)
+{
+	pparse_t *pp = (pparse_t*)arg;
+	const int64_t CHUNK = pp->chunk;
+	uint8_t *carry = (uint8_t*)malloc(CHUNK + 16); int64_t n_carry = 0, m_carry = CHUNK + 16, total = 0;
+	int last_byte = '\n', eof = 0;
+	while (!eof) {
+		pjob_t *jb;
+		int64_t got = 0, cut;
+		pthread_mutex_lock(&pp->mu);
+		while (pp->n_queued - pp->consumed >= pp->njob) pthread_cond_wait(&pp->cv_space, &pp->mu);
+		jb = &pp->job[pp->n_queued % pp->njob];                /* free: taken over by the main thread already */
+		pthread_mutex_unlock(&pp->mu);
+		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+		memcpy(jb->in, carry, n_carry);
+		while (got < CHUNK) {                                 /* gzread may return short counts on pipes */
+			const int r = gzread(pp->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
+			if (r <= 0) { eof = 1; break; }
+			got += r;
+		}
+		total += got;
+		if (got) last_byte = jb->in[n_carry + got - 1];
+		jb->n_in = n_carry + got;
+		if (!eof) {                                           /* keep the unfinished last line for the next block */
+			for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
+			n_carry = jb->n_in - cut;                           /* (cut == 0: one line longer than a block -- everything is carried on) */
+			if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)realloc(carry, m_carry); }
+			memcpy(carry, jb->in + cut, n_carry);
+			jb->n_in = cut;
+		} else n_carry = 0;
+		/* kseq learns about the end of input only from a short refill (kseq.h:70-75, 96-105): an input of k x 16384 bytes
+		 * that ends with a newline (or is empty) yields one more, empty, line */
+		jb->extra_empty = eof && total % RD_BUF == 0 && last_byte == '\n';
+		pthread_mutex_lock(&pp->mu);
+		if (jb->n_in > 0 || jb->extra_empty) {
+			jb->state = 1; ++pp->n_queued;
+			pthread_cond_signal(&pp->cv_work);
+		}
+		if (eof) pp->eof = 1;
+		pthread_cond_broadcast(&pp->cv_done);                  /* (the main thread also waits for blocks to exist) */
+		pthread_mutex_unlock(&pp->mu);
+	}
+	free(carry);
 	return 0;
 }
 
@@ -439,73 +490,44 @@ int main(int argc, char *argv[])
 	if ((flag & F_LINE) && m && pthr > 1) {                 /* -L in batch mode: blocks of whole lines encoded by worker threads */
 		const int64_t CHUNK = getenv("RB2_PARSE_CHUNK") ? atol(getenv("RB2_PARSE_CHUNK")) : 16 << 20;
 		pparse_t pp;
-		pthread_t *th = (pthread_t*)calloc(pthr, sizeof(pthread_t));
-		uint8_t *carry = (uint8_t*)malloc(CHUNK + 16); int64_t n_carry = 0, m_carry = CHUNK + 16, total = 0, consumed = 0;
-		int k, last_byte = '\n', eof = 0;
+		pthread_t *th = (pthread_t*)calloc(pthr, sizeof(pthread_t)), reader;
+		int k;
 		memset(&pp, 0, sizeof(pp));
 		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
-		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0);
+		pp.fp = rd->fp; pp.chunk = CHUNK;
+		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0); pthread_cond_init(&pp.cv_space, 0);
 		for (k = 0; k < pthr; ++k) pthread_create(&th[k], 0, pparse_worker, &pp);
-		while (!eof || consumed < pp.n_queued) {
-			/* 1. take over every finished block that is next in line (blocking only when there is nothing to read into) */
+		pthread_create(&reader, 0, pparse_reader, &pp);
+		for (;;) {                                              /* take over the finished blocks, in order */
+			pjob_t *jb;
+			size_t done = 0, r0 = 0;
 			pthread_mutex_lock(&pp.mu);
-			while (consumed < pp.n_queued && (pp.job[consumed % pp.njob].state == 2 || eof || pp.n_queued - consumed >= pp.njob)) {
-				pjob_t *jb = &pp.job[consumed % pp.njob];
-				size_t done = 0, r0 = 0;
-				while (jb->state != 2) pthread_cond_wait(&pp.cv_done, &pp.mu);
-				pthread_mutex_unlock(&pp.mu);
-				while (done < jb->out.l) {                          /* same flush points as the sequential loop: after the record that fills the batch */
-					size_t lo = r0, hi = jb->n_rec;                 /* first record whose end reaches the threshold */
-					const int64_t need = m - (int64_t)buf.l;
-					while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((int64_t)(jb->rec_end[mid] - done) >= need) hi = mid; else lo = mid + 1; }
-					if (lo == jb->n_rec) { str_append(&buf, jb->out.s + done, jb->out.l - done); done = jb->out.l; }
-					else {
-						str_append(&buf, jb->out.s + done, jb->rec_end[lo] - done); done = jb->rec_end[lo]; r0 = lo + 1;
-						flush_batch(mr, &buf, flag, verbose);
-					}
-				}
-				pthread_mutex_lock(&pp.mu);
-				jb->state = 0; ++consumed;
-			}
+			while (pp.consumed >= pp.n_queued && !pp.eof) pthread_cond_wait(&pp.cv_done, &pp.mu);
+			if (pp.consumed >= pp.n_queued) { pthread_mutex_unlock(&pp.mu); break; }   /* end of input, everything taken over */
+			jb = &pp.job[pp.consumed % pp.njob];
+			while (jb->state != 2) pthread_cond_wait(&pp.cv_done, &pp.mu);
 			pthread_mutex_unlock(&pp.mu);
-			if (eof) continue;
-			/* 2. read the next block, cut it behind its last newline, queue it */
-			{
-				pjob_t *jb = &pp.job[pp.n_queued % pp.njob];     /* free: the loop above keeps n_queued - consumed < njob */
-				int64_t got = 0, cut;
-				if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
-				memcpy(jb->in, carry, n_carry);
-				while (got < CHUNK) {                             /* gzread may return short counts on pipes */
-					const int r = gzread(rd->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
-					if (r <= 0) { eof = 1; break; }
-					got += r;
-				}
-				total += got;
-				if (got) last_byte = jb->in[n_carry + got - 1];
-				jb->n_in = n_carry + got;
-				if (!eof) {                                       /* keep the unfinished last line for the next block */
-					for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
-					n_carry = jb->n_in - cut;                       /* (cut == 0: one line longer than a block -- everything is carried on) */
-					if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)realloc(carry, m_carry); }
-					memcpy(carry, jb->in + cut, n_carry);
-					jb->n_in = cut;
-				} else n_carry = 0;
-				/* kseq learns about the end of input only from a short refill (kseq.h:70-75, 96-105): an input of k x 16384 bytes
-				 * that ends with a newline (or is empty) yields one more, empty, line */
-				jb->extra_empty = eof && total % RD_BUF == 0 && last_byte == '\n';
-				if (jb->n_in > 0 || jb->extra_empty) {
-					pthread_mutex_lock(&pp.mu);
-					jb->state = 1; ++pp.n_queued;
-					pthread_cond_signal(&pp.cv_work);
-					pthread_mutex_unlock(&pp.mu);
+			while (done < jb->out.l) {                          /* same flush points as the sequential loop: after the record that fills the batch */
+				size_t lo = r0, hi = jb->n_rec;                 /* first record whose end reaches the threshold */
+				const int64_t need = m - (int64_t)buf.l;
+				while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((int64_t)(jb->rec_end[mid] - done) >= need) hi = mid; else lo = mid + 1; }
+				if (lo == jb->n_rec) { str_append(&buf, jb->out.s + done, jb->out.l - done); done = jb->out.l; }
+				else {
+					str_append(&buf, jb->out.s + done, jb->rec_end[lo] - done); done = jb->rec_end[lo]; r0 = lo + 1;
+					flush_batch(mr, &buf, flag, verbose);
 				}
 			}
+			pthread_mutex_lock(&pp.mu);
+			jb->state = 0; ++pp.consumed;
+			pthread_cond_broadcast(&pp.cv_space);
+			pthread_mutex_unlock(&pp.mu);
 		}
+		pthread_join(reader, 0);
 		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_mutex_unlock(&pp.mu);
 		for (k = 0; k < pthr; ++k) pthread_join(th[k], 0);
 		for (k = 0; k < pp.njob; ++k) { free(pp.job[k].in); free(pp.job[k].out.s); free(pp.job[k].rec_end); }
-		free(pp.job); free(th); free(carry);
-		pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done);
+		free(pp.job); free(th);
+		pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done); pthread_cond_destroy(&pp.cv_space);
 	} else
 	while ((flag & F_LINE ? read_line_record(rd) : read_fastx_record(rd)) >= 0) {
 		uint8_t *s = (uint8_t*)rd->seq.s;
