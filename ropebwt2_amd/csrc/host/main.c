@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <sys/resource.h>
 #include <sys/time.h>
@@ -479,6 +480,15 @@ int main(int argc, char *argv[])
 	rd = (reader_t*)calloc(1, sizeof(reader_t));
 	rd->fp = optind < argc && strcmp(argv[optind], "-") ? gzopen(argv[optind], "rb") : gzdopen(fileno(stdin), "rb");
 	if (rd->fp == 0) { fprintf(stderr, "[E::%s] fail to open the input\n", __func__); return 1; }
+	if (m && optind < argc && strcmp(argv[optind], "-") && !getenv("RB2_NO_RESERVE")) {   /* a named file: its size bounds the job (one symbol per byte and strand) */
+		struct stat st;
+		if (stat(argv[optind], &st) == 0 && S_ISREG(st.st_mode) && st.st_size > (64 << 20)) {
+			int64_t c[6], have = 0, a, est = (int64_t)st.st_size * (((flag & F_FOR) ? 1 : 0) + ((flag & F_REV) ? 1 : 0));
+			mr_get_c(mr, c);
+			for (a = 0; a < 6; ++a) have += c[a];
+			mr_reserve(mr, 0, have + est);
+		}
+	}
 	ct = cputime(); rt = realtime();
 
 	{

@@ -994,6 +994,8 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 	if (batch_strings > 0) ensure_strings(h, (uint64_t)batch_strings);
 	if (total_symbols > 0) {
 		const uint64_t leaves = (uint64_t)total_symbols / LEAF + NR * (SB + 1);
+		size_t fr = 0, tot = 0;                                    // a hint must not be what runs the device out of memory
+		if (hipMemGetInfo(&fr, &tot) == hipSuccess && 2.0 * leaves * (LEAFB + 2.0 * sizeof(LeafMeta) + 2.0) > 0.6 * (double)fr) return;
 		h->pool[h->pside].ensure(leaves, true, h->st);
 		h->pool[h->pside ^ 1].ensure(leaves, false, h->st);
 		h->LD.ensure(leaves + NR + 16);
