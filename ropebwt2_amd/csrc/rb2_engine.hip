@@ -21,10 +21,70 @@ using namespace rb2;
 
 namespace {
 
+// Large, growing arrays (the leaf pools) live behind a reserved address range and grow by mapping more physical memory at their
+// end (hipMemAddressReserve / hipMemCreate / hipMemMap): what is there stays where it is -- no second allocation, no device copy,
+// no hipFree -- and a growth costs what the added memory costs.  (hipMalloc of tens of GB takes 25-40 ms per GB on some boxes of
+// this pool: growing a 60 GB pool the classic way stalled full configs[3] twice for 1.6 s.)  RB2_NO_VMM=1, or any failing call,
+// falls back to hipMalloc + copy.
+static int g_vmm_ok = -1;
+static size_t g_vmm_va = 0;
+static bool vmm_enabled()
+{
+	if (g_vmm_ok < 0) {
+		size_t fr = 0, tot = 0;
+		g_vmm_ok = getenv("RB2_NO_VMM") ? 0 : 1;
+		if (g_vmm_ok && hipMemGetInfo(&fr, &tot) == hipSuccess && tot > 0) g_vmm_va = (tot + (1ull << 30)) & ~((1ull << 30) - 1);   // no array outgrows the device
+		else g_vmm_ok = 0;
+	}
+	return g_vmm_ok == 1;
+}
+
 template <typename T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
+	bool vm = false;                                            // set by the owner before first use: grow in place
+	size_t vm_div = 1;                                         // the reserved range is 1 / vm_div of the device's memory (+ 1 GiB): small arrays need less address space
+	size_t vm_bytes = 0;                                       // mapped so far (p != nullptr && vm_bytes > 0: p is a reserved range)
+	std::vector<hipMemGenericAllocationHandle_t> vm_h; std::vector<size_t> vm_sz;
+	size_t vm_range() const { return (g_vmm_va / vm_div + (1ull << 30) + (64ull << 20) - 1) / (64ull << 20) * (64ull << 20); }
+	bool vm_grow(size_t n)                                     // false: nothing changed (the caller falls back)
+	{
+		const size_t CH = 64ull << 20;                         // mapping granule of ours (a multiple of the device's)
+		if (!vmm_enabled() || (p && vm_bytes == 0)) return false;   // (a classic allocation stays classic)
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess) return false;
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+		if (!p) {
+			void *base = nullptr;
+			if (hipMemAddressReserve(&base, vm_range(), CH, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); g_vmm_ok = 0; return false; }
+			p = (T*)base;
+		}
+		size_t want = (n * sizeof(T) + CH - 1) / CH * CH;
+		if (want > vm_range()) return false;
+		const size_t add = want - vm_bytes;
+		hipMemGenericAllocationHandle_t h;
+		if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) { (void)hipGetLastError(); if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; } return false; }
+		hipMemAccessDesc acc = {};
+		acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+		if (hipMemMap((char*)p + vm_bytes, add, 0, h, 0) != hipSuccess || hipMemSetAccess((char*)p + vm_bytes, add, &acc, 1) != hipSuccess) {
+			(void)hipGetLastError(); (void)hipMemUnmap((char*)p + vm_bytes, add); (void)hipMemRelease(h);
+			if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; }
+			return false;
+		}
+		vm_h.push_back(h); vm_sz.push_back(add);
+		vm_bytes = want; cap = vm_bytes / sizeof(T);
+		return true;
+	}
+	void vm_release()
+	{
+		size_t off = 0;
+		for (size_t i = 0; i < vm_h.size(); ++i) { (void)hipMemUnmap((char*)p + off, vm_sz[i]); (void)hipMemRelease(vm_h[i]); off += vm_sz[i]; }
+		(void)hipMemAddressFree(p, vm_range());
+		vm_h.clear(); vm_sz.clear(); vm_bytes = 0; p = nullptr; cap = 0;
+	}
 	void ensure(size_t n, bool keep = false, hipStream_t st = 0) {
 		if (n <= cap) return;
+		if (vm && vm_grow(n)) return;
 		size_t ncap = std::max(n, cap + cap / 2);
 		T *q = nullptr;
 		hipError_t e_ = hipMalloc((void**)&q, ncap * sizeof(T));
@@ -37,10 +97,10 @@ template <typename T> struct DevBuf {
 			abort();
 		}
 		if (keep && p && cap) { HIPCHK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
-		if (p) HIPCHK(hipFree(p));
+		if (p) { if (vm_bytes) vm_release(); else HIPCHK(hipFree(p)); }
 		p = q; cap = ncap;
 	}
-	void release() { if (p) HIPCHK(hipFree(p)); p = nullptr; cap = 0; }
+	void release() { if (p) { if (vm_bytes) vm_release(); else HIPCHK(hipFree(p)); } p = nullptr; cap = 0; }
 };
 
 struct Pool {
@@ -48,6 +108,8 @@ struct Pool {
 	uint64_t cap_leaves = 0;
 	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
 		if (leaves <= cap_leaves) return;
+		data.vm = meta.vm = own.vm = sbcum.vm = sbpos.vm = true;   // grow in place (DevBuf::vm_grow)
+		meta.vm_div = own.vm_div = 32; sbcum.vm_div = 256; sbpos.vm_div = 1024;   // (16 of 512, 48 and 8 of 16384 bytes per leaf)
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
 		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); own.ensure(nl, keep, st);
