@@ -59,20 +59,25 @@ template <typename T> struct DevBuf {
 			if (hipMemAddressReserve(&base, vm_range(), CH, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); g_vmm_ok = 0; return false; }
 			p = (T*)base;
 		}
-		size_t want = (n * sizeof(T) + CH - 1) / CH * CH;
+		const size_t want = (n * sizeof(T) + CH - 1) / CH * CH;
 		if (want > vm_range()) return false;
-		const size_t add = want - vm_bytes;
-		hipMemGenericAllocationHandle_t h;
-		if (hipMemCreate(&h, add, &prop, 0) != hipSuccess) { (void)hipGetLastError(); if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; } return false; }
 		hipMemAccessDesc acc = {};
 		acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-		if (hipMemMap((char*)p + vm_bytes, add, 0, h, 0) != hipSuccess || hipMemSetAccess((char*)p + vm_bytes, add, &acc, 1) != hipSuccess) {
-			(void)hipGetLastError(); (void)hipMemUnmap((char*)p + vm_bytes, add); (void)hipMemRelease(h);
-			if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; }
-			return false;
+		while (vm_bytes < want) {                               // pieces of at most 2 GiB (one handle each)
+			const size_t add = std::min<size_t>(want - vm_bytes, 2ull << 30);
+			hipMemGenericAllocationHandle_t h;
+			bool ok = hipMemCreate(&h, add, &prop, 0) == hipSuccess;
+			if (ok && (hipMemMap((char*)p + vm_bytes, add, 0, h, 0) != hipSuccess || hipMemSetAccess((char*)p + vm_bytes, add, &acc, 1) != hipSuccess)) {
+				(void)hipMemUnmap((char*)p + vm_bytes, add); (void)hipMemRelease(h); ok = false;
+			}
+			if (!ok) {                                          // keep what is mapped (cap says how much); the caller falls back to a fresh allocation
+				(void)hipGetLastError();
+				if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; }
+				return false;
+			}
+			vm_h.push_back(h); vm_sz.push_back(add);
+			vm_bytes += add; cap = vm_bytes / sizeof(T);
 		}
-		vm_h.push_back(h); vm_sz.push_back(add);
-		vm_bytes = want; cap = vm_bytes / sizeof(T);
 		return true;
 	}
 	void vm_release()
@@ -394,7 +399,9 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 	const uint64_t slots = slots_for(n_ub, to_sparse), cap = to_sparse ? slots : slots_for(std::max(n_ub, n_grow), false);
 	if (h->pool[h->pside ^ 1].cap_leaves < cap) {              // kernels of earlier rounds may still read the buffers about to be replaced
 		HIPCHK(hipStreamSynchronize(st));
+		const auto tg0 = std::chrono::steady_clock::now();
 		h->pool[h->pside ^ 1].ensure(cap, false, st);
+		if (h->trace) fprintf(stderr, "[rb2_hip] pool grown to %.1f M leaf slots in %.3f s\n", h->pool[h->pside ^ 1].cap_leaves / 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - tg0).count());
 	}
 	{
 		Scope sc(h, RB2_K_RELAYOUT, 0);
