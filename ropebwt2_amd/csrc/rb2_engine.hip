@@ -44,8 +44,10 @@ template <typename T> struct DevBuf {
 	bool vm = false;                                            // set by the owner before first use: grow in place
 	size_t vm_div = 1;                                         // the reserved range is 1 / vm_div of the device's memory (+ 1 GiB): small arrays need less address space
 	size_t vm_bytes = 0;                                       // mapped so far (p != nullptr && vm_bytes > 0: p is a reserved range)
+	size_t vm_piece = 0;                                       // every mapping of this array has this size, a power of two between 64 MiB and 2 GiB chosen at the first
+	                                                           // request (pieces of mixed or odd sizes made hipMemSetAccess fail with 'invalid argument' on this stack)
 	std::vector<hipMemGenericAllocationHandle_t> vm_h; std::vector<size_t> vm_sz;
-	size_t vm_range() const { return (g_vmm_va / vm_div + (1ull << 30) + (64ull << 20) - 1) / (64ull << 20) * (64ull << 20); }
+	size_t vm_range() const { return (g_vmm_va / vm_div + (4ull << 30)) & ~((2ull << 30) - 1); }   // a multiple of every piece size
 	bool vm_grow(size_t n)                                     // false: nothing changed (the caller falls back)
 	{
 		const size_t CH = 64ull << 20;                         // mapping granule of ours (a multiple of the device's)
@@ -56,21 +58,27 @@ template <typename T> struct DevBuf {
 		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
 		if (!p) {
 			void *base = nullptr;
-			if (hipMemAddressReserve(&base, vm_range(), CH, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); g_vmm_ok = 0; return false; }
+			const hipError_t er = hipMemAddressReserve(&base, vm_range(), CH, nullptr, 0);
+			if (er != hipSuccess) {
+				if (getenv("RB2_HIP_TRACE")) fprintf(stderr, "[rb2_hip] hipMemAddressReserve(%.1f GB) failed (%s): pools grow by hipMalloc + copy\n", vm_range() / 1e9, hipGetErrorString(er));
+				(void)hipGetLastError(); g_vmm_ok = 0; return false;
+			}
 			p = (T*)base;
 		}
-		const size_t want = (n * sizeof(T) + CH - 1) / CH * CH;
+		if (!vm_piece) { vm_piece = CH; while (vm_piece < (2ull << 30) && vm_piece * 8 < n * sizeof(T)) vm_piece <<= 1; }
+		const size_t want = (n * sizeof(T) + vm_piece - 1) / vm_piece * vm_piece;
 		if (want > vm_range()) return false;
 		hipMemAccessDesc acc = {};
 		acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-		while (vm_bytes < want) {                               // pieces of at most 2 GiB (one handle each)
-			const size_t add = std::min<size_t>(want - vm_bytes, 2ull << 30);
+		while (vm_bytes < want) {                               // one handle per piece
+			const size_t add = vm_piece;
 			hipMemGenericAllocationHandle_t h;
 			bool ok = hipMemCreate(&h, add, &prop, 0) == hipSuccess;
 			if (ok && (hipMemMap((char*)p + vm_bytes, add, 0, h, 0) != hipSuccess || hipMemSetAccess((char*)p + vm_bytes, add, &acc, 1) != hipSuccess)) {
 				(void)hipMemUnmap((char*)p + vm_bytes, add); (void)hipMemRelease(h); ok = false;
 			}
 			if (!ok) {                                          // keep what is mapped (cap says how much); the caller falls back to a fresh allocation
+				if (getenv("RB2_HIP_TRACE")) fprintf(stderr, "[rb2_hip] mapping %.2f GB behind %.2f GB failed (%s)\n", add / 1e9, vm_bytes / 1e9, hipGetErrorString(hipGetLastError()));
 				(void)hipGetLastError();
 				if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; }
 				return false;
@@ -497,7 +505,10 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
 			const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
 			size_t fr = 0, tot = 0;
-			const double bytes = grow * (double)need * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);   // (the old buffers are freed only after the new ones exist)
+			double leaves_more = 0;                                // pools that grow in place need what is added (+ the 25 % margin of Pool::ensure); others a whole new buffer beside the old one
+			for (int k = 0; k < 2; ++k)
+				if (need > h->pool[k].cap_leaves) leaves_more += h->pool[k].data.vm_bytes ? 1.25 * (double)need - (double)h->pool[k].cap_leaves : (double)need * 1.25;
+			const double bytes = leaves_more * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);
 			if (grow && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
 				want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
 				if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
