@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <assert.h>
 #include <pthread.h>
@@ -327,6 +328,10 @@ void mr_dump(mrope_t *mr, FILE *fp)
 		for (a = 0; a < 6; ++a) tot += c[a];
 		if (tot < ((int64_t)1 << 35) && !getenv("RB2_DUMP_THREADS")) st.st_mode = 0;
 		else if (fflush(fp) != 0 || fstat(fileno(fp), &st) != 0) st.st_mode = 0;
+		else {                                                     /* `>> out.fmr`: pwrite ignores its offset on O_APPEND descriptors (Linux) -- the parts would land in completion order */
+			const int fl = fcntl(fileno(fp), F_GETFL);
+			if (fl < 0 || (fl & O_APPEND)) st.st_mode = 0;
+		}
 	}
 	if (S_ISREG(st.st_mode) && !getenv("RB2_DUMP_SEQUENTIAL")) {
 		dump_pool_t dp;
@@ -340,6 +345,7 @@ void mr_dump(mrope_t *mr, FILE *fp)
 			pthread_mutex_init(&dp.mu, 0);
 			for (a = 0; a < 6; ++a) dp.njob += rope_dump_nparts(mr->r[a]);
 			dp.job = (dump_part_t*)calloc(dp.njob, sizeof(dump_part_t));
+			if (dp.job == 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(1); }
 			for (a = 0, k = 0; a < 6; ++a)
 				for (p = 0; p < rope_dump_nparts(mr->r[a]); ++p, ++k) { dp.job[k].r = mr->r[a]; dp.job[k].part = p; }
 			dp.fd = fileno(fp);
@@ -352,7 +358,7 @@ void mr_dump(mrope_t *mr, FILE *fp)
 			free(dp.job);
 			pthread_mutex_destroy(&dp.mu);
 			if (dp.err) { fprintf(stderr, "[E::%s] write error\n", __func__); exit(1); }
-			fseeko(fp, (off_t)off, SEEK_SET);
+			if (fseeko(fp, (off_t)off, SEEK_SET) != 0) { fprintf(stderr, "[E::%s] cannot seek behind the dump\n", __func__); exit(1); }
 			return;
 		}
 	}

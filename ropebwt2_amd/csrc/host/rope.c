@@ -343,6 +343,7 @@ int rope_dump_part_at(const rope_t *r, int part, int fd, int64_t off)
 	if (part == 0 && r->root->is_bottom) return rope_dump_at(r, fd, off);
 	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
 	w.buf = (uint8_t*)malloc((size_t)w.cap);
+	if (w.buf == 0) return -1;
 	if (part == 0) {
 		const uint8_t isb = 0;
 		const int16_t n = (int16_t)r->root->n;
@@ -359,6 +360,7 @@ int rope_dump_at(const rope_t *r, int fd, int64_t off)
 	dumpw_t w;
 	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
 	w.buf = (uint8_t*)malloc((size_t)w.cap);
+	if (w.buf == 0) return -1;
 	dumpw_put(&w, &r->max_nodes, 4);
 	dumpw_put(&w, &r->block_len, 4);
 	dump_bucket_w(r->root, &w);
@@ -594,7 +596,11 @@ static int64_t canon_segment(const uint8_t *q, const uint8_t *end, uint8_t *out)
 static void *canon_worker(void *arg)
 {
 	canon_job_t *j = (canon_job_t*)arg;
-	j->out = (uint8_t*)malloc((size_t)j->n + 16);
+	/* merging adjacent runs of one symbol can GROW the stream: a 2-byte run of 255 + a 1-byte run of 1 is a 4-byte run of 256, a
+	 * 4-byte run + a 1-byte run that crosses 2^19 an 8-byte one -- at worst 8 bytes out for 5 in.  Twice the input bounds it
+	 * (pages that are never written are never backed). */
+	j->out = (uint8_t*)malloc(2 * (size_t)j->n + 16);
+	if (j->out == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes)\n", __func__, (long long)(2 * j->n + 16)); exit(1); }
 	j->out_n = canon_segment(j->in, j->in + j->n, j->out);
 	return 0;
 }

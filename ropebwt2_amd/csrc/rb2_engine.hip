@@ -43,7 +43,9 @@ template <typename T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
 	bool vm = false;                                            // set by the owner before first use: grow in place
 	size_t vm_div = 1;                                         // the reserved range is 1 / vm_div of the device's memory (+ 1 GiB): small arrays need less address space
-	size_t vm_bytes = 0;                                       // mapped so far (p != nullptr && vm_bytes > 0: p is a reserved range)
+	size_t vm_bytes = 0;                                       // mapped so far
+	bool vm_res = false;                                       // p is a reserved address range (not a hipMalloc pointer), whatever is mapped behind it
+	size_t vm_res_bytes = 0;                                   // ... of this size (vm_range() at the time of the reservation, on the device it was made for)
 	size_t vm_piece = 0;                                       // every mapping of this array has this size, a power of two between 64 MiB and 2 GiB chosen at the first
 	                                                           // request (pieces of mixed or odd sizes made hipMemSetAccess fail with 'invalid argument' on this stack)
 	std::vector<hipMemGenericAllocationHandle_t> vm_h; std::vector<size_t> vm_sz;
@@ -51,7 +53,7 @@ template <typename T> struct DevBuf {
 	bool vm_grow(size_t n)                                     // false: nothing changed (the caller falls back)
 	{
 		const size_t CH = 64ull << 20;                         // mapping granule of ours (a multiple of the device's)
-		if (!vmm_enabled() || (p && vm_bytes == 0)) return false;   // (a classic allocation stays classic)
+		if (!vmm_enabled() || (p && !vm_res)) return false;      // (a classic allocation stays classic)
 		int dev = 0;
 		if (hipGetDevice(&dev) != hipSuccess) return false;
 		hipMemAllocationProp prop = {};
@@ -63,11 +65,14 @@ template <typename T> struct DevBuf {
 				if (getenv("RB2_HIP_TRACE")) fprintf(stderr, "[rb2_hip] hipMemAddressReserve(%.1f GB) failed (%s): pools grow by hipMalloc + copy\n", vm_range() / 1e9, hipGetErrorString(er));
 				(void)hipGetLastError(); g_vmm_ok = 0; return false;
 			}
-			p = (T*)base;
+			p = (T*)base; vm_res = true; vm_res_bytes = vm_range();
 		}
 		if (!vm_piece) { vm_piece = CH; while (vm_piece < (2ull << 30) && vm_piece * 8 < n * sizeof(T)) vm_piece <<= 1; }
 		const size_t want = (n * sizeof(T) + vm_piece - 1) / vm_piece * vm_piece;
-		if (want > vm_range()) return false;
+		if (want > vm_res_bytes) {                              // does not fit the range: back to a classic allocation (ensure() copies what is mapped, then releases the range)
+			if (vm_bytes == 0) vm_release();
+			return false;
+		}
 		hipMemAccessDesc acc = {};
 		acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
 		while (vm_bytes < want) {                               // one handle per piece
@@ -80,7 +85,7 @@ template <typename T> struct DevBuf {
 			if (!ok) {                                          // keep what is mapped (cap says how much); the caller falls back to a fresh allocation
 				if (getenv("RB2_HIP_TRACE")) fprintf(stderr, "[rb2_hip] mapping %.2f GB behind %.2f GB failed (%s)\n", add / 1e9, vm_bytes / 1e9, hipGetErrorString(hipGetLastError()));
 				(void)hipGetLastError();
-				if (vm_bytes == 0) { (void)hipMemAddressFree(p, vm_range()); p = nullptr; }
+				if (vm_bytes == 0) vm_release();
 				return false;
 			}
 			vm_h.push_back(h); vm_sz.push_back(add);
@@ -92,8 +97,8 @@ template <typename T> struct DevBuf {
 	{
 		size_t off = 0;
 		for (size_t i = 0; i < vm_h.size(); ++i) { (void)hipMemUnmap((char*)p + off, vm_sz[i]); (void)hipMemRelease(vm_h[i]); off += vm_sz[i]; }
-		(void)hipMemAddressFree(p, vm_range());
-		vm_h.clear(); vm_sz.clear(); vm_bytes = 0; p = nullptr; cap = 0;
+		if (vm_res) (void)hipMemAddressFree(p, vm_res_bytes);
+		vm_h.clear(); vm_sz.clear(); vm_bytes = 0; vm_res = false; vm_res_bytes = 0; p = nullptr; cap = 0;
 	}
 	void ensure(size_t n, bool keep = false, hipStream_t st = 0) {
 		if (n <= cap) return;
@@ -110,10 +115,10 @@ template <typename T> struct DevBuf {
 			abort();
 		}
 		if (keep && p && cap) { HIPCHK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
-		if (p) { if (vm_bytes) vm_release(); else HIPCHK(hipFree(p)); }
+		if (p) { if (vm_res) vm_release(); else HIPCHK(hipFree(p)); }
 		p = q; cap = ncap;
 	}
-	void release() { if (p) { if (vm_bytes) vm_release(); else HIPCHK(hipFree(p)); } p = nullptr; cap = 0; }
+	void release() { if (p) { if (vm_res) vm_release(); else HIPCHK(hipFree(p)); } p = nullptr; cap = 0; }
 };
 
 struct Pool {
@@ -507,7 +512,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 			size_t fr = 0, tot = 0;
 			double leaves_more = 0;                                // pools that grow in place need what is added (+ the 25 % margin of Pool::ensure); others a whole new buffer beside the old one
 			for (int k = 0; k < 2; ++k)
-				if (need > h->pool[k].cap_leaves) leaves_more += h->pool[k].data.vm_bytes ? 1.25 * (double)need - (double)h->pool[k].cap_leaves : (double)need * 1.25;
+				if (need > h->pool[k].cap_leaves) leaves_more += h->pool[k].data.vm_res ? 1.25 * (double)need - (double)h->pool[k].cap_leaves : (double)need * 1.25;
 			const double bytes = leaves_more * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);
 			if (grow && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
 				want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
@@ -593,7 +598,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 {
 	if (!h) return;
 	HIPCHK(hipSetDevice(h->dev));
-	HIPCHK(hipStreamSynchronize(h->st));
+	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
@@ -841,6 +846,7 @@ void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (nranks < 1 || rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] bad shard rank %d/%d\n", rank, nranks); abort(); }
+	ensure_dense(h);
 	uint32_t own[NR + 1];
 	memset(own, 0, sizeof(own));
 	for (int r = 0; r < NR; ++r) {
@@ -859,6 +865,7 @@ int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || ((uintptr_t)s_dev & 15)) { fprintf(stderr, "[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); abort(); }
 	check_last_byte(h, len, s_dev);
+	ensure_dense(h);                                           /* the protocol below runs dense rounds (k_part / k_merge): a handle that went sparse through rb2_hip_insert_multi is converted first */
 	BatchState *B = new BatchState();
 	batch_begin(h, *B, len, s_dev);
 	h->batch = B;
@@ -887,8 +894,9 @@ void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt)
 void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	HIPCHK(hipStreamSynchronize(h->st));
-	if (h->own_stream) { HIPCHK(hipStreamDestroy(h->st)); h->own_stream = false; }
+	if (!h->own_stream && h->st == (hipStream_t)hip_stream) return;            /* bound already */
+	if (h->own_stream) { HIPCHK(hipStreamSynchronize(h->st)); HIPCHK(hipStreamDestroy(h->st)); h->own_stream = false; }
+	else HIPCHK(hipDeviceSynchronize());                                       /* the previous foreign stream may be gone */
 	h->st = (hipStream_t)hip_stream;
 }
 

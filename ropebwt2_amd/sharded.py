@@ -223,8 +223,10 @@ class TorchComm:
         L, h = bwt.L, bwt.h
         if getattr(self, "gc", None) is None:
             self.gc = torch.zeros(NR * 6, dtype=torch.int64, device=self.dev)
-            L.rb2_hip_use_stream(h, torch.cuda.current_stream().cuda_stream)
             L.rb2_hip_shard_async(h, self.gc.data_ptr())
+        # the collectives below run on torch's CURRENT stream: bind the engine to it on every call (the caller may have
+        # entered another `with torch.cuda.stream(...)` since the last batch)
+        L.rb2_hip_use_stream(h, torch.cuda.current_stream().cuda_stream)
         rounds = L.rb2_hip_shard_begin(h, nbytes, dev_ptr)
         cap = L.rb2_hip_shard_capacity(h)
         send_ptr, recv_ptr = self.send_ptr(cap), self.recv_ptr(cap)

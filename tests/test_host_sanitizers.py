@@ -92,3 +92,50 @@ def test_sanitized_fmr_written_by_six_threads(san_cli, tmp_path):
         f = tmp_path / "p.fmr"
         run(san_cli, ["-LRsb", "-m0", "-o", str(f)] + extra, text, env={"RB2_DUMP_THREADS": "5"})
         assert f.read_bytes() == piped
+
+
+def _noncanonical_fmr(pairs_per_leaf=160, leaves=60):
+    """an .fmr whose leaves hold NON-canonical run streams: a 2-byte run of 255 x followed by a 1-byte run of 1 x (together a
+    4-byte run of 256: the canonical form is LONGER than the input), and 4-byte + 1-byte pairs that cross 2^19 (-> 8 bytes)"""
+    import struct
+
+    def enc(c, l):
+        if l < 16:
+            return bytes([l << 3 | c])
+        n = 2 if l < 256 else 4 if l < (1 << 19) else 8
+        tail = []
+        for _ in range(n - 1):
+            tail.append(0x80 | (l & 0x3f)); l >>= 6
+        return bytes([{2: 0xC0, 4: 0xE0, 8: 0xF0}[n] | l << 3 | c]) + bytes(reversed(tail))
+    out = b"RB\x02\x00"
+    for rope in range(6):
+        out += struct.pack("<ii", 64, 512)
+        out += struct.pack("<Bh", 1, leaves)
+        for lf in range(leaves):
+            body, cnt = b"", [0] * 6
+            for k in range(pairs_per_leaf):
+                c = 1 + (k + lf + rope) % 4
+                if k % 40 == 7 and len(body) < 480:
+                    body += enc(c, (1 << 19) - 1) + enc(c, 1); cnt[c] += 1 << 19
+                else:
+                    body += enc(c, 255) + enc(c, 1); cnt[c] += 256
+                if len(body) > 500:
+                    break
+            out += struct.pack("<6q", *cnt) + struct.pack("<H", len(body)) + body
+    return out
+
+
+def test_sanitized_parallel_loader_growing_canonical_form(san_cli, tmp_path):
+    """rope_load_runs_mt sized the canonical form of a segment as input + 16 bytes; merging adjacent runs of one
+    symbol can grow the stream (255 + 1 -> a 4-byte run).  Reached through `-i file -b` (mr_restore_runs -> mr_sync_host)."""
+    f = tmp_path / "nc.fmr"
+    f.write_bytes(_noncanonical_fmr())
+    seq = run(san_cli, ["-b", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": "1"})
+    for thr in ("2", "4", "8"):
+        par = run(san_cli, ["-b", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": thr, "RB2_LOAD_MIN_SEG": "500"})
+        assert par == seq
+    if H.have_ref():
+        ref = subprocess.run([H.REF_BIN, "-d", "-i", str(f), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        ours = run(san_cli, ["-d", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": "4", "RB2_LOAD_MIN_SEG": "500"})
+        if ref.returncode == 0:
+            assert ours == ref.stdout
