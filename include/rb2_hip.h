@@ -129,6 +129,59 @@ void    rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, 
 void    rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream);       /* e.g. torch.cuda.current_stream().cuda_stream */
 void    rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev);     /* NR*6 int64 on this device; NULL switches back */
 
+
+/* ---- N GPUs behind one handle (round 3) ------------------------------------------------------------------
+ * The reference fans a round out to its workers and joins them INSIDE mr_insert_multi (mrope.c:287-296, 312-329) and reads
+ * every rope's counts after the barrier (mrope.c:332-340); callers just call mr_insert_multi (main.c:240, 248).  This is the
+ * same contract for N engines: one call inserts a batch into ONE index whose 31 sub-ropes are dealt out over the ranks
+ * (owner map as in rb2_hip_shard_setup), the round loop -- count matrix, merge, exchange of the string records, unpack --
+ * runs inside the library, one host thread per local rank, no host <-> device synchronisation between the rounds of a
+ * batch on the PEER transport.  Two transports behind the same loop:
+ *   RB2_TRANSPORT_PEER  one process, every rank an engine of its own on devices[i] (the same device may be listed several
+ *                       times: N "virtual" ranks on one GPU -- how the whole path is tested on a one-GPU box).  The count
+ *                       matrices are summed by a kernel that reads the peers' rows, the string records are fetched by the
+ *                       RECEIVER's unpack kernel straight from the senders' buffers (peer access over xGMI; device events
+ *                       order the streams), so an exchange costs no launch of its own and no host round trip.
+ *   RB2_TRANSPORT_RCCL  RCCL's C API (librccl, loaded on first use): ncclAllReduce of the 31 x 6 matrix in place, grouped
+ *                       ncclSend / ncclRecv of the records.  Works across processes (rb2_hip_multi_create_rank: one process
+ *                       per GPU, the launch contract of bench.py) and inside one (rb2_hip_multi_create on distinct devices).
+ *                       The host reads the reduced matrix from pinned memory behind an event that fires BEFORE the merge
+ *                       kernels of the round run -- it sizes the sends while the GPU merges; the stream never drains.
+ */
+typedef struct rb2_hip_multi_s rb2_hip_multi_t;
+#define RB2_TRANSPORT_PEER 0
+#define RB2_TRANSPORT_RCCL 1
+#define RB2_MULTI_MAX_RANKS 64
+/* one process drives n ranks; devices[i] = HIP device of rank i; owner == NULL: the default owner map (rb2_hip_default_owners) */
+rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_order, int transport, const int *owner /* [NR] or NULL */);
+/* one rank of a group of `nranks` processes (RCCL): `nccl_id` = the 128 bytes rb2_hip_multi_unique_id() produced on rank 0 */
+void rb2_hip_multi_unique_id(void *id128);
+rb2_hip_multi_t *rb2_hip_multi_create_rank(int device, int rank, int nranks, const void *nccl_id, int sorting_order, const int *owner);
+void rb2_hip_multi_destroy(rb2_hip_multi_t *m);
+void rb2_hip_default_owners(int nranks, int owner[] /* NR */);
+int  rb2_hip_multi_nranks(const rb2_hip_multi_t *m);            /* ranks of the whole group */
+int  rb2_hip_multi_nlocal(const rb2_hip_multi_t *m);            /* ... driven by this process */
+rb2_hip_t *rb2_hip_multi_engine(rb2_hip_multi_t *m, int local_rank);   /* the engine of a local rank (profiling, rb2_hip_dev_alloc, ...) */
+/* mr_insert_multi (mrope.c:258) on the sharded index: `s` host memory, borrowed for the call (uploaded once per device) */
+void rb2_hip_multi_insert_multi(rb2_hip_multi_t *m, int64_t len, const uint8_t *s);
+/* the batch already sits on the devices: s_dev[i] = the (whole) batch text in the memory of local rank i's device, 16-byte
+ * aligned; ranks on one device may share a buffer */
+void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8_t *const *s_dev);
+void rb2_hip_multi_get_counts(rb2_hip_multi_t *m, int64_t c[36]);
+/* rope b as run bytes: its pieces (b,x), x = $ACGTN, each from its owner, in order.  A multi-process handle only holds the
+ * pieces of its own rank: the functions then return those (in order) -- gathering across processes is the caller's job */
+int64_t rb2_hip_multi_rope_bytes(rb2_hip_multi_t *m, int b);
+int64_t rb2_hip_multi_download_rope(rb2_hip_multi_t *m, int b, uint8_t *dst);
+int64_t rb2_hip_multi_stream_rope(rb2_hip_multi_t *m, int b, rb2_hip_run_cb cb, void *user);
+void rb2_hip_multi_load_ropes(rb2_hip_multi_t *m, const uint8_t *const rle[6], const int64_t n_bytes[6]);
+void rb2_hip_multi_reserve(rb2_hip_multi_t *m, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols);
+void rb2_hip_multi_reset(rb2_hip_multi_t *m);
+void rb2_hip_multi_sync(rb2_hip_multi_t *m);
+void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
+/* out[0] host <-> device synchronisations inside the round loops so far (PEER: 0), out[1] rounds, out[2] batches,
+ * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
+void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
+
 /* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */
 
 /* allocate / free raw device memory */

@@ -6,6 +6,6 @@ the hot path (``mr_insert_multi``, /root/reference/mrope.c:258-345) happens in h
 kernels for gfx950; there is no Python or CPU fallback -- a missing library or GPU raises.
 """
 from .build import build_all, lib_path  # noqa: F401
-from .hipbwt import HipBwt, load_hip_lib, K_NAMES  # noqa: F401
+from .hipbwt import HipBwt, MultiBwt, load_hip_lib, K_NAMES  # noqa: F401
 
-__all__ = ["HipBwt", "load_hip_lib", "build_all", "lib_path", "K_NAMES"]
+__all__ = ["HipBwt", "MultiBwt", "load_hip_lib", "build_all", "lib_path", "K_NAMES"]

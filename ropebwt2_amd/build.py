@@ -40,12 +40,12 @@ def _run(cmd):
 def build_hip(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     out = lib_path("librb2hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("rb2_engine.hip", "rb2_kernels.h", "rb2_merge.h", "rb2_device.h")] + [os.path.join(INC, "rb2_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("rb2_engine.hip", "rb2_kernels.h", "rb2_merge.h", "rb2_device.h", "rb2_multi.h")] + [os.path.join(INC, "rb2_hip.h")]
     if not force and _newer(out, srcs):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     _run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INC, "-I" + CSRC,
-          "-Wno-unused-value", "-o", out, srcs[0]])
+          "-Wno-unused-value", "-o", out, srcs[0], "-ldl", "-lpthread"])
     return out
 
 

@@ -26,7 +26,8 @@
 
 typedef struct {
 	mrope_t pub;            /* must stay first: callers hold mrope_t* */
-	rb2_hip_t *dev;
+	rb2_hip_t *dev;         /* one GPU ... */
+	rb2_hip_multi_t *mdev;  /* ... or the index sharded over several (RB2_HIP_DEVICES=0,1,2,...): exactly one of the two is set */
 	int host_ok, dev_ok;
 	uint8_t *raw[6]; int64_t raw_n[6]; int raw_ok;          /* mr_restore_runs: the run bytes of the six ropes, no trees yet */
 	int max_nodes, block_len;
@@ -38,6 +39,47 @@ static int device_id(void)
 {
 	const char *e = getenv("RB2_HIP_DEVICE");
 	return e ? atoi(e) : 0;
+}
+
+/* ---- the device side: one engine, or N behind one handle -------------------------------------------------------------------
+ * RB2_HIP_DEVICES=0,1,2,3,4,5,6,7 shards the index over the listed devices (the reference fans a round out to its worker
+ * threads inside mr_insert_multi, mrope.c:287-296, 312-329: same call, same contract -- the workers are GPUs).  A device may
+ * be listed several times (virtual ranks on one GPU: how the sharded path is tested on a one-GPU box).  RB2_HIP_TRANSPORT =
+ * peer (default: peer access + device events inside this process) | rccl (RCCL's C API). */
+static int has_dev(const mrx_t *x) { return x->dev != 0 || x->mdev != 0; }
+
+static void dev_create(mrx_t *x)
+{
+	const char *e = getenv("RB2_HIP_DEVICES"), *t = getenv("RB2_HIP_TRANSPORT");
+	int devs[RB2_MULTI_MAX_RANKS], n = 0;
+	if (has_dev(x)) return;
+	if (e && *e) {
+		const char *p = e;
+		while (*p && n < RB2_MULTI_MAX_RANKS) {
+			char *q;
+			const long v = strtol(p, &q, 10);
+			if (q == p) break;
+			devs[n++] = (int)v;
+			p = *q == ',' ? q + 1 : q;
+		}
+	}
+	if (n > 1) x->mdev = rb2_hip_multi_create(n, devs, x->pub.so, (t && (t[0] == 'r' || t[0] == 'R')) ? RB2_TRANSPORT_RCCL : RB2_TRANSPORT_PEER, 0);
+	else x->dev = rb2_hip_create(n == 1 ? devs[0] : device_id(), x->pub.so);
+}
+static void dev_destroy(mrx_t *x)
+{
+	if (x->dev) rb2_hip_destroy(x->dev);
+	if (x->mdev) rb2_hip_multi_destroy(x->mdev);
+	x->dev = 0; x->mdev = 0;
+}
+static void dev_get_counts(mrx_t *x, int64_t c[36]) { if (x->mdev) rb2_hip_multi_get_counts(x->mdev, c); else rb2_hip_get_counts(x->dev, c); }
+static int64_t dev_stream_rope(mrx_t *x, int a, rb2_hip_run_cb cb, void *user)
+{
+	return x->mdev ? rb2_hip_multi_stream_rope(x->mdev, a, cb, user) : rb2_hip_stream_rope(x->dev, a, cb, user);
+}
+static void dev_load_ropes(mrx_t *x, const uint8_t *const rle[6], const int64_t nb[6])
+{
+	if (x->mdev) rb2_hip_multi_load_ropes(x->mdev, rle, nb); else rb2_hip_load_ropes(x->dev, rle, nb);
 }
 
 mrope_t *mr_init(int max_nodes, int block_len, int sorting_order)
@@ -59,7 +101,7 @@ void mr_destroy(mrope_t *mr)
 	int a;
 	if (!mr) return;
 	for (a = 0; a < 6; ++a) if (mr->r[a]) rope_destroy(mr->r[a]);   /* r[a] may be NULL after a freeing iteration */
-	if (X(mr)->dev) rb2_hip_destroy(X(mr)->dev);
+	dev_destroy(X(mr));
 	for (a = 0; a < 6; ++a) free(X(mr)->raw[a]);
 	free(mr);
 }
@@ -71,14 +113,16 @@ int mr_thr_min(mrope_t *mr, int thr_min)
 }
 
 void *mr_hip_handle(mrope_t *mr) { return X(mr)->dev; }
+void *mr_hip_multi_handle(mrope_t *mr) { return X(mr)->mdev; }
 
 /* rb2 extension: what the caller knows about the job ahead (the size of one batch buffer, the symbols the finished index will
  * hold) -- the engine sizes its buffers once instead of growing them batch by batch (hipMalloc costs 25-40 ms per GB here) */
 void mr_reserve(mrope_t *mr, int64_t batch_bytes, int64_t total_symbols)
 {
 	mrx_t *x = X(mr);
-	if (!x->dev) x->dev = rb2_hip_create(device_id(), mr->so);
-	rb2_hip_reserve(x->dev, batch_bytes, 0, total_symbols);
+	dev_create(x);
+	if (x->mdev) rb2_hip_multi_reserve(x->mdev, batch_bytes, 0, total_symbols);
+	else rb2_hip_reserve(x->dev, batch_bytes, 0, total_symbols);
 }
 
 /* ---- host <-> device ------------------------------------------------------------------------- */
@@ -109,7 +153,7 @@ void mr_sync_host(mrope_t *mr)
 	pthread_t th[6];
 	int a;
 	if (x->host_ok) return;
-	if (x->raw_ok && !(x->dev && x->dev_ok)) {                  /* restored run bytes nobody has used yet: bulk-load the six trees */
+	if (x->raw_ok && !(has_dev(x) && x->dev_ok)) {                  /* restored run bytes nobody has used yet: bulk-load the six trees */
 		for (a = 0; a < 6; ++a) {
 			memset(&job[a], 0, sizeof(job[a]));
 			job[a].rb.p = x->raw[a]; job[a].rb.n = x->raw_n[a]; x->raw[a] = 0;
@@ -121,7 +165,7 @@ void mr_sync_host(mrope_t *mr)
 		x->raw_ok = 0; x->host_ok = 1;
 		return;
 	}
-	assert(x->dev && x->dev_ok);
+	assert(has_dev(x) && x->dev_ok);
 	/* the six ropes are independent trees: each is bulk-loaded by its own thread as soon as its run bytes have arrived, while
 	 * the next rope is still streaming off the device (the reference has nothing to do here: its ropes were built on the host) */
 	{
@@ -132,13 +176,13 @@ void mr_sync_host(mrope_t *mr)
 		{	/* a run holds at least one symbol: the symbols of the rope bound its run bytes -- one allocation, no growing copies
 			 * (pages that are never written are never backed) */
 			int64_t c[36], ub = 1 << 20; int b;
-			rb2_hip_get_counts(x->dev, c);
+			dev_get_counts(x, c);
 			for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
 			job[a].rb.p = (uint8_t*)malloc((size_t)ub);
 			job[a].rb.m = job[a].rb.p ? ub : 0;
 		}
 		clock_gettime(CLOCK_MONOTONIC, &t0);
-		rb2_hip_stream_rope(x->dev, a, runbuf_add, &job[a].rb);
+		dev_stream_rope(x, a, runbuf_add, &job[a].rb);
 		clock_gettime(CLOCK_MONOTONIC, &t1);
 		if (trace) fprintf(stderr, "[mr_sync_host] rope %d: %.2f GB of runs off the device in %.3f s\n", a, job[a].rb.n / 1e9, (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9);
 		if (!mr->r[a]) mr->r[a] = rope_init(x->max_nodes, x->block_len);
@@ -158,8 +202,8 @@ void mr_stream_runs(mrope_t *mr, void (*cb)(void *user, const uint8_t *runs, int
 {
 	mrx_t *x = X(mr);
 	int a;
-	if (!x->host_ok && x->dev && x->dev_ok) {
-		for (a = 0; a < 6; ++a) rb2_hip_stream_rope(x->dev, a, cb, user);
+	if (!x->host_ok && has_dev(x) && x->dev_ok) {
+		for (a = 0; a < 6; ++a) dev_stream_rope(x, a, cb, user);
 	} else {
 		mritr_t itr;
 		const uint8_t *blk;
@@ -173,17 +217,17 @@ static void sync_dev(mrope_t *mr)
 {
 	mrx_t *x = X(mr);
 	uint8_t *rle[6]; int64_t nb[6]; int a;
-	if (!x->dev) x->dev = rb2_hip_create(device_id(), mr->so);
+	dev_create(x);
 	if (x->dev_ok) return;
 	if (x->raw_ok) {                                            /* straight from the restored file to the device: no host trees */
-		rb2_hip_load_ropes(x->dev, (const uint8_t *const*)x->raw, x->raw_n);
+		dev_load_ropes(x, (const uint8_t *const*)x->raw, x->raw_n);
 		for (a = 0; a < 6; ++a) { free(x->raw[a]); x->raw[a] = 0; }
 		x->raw_ok = 0; x->dev_ok = 1;
 		return;
 	}
 	assert(x->host_ok);
 	for (a = 0; a < 6; ++a) nb[a] = rope_export_runs(mr->r[a], &rle[a]);
-	rb2_hip_load_ropes(x->dev, (const uint8_t *const*)rle, nb);
+	dev_load_ropes(x, (const uint8_t *const*)rle, nb);
 	for (a = 0; a < 6; ++a) free(rle[a]);
 	x->dev_ok = 1;
 }
@@ -198,8 +242,9 @@ void mr_insert_multi(mrope_t *mr, int64_t len, const uint8_t *s, int is_thr)
 	(void)is_thr;                                               /* the reference's 5-thread switch has no meaning here */
 	assert(len > 0 && s[len-1] == 0);                           /* mrope.c:268 */
 	sync_dev(mr);
-	rb2_hip_insert_multi(x->dev, len, s);
-	rb2_hip_get_counts(x->dev, c);
+	if (x->mdev) rb2_hip_multi_insert_multi(x->mdev, len, s);   /* N GPUs: the round loop, the count matrix and the exchange of the strings all run inside this call */
+	else rb2_hip_insert_multi(x->dev, len, s);
+	dev_get_counts(x, c);
 	for (a = 0; a < 6; ++a)
 		for (b = 0; b < 6; ++b) mr->r[a]->c[b] = c[a*6+b];      /* keep mr_get_c()/mr_get_ac() truthful */
 	x->host_ok = 0;
@@ -244,7 +289,7 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
 	 * rank is asked from the device (rb2_hip_rank1a) instead of materialising the host trees for a few queries. */
 	int a, b, pass;
 	const mrx_t *xx = X(mr);
-	const int on_dev = !xx->host_ok && xx->dev && xx->dev_ok;
+	const int on_dev = !xx->host_ok && has_dev(xx) && xx->dev_ok;
 	if (!xx->host_ok && !on_dev) mr_sync_host((mrope_t*)mr);   /* restored run bytes: the trees are built on first use */
 	for (pass = 0; pass < 2; ++pass) {
 		int64_t pos = pass == 0 ? x : y, *out = pass == 0 ? cx : cy, z = 0, acc[6] = { 0, 0, 0, 0, 0, 0 };
@@ -258,6 +303,7 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
 		}
 		assert(a < 6);
 		if (pos == z) memset(out, 0, 48);
+		else if (on_dev && xx->mdev) rb2_hip_multi_rank1a(xx->mdev, a, pos - z, out);
 		else if (on_dev) rb2_hip_rank1a(xx->dev, a, pos - z, out);
 		else rope_rank1a(mr->r[a], pos - z, out);
 		for (b = 0; b < 6; ++b) out[b] += acc[b];

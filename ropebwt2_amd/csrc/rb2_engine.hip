@@ -1049,6 +1049,17 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
 	rb2_hip_rank_batch(h, b, 1, &x, cx);
 }
 
+/* rank inside one sub-rope (rb2_multi.h: the pieces of a sharded rope live on different handles) */
+static void rank_piece(rb2_hip_t *h, int r, int64_t p, int64_t out[6])
+{
+	HIPCHK(hipSetDevice(h->dev));
+	h->qbuf.ensure(8);
+	hipLaunchKernelGGL(k_rank_piece, dim3(1), dim3(64), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), r, (uint64_t)p, h->qbuf.p, (int)h->sparse);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(out, h->qbuf.p, 48, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+}
+
 void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)
 {
 	HIPCHK(hipSetDevice(h->dev));
@@ -1119,3 +1130,5 @@ void rb2_hip_layout(int *leaf_syms, int *tile_leaves, int *string_tile)
 }
 
 } // extern "C"
+
+#include "rb2_multi.h"

@@ -1202,6 +1202,15 @@ __global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, Po
 	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
+// one wave: counts of the six symbols in [0, p) of PIECE r (a sharded index answers a rope query piece by piece, each from its owner)
+__global__ __launch_bounds__(64) void k_rank_piece(const Ctl *ctl, int side, PoolView pv, int r, uint64_t p, uint64_t *out, int sparse)
+{
+	const RopeDesc &d = ctl->rope[side][r];
+	uint64_t c[6];
+	if (sparse) wave_rank_all<true>(pv, d, p, c); else wave_rank_all<false>(pv, d, p, c);
+	if (lane_id() < 6) { uint64_t v = c[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = c[s]; out[lane_id()] = v; }
+}
+
 // ---------------------------------------------------------------------------------------------
 // loader: ropebwt2's run-length bytes (43+3 codec, rle.h:39-75) -> packed leaves of the dense layout, for an index that
 // arrives from the host (mr_restore / -i old.fmr, rope_load_runs' counterpart).  The codec resynchronises on any byte --

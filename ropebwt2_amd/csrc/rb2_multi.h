@@ -1,0 +1,530 @@
+// rb2_multi.h -- N engines behind one handle: the sharded build driven from INSIDE the library (include/rb2_hip.h,
+// "N GPUs behind one handle").  Included at the end of rb2_engine.hip (one translation unit: it drives the engine's phases
+// batch_begin / round_counts / round_merge / batch_end directly).
+//
+// What the reference does (mrope.c:287-296, 312-340): mr_insert_multi hands the buckets of a round to its worker threads,
+// waits for them, reads every rope's counts, moves the strings to their next buckets -- all inside the call.  Here a "worker"
+// is a GPU (or a virtual rank on one), the buckets are the 31 sub-ropes dealt out by the owner map, and the two places where
+// the reference's master touches all ropes become the two exchange steps of a round:
+//
+//   counts     every rank's rows of the 31 x 6 matrix "members of bucket r that insert a"  ->  their sum on every rank
+//              PEER: k_mreduce reads the peers' rows (peer access), RCCL: ncclAllReduce in place
+//   layout     k_mlayout (one block, on every rank, from the summed matrix and the owner map): where this rank's k_advance
+//              writes the records it sends (Ctl::sdest) and the list of pieces k_munpack fetches (MTab) -- the host never
+//              needs the matrix for that
+//   records    16-byte ShardRec {l, size, id} per surviving string, from the owner of piece (b,x) to the owner of (a,b)
+//              PEER: the receiver's k_munpack reads them from the senders' buffers, RCCL: grouped ncclSend / ncclRecv
+//
+// Ordering between ranks on the PEER transport is by device events (hipStreamWaitEvent), two per round and rank; the host
+// threads only meet at a spin barrier so that nobody waits on an event that has not been recorded yet.  No host <-> device
+// synchronisation inside a batch.  Buffers a peer reads are never rewritten before that peer is done with them:
+//   gcnt (local rows)  written by round_counts(r), read by the peers' k_mreduce(r); rewritten by round_counts(r + 1), which
+//                      is queued behind this rank's k_munpack(r), which waited for every peer's evB(r), recorded behind
+//                      that peer's k_mreduce(r);
+//   send[r & 1]        written by k_advance(r), read by the peers' k_munpack(r); rewritten by k_advance(r + 2), queued
+//                      behind this rank's k_munpack(r + 1), which waited for every peer's evB(r + 1), recorded behind that
+//                      peer's k_munpack(r).
+#pragma once
+#include <atomic>
+#include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace rb2 {
+
+struct MPiece { uint64_t vsrc, dst, cnt; const ShardRec *src; };   // cnt records at src[0..) (virtual receive index vsrc..) go to the next arrays at dst
+constexpr int MPIECES = NR * 6;
+struct MTab { uint64_t total; uint32_t npieces, pad; MPiece pc[MPIECES]; };
+struct MPtrs { const void *p[RB2_MULTI_MAX_RANKS]; };
+struct MOwner { uint8_t o[32]; };
+
+__global__ __launch_bounds__(256) void k_mreduce(MPtrs rows, int n, uint64_t *out)
+{
+	const int i = threadIdx.x;
+	if (i >= NR * 6) return;
+	uint64_t s = 0;
+	for (int p = 0; p < n; ++p) s += ((const uint64_t*)rows.p[p])[i];
+	out[i] = s;
+}
+
+// The exchange plan of a round, on the device, from the global count matrix g and the owner map.  An ENTRY is (r, a):
+// the members of bucket r that insert a (a = 1..5; strings that insert $ retire, mrope.c:310); it travels from
+// s = owner[r] to d = owner[(a, rope_sym(r))].  One thread per entry; every quantity is an exclusive sum over the entries
+// in some order:
+//   off   place in s's send buffer: entries of the same source in (d, r2, r) order            (== shard_layout())
+//   vsrc  place in d's receive order: entries of the same destination in (s, r2, r) order      (the RCCL receive buffer)
+//   dst   place in d's next string arrays: entries of the same destination in (r2, r) order    (== k_setup's seg.start + dest)
+__global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in, MOwner ow, int me, int peer, MPtrs srcs, const ShardRec *recv, MTab *tab)
+{
+	__shared__ uint64_t g[NR * 6];
+	__shared__ unsigned long long s_tot;
+	__shared__ uint32_t s_np;
+	for (int i = threadIdx.x; i < NR * 6; i += 256) g[i] = g_in[i];
+	if (threadIdx.x == 0) { s_tot = 0; s_np = 0; }
+	__syncthreads();
+	const int t = threadIdx.x;
+	if (t < NR * 5) {
+		const int r = t / 5, a = 1 + t % 5;
+		const int r2 = rope_of(a, rope_sym(r)), s = ow.o[r], d = ow.o[r2];
+		const uint64_t gv = g[r * 6 + a];
+		uint64_t off = 0, vsrc = 0, dst = 0; uint32_t pidx = 0;
+		for (int t2 = 0; t2 < NR * 5; ++t2) {
+			const int rr = t2 / 5, aa = 1 + t2 % 5;
+			const int rr2 = rope_of(aa, rope_sym(rr)), ss = ow.o[rr], dd = ow.o[rr2];
+			const uint64_t v = g[rr * 6 + aa];
+			const bool lt = rr2 < r2 || (rr2 == r2 && rr < r);
+			if (ss == s && (dd < d || (dd == d && lt))) off += v;
+			if (dd == d) {
+				if (ss < s || (ss == s && lt)) { vsrc += v; pidx += v != 0; }
+				if (lt) dst += v;
+			}
+		}
+		if (s == me) ctl->sdest[r][a] = off;
+		if (d == me && gv) {
+			MPiece p;
+			p.vsrc = vsrc; p.dst = dst; p.cnt = gv;
+			p.src = peer ? (const ShardRec*)srcs.p[s] + off : recv + vsrc;
+			tab->pc[pidx] = p;
+			atomicAdd(&s_tot, (unsigned long long)gv); atomicAdd(&s_np, 1u);
+		}
+	}
+	__syncthreads();
+	if (t == 0) { tab->total = s_tot; tab->npieces = s_np; tab->pad = 0; }
+}
+
+// records -> next round's SoA arrays in bucket order (k_unpack's job), fetched from wherever k_mlayout says they are: the
+// senders' buffers (PEER: loads over xGMI, 16 bytes per lane, coalesced per piece) or the local receive buffer (RCCL).
+// The grid is sized for the batch (the host does not know how many strings arrive); blocks behind the end return at once.
+__global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, const uint64_t *START, uint32_t round,
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+{
+	const uint64_t total = tab->total;
+	if ((uint64_t)blockIdx.x * 256 >= total) return;
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	bool nonempty = false;
+	if (i < total) {
+		int lo = 0, hi = (int)tab->npieces - 1;                  // last piece with vsrc <= i (pieces tile the receive order)
+		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab->pc[mid].vsrc <= i) lo = mid; else hi = mid - 1; }
+		const MPiece &pc = tab->pc[lo];
+		const ShardRec r = pc.src[i - pc.vsrc];
+		const uint64_t d = pc.dst + (i - pc.vsrc);
+		const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
+		const uint32_t id = (uint32_t)r.b;
+		L2[d] = l; U2[d] = l + size; ID2[d] = id;
+		W2[d] = pack16(s, ctl->len, START[id] + round + 1);
+		nonempty = size != 0;
+	}
+	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
+}
+
+} // namespace rb2
+
+namespace {
+
+// ---- librccl, loaded when the first RCCL handle is created (the one-GPU product path never maps its 570 MB) ----
+struct RcclApi {
+	void *lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+RcclApi &rccl()
+{
+	if (g_rccl.lib) return g_rccl;
+	// a process that already has an RCCL mapped (torch brings its own) must use THAT one: two copies would each think they own the
+	// devices' communication resources
+	void *lib = nullptr;
+	const char *cand[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" };
+	if (dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) lib = dlopen(nullptr, RTLD_NOW);
+	for (int i = 0; !lib && i < 4; ++i) lib = dlopen(cand[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+	for (int i = 0; !lib && i < 4; ++i) lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) { fprintf(stderr, "[rb2_hip] the RCCL transport was asked for but librccl cannot be loaded (%s)\n", dlerror()); abort(); }
+	RcclApi &R = g_rccl;
+	R.lib = lib;
+#define RB2_NCCL_SYM(field, name) do { *(void**)&R.field = dlsym(lib, name); if (!R.field) { fprintf(stderr, "[rb2_hip] librccl has no %s\n", name); abort(); } } while (0)
+	RB2_NCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RB2_NCCL_SYM(CommInitRank, "ncclCommInitRank"); RB2_NCCL_SYM(CommInitAll, "ncclCommInitAll");
+	RB2_NCCL_SYM(CommDestroy, "ncclCommDestroy"); RB2_NCCL_SYM(AllReduce, "ncclAllReduce"); RB2_NCCL_SYM(Send, "ncclSend"); RB2_NCCL_SYM(Recv, "ncclRecv");
+	RB2_NCCL_SYM(GroupStart, "ncclGroupStart"); RB2_NCCL_SYM(GroupEnd, "ncclGroupEnd"); RB2_NCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RB2_NCCL_SYM
+	return R;
+}
+#define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+	fprintf(stderr, "[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, rccl().GetErrorString(r_)); abort(); } } while (0)
+
+// the host threads of the local ranks meet here (never the devices): sense-reversing, spins briefly, then yields
+struct SpinBarrier {
+	std::atomic<int> count{0}, gen{0};
+	int n = 1;
+	void wait()
+	{
+		if (n <= 1) return;
+		const int g = gen.load(std::memory_order_acquire);
+		if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); return; }
+		for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) if (spins > 4000) std::this_thread::yield();
+	}
+};
+
+struct MRank {
+	rb2_hip_t *h = nullptr;
+	int dev = 0, grank = 0;
+	ShardRec *send[2] = {nullptr, nullptr}; size_t send_cap = 0;
+	ShardRec *recv = nullptr; size_t recv_cap = 0;
+	uint64_t *gred = nullptr;               // PEER: the summed matrix (h->gcnt keeps this rank's rows for the peers to read)
+	uint64_t *gloc = nullptr;               // = h->gcnt as created
+	MTab *tab = nullptr;
+	hipEvent_t evA = nullptr, evB = nullptr, evG = nullptr;
+	uint64_t *pin_g = nullptr;              // RCCL: 2 x (NR * 6) pinned, the reduced matrix of the round (host sizes the sends from it)
+	ncclComm_t comm = nullptr;
+	DevBuf<uint8_t> text;                   // the batch on this rank's device (host-buffer entry point)
+	const uint8_t *s_dev = nullptr;
+	BatchState B;
+};
+
+} // namespace
+
+struct rb2_hip_multi_s {
+	int n = 0, world = 0, rank0 = 0, transport = 0, so = 0;
+	int owner[NR];
+	std::vector<MRank> rk;
+	SpinBarrier bar;
+	int64_t n_sync = 0, n_rounds = 0, n_batches = 0;
+	int trace = 0;
+	int rccl_self = 0;                      // RB2_RCCL_SELF=1: a rank's own block travels through ncclSend / ncclRecv too (exercises librccl on a one-GPU box)
+};
+
+namespace {
+
+void multi_ensure_exchange(rb2_hip_multi_t *m, MRank &R, uint64_t records)
+{
+	if (records <= R.send_cap) return;
+	const size_t cap = records + records / 8 + 1024;
+	for (int i = 0; i < 2; ++i) { if (R.send[i]) HIPCHK(hipFree(R.send[i])); HIPCHK(hipMalloc((void**)&R.send[i], cap * sizeof(ShardRec))); }
+	if (m->transport == RB2_TRANSPORT_RCCL) { if (R.recv) HIPCHK(hipFree(R.recv)); HIPCHK(hipMalloc((void**)&R.recv, cap * sizeof(ShardRec))); R.recv_cap = cap; }
+	R.send_cap = cap;
+}
+
+// one batch on one local rank (its own host thread); every rank runs the same number of rounds
+void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
+{
+	MRank &R = m->rk[k];
+	rb2_hip_t *h = R.h;
+	HIPCHK(hipSetDevice(R.dev));
+	hipStream_t st = h->st;
+	const bool peer = m->transport == RB2_TRANSPORT_PEER;
+	ensure_dense(h);                                           // (in-place rounds on a sharded index: round_merge_sparse below decides per round)
+	BatchState &B = R.B;
+	B = BatchState();
+	batch_begin(h, B, len, R.s_dev);
+	// exchange buffers: a rank never holds (or receives) more strings than the batch has.  They are (re)allocated between
+	// batches only, and the peers learn the new addresses behind the barrier below.
+	multi_ensure_exchange(m, R, B.m);
+	m->bar.wait();
+	MOwner ow;
+	memset(&ow, 0, sizeof(ow));
+	for (int r = 0; r < NR; ++r) ow.o[r] = (uint8_t)m->owner[r];
+	MPtrs rows, sends[2];
+	memset(&rows, 0, sizeof(rows)); memset(sends, 0, sizeof(sends));
+	if (peer) for (int p = 0; p < m->n; ++p) { rows.p[p] = m->rk[p].gloc; sends[0].p[p] = m->rk[p].send[0]; sends[1].p[p] = m->rk[p].send[1]; }
+	const unsigned grid_m = cdiv(B.m, 256);
+	for (uint64_t r = 0; r <= B.max_len; ++r) {                 // one round per string position (mrope.c:299-342)
+		h->gcnt = R.gloc;
+		round_counts(h, B, r);
+		if (peer) {
+			HIPCHK(hipEventRecord(R.evA, st));
+			m->bar.wait();                                        // every evA of this round is recorded
+			for (int p = 0; p < m->n; ++p) if (p != k) HIPCHK(hipStreamWaitEvent(st, m->rk[p].evA, 0));
+			hipLaunchKernelGGL(k_mreduce, dim3(1), dim3(256), 0, st, rows, m->n, R.gred);
+			h->gcnt = R.gred;
+		} else {
+			if (R.comm) NCCLCHK(rccl().AllReduce(h->gcnt, h->gcnt, NR * 6, ncclUint64, ncclSum, R.comm, st));
+			HIPCHK(hipMemcpyAsync(R.pin_g + (r & 1) * NR * 6, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipEventRecord(R.evG, st));
+		}
+		hipLaunchKernelGGL(k_mlayout, dim3(1), dim3(256), 0, st, h->ctl, (const uint64_t*)h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab);
+		round_merge(h, B, r, R.send[r & 1]);                      // flips side / cur: B.cur now names next round's arrays
+		if (peer) {
+			HIPCHK(hipEventRecord(R.evB, st));
+			m->bar.wait();                                        // every evB of this round is recorded
+			for (int p = 0; p < m->n; ++p) if (p != k) HIPCHK(hipStreamWaitEvent(st, m->rk[p].evB, 0));
+		} else {
+			// the reduced matrix reached pinned memory before the merge kernels of this round started: waiting for it does not
+			// drain the stream -- the host sizes the sends while the GPU merges
+			HIPCHK(hipEventSynchronize(R.evG));
+			if (k == 0) ++m->n_sync;
+			const int64_t *g = (const int64_t*)(R.pin_g + (r & 1) * NR * 6);
+			int64_t off[NR][6], per[RB2_MULTI_MAX_RANKS], start[RB2_MULTI_MAX_RANKS];
+			memset(off, 0, sizeof(off));
+			shard_layout(m->owner, m->world, R.grank, g, off, per, start);
+			int64_t rbase = 0;
+			RcclApi &N = rccl();
+			NCCLCHK(N.GroupStart());
+			for (int p = 0; p < m->world; ++p) {
+				int64_t off2[NR][6], per2[RB2_MULTI_MAX_RANKS], start2[RB2_MULTI_MAX_RANKS];
+				memset(off2, 0, sizeof(off2));
+				shard_layout(m->owner, m->world, p, g, off2, per2, start2);
+				const int64_t nrecv = per2[R.grank], nsend = per[p];
+				if (p == R.grank && !(m->rccl_self && R.comm)) {     // own block: a device copy, not a message (RB2_RCCL_SELF=1: through RCCL all the same)
+					if (nsend) HIPCHK(hipMemcpyAsync(R.recv + rbase, R.send[r & 1] + start[p], (size_t)nsend * sizeof(ShardRec), hipMemcpyDeviceToDevice, st));
+				} else {
+					if (nsend) NCCLCHK(N.Send(R.send[r & 1] + start[p], (size_t)nsend * 2, ncclUint64, p, R.comm, st));
+					if (nrecv) NCCLCHK(N.Recv(R.recv + rbase, (size_t)nrecv * 2, ncclUint64, p, R.comm, st));
+				}
+				rbase += nrecv;
+			}
+			NCCLCHK(N.GroupEnd());
+		}
+		const int cur = B.cur;
+		hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, (const uint64_t*)h->START.p, (uint32_t)r,
+				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
+		HIPCHK(hipGetLastError());
+	}
+	h->gcnt = R.gloc;
+	batch_end(h);                                                // the one synchronisation of the batch (+ two in batch_begin)
+	if (k == 0) { m->n_rounds += (int64_t)B.max_len + 1; ++m->n_batches; }
+	m->bar.wait();
+}
+
+void multi_run(rb2_hip_multi_t *m, int64_t len)
+{
+	if (m->n == 1) { multi_rank_batch(m, 0, len); return; }
+	std::vector<std::thread> th;
+	for (int k = 0; k < m->n; ++k) th.emplace_back(multi_rank_batch, m, k, len);
+	for (auto &t : th) t.join();
+}
+
+rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int so, int transport, const int *owner)
+{
+	if (n < 1 || world < n || world > RB2_MULTI_MAX_RANKS) { fprintf(stderr, "[rb2_hip] multi: bad number of ranks (%d local of %d, at most %d)\n", n, world, RB2_MULTI_MAX_RANKS); abort(); }
+	if (transport != RB2_TRANSPORT_PEER && transport != RB2_TRANSPORT_RCCL) { fprintf(stderr, "[rb2_hip] multi: unknown transport %d\n", transport); abort(); }
+	rb2_hip_multi_t *m = new rb2_hip_multi_s();
+	m->n = n; m->world = world; m->rank0 = rank0; m->transport = transport; m->so = so;
+	m->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
+	m->rccl_self = getenv("RB2_RCCL_SELF") ? atoi(getenv("RB2_RCCL_SELF")) : 0;
+	if (owner) { for (int r = 0; r < NR; ++r) m->owner[r] = owner[r]; } else rb2_hip_default_owners(world, m->owner);
+	for (int r = 0; r < NR; ++r) if (m->owner[r] < 0 || m->owner[r] >= world) { fprintf(stderr, "[rb2_hip] multi: bad owner of sub-rope %d\n", r); abort(); }
+	m->bar.n = n;
+	m->rk.resize(n);
+	for (int k = 0; k < n; ++k) {
+		MRank &R = m->rk[k];
+		R.dev = devices[k]; R.grank = rank0 + k;
+		R.h = rb2_hip_create(R.dev, so);
+		rb2_hip_shard_setup(R.h, R.grank, world, m->owner);
+		HIPCHK(hipSetDevice(R.dev));
+		R.gloc = R.h->gcnt;
+		HIPCHK(hipMalloc((void**)&R.gred, NR * 6 * 8));
+		HIPCHK(hipMalloc((void**)&R.tab, sizeof(MTab)));
+		HIPCHK(hipMemset(R.tab, 0, sizeof(MTab)));
+		HIPCHK(hipEventCreateWithFlags(&R.evA, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&R.evB, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&R.evG, hipEventDisableTiming));
+		HIPCHK(hipHostMalloc((void**)&R.pin_g, 2 * NR * 6 * 8, hipHostMallocDefault));
+	}
+	if (transport == RB2_TRANSPORT_PEER) {
+		// the receiver's kernels read the senders' memory: every pair of distinct devices needs peer access
+		for (int k = 0; k < n; ++k) for (int p = 0; p < n; ++p) {
+			if (m->rk[k].dev == m->rk[p].dev) continue;
+			int can = 0;
+			HIPCHK(hipDeviceCanAccessPeer(&can, m->rk[k].dev, m->rk[p].dev));
+			if (!can) { fprintf(stderr, "[rb2_hip] multi: device %d cannot access device %d (no peer access): use the RCCL transport\n", m->rk[k].dev, m->rk[p].dev); abort(); }
+			HIPCHK(hipSetDevice(m->rk[k].dev));
+			const hipError_t e = hipDeviceEnablePeerAccess(m->rk[p].dev, 0);
+			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e);
+			(void)hipGetLastError();
+		}
+	}
+	return m;
+}
+
+// run f(local rank) on every local rank, each on a thread of its own
+template <class F> void multi_each(rb2_hip_multi_t *m, F f)
+{
+	if (m->n == 1) { f(0); return; }
+	std::vector<std::thread> th;
+	for (int k = 0; k < m->n; ++k) th.emplace_back([&f, k]() { f(k); });
+	for (auto &t : th) t.join();
+}
+
+} // namespace
+
+extern "C" {
+
+/* piece -> rank.  On DNA the 16 pieces (b,x), b,x in ACGT, carry ~1/16 of the rows each; they are dealt out in contiguous
+ * blocks, so up to 16 ranks get load.  The light pieces ((b,$): one row per read; everything with N) ride with a neighbour,
+ * rope $ with rank 0.  (The same map as ropebwt2_amd/sharded.py default_owners.) */
+void rb2_hip_default_owners(int nranks, int owner[])
+{
+	for (int r = 0; r < NR; ++r) owner[r] = 0;
+	if (nranks <= 1) return;
+	for (int b = 1; b < 6; ++b) for (int x = 0; x < 6; ++x) {
+		const int k = (std::min(b, 4) - 1) * 4 + (std::min(std::max(x, 1), 4) - 1);
+		owner[rope_of(b, x)] = std::min(k * nranks / 16, nranks - 1);
+	}
+}
+
+rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_order, int transport, const int *owner)
+{
+	rb2_hip_multi_t *m = multi_new(n, devices, n, 0, sorting_order, transport, owner);
+	if (transport == RB2_TRANSPORT_RCCL && n > 1) {
+		for (int k = 0; k < n; ++k) for (int p = 0; p < k; ++p)
+			if (devices[k] == devices[p]) { fprintf(stderr, "[rb2_hip] multi: RCCL needs one device per rank (device %d is listed twice); several ranks on one device run on the PEER transport\n", devices[k]); abort(); }
+		std::vector<ncclComm_t> comms(n);
+		NCCLCHK(rccl().CommInitAll(comms.data(), n, devices));
+		for (int k = 0; k < n; ++k) m->rk[k].comm = comms[k];
+	} else if (transport == RB2_TRANSPORT_RCCL) {               // a group of one: the same calls on a one-rank communicator
+		ncclUniqueId id;
+		HIPCHK(hipSetDevice(devices[0]));
+		NCCLCHK(rccl().GetUniqueId(&id));
+		NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, 1, id, 0));
+	}
+	return m;
+}
+
+void rb2_hip_multi_unique_id(void *id128)
+{
+	ncclUniqueId id;
+	NCCLCHK(rccl().GetUniqueId(&id));
+	static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+	memcpy(id128, &id, sizeof(id));
+}
+
+rb2_hip_multi_t *rb2_hip_multi_create_rank(int device, int rank, int nranks, const void *nccl_id, int sorting_order, const int *owner)
+{
+	if (rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] multi: bad rank %d of %d\n", rank, nranks); abort(); }
+	rb2_hip_multi_t *m = multi_new(1, &device, nranks, rank, sorting_order, RB2_TRANSPORT_RCCL, owner);
+	ncclUniqueId id;
+	if (nccl_id) memcpy(&id, nccl_id, sizeof(id));
+	else if (nranks == 1) NCCLCHK(rccl().GetUniqueId(&id));
+	else { fprintf(stderr, "[rb2_hip] multi: a group of %d ranks needs the id of rb2_hip_multi_unique_id() from rank 0\n", nranks); abort(); }
+	HIPCHK(hipSetDevice(device));
+	NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, nranks, id, rank));
+	return m;
+}
+
+void rb2_hip_multi_destroy(rb2_hip_multi_t *m)
+{
+	if (!m) return;
+	for (auto &R : m->rk) {
+		HIPCHK(hipSetDevice(R.dev));
+		HIPCHK(hipStreamSynchronize(R.h->st));
+		if (R.comm) NCCLCHK(rccl().CommDestroy(R.comm));
+		for (int i = 0; i < 2; ++i) if (R.send[i]) HIPCHK(hipFree(R.send[i]));
+		if (R.recv) HIPCHK(hipFree(R.recv));
+		HIPCHK(hipFree(R.gred)); HIPCHK(hipFree(R.tab));
+		HIPCHK(hipEventDestroy(R.evA)); HIPCHK(hipEventDestroy(R.evB)); HIPCHK(hipEventDestroy(R.evG));
+		HIPCHK(hipHostFree(R.pin_g));
+		R.text.release();
+		R.h->gcnt = R.gloc;
+		rb2_hip_destroy(R.h);
+	}
+	delete m;
+}
+
+int rb2_hip_multi_nranks(const rb2_hip_multi_t *m) { return m->world; }
+int rb2_hip_multi_nlocal(const rb2_hip_multi_t *m) { return m->n; }
+rb2_hip_t *rb2_hip_multi_engine(rb2_hip_multi_t *m, int k) { return (k >= 0 && k < m->n) ? m->rk[k].h : nullptr; }
+
+void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8_t *const *s_dev)
+{
+	if (len <= 0) { fprintf(stderr, "[rb2_hip] insert_multi: len must be > 0\n"); abort(); }   // mrope.c:268
+	for (int k = 0; k < m->n; ++k) {
+		if ((uintptr_t)s_dev[k] & 15) { fprintf(stderr, "[rb2_hip] multi insert: the device buffers must be 16-byte aligned\n"); abort(); }
+		m->rk[k].s_dev = s_dev[k];
+	}
+	HIPCHK(hipSetDevice(m->rk[0].dev));
+	check_last_byte(m->rk[0].h, len, s_dev[0]);
+	multi_run(m, len);
+}
+
+void rb2_hip_multi_insert_multi(rb2_hip_multi_t *m, int64_t len, const uint8_t *s)
+{
+	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
+	// one copy of the batch text per DEVICE (every rank reads all of it: the 16-symbol cursor refills), uploaded by the first rank on it
+	std::vector<const uint8_t*> ptr(m->n, nullptr);
+	multi_each(m, [&](int k) {
+		MRank &R = m->rk[k];
+		for (int p = 0; p < k; ++p) if (m->rk[p].dev == R.dev) return;
+		HIPCHK(hipSetDevice(R.dev));
+		R.text.ensure((size_t)len + 64);
+		HIPCHK(hipMemcpyAsync(R.text.p, s, (size_t)len, hipMemcpyHostToDevice, R.h->st));
+		HIPCHK(hipStreamSynchronize(R.h->st));                  // ranks on other streams read it
+		ptr[k] = R.text.p;
+	});
+	for (int k = 0; k < m->n; ++k) if (!ptr[k]) for (int p = 0; p < k; ++p) if (m->rk[p].dev == m->rk[k].dev) { ptr[k] = ptr[p]; break; }
+	for (int k = 0; k < m->n; ++k) m->rk[k].s_dev = ptr[k];
+	multi_run(m, len);
+}
+
+void rb2_hip_multi_get_counts(rb2_hip_multi_t *m, int64_t c[36]) { rb2_hip_get_counts(m->rk[0].h, c); }   /* every rank tracks the counts of all pieces */
+
+static int64_t multi_export(rb2_hip_multi_t *m, int b, uint8_t *dst, rb2_hip_run_cb cb, void *user)
+{
+	int64_t k = 0;
+	for (int r = 0; r < NR; ++r) {
+		if (rope_sym(r) != b) continue;
+		const int o = m->owner[r] - m->rank0;
+		if (o < 0 || o >= m->n) continue;                        /* another process holds it */
+		rb2_hip_t *h = m->rk[o].h;
+		HIPCHK(hipSetDevice(h->dev));
+		ensure_dense(h);
+		k += export_piece(h, r, dst ? dst + k : nullptr, cb, user);
+	}
+	return k;
+}
+int64_t rb2_hip_multi_rope_bytes(rb2_hip_multi_t *m, int b) { return multi_export(m, b, nullptr, nullptr, nullptr); }
+int64_t rb2_hip_multi_download_rope(rb2_hip_multi_t *m, int b, uint8_t *dst) { return multi_export(m, b, dst, nullptr, nullptr); }
+int64_t rb2_hip_multi_stream_rope(rb2_hip_multi_t *m, int b, rb2_hip_run_cb cb, void *user) { return multi_export(m, b, nullptr, cb, user); }
+
+void rb2_hip_multi_load_ropes(rb2_hip_multi_t *m, const uint8_t *const rle[6], const int64_t n_bytes[6])
+{
+	multi_each(m, [&](int k) { rb2_hip_load_ropes(m->rk[k].h, rle, n_bytes); });   /* every rank decodes the stream, keeps its pieces, counts the others */
+}
+
+void rb2_hip_multi_reserve(rb2_hip_multi_t *m, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols)
+{
+	int active = 0;
+	{ bool seen[RB2_MULTI_MAX_RANKS] = {false}; for (int r = 1; r < NR; ++r) if (!seen[m->owner[r]]) { seen[m->owner[r]] = true; ++active; } }
+	const int64_t share = total_symbols > 0 ? (int64_t)((double)total_symbols * 1.25 / std::max(1, active)) : 0;
+	multi_each(m, [&](int k) { rb2_hip_reserve(m->rk[k].h, batch_bytes, batch_strings, share); });
+}
+
+void rb2_hip_multi_reset(rb2_hip_multi_t *m) { for (auto &R : m->rk) rb2_hip_reset(R.h); }
+void rb2_hip_multi_sync(rb2_hip_multi_t *m) { for (auto &R : m->rk) rb2_hip_sync(R.h); }
+
+/* rank of all six symbols in [0,x) of rope b: the pieces in front of the one that holds x are known by their counts (every
+ * rank tracks them), the rest is a rank query inside one piece, answered by its owner */
+void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6])
+{
+	for (int a = 0; a < 6; ++a) cx[a] = 0;
+	if (x <= 0 || b < 0 || b > 5) return;
+	const RopeDesc *hr = m->rk[0].h->h_rope;
+	uint64_t p = (uint64_t)x;
+	for (int r = 0; r < NR && p > 0; ++r) {
+		if (rope_sym(r) != b) continue;
+		uint64_t n = 0;
+		for (int a = 0; a < 6; ++a) n += hr[r].cnt[a];
+		if (p >= n) { for (int a = 0; a < 6; ++a) cx[a] += (int64_t)hr[r].cnt[a]; p -= n; continue; }
+		const int o = m->owner[r] - m->rank0;
+		if (o < 0 || o >= m->n) { fprintf(stderr, "[rb2_hip] multi rank: piece %d lives in another process\n", r); abort(); }
+		int64_t c[6];
+		rank_piece(m->rk[o].h, r, (int64_t)p, c);
+		for (int a = 0; a < 6; ++a) cx[a] += c[a];
+		p = 0;
+	}
+}
+
+void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6])
+{
+	out[0] = m->n_sync; out[1] = m->n_rounds; out[2] = m->n_batches; out[3] = out[4] = out[5] = 0;
+	for (auto &R : m->rk) { out[3] += R.h->n_sparse_rounds; out[4] += R.h->n_void; out[5] += R.h->n_relayout; }
+}
+
+} // extern "C"

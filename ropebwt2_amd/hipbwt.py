@@ -62,6 +62,26 @@ def load_hip_lib():
         "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
         "rb2_hip_kernel_name": (C.c_char_p, [i32]),
         "rb2_hip_layout": (None, [vp, vp, vp]),
+        "rb2_hip_multi_create": (vp, [i32, vp, i32, i32, vp]),
+        "rb2_hip_multi_unique_id": (None, [vp]),
+        "rb2_hip_multi_create_rank": (vp, [i32, i32, i32, vp, i32, vp]),
+        "rb2_hip_multi_destroy": (None, [vp]),
+        "rb2_hip_default_owners": (None, [i32, vp]),
+        "rb2_hip_multi_nranks": (i32, [vp]),
+        "rb2_hip_multi_nlocal": (i32, [vp]),
+        "rb2_hip_multi_engine": (vp, [vp, i32]),
+        "rb2_hip_multi_insert_multi": (None, [vp, i64, vp]),
+        "rb2_hip_multi_insert_multi_dev": (None, [vp, i64, vp]),
+        "rb2_hip_multi_get_counts": (None, [vp, vp]),
+        "rb2_hip_multi_rope_bytes": (i64, [vp, i32]),
+        "rb2_hip_multi_download_rope": (i64, [vp, i32, vp]),
+        "rb2_hip_multi_stream_rope": (i64, [vp, i32, vp, vp]),
+        "rb2_hip_multi_load_ropes": (None, [vp, vp, vp]),
+        "rb2_hip_multi_reserve": (None, [vp, i64, i64, i64]),
+        "rb2_hip_multi_reset": (None, [vp]),
+        "rb2_hip_multi_sync": (None, [vp]),
+        "rb2_hip_multi_rank1a": (None, [vp, i32, i64, vp]),
+        "rb2_hip_multi_stats": (None, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -79,6 +99,10 @@ ABI_SYMBOLS = [
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
+    "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
+    "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
+    "rb2_hip_multi_get_counts", "rb2_hip_multi_rope_bytes", "rb2_hip_multi_download_rope", "rb2_hip_multi_stream_rope",
+    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
 ]
 
 
@@ -223,3 +247,117 @@ class HipBwt:
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         L.rb2_hip_layout(C.byref(a), C.byref(b), C.byref(c))
         return {"leaf_syms": a.value, "tile_leaves": b.value, "string_tile": c.value}
+
+
+TRANSPORTS = {"peer": 0, "rccl": 1}
+
+
+class _Engine(HipBwt):
+    """a local rank's engine inside a MultiBwt (borrowed handle: never destroyed from here)"""
+
+    def __init__(self, lib, h, so):
+        self.L, self.h, self.so = lib, h, so
+
+    def close(self):
+        self.h = None
+
+
+class MultiBwt:
+    """One BWT whose 31 sub-ropes are sharded over N ranks, driven inside the library (include/rb2_hip.h, rb2_hip_multi_*):
+    the same ``insert_multi(buf)`` contract as ``HipBwt`` / mr_insert_multi (mrope.c:258), no Python in the round loop.
+
+    ``devices``: one entry per rank; the same device may appear several times (virtual ranks on one GPU, PEER transport).
+    ``rank``/``nranks``/``nccl_id``: this process is ONE rank of a multi-process group over RCCL (bench.py under torchrun)."""
+
+    def __init__(self, sorting_order, devices, transport="peer", owners=None, rank=None, nranks=None, nccl_id=None):
+        self.L = load_hip_lib()
+        if self.L.rb2_hip_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the gfx950 engine has no CPU fallback")
+        own = (C.c_int * len(owners))(*owners) if owners is not None else None
+        self.so = sorting_order
+        if rank is None:
+            devs = (C.c_int * len(devices))(*devices)
+            self.h = self.L.rb2_hip_multi_create(len(devices), devs, sorting_order, TRANSPORTS[transport], own)
+        else:
+            idb = C.create_string_buffer(bytes(nccl_id), 128) if nccl_id is not None else None
+            self.h = self.L.rb2_hip_multi_create_rank(devices[0], rank, nranks, idb, sorting_order, own)
+        self.n = self.L.rb2_hip_multi_nlocal(self.h)
+        self.world = self.L.rb2_hip_multi_nranks(self.h)
+
+    @staticmethod
+    def unique_id():
+        b = C.create_string_buffer(128)
+        load_hip_lib().rb2_hip_multi_unique_id(b)
+        return b.raw
+
+    @staticmethod
+    def default_owners(nranks):
+        a = (C.c_int * 31)()
+        load_hip_lib().rb2_hip_default_owners(nranks, a)
+        return list(a)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rb2_hip_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def engine(self, k=0):
+        return _Engine(self.L, self.L.rb2_hip_multi_engine(self.h, k), self.so)
+
+    def insert_multi(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.L.rb2_hip_multi_insert_multi(self.h, len(buf), buf.ctypes.data)
+
+    def insert_multi_dev(self, dev_ptrs, nbytes):
+        """dev_ptrs: one device pointer per local rank (or a single pointer all local ranks share)"""
+        if not isinstance(dev_ptrs, (list, tuple)):
+            dev_ptrs = [dev_ptrs] * self.n
+        arr = (C.c_void_p * self.n)(*dev_ptrs)
+        self.L.rb2_hip_multi_insert_multi_dev(self.h, nbytes, arr)
+
+    def counts(self):
+        c = np.zeros(36, np.int64)
+        self.L.rb2_hip_multi_get_counts(self.h, c.ctypes.data)
+        return c.reshape(6, 6)
+
+    def rope_rle(self, b):
+        n = self.L.rb2_hip_multi_rope_bytes(self.h, b)
+        out = np.zeros(max(n, 1), np.uint8)
+        got = self.L.rb2_hip_multi_download_rope(self.h, b, out.ctypes.data)
+        assert got == n
+        return out[:n]
+
+    def rope(self, b):
+        return expand_runs(self.rope_rle(b))
+
+    def load_ropes(self, rles):
+        arrs = [np.ascontiguousarray(r, dtype=np.uint8) for r in rles]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data if len(a) else None for a in arrs])
+        lens = (C.c_int64 * 6)(*[len(a) for a in arrs])
+        self.L.rb2_hip_multi_load_ropes(self.h, ptrs, lens)
+
+    def reserve(self, batch_bytes=0, batch_strings=0, total_symbols=0):
+        self.L.rb2_hip_multi_reserve(self.h, batch_bytes, batch_strings, total_symbols)
+
+    def reset(self):
+        self.L.rb2_hip_multi_reset(self.h)
+
+    def sync(self):
+        self.L.rb2_hip_multi_sync(self.h)
+
+    def rank1a(self, b, x):
+        c = np.zeros(6, np.int64)
+        self.L.rb2_hip_multi_rank1a(self.h, b, x, c.ctypes.data)
+        return c
+
+    def stats(self):
+        a = np.zeros(6, np.int64)
+        self.L.rb2_hip_multi_stats(self.h, a.ctypes.data)
+        return {"host_syncs_in_rounds": int(a[0]), "rounds": int(a[1]), "batches": int(a[2]), "sparse_rounds": int(a[3]),
+                "void_rounds": int(a[4]), "relayouts": int(a[5])}

@@ -1,0 +1,292 @@
+"""N GPUs behind ONE handle (include/rb2_hip.h rb2_hip_multi_*, csrc/rb2_multi.h): the sharded build driven inside the
+library -- what mr_insert_multi does with its worker threads (/root/reference/mrope.c:287-296, 312-340) -- through the C ABI,
+the mrope C API and the CLI (RB2_HIP_DEVICES).
+
+CPU  : the owner map and the symbols.
+GPU  : N virtual ranks on one device over the PEER transport (the complete round loop, device-side exchange plan, records
+       fetched from the senders' buffers, no host synchronisation between rounds) bit-exact against the oracle and the
+       reference's goldens; the RCCL transport on a group of one (librccl really loaded and called); a real multi-GPU run
+       of both transports whenever the box has >= 2 GPUs."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def test_default_owners_match_python_driver():
+    from ropebwt2_amd import MultiBwt, build_all
+    from ropebwt2_amd.sharded import default_owners
+    build_all()
+    for n in (1, 2, 3, 4, 5, 7, 8, 16, 20, 64):
+        assert MultiBwt.default_owners(n) == default_owners(n)
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def _batches(so):
+    reads = H.repetitive_reads(3000, seed=60 + so, genome_len=800, max_len=100)
+    codes = H.splitmix_bases(4000, 75, seed=3)
+    return [H.encode_batch(reads[:1800]), H.encode_batch_fixed(codes), H.encode_batch(reads[1800:], True, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("so", [0, 1, 2])
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+def test_peer_virtual_ranks_match_oracle(hip, so, n):
+    from ropebwt2_amd import MultiBwt
+    o = H.Oracle(so)
+    m = MultiBwt(so, [0] * n, "peer")
+    for buf in _batches(so):
+        o.insert_multi(buf)
+        m.insert_multi(buf)
+        assert np.array_equal(m.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+    st = m.stats()
+    assert st["host_syncs_in_rounds"] == 0 and st["batches"] == 3 and st["rounds"] > 100
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 6, 18])
+def test_peer_many_ranks_and_odd_counts(hip, n):
+    """18 ranks: ranks >= 16 own nothing but take part in every round; 3 and 6: unbalanced owner maps"""
+    from ropebwt2_amd import MultiBwt
+    codes = H.splitmix_bases(6000, 50, seed=21)
+    reads = H.repetitive_reads(1200, seed=33)
+    o = H.Oracle(2)
+    m = MultiBwt(2, [0] * n, "peer")
+    for buf in (H.encode_batch_fixed(codes, True, True), H.encode_batch(reads)):
+        o.insert_multi(buf)
+        m.insert_multi(buf)
+    assert np.array_equal(m.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_peer_random_owner_maps(hip, seed):
+    """any assignment of the 31 sub-ropes to ranks gives the same BWT: the device-side exchange plan (k_mlayout) against
+    pieces of one rope scattered over ranks, ranks with only light pieces, a rank that owns nothing"""
+    from ropebwt2_amd import MultiBwt
+    rng = np.random.RandomState(seed)
+    n = 5
+    owners = [int(x) for x in rng.randint(0, n - 1, size=31)]
+    so = seed % 3
+    reads = H.repetitive_reads(2000, seed=70 + seed, genome_len=600, max_len=70)
+    codes = H.splitmix_bases(3000, 64, seed=9 + seed)
+    o = H.Oracle(so)
+    m = MultiBwt(so, [0] * n, "peer", owners=owners)
+    for buf in (H.encode_batch(reads[:1200]), H.encode_batch_fixed(codes), H.encode_batch(reads[1200:], True, True)):
+        o.insert_multi(buf)
+        m.insert_multi(buf)
+    assert np.array_equal(m.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+    m.close()
+
+
+@pytest.mark.gpu
+def test_peer_edge_batches(hip):
+    """empty strings, one string, a batch of sentinels only, strings of very different lengths"""
+    from ropebwt2_amd import MultiBwt
+    for so in (0, 1, 2):
+        o = H.Oracle(so)
+        m = MultiBwt(so, [0] * 4, "peer")
+        bufs = [np.zeros(5, np.uint8), H.encode_batch([[1, 2, 3, 4, 5, 1]]), H.encode_batch([[], [1], [], [2, 2, 2, 2] * 200, [4, 3]]),
+                H.encode_batch(H.repetitive_reads(300, seed=5), True, True)]
+        for buf in bufs:
+            o.insert_multi(buf)
+            m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(m.rope(b), o.rope(b)), "rope %d (so %d)" % (b, so)
+        m.close()
+
+
+@pytest.mark.gpu
+def test_peer_golden_1M_rclo_both_strands(hip, golden):
+    from ropebwt2_amd import MultiBwt
+    g = golden["sets"]["1M_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    m = MultiBwt(2, [0] * 8, "peer")
+    m.insert_multi(H.encode_batch_fixed(codes[:600000], True, True))
+    m.insert_multi(H.encode_batch_fixed(codes[600000:], True, True))
+    bwt = np.concatenate([m.rope(b) for b in range(6)])
+    assert H.md5(H.bwt_text(bwt) + b"\n") == g["text_md5"]["-Lr"]
+    assert m.stats()["host_syncs_in_rounds"] == 0
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_peer_continue_a_loaded_index(hip, n):
+    """configs[4] on a sharded index through the one-handle API: load_ropes (every rank keeps its pieces), more batches, rank queries"""
+    from ropebwt2_amd import MultiBwt
+    from ropebwt2_amd.hipbwt import encode_runs
+    reads = H.repetitive_reads(2400, seed=71, genome_len=600, max_len=90) + [[1] * 400] * 30
+    for so in (0, 2):
+        o = H.Oracle(so)
+        o.insert_multi(H.encode_batch(reads[:1300]))
+        m = MultiBwt(so, [0] * n, "peer")
+        m.load_ropes([encode_runs(o.rope(b)) for b in range(6)])
+        assert np.array_equal(m.counts(), o.counts())
+        for buf in (H.encode_batch(reads[1300:2000]), H.encode_batch(reads[2000:], True, so == 2)):
+            o.insert_multi(buf)
+            m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts())
+        for b in range(6):
+            ro = o.rope(b)
+            assert np.array_equal(m.rope(b), ro), "rope %d (so %d)" % (b, so)
+            for x in (0, 1, len(ro) // 3, len(ro) - 1, len(ro)):
+                if 0 <= x <= len(ro):
+                    assert np.array_equal(m.rank1a(b, x), np.bincount(ro[:x], minlength=6)), (b, x)
+        m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("so", [0, 2])
+def test_rccl_group_of_one(hip, so):
+    """the RCCL transport on a one-rank communicator: librccl is loaded, ncclAllReduce reduces the matrix in place, the rank's
+    own block travels through grouped ncclSend / ncclRecv (RB2_RCCL_SELF=1) -- every call of the multi-GPU transport, on one GPU"""
+    from ropebwt2_amd import MultiBwt
+    for self_msgs in ("1", "0"):
+        os.environ["RB2_RCCL_SELF"] = self_msgs
+        try:
+            o = H.Oracle(so)
+            m = MultiBwt(so, [0], "rccl")
+            for buf in _batches(so):
+                o.insert_multi(buf)
+                m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts())
+            for b in range(6):
+                assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+            assert m.stats()["host_syncs_in_rounds"] == m.stats()["rounds"]     # one event wait per round, behind nothing but the reduce
+            m.close()
+        finally:
+            del os.environ["RB2_RCCL_SELF"]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs on the box")
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+def test_real_devices_one_process(hip, transport):
+    """one process, one rank per visible GPU: peer access over xGMI / RCCL inside a process"""
+    from ropebwt2_amd import MultiBwt
+    n = min(_gpu_count(), 8)
+    for so in (0, 2):
+        o = H.Oracle(so)
+        m = MultiBwt(so, list(range(n)), transport)
+        for buf in _batches(so):
+            o.insert_multi(buf)
+            m.insert_multi(buf)
+        assert np.array_equal(m.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+        m.close()
+
+
+# ---- through the drop-in boundary: the CLI and the mrope C API with RB2_HIP_DEVICES ---------------------------------------
+
+def _cli_env(flags, data, devices, transport=None, extra_env=None):
+    from test_host_layer import CLI
+    env = dict(os.environ, RB2_HIP_DEVICES=devices)
+    if transport:
+        env["RB2_HIP_TRANSPORT"] = transport
+    env.update(extra_env or {})
+    p = subprocess.run([CLI] + list(flags) + ["-"], input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", ["-LR", "-LRs", "-LRr", "-L", "-Lr", "-LRN"])
+def test_cli_kat_on_8_ranks(hip, golden, flag):
+    assert _cli_env([flag], golden["kat_input"].encode(), "0,0,0,0,0,0,0,0").decode().strip() == golden["kat"][flag]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["10k_x_101", "1M_x_101"])
+@pytest.mark.parametrize("flag", ["-LRrd", "-Lrd", "-LRsd"])
+def test_cli_goldens_on_8_ranks(hip, golden, name, flag):
+    """`ropebwt2 -brR`-style builds with the index sharded over 8 ranks behind mr_insert_multi: the reference's .fmd bytes"""
+    g = golden["sets"][name]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    extra = ["-m20m"] if name == "1M_x_101" else []                  # several batches onto the sharded index
+    assert H.md5(_cli_env([flag] + extra, text, "0,0,0,0,0,0,0,0")) == g["fmd_md5"][flag]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("so_flag", ["", "s", "r"])
+def test_cli_incremental_on_8_ranks(hip, golden, so_flag, tmp_path):
+    """configs[4] shape (-bi) through the CLI on a sharded index: .fmr of the first half (one GPU) + second half on 8 ranks"""
+    from test_host_layer import cli
+    g = golden["sets"]["10k_x_101"]
+    codes = H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"])
+    half = tmp_path / "half.fmr"
+    half.write_bytes(cli(["-LRb" + so_flag], H.reads_to_text(codes[:5000])))
+    out = _cli_env(["-LRd", "-i", str(half)], H.reads_to_text(codes[5000:]), "0,0,0,0,0,0,0,0")
+    assert H.md5(out) == g["fmd_md5"]["-LR" + so_flag + "d"]
+    # and the other way round: the sharded build's .fmr continues on one GPU
+    half.write_bytes(_cli_env(["-LRb" + so_flag], H.reads_to_text(codes[:5000]), "0,0,0,0"))
+    assert H.md5(cli(["-LRd", "-i", str(half)], H.reads_to_text(codes[5000:]))) == g["fmd_md5"]["-LR" + so_flag + "d"]
+
+
+@pytest.mark.gpu
+def test_cli_rccl_transport_group_of_one(hip, golden):
+    """RB2_HIP_DEVICES with ONE device selects the single engine; two entries + rccl on one device must refuse loudly"""
+    from test_host_layer import CLI
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    assert H.md5(_cli_env(["-LRsd"], text, "0")) == g["fmd_md5"]["-LRsd"]
+    p = subprocess.run([CLI, "-LRsd", "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RB2_HIP_DEVICES="0,0", RB2_HIP_TRANSPORT="rccl"))
+    assert p.returncode != 0 and b"one device per rank" in p.stderr
+
+
+@pytest.mark.gpu
+def test_mrope_c_api_on_4_ranks(hip):
+    """mr_init / mr_insert_multi / mr_rank2a / mr_itr_* of libropebwt2.so with the index sharded over four ranks"""
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers as H
+from ropebwt2_amd.build import lib_path
+L = C.CDLL(lib_path("libropebwt2.so"))
+L.mr_init.restype = C.c_void_p; L.mr_init.argtypes = [C.c_int, C.c_int, C.c_int]
+L.mr_insert_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+L.mr_rank2a.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+L.mr_destroy.argtypes = [C.c_void_p]
+L.mr_hip_multi_handle.restype = C.c_void_p; L.mr_hip_multi_handle.argtypes = [C.c_void_p]
+L.mr_hip_handle.restype = C.c_void_p; L.mr_hip_handle.argtypes = [C.c_void_p]
+for so in (0, 1, 2):
+    o = H.Oracle(so)
+    mr = L.mr_init(64, 512, so)
+    reads = H.repetitive_reads(1500, seed=11 + so, genome_len=500, max_len=80)
+    for buf in (H.encode_batch(reads[:900]), H.encode_batch(reads[900:], True, True)):
+        o.insert_multi(buf)
+        L.mr_insert_multi(mr, len(buf), buf.ctypes.data, 1)
+    assert L.mr_hip_multi_handle(mr) and not L.mr_hip_handle(mr)
+    bwt = o.bwt()
+    for x in (0, 1, 17, len(bwt) // 2, len(bwt) - 1, len(bwt)):
+        cx = (C.c_int64 * 6)()
+        L.mr_rank2a(mr, x, -1, cx, None)
+        assert list(cx) == list(np.bincount(bwt[:x], minlength=6)), (so, x)
+    L.mr_destroy(mr)
+print("c api ok")
+''' % (H.ROOT, os.path.join(H.ROOT, "tests"))
+    import sys
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RB2_HIP_DEVICES="0,0,0,0"))
+    assert p.returncode == 0 and b"c api ok" in p.stdout, p.stderr.decode()[-2000:]
