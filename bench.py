@@ -20,8 +20,16 @@ in HBM.  Beside it the line reports
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: ONE index, its 31 sub-ropes sharded over the ranks (owner map in ropebwt2_amd/sharded.py), per
-round an all_reduce of the 31x6 count matrix and an all_to_all of 16-byte string records over RCCL.
+N > 1: ONE index, its 31 sub-ropes sharded over the ranks (rb2_hip_default_owners), per round a sum of the
+31x6 count matrix and an exchange of 16-byte string records.  The round loop runs INSIDE librb2hip.so
+(rb2_hip_multi_*, csrc/rb2_multi.h) -- Python only hands over one batch at a time:
+  under torch.distributed.run  one process per GPU; every process is one rank of an RCCL group
+                               (rb2_hip_multi_create_rank; the ncclUniqueId travels through torch.distributed):
+                               ncclAllReduce + grouped ncclSend/ncclRecv.  RB2_BENCH_DRIVER=python selects the
+                               round-2 driver (ropebwt2_amd/sharded.py, collectives issued from Python) as a cross-check
+  plain `python bench.py --gpus N`  ONE process drives N devices over the PEER transport (peer access + device
+                               events, no host synchronisation between rounds); RB2_BENCH_DEVICES=0,0,0,0 lists the
+                               devices explicitly (virtual ranks on one GPU)
   --mode weak (default)   the job grows with N: N x 100 M reads in three batches of -m(4N)g, so every GPU
                           keeps ~40.8 M strings per round and 1/N of an N-times larger index ("weak";
                           N = 8 is within a factor 1.5 of BASELINE.json configs[2]'s 1.2 B reads)
@@ -44,7 +52,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
 CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
 # the real reference on the FULL configs[1] job, same kind of box (profiles/r01_configs1_cli_vs_reference.json)
-CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5,
+CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5, "measured_in_round": 1,
                    "source": "profiles/r01_configs1_cli_vs_reference.json (oracle/_ref/ropebwt2 -LRds -m4g on all 100 M reads, MI355X box host)"}
 
 
@@ -175,6 +183,148 @@ def whole_process(reads, read_len, so_flag, batch_gib):
                     % (" ".join(flags), reads, read_len, "both in /dev/shm" if mode == "file" else "piped from synth_reads, output to /dev/null")}
 
 
+class Single:
+    """one engine (HipBwt) behind the small interface the job loop needs"""
+
+    def __init__(self, so, dev):
+        from ropebwt2_amd import HipBwt
+        self.b = HipBwt(so, dev)
+        self.eng = self.b
+
+    def alloc(self, nbytes):
+        return [self.b.dev_alloc(nbytes)]
+
+    def free(self, ptrs):
+        self.b.dev_free(ptrs[0])
+
+    def synth(self, ptrs, first, n, L, seed, strand=0):
+        self.b.synth_reads(ptrs[0], first, n, L, seed=seed, strand=strand)
+
+    def insert(self, ptrs, nbytes):
+        self.b.insert_multi_dev(ptrs[0], nbytes)
+
+    def reserve(self, *a):
+        self.b.reserve(*a)
+
+    def __getattr__(self, k):                  # sync, reset, counts, close
+        return getattr(self.b, k)
+
+
+class Multi:
+    """N ranks behind one handle (MultiBwt): the ranks this process drives each need the batch text on their device"""
+
+    def __init__(self, so, devices, transport, rank=None, nranks=None, nccl_id=None):
+        from ropebwt2_amd import MultiBwt
+        self.m = MultiBwt(so, devices, transport, rank=rank, nranks=nranks, nccl_id=nccl_id)
+        self.devices = list(devices)
+        self.engs = [self.m.engine(k) for k in range(self.m.n)]
+        self.eng = self.engs[0]
+        self.lead = [self.devices.index(d) for d in self.devices]       # first local rank on the same device
+
+    def alloc(self, nbytes):
+        own = {k: self.engs[k].dev_alloc(nbytes) for k in set(self.lead)}
+        return [own[k] for k in self.lead]
+
+    def free(self, ptrs):
+        for k in set(self.lead):
+            self.engs[k].dev_free(ptrs[k])
+
+    def synth(self, ptrs, first, n, L, seed, strand=0):
+        for k in set(self.lead):
+            self.engs[k].synth_reads(ptrs[k], first, n, L, seed=seed, strand=strand)
+            self.engs[k].sync()
+
+    def insert(self, ptrs, nbytes):
+        self.m.insert_multi_dev(list(ptrs), nbytes)
+
+    def reserve(self, *a):
+        self.m.reserve(*a)
+
+    def __getattr__(self, k):
+        return getattr(self.m, k)
+
+
+def src_sha():
+    """identifies the kernels a committed PMC summary was taken from"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("rb2_merge.h", "rb2_kernels.h", "rb2_device.h"):
+        h.update(open(os.path.join(ROOT, "ropebwt2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def measure_traffic(budget_s=240):
+    """HBM bytes per k_merge launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass,
+    MI355X_MICROARCH.md) of one configs[1] job of this same script, kernel-trace only; FETCH_SIZE doubled per the guide's
+    gfx950 note.  None when rocprofv3 is missing or a pass fails (the caller then falls back to the committed summary)."""
+    import csv, glob, shutil, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="rb2_pmc_", dir="/tmp")
+    res = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "0", "--no-cpu-baseline", "--no-extras"]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                sys.stderr.write("[bench] PMC pass %s failed (rc %d)\n%s\n" % (ctr, p.returncode, p.stderr.decode()[-300:]))
+                return None
+            tot, n = 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                if r["Kernel_Name"].split("(")[0].split("<")[0].endswith("k_merge"):
+                    tot += float(r["Counter_Value"]); n += 1
+            res[ctr] = (tot, n)
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("[bench] PMC passes failed: %r\n" % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    (fe, n), (wr, n2) = res["FETCH_SIZE"], res["WRITE_SIZE"]
+    if n == 0 or n != n2:
+        return None
+    return {"bytes_per_launch": (2 * fe + wr) * 1024 / n, "fetch_bytes_per_launch_corrected": 2 * fe * 1024 / n, "write_bytes_per_launch": wr * 1024 / n,
+            "launches": n, "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 3 --warmup 0 "
+                                     "--no-cpu-baseline --no-extras` (one configs[1] job, %d k_merge launches); counters in KiB, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)" % n}
+
+
+def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.0):
+    """BASELINE.json configs[2]'s shape on ONE GPU (1.2 B x 101 bp, RCLO, -R, ropebwt2's default -m10g: 12 batches on a growing
+    index): how the rate falls as the index grows.  Batches are generated on the device just before they are inserted; only the
+    inserts are timed.  Result checked through the count matrix (sums, LF consistency)."""
+    from ropebwt2_amd import HipBwt
+    so = {"io": 0, "rlo": 1, "rclo": 2}[so_name]
+    per_batch = batch_reads(batch_gib * 1024 ** 3, L)
+    b = HipBwt(so, 0)
+    try:
+        total = reads * (L + 1)
+        b.reserve(per_batch * (L + 1), per_batch, total)
+        buf = b.dev_alloc(per_batch * (L + 1) + 64)
+        done, times = 0, []
+        while done < reads:
+            n = min(per_batch, reads - done)
+            b.synth_reads(buf, done, n, L, seed=42)
+            b.sync()
+            t0 = time.perf_counter()
+            b.insert_multi_dev(buf, n * (L + 1))
+            b.sync()
+            times.append(time.perf_counter() - t0)
+            done += n
+        c = b.counts()
+        sizes, occ = c.sum(axis=1), c.sum(axis=0)
+        ok = int(c.sum()) == total and int(c[:, 0].sum()) == reads and all(int(sizes[a]) == int(occ[a]) for a in range(1, 6))
+        st = b.sparse_stats()
+        b.dev_free(buf)
+    finally:
+        b.close()
+    return {"value": total / sum(times) / 1e9, "unit": "Gsymbols/s", "insert_s": sum(times), "batch_s": [round(t, 3) for t in times], "counts_ok": bool(ok),
+            "layout": st, "what": "configs[2] shape on 1 GPU: %d x %d bp, %s, forward strand, -m%gg (%d batches, %.1f G symbols), inputs generated on the device, inserts timed"
+                                  % (reads, L, so_name.upper(), batch_gib, len(times), total / 1e9)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +336,9 @@ def main():
     ap.add_argument("--order", default="rlo", choices=["io", "rlo", "rclo"])
     ap.add_argument("--mode", default="weak", choices=["weak", "strong", "independent"], help="what N > 1 ranks do (see module docstring)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the value_host_api / whole_process legs (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the value_host_api / whole_process / secondary / PMC legs (profiling runs)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]-shape leg")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in-run (use the committed summary if it matches the sources)")
     ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
     args = ap.parse_args()
 
@@ -195,7 +347,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         sys.stderr.write("[bench] WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE\n" % (world, args.gpus))
-    n_gpus = world if world > 1 else 1
+    # one process may drive several devices itself (no launcher): --gpus N, or an explicit device list (virtual ranks)
+    local_devices = None
+    if world == 1:
+        if os.environ.get("RB2_BENCH_DEVICES"):
+            local_devices = [int(x) for x in os.environ["RB2_BENCH_DEVICES"].split(",")]
+        elif args.gpus > 1:
+            local_devices = list(range(args.gpus))
+        if local_devices is not None and len(local_devices) < 2:
+            local_devices = None
+    n_ranks = world if world > 1 else (len(local_devices) if local_devices else 1)
+    n_gpus = world if world > 1 else (len(set(local_devices)) if local_devices else 1)
 
     import torch
     dist = None
@@ -203,7 +365,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # test hook for single-GPU boxes: RB2_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages
-        # the exchange through host memory (tests/test_sharded.py uses the same path)
+        # the exchange through host memory (tests/test_sharded.py uses the same path; Python driver only)
         if os.environ.get("RB2_BENCH_BACKEND") == "gloo":
             local_rank = 0
             torch.cuda.set_device(0)
@@ -212,50 +374,75 @@ def main():
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from ropebwt2_amd import HipBwt, build_all
+    from ropebwt2_amd import HipBwt, MultiBwt, build_all
     if rank == 0:
         build_all()
     if dist is not None:
         dist.barrier()
-    sharded = world > 1 and args.mode in ("weak", "strong")
+    sharded = n_ranks > 1 and args.mode in ("weak", "strong")
     if sharded and args.mode == "weak":                 # per-GPU work fixed: N times the reads, N times the batch
-        args.reads *= world
-        args.batch *= world
+        args.reads *= n_gpus
+        args.batch *= n_gpus
     so = {"io": 0, "rlo": 1, "rclo": 2}[args.order]
     so_flag = {"io": "", "rlo": "-s", "rclo": "-r"}[args.order]
     L = args.read_len
     per_batch = batch_reads(args.batch * 1024 ** 3, L)
     dev = local_rank if world > 1 else 0
+    py_driver = world > 1 and (os.environ.get("RB2_BENCH_DRIVER") == "python" or os.environ.get("RB2_BENCH_BACKEND") == "gloo")
+    driver = "single engine"
+    nccl_id = None
+    if sharded and world > 1 and not py_driver:          # the RCCL group of the C-level driver: rank 0's id, through torch.distributed
+        box = [MultiBwt.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        nccl_id = box[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    class PyDriver(Single):
+        """round 2's driver: collectives issued from Python (ropebwt2_amd/sharded.py) -- kept as a cross-check"""
+
+        def __init__(self, so_, dev_):
+            from ropebwt2_amd.sharded import ShardedBwt, TorchComm
+            self.b = ShardedBwt(so_, rank, world, dev_)
+            self.eng = self.b
+            self.comm = TorchComm(self.b)
+
+        def insert(self, ptrs, nbytes):
+            self.comm.insert_multi_dev(ptrs[0], nbytes)
+
     def make(so_, dev_):
+        nonlocal driver
         if not sharded:
-            b_ = HipBwt(so_, dev_)
-            return b_, b_.insert_multi_dev
-        from ropebwt2_amd.sharded import ShardedBwt, TorchComm
-        b_ = ShardedBwt(so_, rank, world, dev_)
-        return b_, TorchComm(b_).insert_multi_dev
+            return Single(so_, dev_)
+        if py_driver:
+            driver = "python round loop (sharded.py) over %s" % dist.get_backend()
+            return PyDriver(so_, dev_)
+        if world > 1:
+            driver = "librb2hip round loop, one process per GPU, RCCL C API (ncclAllReduce + grouped ncclSend/ncclRecv)"
+            return Multi(so_, [dev_], "rccl", rank=rank, nranks=world, nccl_id=nccl_id)
+        tr = os.environ.get("RB2_BENCH_TRANSPORT", "peer")
+        driver = "librb2hip round loop, one process, %d ranks on devices %s, %s transport" % (len(local_devices), local_devices, tr.upper())
+        return Multi(so_, local_devices, tr)
 
     # ---- warm-up: same kernels (and collectives) on a small scratch index (untimed)
     for _ in range(max(0, args.warmup)):
-        w, w_insert = make(so, dev)
+        w = make(so, dev)
         n = 200_000
-        p = w.dev_alloc(n * (L + 1))
+        p = w.alloc(n * (L + 1))
         for i in range(2):
-            w.synth_reads(p, i * n, n, L, seed=7)
+            w.synth(p, i * n, n, L, 7)
             w.sync()
-            w_insert(p, n * (L + 1))
-        w.dev_free(p)
+            w.insert(p, n * (L + 1))
+        w.free(p)
         w.close()
 
     # ---- the job: its -m batches (sharded: the same batches on every rank, one index; independent: this rank's own
     # ---- slice of the read stream, its own index).  Step k = batch k % nb of job k // nb; a job starts on an empty index.
-    bwt, do_insert = make(so, dev)
-    bwt.profile(True)
+    bwt = make(so, dev)
+    bwt.eng.profile(True)
     first = 0 if sharded or world == 1 else rank * args.reads
     job, done = [], 0
     while done < args.reads:
@@ -265,23 +452,26 @@ def main():
     nb = len(job)
     bufs = []
     for (f, n) in job:                            # inputs resident in HBM before the clock starts
-        p = bwt.dev_alloc(n * (L + 1))
-        bwt.synth_reads(p, f, n, L, seed=42)
+        p = bwt.alloc(n * (L + 1))
+        bwt.synth(p, f, n, L, 42)
         bufs.append(p)
     sizes = [n * (L + 1) for _, n in job]
     # capacity hint (rb2_hip_reserve): the job's size is known up front, as it is to `ropebwt2 -m`; without it
     # the engine grows its buffers batch by batch (hipMalloc + copy + hipFree inside the timed region)
     tot_syms = sum(sizes)
-    bwt.reserve(max(sizes), max(n for _, n in job), tot_syms if not sharded else int(tot_syms * 1.25 / world))
+    if sharded and (world > 1 and py_driver):
+        bwt.reserve(max(sizes), max(n for _, n in job), int(tot_syms * 1.25 / world))
+    else:
+        bwt.reserve(max(sizes), max(n for _, n in job), tot_syms)          # (a Multi handle divides by its active ranks itself)
     bwt.sync()
-    bwt.profile_get(reset=True)
+    bwt.eng.profile_get(reset=True)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         j = k % nb
         if j == 0 and k > 0:
             bwt.reset()                           # next job: empty index, same buffers
-        do_insert(bufs[j], sizes[j])
+        bwt.insert(bufs[j], sizes[j])
     bwt.sync()
     barrier()
     dt = time.perf_counter() - t0
@@ -291,33 +481,33 @@ def main():
         dt = float(t.item())
     symbols = sum(sizes[k % nb] for k in range(args.steps))
     last = (args.steps - 1) % nb + 1 if args.steps else 0      # batches in the index at the end (last job, maybe partial)
-    prof = bwt.profile_get()
+    prof = bwt.eng.profile_get()
     counts = bwt.counts()
     ok_counts = int(counts.sum()) == sum(sizes[:last]) and int(counts[:, 0].sum()) == sum(n for _, n in job[:last])
+    mstats = bwt.stats() if isinstance(bwt, Multi) else None
     host_api = None
-    if rank == 0 and n_gpus == 1 and not args.no_extras:
+    if rank == 0 and n_ranks == 1 and not args.no_extras:
         bwt.reset()
-        host_api = host_api_rate(HipBwt, so, dev, bufs, sizes)
+        host_api = host_api_rate(HipBwt, so, dev, [p[0] for p in bufs], sizes)
     for p in bufs:
-        bwt.dev_free(p)
+        bwt.free(p)
     bwt.close()
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    total_symbols = symbols if sharded else symbols * n_gpus
+    total_symbols = symbols if (sharded or n_ranks == 1) else symbols * n_gpus
     active, owners = 1, None
     if sharded:
-        from ropebwt2_amd.sharded import default_owners
-        owners = default_owners(world)
+        owners = MultiBwt.default_owners(n_ranks)
         active = len(set(owners))
     mk = prof["k_merge"]
     units = mk["units"] / (active if sharded else 1)
     ach = ALG_BYTES_PER_SYMBOL * units / (mk["ms"] * 1e-3) / 1e9 if mk["ms"] > 0 else 0.0
     njobs = -(-args.steps // nb)
     reads_job = sum(n for _, n in job)
-    name = "configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % world
+    name = "configs[1]" if not (sharded and args.mode == "weak") else "configs[1] x %d (weak scaling of one sharded index)" % n_gpus
     out = {
         "metric": "Gsymbols/s inserted (wall-clock), bit-identical .fmd",
         "value": total_symbols / dt / 1e9,
@@ -330,11 +520,12 @@ def main():
                                "(%s reads); %d steps = %d job(s) of %d batches, each job on an empty index%s"
                                % (name, reads_job, L, so_flag.strip("-"), args.batch, n_gpus, "/".join(str(n) for _, n in job), args.steps, njobs, nb,
                                   "" if args.steps % nb == 0 else " (the last job stops after batch %d)" % (args.steps % nb)),
-                   "reads_per_job": reads_job * (1 if sharded else n_gpus), "jobs": args.steps / nb,
+                   "reads_per_job": reads_job * (1 if (sharded or n_ranks == 1) else n_gpus), "jobs": args.steps / nb,
                    "symbols": total_symbols, "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
-                   "parallelism": "1 GPU" if n_gpus == 1 else
-                                  ("31 sub-ropes (b,x) sharded over %d of %d GPUs (owner map %s); per round all_reduce(31x6 counts) + all_to_all(16 B string records) over RCCL"
-                                   % (active, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
+                   "parallelism": "1 GPU" if n_ranks == 1 else
+                                  ("31 sub-ropes (b,x) sharded over %d of %d ranks on %d GPU(s) (owner map %s); per round: sum of the 31x6 count matrix + exchange of 16 B string records"
+                                   % (active, n_ranks, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
+                   "driver": driver, "multi_stats": mstats,
                    "counts_ok": bool(ok_counts)},
         "roofline": {"bound": "hbm", "kernel": "k_merge", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -344,23 +535,39 @@ def main():
                      "note": None if not sharded else "rank 0 only; units per launch approximated by strings / active ranks"},
         "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
     }
-    # HBM bytes per k_merge launch from the PMC passes of this same command (tools/collect_profiles.sh -> profiles/):
-    # the per-launch average does not depend on K because every job is the same configs[1] job
+    # HBM bytes per k_merge launch: measured now (two PMC passes of one configs[1] job -- the per-launch average does not depend on
+    # K because every job is the same job); else the committed summary of the same command, but only if it was taken from the
+    # kernels that are being benchmarked (sha of the kernel sources)
+    is_cfg1 = n_ranks == 1 and args.reads == 100_000_000 and args.batch == 4.0 and args.order == "rlo" and L == 101
+    if is_cfg1 and not args.no_extras and not args.no_pmc:
+        tr = measure_traffic()
+        if tr is not None:
+            out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["traffic_detail"] = tr
     traffic_file = os.path.join(ROOT, "profiles", "k_merge_traffic.json")
-    if os.path.exists(traffic_file) and n_gpus == 1 and args.reads == 100_000_000 and args.batch == 4.0 and args.order == "rlo":
+    if out["roofline"]["traffic"] is None and os.path.exists(traffic_file) and is_cfg1:
         try:
             tf = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = tf.get("bytes_per_launch")
-            out["roofline"]["traffic_source"] = tf.get("source")
+            if tf.get("src_sha") == src_sha():
+                out["roofline"]["traffic"] = tf.get("bytes_per_launch")
+                out["roofline"]["traffic_detail"] = {"source": tf.get("source"), "src_sha": tf.get("src_sha")}
+            else:
+                out["roofline"]["traffic_detail"] = {"stale": "profiles/k_merge_traffic.json was taken from other kernel sources (sha %s, now %s): not used"
+                                                             % (tf.get("src_sha"), src_sha())}
         except Exception:  # noqa: BLE001
             pass
     if host_api is not None:
         out["value_host_api"] = host_api
-    if n_gpus == 1 and not args.no_extras:
+    if n_ranks == 1 and not args.no_extras:
         wp = whole_process(args.reads, L, so_flag, args.batch)
         if wp is not None:
             out["whole_process"] = wp
-    if not args.no_cpu_baseline and n_gpus == 1:
+        if not args.no_secondary and is_cfg1:
+            try:
+                out["secondary"] = {"configs2_shape_1gpu": secondary_configs2()}
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("[bench] secondary leg failed: %r\n" % (e,))
+    if not args.no_cpu_baseline and n_ranks == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
     print(json.dumps(out))
     if dist is not None:

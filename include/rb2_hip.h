@@ -94,6 +94,12 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6]);
  * that ask millions of ranks (x, out: host memory). */
 void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_t *out);
 
+/* 64-bit checksum of rope b computed on the device (position-weighted sum over the packed words of its pieces): equal for
+ * equal symbol sequences however the index was built (one engine, N ranks, an .fmr loaded back), sensitive to order.  Lets
+ * tests compare indexes of 10^11 symbols without moving them off the device (the reference has no counterpart; its ropes are
+ * compared through their .fmd) */
+uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b);
+
 /* ---- rope sharding across GPUs ---------------------------------------------------------------
  * One handle per GPU (one process per GPU).  The unit of ownership is a SUB-ROPE: rope b is kept as
  * six independent pieces (b,x), x = the symbol that follows b in the row's suffix (piece (b,x) holds
@@ -181,6 +187,7 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
 /* out[0] host <-> device synchronisations inside the round loops so far (PEER: 0), out[1] rounds, out[2] batches,
  * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
+uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);   /* == rb2_hip_rope_hash of the same rope on one engine */
 
 /* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */
 

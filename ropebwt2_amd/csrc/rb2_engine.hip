@@ -1049,6 +1049,34 @@ void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
 	rb2_hip_rank_batch(h, b, 1, &x, cx);
 }
 
+/* checksum of sub-rope r (k_piece_hash); the handle must hold the piece in the dense layout */
+static uint64_t piece_hash(rb2_hip_t *h, int r)
+{
+	HIPCHK(hipSetDevice(h->dev));
+	ensure_dense(h);
+	if (h->h_rope[r].n == 0) return 0;
+	h->qbuf.ensure(8);
+	HIPCHK(hipMemsetAsync(h->qbuf.p, 0, 8, h->st));
+	hipLaunchKernelGGL(k_piece_hash, dim3(2048), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), r, (unsigned long long*)h->qbuf.p);
+	HIPCHK(hipGetLastError());
+	uint64_t v = 0;
+	HIPCHK(hipMemcpyAsync(&v, h->qbuf.p, 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	return v;
+}
+static uint64_t hash_mix(uint64_t acc, uint64_t piece, uint64_t n)      /* pieces of a rope, in order */
+{
+	acc = (acc ^ piece) * 0x9E3779B97F4A7C15ull; acc ^= acc >> 29;
+	return (acc ^ n) * 0xBF58476D1CE4E5B9ull;
+}
+uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b)
+{
+	uint64_t acc = 0;
+	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rope_hash: this handle holds only its own sub-ropes of a sharded index (use rb2_hip_multi_rope_hash)\n"); abort(); }
+	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) acc = hash_mix(acc, piece_hash(h, r), h->h_rope[r].n);
+	return acc;
+}
+
 /* rank inside one sub-rope (rb2_multi.h: the pieces of a sharded rope live on different handles) */
 static void rank_piece(rb2_hip_t *h, int r, int64_t p, int64_t out[6])
 {

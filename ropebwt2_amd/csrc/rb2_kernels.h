@@ -1202,6 +1202,26 @@ __global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, Po
 	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
+// position-weighted checksum of the symbols of piece r (dense layout: a flat array of 21-symbol words): sum over its words of
+// word_j * (2j + 1) mod 2^64 -- equal for equal symbol sequences whatever built them (one engine, N ranks, a loaded .fmr),
+// sensitive to order.  Bits behind the last symbol are masked.  *out must be zeroed by the caller.
+__global__ __launch_bounds__(256) void k_piece_hash(const Ctl *ctl, int side, PoolView pv, int r, unsigned long long *out)
+{
+	__shared__ uint64_t s_w[4];
+	const RopeDesc &d = ctl->rope[side][r];
+	const uint64_t nw = (d.n + SPW - 1) / SPW;
+	const uint64_t *w = (const uint64_t*)pv.data + d.leaf0 * LEAFW;
+	uint64_t acc = 0;
+	for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < nw; j += (uint64_t)gridDim.x * 256) {
+		uint64_t v = w[j] & MALL;
+		if (j == nw - 1) v &= nib_below((uint32_t)(d.n - j * SPW));
+		acc += v * (2 * j + 1);
+	}
+	uint64_t tot;
+	block_excl_add<uint64_t>(acc, s_w, &tot);
+	if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long)tot);
+}
+
 // one wave: counts of the six symbols in [0, p) of PIECE r (a sharded index answers a rope query piece by piece, each from its owner)
 __global__ __launch_bounds__(64) void k_rank_piece(const Ctl *ctl, int side, PoolView pv, int r, uint64_t p, uint64_t *out, int sparse)
 {

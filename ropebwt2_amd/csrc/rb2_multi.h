@@ -521,6 +521,19 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6])
 	}
 }
 
+/* the same value rb2_hip_rope_hash gives for the same rope on one engine: every piece hashed by its owner */
+uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b)
+{
+	uint64_t acc = 0;
+	for (int r = 0; r < NR; ++r) {
+		if (rope_sym(r) != b) continue;
+		const int o = m->owner[r] - m->rank0;
+		if (o < 0 || o >= m->n) { fprintf(stderr, "[rb2_hip] multi rope_hash: piece %d lives in another process\n", r); abort(); }
+		acc = hash_mix(acc, piece_hash(m->rk[o].h, r), m->rk[o].h->h_rope[r].n);
+	}
+	return acc;
+}
+
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6])
 {
 	out[0] = m->n_sync; out[1] = m->n_rounds; out[2] = m->n_batches; out[3] = out[4] = out[5] = 0;

@@ -82,6 +82,8 @@ def load_hip_lib():
         "rb2_hip_multi_sync": (None, [vp]),
         "rb2_hip_multi_rank1a": (None, [vp, i32, i64, vp]),
         "rb2_hip_multi_stats": (None, [vp, vp]),
+        "rb2_hip_multi_rope_hash": (u64, [vp, i32]),
+        "rb2_hip_rope_hash": (u64, [vp, i32]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -102,7 +104,7 @@ ABI_SYMBOLS = [
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
     "rb2_hip_multi_get_counts", "rb2_hip_multi_rope_bytes", "rb2_hip_multi_download_rope", "rb2_hip_multi_stream_rope",
-    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
+    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
 ]
 
 
@@ -198,6 +200,10 @@ class HipBwt:
 
     def reserve(self, batch_bytes=0, batch_strings=0, total_symbols=0):
         self.L.rb2_hip_reserve(self.h, batch_bytes, batch_strings, total_symbols)
+
+    def rope_hashes(self):
+        """device-side checksums of the six ropes (rb2_hip_rope_hash)"""
+        return [int(self.L.rb2_hip_rope_hash(self.h, b)) for b in range(6)]
 
     def rank1a(self, b, x):
         c = np.zeros(6, np.int64)
@@ -347,6 +353,9 @@ class MultiBwt:
 
     def reset(self):
         self.L.rb2_hip_multi_reset(self.h)
+
+    def rope_hashes(self):
+        return [int(self.L.rb2_hip_multi_rope_hash(self.h, b)) for b in range(6)]
 
     def sync(self):
         self.L.rb2_hip_multi_sync(self.h)

@@ -10,7 +10,7 @@ N, L, SEED = 10_000_000, 101, 42
 out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropebwt2 r187 (oracle/_ref)",
        "n_reads": N, "read_len": L, "seed": SEED, "fmd_md5": {}}
 if os.path.exists(os.path.join(HERE, "golden_large.json")):           # keep entries produced by other invocations
-    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs1") or k.startswith("coverage") or k.startswith("longreads")})
+    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs") or k.startswith("coverage") or k.startswith("longreads")})
 if "--longreads" in sys.argv:
     # long-read path: 200 k x 5 kbp, input order, one batch of 5001 rounds
     g = subprocess.Popen([GEN, "200000", "5000", "44"], stdout=subprocess.PIPE)
@@ -34,6 +34,19 @@ if "--coverage" in sys.argv:
         assert p.wait() == 0 and g.wait() == 0
         cov["runs"][flags] = {"fmd_bytes": n, "fmd_md5": h.hexdigest()}
     out["coverage30x"] = cov
+    json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
+    sys.exit(0)
+if "--configs2-order" in sys.argv:
+    # BASELINE.json configs[2]'s ORDER AND FLAGS at configs[1]'s size: 100 M x 101 bp, RCLO, forward strand (-brR -> -LRdr for the .fmd),
+    # ropebwt2's default -m10g (two batches).  Pins the RCLO order against the real reference above 1 M reads.
+    g = subprocess.Popen([GEN, "100000000", "101", "42"], stdout=subprocess.PIPE)
+    p = subprocess.Popen([REF, "-LRdr", "-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    h, n = hashlib.md5(), 0
+    for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+        h.update(chunk); n += len(chunk)
+    assert p.wait() == 0 and g.wait() == 0
+    out["configs2_order_100M"] = {"n_reads": 100000000, "read_len": 101, "seed": 42, "flags": "-LRdr", "fmd_bytes": n, "fmd_md5": h.hexdigest(),
+                                  "provenance": "oracle/_ref/ropebwt2 (the real reference) in the build container: synth_reads 100000000 101 42 | ropebwt2 -LRdr - ; make_golden_large.py --configs2-order"}
     json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
     sys.exit(0)
 if "--configs1" in sys.argv:

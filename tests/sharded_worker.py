@@ -4,6 +4,8 @@ mode "gpu":  every rank drives a real HIP engine on cuda:0 (several processes sh
              test box), exchange over gloo with host staging; owned ropes are compared with the oracle.
 mode "nccl": the same check with one GPU per rank and the exchange on device tensors over RCCL (backend "nccl"); needs as many
              GPUs as ranks -- tests/test_sharded.py runs it whenever torch.cuda.device_count() >= 2.
+mode "crank": one process per GPU, the round loop INSIDE librb2hip.so (MultiBwt(rank=...) = rb2_hip_multi_create_rank): RCCL's C API,
+             the ncclUniqueId handed round through torch.distributed; every rank compares the pieces it holds with the oracle.
 mode "mock": no GPU: a toy engine emits tagged records following a random count matrix; checks that
              TorchComm delivers them exactly where rb2_hip_shard_finish's layout expects them.
 """
@@ -21,7 +23,7 @@ def main():
     import torch.distributed as dist
     mode = sys.argv[1]
     dev = 0
-    if mode == "nccl":
+    if mode in ("nccl", "crank"):
         import torch
         dev = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(dev)
@@ -30,7 +32,36 @@ def main():
         dist.init_process_group("gloo")
     rank, n = dist.get_rank(), dist.get_world_size()
     from ropebwt2_amd import sharded
-    if mode in ("gpu", "nccl"):
+    if mode == "crank":
+        import helpers as H
+        from ropebwt2_amd import MultiBwt
+        so = int(sys.argv[2])
+        box = [MultiBwt.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        m = MultiBwt(so, [dev], "rccl", rank=rank, nranks=n, nccl_id=box[0])
+        owner = MultiBwt.default_owners(n)
+        reads = H.repetitive_reads(2500, seed=90 + so, genome_len=700, max_len=90)
+        codes = H.splitmix_bases(3000, 60, seed=5)
+        o = H.Oracle(so)
+        for buf in (H.encode_batch(reads[:1500]), H.encode_batch_fixed(codes), H.encode_batch(reads[1500:], True, True)):
+            o.insert_multi(buf)
+            m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts()), "rank %d: count matrix differs" % rank
+        c = o.counts()
+        for b in range(6):                                          # a multi-process handle returns the pieces of rope b it holds, in order
+            want = []
+            for r in range(sharded.NR):
+                if sharded.rope_sym(r) != b or owner[r] != rank:
+                    continue
+                x = sharded.rope_prev(r)
+                lo = int(c[:x, b].sum()) if b else 0
+                k = int(c[x, b]) if b else int(c[0].sum())
+                want.append(o.rope(b)[lo:lo + k])
+            want = np.concatenate(want) if want else np.zeros(0, np.uint8)
+            assert np.array_equal(m.rope(b), want), "rank %d: pieces of rope %d differ" % (rank, b)
+        print("rank %d/%d so %d C-level RCCL driver ok (host syncs in rounds: %d of %d rounds)" % (rank, n, so, m.stats()["host_syncs_in_rounds"], m.stats()["rounds"]))
+        m.close()
+    elif mode in ("gpu", "nccl"):
         import helpers as H
         so = int(sys.argv[2])
         bwt = sharded.ShardedBwt(so, rank, n, device=dev)

@@ -198,6 +198,31 @@ def test_real_devices_one_process(hip, transport):
         m.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs on the box (one process per GPU)")
+@pytest.mark.parametrize("so", [0, 2])
+def test_processes_over_rccl_c_driver(hip, so):
+    """one process per GPU, each ONE rank of an RCCL group driven inside librb2hip.so (rb2_hip_multi_create_rank): what
+    bench.py runs under torch.distributed.run"""
+    from test_sharded import launch
+    n = min(_gpu_count(), 8)
+    p = launch(n, ["crank", so], 29750 + so)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert out.count("C-level RCCL driver ok") >= n, out
+
+
+@pytest.mark.gpu
+def test_one_process_group_over_rccl_c_driver(hip):
+    """the same worker as a group of ONE process on the one-GPU box: unique id through torch.distributed, ncclCommInitRank,
+    the round loop with ncclAllReduce on the real communicator"""
+    from test_sharded import launch
+    p = launch(1, ["crank", 2], 29760)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert "C-level RCCL driver ok" in out, out
+
+
 # ---- through the drop-in boundary: the CLI and the mrope C API with RB2_HIP_DEVICES ---------------------------------------
 
 def _cli_env(flags, data, devices, transport=None, extra_env=None):
