@@ -184,7 +184,8 @@ void rb2_hip_multi_reserve(rb2_hip_multi_t *m, int64_t batch_bytes, int64_t batc
 void rb2_hip_multi_reset(rb2_hip_multi_t *m);
 void rb2_hip_multi_sync(rb2_hip_multi_t *m);
 void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
-/* out[0] host <-> device synchronisations inside the round loops so far (PEER: 0), out[1] rounds, out[2] batches,
+/* out[0] host <-> device synchronisations inside the round loops so far (PEER: none in dense rounds; an in-place round reads a
+ * one-word verdict before its exchange; RCCL: one event wait per round, behind the reduce only), out[1] rounds, out[2] batches,
  * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
 uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);   /* == rb2_hip_rope_hash of the same rope on one engine */
@@ -211,6 +212,9 @@ void rb2_hip_sync(rb2_hip_t *h);
 /* leaf-layout statistics since rb2_hip_create: out[0] re-layouts (dense <-> sparse), out[1] void sparse rounds (a leaf ran out
  * of slack; the round was redone densely), out[2] rounds inserted in place, out[3] 1 when the index currently has the sparse layout */
 void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4]);
+/* the same four, then out[4] re-spreads among the re-layouts (sparse -> sparse: a superblock had no free slot for a split),
+ * out[5] leaves split in place by k_split (the leaf split of rope.c:143-146); out[6..7] reserved */
+void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8]);
 
 /* per-kernel timing, measured with hipEvents on the engine's own stream when enabled */
 #define RB2_K_SYM      0

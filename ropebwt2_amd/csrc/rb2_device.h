@@ -55,7 +55,10 @@ __host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (
 
 struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: prefixes inside the superblock + own fill; own[]: own counts + own fill
 constexpr int SP_FILL = 1008;          // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 336 inserts)
-constexpr int SP_USED = 24;            // ... leaf slots in use per superblock (the other 8 stay empty)
+constexpr int SP_USED = 24;            // ... leaf slots in use per superblock; the other 8 are the superblock's own reserve: a leaf that comes within
+                                       // SP_MARGIN symbols of LEAF is split into one of them at the end of the round (k_split: the counterpart of the
+                                       // reference's leaf split, rope.c:143-146 / split_node rope.c:78-112, one level of its B+ tree)
+constexpr int SP_MARGIN = 128;         // a leaf is split when its fill exceeds LEAF - SP_MARGIN: whatever a round brings, a leaf takes 128 more symbols
 struct Cnt6 { uint64_t v[6]; };
 struct SbTot { uint32_t p01, p23, p45, pad; };             // symbol counts of one superblock, six 16-bit fields (<= SB * LEAF each)
 
@@ -90,6 +93,10 @@ struct Ctl {
 	// ---- sparse (in-place) rounds
 	uint32_t nwork;         // work orders (touched leaves) appended by k_part_sparse this round
 	uint32_t overflow;      // some touched leaf cannot take its inserts: the round is void (every later kernel returns) and the host redoes it densely
+	uint32_t sbfull;        // (same 8-byte verdict word) k_split found a leaf to split in a superblock without a free slot: the host re-spreads the index before the next round
+	uint32_t nsplit;        // leaves that came within SP_MARGIN of LEAF this round (k_part_sparse appends them, k_split splits them)
+	uint32_t pad_sp;
+	uint64_t nsplit_total;  // leaves split since the handle was created (statistics)
 	RopeDesc relay_old[NR]; // k_relayout: the layout being read while rope[side] already describes the one being written
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
 	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
@@ -286,12 +293,12 @@ __device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, Ni
 // path, rope.c:139-146); a query sums the row in front of its slot, one 48-byte read per symbol.
 constexpr int DIRW = 8 * SB;            // 16-bit values per superblock
 __device__ __forceinline__ uint16_t *dir_row(const PoolView &pv, uint64_t sb, int row) { return (uint16_t*)pv.meta + sb * DIRW + row * SB; }
-__device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, int row, uint32_t k)   // sum of slots [0, k) of a row, k <= SP_USED
+__device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, int row, uint32_t k)   // sum of slots [0, k) of a row, k <= SB
 {
 	const uint4 *q = (const uint4*)dir_row(pv, sb, row);
-	uint32_t acc = 0;                                          // two 16-bit sums side by side (<= 12 * LEAF each)
+	uint32_t acc = 0;                                          // two 16-bit sums side by side (<= 16 * LEAF each)
 #pragma unroll
-	for (int i = 0; i < SP_USED / 8; ++i) {
+	for (int i = 0; i < SB / 8; ++i) {                           // all 32 slots: splits fill the reserve behind the first SP_USED
 		const uint4 v = q[i];
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -339,7 +346,7 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 	const uint4 *q = (const uint4*)dir_row(pv, rp.sb0 + lo, 0);
 	uint32_t run = 0, klo = 0, pre = 0, nk = 0;
 #pragma unroll
-	for (int i = 0; i < SP_USED / 8; ++i) {
+	for (int i = 0; i < SB / 8; ++i) {
 		const uint4 v = q[i];
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll

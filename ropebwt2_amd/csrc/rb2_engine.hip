@@ -163,6 +163,10 @@ struct rb2_hip_s {
 	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
 	DevBuf<uint16_t> RKREL;
 	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
+	DevBuf<uint32_t> SPL;               // sparse rounds: leaves to split at the end of the round (k_part_sparse -> k_split)
+	uint32_t split_epoch = 0;           // claim word of k_split: one value per in-place round, never repeated (rb2_kernels.h)
+	bool want_respread = false;         // k_split met a superblock without a free slot: re-spread (sparse -> sparse) before the next round
+	int64_t n_respread = 0;
 	DevBuf<uint64_t> qbuf;              // rank queries and their answers
 	uint64_t sp_nsb = 0;                // superblocks of the sparse pool (upper bound)
 	DevBuf<uint32_t> ID[2];
@@ -263,7 +267,7 @@ struct BatchState {
 void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m);
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
 	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
@@ -439,12 +443,16 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 // Sparse round: the strings of the batch touch few leaves, each touched leaf is rewritten where it lies (k_merge_leaf),
 // the rest of the index keeps its bytes.  Returns false when some leaf could not take its inserts: nothing was
 // changed (every kernel behind k_part_sparse saw ctl->overflow and returned) and the caller redoes the round densely.
-bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
+// send: sharded build -- the surviving strings are written as ShardRec for the exchange (round_merge).
+// spec: queue the counting phase of round r + 1 while the verdict of this round travels to the host (single-GPU path; a sharded
+// round cannot: its next counting phase needs the strings the other ranks send).
+bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send = nullptr, bool spec = true)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView pv = h->pool[h->pside].view();
+	if (++h->split_epoch == 0) ++h->split_epoch;
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -453,29 +461,34 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r)
 	  hipLaunchKernelGGL((k_prep<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p); }
+	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p);
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
 	  hipLaunchKernelGGL((k_advance<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, (ShardRec*)nullptr, (const uint32_t*)h->RKLEAF.p); }
-	// The verdict of the round (did every leaf fit?) travels to pinned host memory behind the last kernel.  While it is on its
-	// way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch, and a void round r is
-	// redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues the next merge.
-	if (!B.known_ae) ne_snapshot(h, r);
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
+	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
+	{ Scope sc(h, RB2_K_MERGE, 0);
+	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch); }
+	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
+	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
+	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
+	// the next merge.
+	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 8, hipMemcpyDeviceToHost, st));   // {overflow, sbfull}
 	HIPCHK(hipEventRecord(h->ev_flag, st));
 	h->side ^= 1; B.cur ^= 1;
-	const bool spec = r + 1 <= B.max_len;
-	if (spec) round_counts(h, B, r + 1);
+	const bool sp = spec && r + 1 <= B.max_len;
+	if (sp) round_counts(h, B, r + 1);
 	HIPCHK(hipEventSynchronize(h->ev_flag));
-	if (*h->h_flag) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
-	B.counted = spec ? r + 1 : (uint64_t)-1;
+	if (h->h_flag[0]) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
+	if (h->h_flag[1]) h->want_respread = true;
+	B.counted = sp ? r + 1 : (uint64_t)-1;
 	++h->n_sparse_rounds;
 	return true;
 }
@@ -488,8 +501,55 @@ void batch_end(rb2_hip_t *h)
 	drain_profile(h);
 }
 
-// Which regime is a round in?  lambda = strings of the batch / leaves of the index: the dense rewrite costs ~ the index, the
+// Which regime is a round in?  lambda = strings of the round / leaves of the index: the dense rewrite costs ~ the index, the
 // in-place round ~ the touched leaves (+ a search per string).  The host only knows upper bounds of both; that is enough.
+// m_eff: the strings this handle expects per round (the batch on one GPU; its share of it on a rank of a sharded index).
+// Changes the layout when the regime changes (dense <-> sparse) and re-spreads a sparse index whose superblocks ran out of slots.
+void choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
+{
+	const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
+	const double lambda = (double)m_eff / ((double)n_ub / LEAF + 1.0);
+	bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LPWV work orders, 2^32 threads per launch)
+	if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
+	if (h->sp_backoff > 0) --h->sp_backoff;
+	if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
+		const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
+		const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
+		size_t fr = 0, tot = 0;
+		double leaves_more = 0;                                // pools that grow in place need what is added (+ the 25 % margin of Pool::ensure); others a whole new buffer beside the old one
+		for (int k = 0; k < 2; ++k)
+			if (need > h->pool[k].cap_leaves) leaves_more += h->pool[k].data.vm_res ? 1.25 * (double)need - (double)h->pool[k].cap_leaves : (double)need * 1.25;
+		const double bytes = leaves_more * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);
+		if (grow && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
+			want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
+			if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
+		}
+	}
+	if (want != h->sparse) { relayout(h, want, n_ub, B.n_tot + B.len); h->want_respread = false; }
+	else if (h->sparse && h->want_respread) {               // a superblock ran out of slots: spread the index over fresh superblocks (sparse -> sparse)
+		if (h->trace) fprintf(stderr, "[rb2_hip] round %llu: re-spread (a superblock has no free slot left)\n", (unsigned long long)r);
+		relayout(h, true, n_ub, B.n_tot + B.len);
+		h->want_respread = false; ++h->n_respread;
+	}
+}
+
+// the merge phase of round r in whatever layout the index has (its counting phase is queued); a void in-place round is redone densely
+void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool spec)
+{
+	if (h->sparse) {
+		if (round_merge_sparse(h, B, r, send, spec)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; return; }
+		// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
+		++h->n_void;
+		if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
+		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);
+		relayout(h, false, n_ub, B.n_tot + B.len);
+		h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
+		h->sp_backoff = 1 << h->sp_penalty;
+		if (spec) round_counts(h, B, r);                       // the scratch of this round's counting phase was reused by the look-ahead
+	}
+	round_merge(h, B, r, send);
+}
+
 void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 {
 	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); abort(); }
@@ -501,41 +561,13 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
-		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
-		const double lambda = (double)B.m / ((double)n_ub / LEAF + 1.0);
-		bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LPWV work orders, 2^32 threads per launch)
-		if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
-		if (h->sp_backoff > 0) --h->sp_backoff;
-		if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
-			const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
-			const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
-			size_t fr = 0, tot = 0;
-			double leaves_more = 0;                                // pools that grow in place need what is added (+ the 25 % margin of Pool::ensure); others a whole new buffer beside the old one
-			for (int k = 0; k < 2; ++k)
-				if (need > h->pool[k].cap_leaves) leaves_more += h->pool[k].data.vm_res ? 1.25 * (double)need - (double)h->pool[k].cap_leaves : (double)need * 1.25;
-			const double bytes = leaves_more * (LEAFB + 2 * sizeof(LeafMeta) + 2.0) * 1.02 + (256u << 20);
-			if (grow && hipMemGetInfo(&fr, &tot) == hipSuccess && bytes > (double)fr) {
-				want = false; h->sp_backoff = 1 << 30;             // not again in this handle's lifetime
-				if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
-			}
-		}
-		if (want != h->sparse) relayout(h, want, n_ub, B.n_tot + B.len);
+		choose_layout(h, B, r, B.m);
 		if (B.counted != r) round_counts(h, B, r);
-		if (h->sparse) {
-			if (round_merge_sparse(h, B, r)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; continue; }
-			// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
-			++h->n_void;
-			if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
-			relayout(h, false, n_ub, B.n_tot + B.len);
-			h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
-			h->sp_backoff = 1 << h->sp_penalty;
-			round_counts(h, B, r);                                 // the scratch of this round's counting phase was reused by the look-ahead
-		}
-		round_merge(h, B, r, nullptr);
+		round_merge_any(h, B, r, nullptr, true);
 	}
 	batch_end(h);
-	if (h->trace) fprintf(stderr, "[rb2_hip] batch done: layout %s, relayouts %lld, void sparse rounds %lld, sparse rounds %lld\n", h->sparse ? "sparse" : "dense",
-			(long long)h->n_relayout, (long long)h->n_void, (long long)h->n_sparse_rounds);
+	if (h->trace) fprintf(stderr, "[rb2_hip] batch done: layout %s, relayouts %lld (of them re-spreads %lld), void sparse rounds %lld, sparse rounds %lld\n", h->sparse ? "sparse" : "dense",
+			(long long)h->n_relayout, (long long)h->n_respread, (long long)h->n_void, (long long)h->n_sparse_rounds);
 }
 
 // the batch must end with a sentinel (mrope.c:268): bytes after the last 0 would be sized for but never inserted
@@ -600,7 +632,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->qbuf.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
@@ -1132,6 +1164,16 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4])
 {
 	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
+}
+
+void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
+{
+	uint64_t ns = 0;
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipMemcpyAsync(&ns, &h->ctl->nsplit_total, 8, hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
+	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = out[7] = 0;
 }
 
 void rb2_hip_sync(rb2_hip_t *h) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }

@@ -477,7 +477,7 @@ template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, i
 {
 	if (blockIdx.x) return;
 	const int r = threadIdx.x;
-	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; }   // ne: k_advance / k_unpack of this round count into it
+	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_unpack of this round count into it
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD)
+__global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	__shared__ uint64_t s_gl[STILE + 1];
 	const TileFix &tfx = tf[blockIdx.x];
@@ -828,6 +828,10 @@ __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolVie
 		d.i0 = lc[h].s; d.ins0 = g; d.gl = lc[h].gl; d.oleaf0 = 0;
 		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)min(lc[h].n + ni, (uint64_t)LEAF);
 		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = 1;  // the leaf cannot take them: void round
+		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)
+			const uint32_t e = atomicAdd(&ctl->nsplit, 1u);
+			if (e < spl_cap) SPL[e] = (uint32_t)lc[h].gl;
+		}
 		LD[off++] = d;
 	}
 }
@@ -932,6 +936,89 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_split: the leaf split of a B+ tree (split_node, rope.c:78-112: "move the upper half of a full leaf to a new sibling, shift the
+// parent's entries"), for the sparse layout.  Runs as the LAST kernel of an in-place round -- nothing else touches the pool then,
+// and every number the round handed out (RKLEAF, RKREL, the work orders) has been consumed.  k_part_sparse listed the leaves
+// whose fill exceeds LEAF - SP_MARGIN; one wave per listed leaf, but only the first wave to CLAIM the leaf's superblock acts (an
+// atomic exchange of this round's epoch into the spare directory row 7), and does all of that superblock's splits: slots behind a split leaf move up by one (from the last one down), the split leaf
+// keeps its first h symbols (h = a whole number of words, about half) and hands the rest to the slot behind it, and the directory
+// rows (fills + own counts) are rewritten to match.  The superblock's total does not change: sbcum / sbpos stay valid.
+// A marked leaf in a superblock without a free slot sets ctl->sbfull: the host re-spreads the index before the next round.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */)
+{
+	__shared__ uint16_t s_row[MW][7][SB];
+	if (ctl->overflow) return;                                   // void round: nothing was inserted
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int ln = lane_id();
+	const uint32_t nsp_all = min(ctl->nsplit, spl_cap);
+	if (ctl->nsplit > spl_cap && blockIdx.x == 0 && threadIdx.x == 0) ctl->sbfull = 1;   // list overflow (never in practice): re-spread
+	for (uint32_t e = blockIdx.x * MW + wv; e < nsp_all; e += gridDim.x * MW) {
+		const uint64_t gl = SPL[e], sb = gl / SB;
+		uint32_t mine = 0;
+		if (ln == 0) mine = atomicExch((uint32_t*)dir_row(pool, sb, 7), epoch) != epoch;
+		if (!__shfl((int)mine, 0)) continue;                     // a wave that came earlier does (or did) this superblock
+		uint16_t v[7];
+#pragma unroll
+		for (int r = 0; r < 7; ++r) v[r] = ln < SB ? dir_row(pool, sb, r)[ln] : (uint16_t)0;
+		const uint32_t used = (uint32_t)__popcll(__ballot(ln < SB && v[0] > 0));
+		uint32_t marked = (uint32_t)__ballot(ln < SB && v[0] > (uint16_t)(LEAF - SP_MARGIN));
+		if (marked == 0) continue;
+		const uint32_t room = SB - used;
+		if ((uint32_t)__popc(marked) > room) {
+			if (ln == 0) ctl->sbfull = 1;
+			while ((uint32_t)__popc(marked) > room) marked &= ~(1u << (31 - __builtin_clz(marked)));   // split the lowest ones that fit
+			if (marked == 0) continue;
+		}
+		const uint32_t first = (uint32_t)__builtin_ctz(marked);
+		uint16_t (*R)[SB] = s_row[wv];
+		// directory entries of the slots that only move (or stay): lane j = old slot j
+		if (ln < (int)used && !((marked >> ln) & 1u)) {
+			const uint32_t nj = (uint32_t)ln + (uint32_t)__popc(marked & ((1u << ln) - 1u));
+#pragma unroll
+			for (int r = 0; r < 7; ++r) R[r][nj] = v[r];
+		}
+		uint64_t *leaves = (uint64_t*)pool.data + sb * SB * LEAFW;
+		for (int k = (int)used - 1; k >= (int)first; --k) {      // from the last slot down: a target slot has always been read already
+			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
+			const bool split = (marked >> k) & 1u;
+			if (!split && nk == (uint32_t)k) continue;
+			const uint64_t w = leaves[(uint64_t)k * LEAFW + ln];
+			if (!split) { leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
+			uint32_t n = 0, ck[6];
+			n = (uint32_t)__shfl((int)v[0], k);
+#pragma unroll
+			for (int s = 0; s < 6; ++s) ck[s] = (uint32_t)__shfl((int)v[1 + s], k);
+			const uint32_t hw = (n / 2) / SPW, h = hw * SPW;        // the first hw words stay
+			NibAcc A;
+			nib_acc(A, w, (uint32_t)ln < hw ? MLOW : 0ull);
+			const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
+			NibAcc T;
+			T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
+			uint32_t c1[6];
+			nib_finish(T, h, c1);
+			const uint64_t up = (uint64_t)__shfl((unsigned long long)w, (ln + (int)hw) & 63);   // word ln + hw of the old leaf
+			leaves[(uint64_t)(nk + 1) * LEAFW + ln] = (uint32_t)ln + hw < (uint32_t)LEAFW ? up : 0ull;
+			leaves[(uint64_t)nk * LEAFW + ln] = (uint32_t)ln < hw ? w : 0ull;
+			if (ln == 0) {
+				R[0][nk] = (uint16_t)h; R[0][nk + 1] = (uint16_t)(n - h);
+#pragma unroll
+				for (int s = 0; s < 6; ++s) { R[1 + s][nk] = (uint16_t)c1[s]; R[1 + s][nk + 1] = (uint16_t)(ck[s] - c1[s]); }
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+		const uint32_t nused = used + (uint32_t)__popc(marked);
+		if (ln == 0) atomicAdd((unsigned long long*)&ctl->nsplit_total, (unsigned long long)__popc(marked));
+		if ((uint32_t)ln >= first && (uint32_t)ln < nused) {
+#pragma unroll
+			for (int r = 0; r < 7; ++r) dir_row(pool, sb, r)[ln] = R[r][ln];
+		}
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // R is reused by the wave's next entry
+	}
+}
+
 } // namespace rb2
 #include "rb2_merge.h"
 namespace rb2 {
@@ -976,6 +1063,7 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 			dr[0] = m.n;
 #pragma unroll
 			for (int s = 0; s < 6; ++s) dr[(1 + s) * SB] = m.c[s];
+			dr[7 * SB] = 0;                                        // spare row: the claim word of k_split
 		}
 	} else if (ok) {
 		m.c[0] = (uint16_t)x01; m.c[1] = (uint16_t)(x01 >> 16); m.c[2] = (uint16_t)x23; m.c[3] = (uint16_t)(x23 >> 16);

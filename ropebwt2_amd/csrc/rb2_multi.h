@@ -197,6 +197,7 @@ struct rb2_hip_multi_s {
 	std::vector<MRank> rk;
 	SpinBarrier bar;
 	int64_t n_sync = 0, n_rounds = 0, n_batches = 0;
+	int active = 1;                         // ranks that own one of the 16 heavy pieces
 	int trace = 0;
 	int rccl_self = 0;                      // RB2_RCCL_SELF=1: a rank's own block travels through ncclSend / ncclRecv too (exercises librccl on a one-GPU box)
 };
@@ -220,10 +221,14 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	HIPCHK(hipSetDevice(R.dev));
 	hipStream_t st = h->st;
 	const bool peer = m->transport == RB2_TRANSPORT_PEER;
-	ensure_dense(h);                                           // (in-place rounds on a sharded index: round_merge_sparse below decides per round)
 	BatchState &B = R.B;
 	B = BatchState();
 	batch_begin(h, B, len, R.s_dev);
+	// the layout of this rank's slice follows ITS regime: strings it expects per round against the leaves it holds (choose_layout);
+	// the first rounds of a batch are hot spots by construction (see insert_dev)
+	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
+	const uint64_t m_eff = std::max<uint64_t>(1, B.m / (uint64_t)std::max(1, m->active) + B.m / (uint64_t)(4 * std::max(1, m->active)));
+	const int64_t sp0 = h->n_sparse_rounds + h->n_void;
 	// exchange buffers: a rank never holds (or receives) more strings than the batch has.  They are (re)allocated between
 	// batches only, and the peers learn the new addresses behind the barrier below.
 	multi_ensure_exchange(m, R, B.m);
@@ -250,7 +255,10 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			HIPCHK(hipEventRecord(R.evG, st));
 		}
 		hipLaunchKernelGGL(k_mlayout, dim3(1), dim3(256), 0, st, h->ctl, (const uint64_t*)h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab);
-		round_merge(h, B, r, R.send[r & 1]);                      // flips side / cur: B.cur now names next round's arrays
+		// dense round: the slice is rewritten pool -> pool; in-place round: only the touched leaves, and the host reads a one-word
+		// verdict before the exchange may go ahead (a void round is redone densely: its records do not exist yet)
+		choose_layout(h, B, r, m_eff);
+		round_merge_any(h, B, r, R.send[r & 1], false);           // flips side / cur: B.cur now names next round's arrays
 		if (peer) {
 			HIPCHK(hipEventRecord(R.evB, st));
 			m->bar.wait();                                        // every evB of this round is recorded
@@ -289,7 +297,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	}
 	h->gcnt = R.gloc;
 	batch_end(h);                                                // the one synchronisation of the batch (+ two in batch_begin)
-	if (k == 0) { m->n_rounds += (int64_t)B.max_len + 1; ++m->n_batches; }
+	if (k == 0) { m->n_rounds += (int64_t)B.max_len + 1; ++m->n_batches; m->n_sync += h->n_sparse_rounds + h->n_void - sp0; }
 	m->bar.wait();
 }
 
@@ -311,6 +319,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 	m->rccl_self = getenv("RB2_RCCL_SELF") ? atoi(getenv("RB2_RCCL_SELF")) : 0;
 	if (owner) { for (int r = 0; r < NR; ++r) m->owner[r] = owner[r]; } else rb2_hip_default_owners(world, m->owner);
 	for (int r = 0; r < NR; ++r) if (m->owner[r] < 0 || m->owner[r] >= world) { fprintf(stderr, "[rb2_hip] multi: bad owner of sub-rope %d\n", r); abort(); }
+	{ bool seen[RB2_MULTI_MAX_RANKS] = {false}; m->active = 0; for (int r = 1; r < NR; ++r) if (!seen[m->owner[r]]) { seen[m->owner[r]] = true; ++m->active; } }
 	m->bar.n = n;
 	m->rk.resize(n);
 	for (int k = 0; k < n; ++k) {
@@ -490,9 +499,7 @@ void rb2_hip_multi_load_ropes(rb2_hip_multi_t *m, const uint8_t *const rle[6], c
 
 void rb2_hip_multi_reserve(rb2_hip_multi_t *m, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols)
 {
-	int active = 0;
-	{ bool seen[RB2_MULTI_MAX_RANKS] = {false}; for (int r = 1; r < NR; ++r) if (!seen[m->owner[r]]) { seen[m->owner[r]] = true; ++active; } }
-	const int64_t share = total_symbols > 0 ? (int64_t)((double)total_symbols * 1.25 / std::max(1, active)) : 0;
+	const int64_t share = total_symbols > 0 ? (int64_t)((double)total_symbols * 1.25 / std::max(1, m->active)) : 0;
 	multi_each(m, [&](int k) { rb2_hip_reserve(m->rk[k].h, batch_bytes, batch_strings, share); });
 }
 

@@ -58,6 +58,7 @@ def load_hip_lib():
         "rb2_hip_synth_reads_cov": (None, [vp, vp, i64, i64, i32, u64, i32, i64]),
         "rb2_hip_sync": (None, [vp]),
         "rb2_hip_sparse_stats": (None, [vp, vp]),
+        "rb2_hip_layout_stats": (None, [vp, vp]),
         "rb2_hip_profile": (None, [vp, i32]),
         "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
         "rb2_hip_kernel_name": (C.c_char_p, [i32]),
@@ -99,7 +100,7 @@ ABI_SYMBOLS = [
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
-    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_profile",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
@@ -235,6 +236,12 @@ class HipBwt:
         a = np.zeros(4, np.int64)
         self.L.rb2_hip_sparse_stats(self.h, a.ctypes.data)
         return {"relayouts": int(a[0]), "void_rounds": int(a[1]), "sparse_rounds": int(a[2]), "sparse_now": bool(a[3])}
+
+    def layout_stats(self):
+        a = np.zeros(8, np.int64)
+        self.L.rb2_hip_layout_stats(self.h, a.ctypes.data)
+        return {"relayouts": int(a[0]), "void_rounds": int(a[1]), "sparse_rounds": int(a[2]), "sparse_now": bool(a[3]),
+                "respreads": int(a[4]), "leaf_splits": int(a[5])}
 
     def profile(self, on=True):
         self.L.rb2_hip_profile(self.h, 1 if on else 0)
