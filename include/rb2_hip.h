@@ -23,7 +23,12 @@
  *   - fewer than 2^32 - 1024 strings per batch (string ids are 32 bit on the device; ropebwt2's default -m10g holds at most
  *     ~10^10 one-symbol strings, so this only excludes batches of degenerate reads);
  *   - positions inside one sub-rope below 2^48 (the sharded wire format packs l into 48 bits, rb2_device.h ShardRec);
- *   - at most 64 ranks in the sharded protocol (31 sub-ropes exist; more than 16 ranks carry no additional load on DNA);
+ *   - at most 64 ranks in the sharded protocol (RB2_MULTI_MAX_RANKS; 31 sub-ropes exist; more than 16 ranks carry no additional load on DNA);
+ *   - one dense merge launch covers at most 2^32 threads = 2^26 windows of 5376 symbols: about 360 G symbols per GPU and round
+ *     (checked per round, with a message); larger indexes are what the sharded build is for;
+ *   - in-place (sparse) rounds are used for batches of fewer than 2^27 strings (one wave per four touched leaves in one launch);
+ *     larger batches simply stay on the dense path -- a performance boundary, not an error;
+ *   - leaf slots of one pool are addressed with 32 bits in the sparse layout (RKLEAF, the split list): 2^32 slots = 4.3 T symbols;
  *   - symbols must be nt6 codes 0..5, the buffer must end with a sentinel (mrope.c:268);
  *   - the index lives in HBM: 2 x 0.38 B per symbol (dense layout) plus ~100 B per string of the batch; running out of device
  *     memory reports the size that was needed.
@@ -61,6 +66,15 @@ void rb2_hip_reset(rb2_hip_t *h);
 /* mr_insert_multi (mrope.c:258): insert all strings of `s` (concatenated, each REVERSED and
  * 0-terminated, nt6 codes 0..5, s[len-1]==0).  `s` is a host buffer, borrowed for the call. */
 void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s);
+
+/* optional: bytes [0, n_final) of the buffer a LATER rb2_hip_insert_multi(h, len >= n_final, s) will pass are final -- start
+ * uploading them now (copy stream, second text buffer), concurrently with an insert running on another thread.  capacity = the
+ * largest len that call may have.  `s` must stay where it is until that call; s == NULL cancels (waits for copies in flight:
+ * call it before reallocating or freeing a buffer that was announced).  (The reference reads and inserts in one thread,
+ * main.c:238-242; this is what lets the PCIe crossing of batch k+1 hide behind the insertion of batch k.) */
+void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t capacity);
+/* free / total memory of a device in bytes (0, 0 without a usable GPU; never aborts): what `ropebwt2 -m auto` sizes its batches from */
+void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 /* same, but `s_dev` already resides in this device's HBM (no PCIe transfer in the call) */
 void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev);
@@ -188,7 +202,9 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
  * one-word verdict before its exchange; RCCL: one event wait per round, behind the reduce only), out[1] rounds, out[2] batches,
  * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
-uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);   /* == rb2_hip_rope_hash of the same rope on one engine */
+uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);
+/* the device-side exchange plan (k_mlayout) evaluated on the host, for tests: see csrc/rb2_multi.h */
+int rb2_hip_multi_plan_host(const int *owner /* [NR] */, int nranks, const int64_t *g /* [NR*6] */, int me, int64_t *sdest /* [NR*6] */, int64_t (*pieces)[5] /* [NR*6] */, int64_t *total);   /* == rb2_hip_rope_hash of the same rope on one engine */
 
 /* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */
 

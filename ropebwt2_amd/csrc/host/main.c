@@ -341,6 +341,25 @@ static int usage(int block_len, int max_nodes)
 	return 1;
 }
 
+/* ---- the batch buffer travels to the device while it is being filled (mr_prefetch): every PF_STEP bytes the reader announces what
+ * is final so far.  The device copy reads the host buffer asynchronously, so the buffer must not move: it is reserved at its full
+ * size when the batch starts, and an append that would outgrow it (one giant record) cancels the announcements first. ---- */
+#define PF_STEP ((size_t)256 << 20)
+static struct { size_t sent; int on; int64_t cap; } PF = { 0, 0, 0 };
+
+static void batch_room(mrope_t *mr, str_t *buf, int64_t m, size_t add)
+{
+	if (!PF.on) return;
+	if (buf->l == 0 && buf->m < (size_t)m + (64 << 20)) { mr_prefetch(mr, 0, 0, 0); str_reserve(buf, (size_t)m + (64 << 20)); PF.sent = 0; }
+	if (buf->l + add + 1 > buf->m) { mr_prefetch(mr, 0, 0, 0); PF.sent = (size_t)-1; }      /* it will move: no announcements for the rest of this batch */
+}
+static void batch_announce(mrope_t *mr, str_t *buf)
+{
+	if (!PF.on || PF.sent == (size_t)-1 || buf->l < PF.sent + PF_STEP) return;
+	mr_prefetch(mr, (const uint8_t*)buf->s, (int64_t)buf->l, (int64_t)buf->m);
+	PF.sent = buf->l;
+}
+
 static void flush_batch_now(mrope_t *mr, str_t *buf, int flag, int verbose)
 {
 	const double c0 = cputime(), r0 = realtime();
@@ -410,7 +429,7 @@ static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
 	pthread_mutex_lock(&AF.mu);
 	while (AF.busy) pthread_cond_wait(&AF.cv, &AF.mu);       /* the batch before this one */
 	t = AF.job; AF.job = *buf; *buf = t;                       /* the reader goes on in the buffer the inserter is done with */
-	buf->l = 0;
+	buf->l = 0; PF.sent = 0;
 	AF.mr = mr; AF.flag = flag; AF.verbose = verbose; AF.busy = 1;
 	pthread_cond_broadcast(&AF.cv);
 	pthread_mutex_unlock(&AF.mu);
@@ -422,6 +441,7 @@ int main(int argc, char *argv[])
 	FILE *fp_restore = 0;
 	reader_t *rd;
 	int64_t m = (int64_t)(.97 * 10 * 1024 * 1024 * 1024) + 1;   /* main.c:94 */
+	int m_auto = 0;
 	int c, i, block_len = ROPE_DEF_BLOCK_LEN, max_nodes = ROPE_DEF_MAX_NODES, verbose = 3, so = MR_SO_IO, min_q = 0, thr_min = -1, min_cut = 0;
 	int flag = F_FOR | F_REV | F_THR, ret = 0;
 	str_t buf = { 0, 0, 0 };
@@ -457,7 +477,9 @@ int main(int argc, char *argv[])
 			fp_restore = fp;
 			break; }
 		case 'm': {
-			char *p; double x = strtod(optarg, &p);
+			char *p; double x;
+			if (strcmp(optarg, "auto") == 0) { m_auto = 1; break; }   /* rb2 extension: sized from the device's free memory once the index exists */
+			x = strtod(optarg, &p);
 			if (*p == 'K' || *p == 'k') x *= 1024;
 			else if (*p == 'M' || *p == 'm') x *= 1024 * 1024;
 			else if (*p == 'G' || *p == 'g') x *= 1024 * 1024 * 1024;
@@ -476,6 +498,10 @@ int main(int argc, char *argv[])
 
 	nt6_init();
 	if (mr == 0) mr = mr_init(max_nodes, block_len, so);
+	if (m_auto) {
+		m = (int64_t)(mr_auto_batch_bytes(mr) * .97) + 1;
+		if (verbose >= 3) fprintf(stderr, "[M::%s] -m auto: batches of %.1f GiB\n", "main_ropebwt2", m / .97 / 1073741824.0);
+	}
 	if (thr_min > 0) mr_thr_min(mr, thr_min);
 	rd = (reader_t*)calloc(1, sizeof(reader_t));
 	rd->fp = optind < argc && strcmp(argv[optind], "-") ? gzopen(argv[optind], "rb") : gzdopen(fileno(stdin), "rb");
@@ -495,6 +521,7 @@ int main(int argc, char *argv[])
 	enc_cfg_t cfg;
 	long pthr = sysconf(_SC_NPROCESSORS_ONLN) - 1;
 	cfg.flag = flag; cfg.min_q = min_q; cfg.min_cut = min_cut; cfg.batch = m != 0;
+	PF.on = m >= (int64_t)(2 * PF_STEP) && !getenv("RB2_DUMP_BATCHES") && !getenv("RB2_SYNC_INSERT") && !getenv("RB2_NO_PREFETCH");   /* batches worth announcing */
 	if (getenv("RB2_PARSE_THREADS")) pthr = atol(getenv("RB2_PARSE_THREADS"));
 	if (pthr > 16) pthr = 16;
 	if ((flag & F_LINE) && m && pthr > 1) {                 /* -L in batch mode: blocks of whole lines encoded by worker threads */
@@ -521,8 +548,9 @@ int main(int argc, char *argv[])
 				size_t lo = r0, hi = jb->n_rec;                 /* first record whose end reaches the threshold */
 				const int64_t need = m - (int64_t)buf.l;
 				while (lo < hi) { const size_t mid = (lo + hi) >> 1; if ((int64_t)(jb->rec_end[mid] - done) >= need) hi = mid; else lo = mid + 1; }
-				if (lo == jb->n_rec) { str_append(&buf, jb->out.s + done, jb->out.l - done); done = jb->out.l; }
+				if (lo == jb->n_rec) { batch_room(mr, &buf, m, jb->out.l - done); str_append(&buf, jb->out.s + done, jb->out.l - done); done = jb->out.l; batch_announce(mr, &buf); }
 				else {
+					batch_room(mr, &buf, m, jb->rec_end[lo] - done);
 					str_append(&buf, jb->out.s + done, jb->rec_end[lo] - done); done = jb->rec_end[lo]; r0 = lo + 1;
 					flush_batch(mr, &buf, flag, verbose);
 				}
@@ -544,8 +572,10 @@ int main(int argc, char *argv[])
 		int l = prepare_record(&cfg, s, (int)rd->seq.l, rd->qual.s, (int)rd->qual.l);
 		if (l < 0) continue;
 		if (m) {
+			batch_room(mr, &buf, m, 2 * ((size_t)l + 1));
 			append_strands(&cfg, s, l, &buf);
 			if ((int64_t)buf.l >= m) flush_batch(mr, &buf, flag, verbose);
+			else batch_announce(mr, &buf);
 		} else {
 			if (flag & F_FOR) mr_insert1(mr, s);
 			if (flag & F_REV) { revcomp_in_place(s, l); mr_insert1(mr, s); }

@@ -48,7 +48,15 @@ static int device_id(void)
  * peer (default: peer access + device events inside this process) | rccl (RCCL's C API). */
 static int has_dev(const mrx_t *x) { return x->dev != 0 || x->mdev != 0; }
 
+static pthread_mutex_t g_dev_mu = PTHREAD_MUTEX_INITIALIZER;      /* mr_prefetch (reader thread) and mr_insert_multi (inserter thread) may both be first */
+static void dev_create_locked(mrx_t *x);
 static void dev_create(mrx_t *x)
+{
+	pthread_mutex_lock(&g_dev_mu);
+	dev_create_locked(x);
+	pthread_mutex_unlock(&g_dev_mu);
+}
+static void dev_create_locked(mrx_t *x)
 {
 	const char *e = getenv("RB2_HIP_DEVICES"), *t = getenv("RB2_HIP_TRANSPORT");
 	int devs[RB2_MULTI_MAX_RANKS], n = 0;
@@ -123,6 +131,30 @@ void mr_reserve(mrope_t *mr, int64_t batch_bytes, int64_t total_symbols)
 	dev_create(x);
 	if (x->mdev) rb2_hip_multi_reserve(x->mdev, batch_bytes, 0, total_symbols);
 	else rb2_hip_reserve(x->dev, batch_bytes, 0, total_symbols);
+}
+
+/* rb2 extension: the caller is still filling the buffer it will pass to mr_insert_multi next; bytes [0, n_final) are final
+ * (rb2_hip_prefetch).  A no-op on a sharded index (every device takes its own copy inside the call). */
+void mr_prefetch(mrope_t *mr, const uint8_t *s, int64_t n_final, int64_t capacity)
+{
+	mrx_t *x = X(mr);
+	dev_create(x);
+	if (x->dev) rb2_hip_prefetch(x->dev, s, n_final, capacity);
+}
+
+/* rb2 extension (`ropebwt2 -m auto`): a batch size in bytes that the device holding this index can take comfortably -- about an
+ * eighth of its free memory (a batch costs ~2.2 bytes of HBM per byte: text, 100 B of state per string, merge scratch; the index
+ * itself 0.76 B per symbol), between 1 and 40 GiB.  The BWT does not depend on the batch size. */
+int64_t mr_auto_batch_bytes(mrope_t *mr)
+{
+	int64_t fr = 0, tot = 0, m;
+	const char *e = getenv("RB2_HIP_DEVICES");
+	(void)mr;
+	rb2_hip_mem_info(e && *e ? atoi(e) : device_id(), &fr, &tot);
+	m = fr / 8;
+	if (m > ((int64_t)40 << 30)) m = (int64_t)40 << 30;
+	if (m < ((int64_t)1 << 30)) m = (int64_t)1 << 30;
+	return m;
 }
 
 /* ---- host <-> device ------------------------------------------------------------------------- */

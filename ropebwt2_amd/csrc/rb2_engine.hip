@@ -11,6 +11,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include "rb2_hip.h"
 #include "rb2_kernels.h"
 
@@ -172,6 +173,8 @@ struct rb2_hip_s {
 	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
+	// rb2_hip_prefetch: the NEXT batch travels to the device (second text buffer, copy stream) while the current one is inserted
+	DevBuf<uint8_t> sbuf2; hipStream_t st_copy = nullptr; const uint8_t *pf_host = nullptr; size_t pf_done = 0; std::mutex pf_mu;
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<TileFix> tfix; DevBuf<ChunkPart> cpart;
 	DevBuf<SbTot> sbtot; DevBuf<Cnt6> sbpart;
 	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
@@ -187,6 +190,7 @@ struct rb2_hip_s {
 	int async_proto = 0; bool own_stream = true;
 	uint64_t *pin_sd = nullptr; ShardPiece *pin_pcs = nullptr;   // pinned staging of the per-round exchange layout (async protocol)
 	int rank = 0, nranks = 1; int owner[NR] = {0};
+	int nactive = 1;                    // ranks that own a sub-rope other than rope $ (sizes the grids of a sharded rank: tile_grid)
 	void *batch = nullptr;              // BatchState of a sharded batch in flight
 	DevBuf<ShardPiece> pieces;
 	DevBuf<uint8_t> xstage, xpack; DevBuf<uint16_t> xnb; DevBuf<uint64_t> xoff;   // k_export staging, packed bytes, chunk offsets
@@ -231,16 +235,28 @@ void drain_profile(rb2_hip_t *h)
 
 inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// Grids of a rank of a sharded index.  The host knows the batch (m strings, len symbols), not the rank's share of it this round --
+// asking would cost a synchronisation per round.  The upper bound "all of it" makes every launch N times too large: at N = 8
+// (weak scaling, 327 M strings) 640 k workgroups per tile kernel of which 80 k find a tile -- empty workgroups alone then cost
+// more than a millisecond per round.  The kernels walk their work with a grid stride, so the grid is a hint: twice the fair
+// share (+ slack); a rank that holds more than that loops.  One GPU: the exact upper bound, one tile per block as before.
+inline uint64_t rank_share(const rb2_hip_t *h, uint64_t whole)
+{
+	if (h->nranks <= 1) return whole;
+	return std::min<uint64_t>(whole, 2 * whole / (uint64_t)std::max(1, h->nactive) + 64);
+}
+
 // recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
-void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false)
+void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false, uint64_t nsb_grid = 0)
 {
 	if (nsb_ub == 0) return;
+	if (nsb_grid == 0 || nsb_grid > nsb_ub) nsb_grid = nsb_ub;    // k_meta_sb walks the superblocks with a grid stride (rank_share); the scans need the true bound
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
 	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
 	PoolView pv = h->pool[pool].view();
 	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
 	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
-	if (!leaves_done) hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_ub, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
+	if (!leaves_done) hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
 	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);
@@ -348,7 +364,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	const int64_t units = (int64_t)B.m;
 	h->cur_round = (int)r;
 	{ Scope sc(h, RB2_K_SYM, units);
-	  hipLaunchKernelGGL(k_sym, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+	  hipLaunchKernelGGL(k_sym, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
 	if (B.nst_ub <= 4 * SCHUNK) {                              // few tiles (long reads): one single-block launch instead of five
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  hipLaunchKernelGGL(k_tscan_fused, dim3(1), dim3(SCHUNK), 0, st, (const Ctl*)h->ctl, sd, (const TileRec*)h->trec.p, h->tsc.p, h->tfix.p, h->gcnt);
@@ -372,24 +388,26 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
+	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);      // string tiles / output windows this handle launches blocks for (rank_share)
+	const unsigned wg = cdiv(B.n_tot + rank_share(h, std::min<uint64_t>(B.len, (r + 1) * B.m)), WIN) + NR;
 	if ((uint64_t)nlf * 64 >= (1ull << 32)) { fprintf(stderr, "[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); abort(); }
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  hipLaunchKernelGGL((k_prep<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  hipLaunchKernelGGL((k_prep<true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part, dim3(cdiv(nlf + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
+	  hipLaunchKernelGGL(k_part, dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge, dim3(cdiv(nlf, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
+	  hipLaunchKernelGGL(k_merge, dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
 	{ Scope sc(h, RB2_K_META, units);
-	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1)); }
+	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
-	  hipLaunchKernelGGL((k_advance<true, false>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  hipLaunchKernelGGL((k_advance<true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
@@ -452,24 +470,25 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView pv = h->pool[h->pside].view();
+	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);
 	if (++h->split_epoch == 0) ++h->split_epoch;
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  hipLaunchKernelGGL((k_prep<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  hipLaunchKernelGGL((k_prep<true, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part_sparse, dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
+	  hipLaunchKernelGGL(k_part_sparse, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(B.m, MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
-	  hipLaunchKernelGGL((k_advance<true, true>), dim3(B.nst_ub), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  hipLaunchKernelGGL((k_advance<true, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
 	{ Scope sc(h, RB2_K_MERGE, 0);
@@ -633,7 +652,8 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
-	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release();
+	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
+	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
@@ -671,10 +691,59 @@ void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 	insert_dev(h, len, s_dev);
 }
 
+/* The caller is still assembling the batch it will pass to rb2_hip_insert_multi next: bytes [0, n_final) of `s` are final.
+ * Upload what is new since the last call on a copy stream, into a second text buffer -- concurrently with whatever the handle is
+ * inserting on another thread (the CLI's reader thread calls this while its inserter thread is inside mr_insert_multi for the
+ * previous batch): when the batch is handed over, only its tail still has to cross PCIe.  `capacity` = the largest size the
+ * batch may reach (the device buffer must not move once bytes are in it).  The buffer `s` must not be reallocated or freed
+ * between the first prefetch and the insert.  Entirely optional: an insert of a buffer that was not prefetched uploads all of it. */
+void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t capacity)
+{
+	std::lock_guard<std::mutex> lk(h->pf_mu);
+	HIPCHK(hipSetDevice(h->dev));
+	if (!h->st_copy) HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
+	if (s == nullptr) {                                          // cancel: the caller is about to move or free the buffer -- no copy may still read it
+		HIPCHK(hipStreamSynchronize(h->st_copy));
+		h->pf_host = nullptr; h->pf_done = 0;
+		return;
+	}
+	if (h->pf_host != s) { h->pf_host = s; h->pf_done = 0; }
+	if (n_final <= (int64_t)h->pf_done) return;
+	const size_t need = (size_t)std::max(n_final, capacity) + 64;
+	if (need > h->sbuf2.cap) {                                  // (first call of a batch, normally; a moved buffer starts over)
+		HIPCHK(hipStreamSynchronize(h->st_copy));
+		h->sbuf2.ensure(need);
+		h->pf_done = 0;
+	}
+	HIPCHK(hipMemcpyAsync(h->sbuf2.p + h->pf_done, s + h->pf_done, (size_t)n_final - h->pf_done, hipMemcpyHostToDevice, h->st_copy));
+	h->pf_done = (size_t)n_final;
+}
+
+void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
+{
+	size_t fr = 0, tot = 0;
+	if (rb2_hip_device_count() <= device || hipSetDevice(device) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { fr = tot = 0; (void)hipGetLastError(); }
+	if (free_bytes) *free_bytes = (int64_t)fr;
+	if (total_bytes) *total_bytes = (int64_t)tot;
+}
+
 void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
+	{	// (most of) the batch is on the device already?  (rb2_hip_prefetch)
+		std::unique_lock<std::mutex> lk(h->pf_mu);
+		if (h->pf_host == s && h->pf_done > 0 && (int64_t)h->pf_done <= len && h->sbuf2.cap >= (size_t)len + 64) {
+			if ((size_t)len > h->pf_done) HIPCHK(hipMemcpyAsync(h->sbuf2.p + h->pf_done, s + h->pf_done, (size_t)len - h->pf_done, hipMemcpyHostToDevice, h->st_copy));
+			HIPCHK(hipStreamSynchronize(h->st_copy));
+			std::swap(h->sbuf, h->sbuf2);                           // the previous batch's text is dead: it becomes the target of the next prefetch
+			h->pf_host = nullptr; h->pf_done = 0;
+			lk.unlock();
+			insert_dev(h, len, h->sbuf.p);
+			return;
+		}
+		if (h->pf_host == s) { h->pf_host = nullptr; h->pf_done = 0; }
+	}
 	h->sbuf.ensure((size_t)len + 64);
 	HIPCHK(hipMemcpyAsync(h->sbuf.p, s, (size_t)len, hipMemcpyHostToDevice, h->st));
 	insert_dev(h, len, h->sbuf.p);
@@ -886,6 +955,7 @@ void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 		h->owner[r] = owner[r]; own[r] = owner[r] == rank;
 	}
 	h->rank = rank; h->nranks = nranks;
+	{ bool seen[64] = {false}; h->nactive = 0; for (int r = 1; r < NR; ++r) if (owner[r] < 64 && !seen[owner[r]]) { seen[owner[r]] = true; ++h->nactive; } if (h->nactive < 1) h->nactive = 1; }
 	HIPCHK(hipMemcpyAsync(&h->ctl->own[0], own, sizeof(own), hipMemcpyHostToDevice, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 }

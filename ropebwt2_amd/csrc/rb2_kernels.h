@@ -189,13 +189,20 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 }
 
 // When every interval of the round is empty (u == l, ctl->ne[par] == 0) U is dead and L is read in its place.
+// Tile kernels (k_sym, k_prep, k_part_sparse, k_advance) walk the string tiles with a GRID STRIDE: on one GPU the grid covers every
+// tile the round can have and a block runs one; a rank of a sharded index launches about twice its fair share of the batch's
+// tiles (the host cannot know how many strings the rank holds this round without asking the device) and a block takes more
+// tiles when the rank holds more -- an upper-bound grid of N times the work would cost more in empty workgroups than the work itself.
 __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
 		uint8_t *A, TileRec *trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
+	const uint32_t ntiles = ctl->seg[side].tile0[NR];
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+	if (tile != blockIdx.x) __syncthreads();                    // the LDS tables of the previous tile are done with
 	TileCtx t;
-	if (!tile_ctx(ctl->seg[side], blockIdx.x, t)) return;
+	if (!tile_ctx(ctl->seg[side], tile, t)) return;
 	const int ln = lane_id(), w = wave_id();
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
@@ -226,9 +233,10 @@ __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, 
 			}
 			run += __popcll(bm);
 		}
-		TileRec &r = trec[blockIdx.x];
+		TileRec &r = trec[tile];
 		r.hist[s] = run; r.fhpre[s] = fhpre; r.lhpre[s] = lhpre;
 		if (s == 0) { r.fh = fh; r.lh = lh; }
+	}
 	}
 }
 
@@ -545,10 +553,10 @@ struct GroupLds {
 };
 
 // fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none)
-__device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint8_t *A, const TileFix *tf, int sym2[2], int flag2[2])
+__device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint8_t *A, const TileFix *tf, uint32_t tile, int sym2[2], int flag2[2])
 {
 	const int ln = lane_id(), w = wave_id();
-	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[blockIdx.x])[threadIdx.x];
+	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[tile])[threadIdx.x];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
@@ -618,15 +626,28 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	return m;
 }
 
+template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, const PoolView &oldp,
+		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
+		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE);
+
 template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
-	__shared__ GroupLds G;
-	const TileFix &tfx = tf[blockIdx.x];                        // issued together with the mode and tile-count loads
-	const SegDesc &sg = ctl->seg[side];
+	const uint32_t ntiles = ctl->seg[side].tile0[NR];
 	if ((ctl->ne[par] == 0) != AE) return;
-	if (blockIdx.x >= sg.tile0[NR]) return;
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
+		if (tile != blockIdx.x) __syncthreads();
+		prep_tile<AE, SPARSE>(tile, ctl, side, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE);
+	}
+}
+
+template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, const PoolView &oldp,
+		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
+		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
+{
+	__shared__ GroupLds G;
+	const TileFix &tfx = tf[tile];
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
@@ -637,7 +658,7 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 		l2[h] = u2[h] = 0;
 		if (k < t.segend) { l2[h] = L[k]; u2[h] = AE ? l2[h] : U[k]; }
 	}
-	group_setup(G, t, A, tf, sym2, flag2);
+	group_setup(G, t, A, tf, tile, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 	if (AE) {
@@ -734,7 +755,9 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	__shared__ uint32_t s_q[256];
 	if (threadIdx.x <= NR) s_wf0[threadIdx.x] = ctl->wf0[threadIdx.x];
 	__syncthreads();
-	const uint64_t gid = (uint64_t)blockIdx.x * 255 + threadIdx.x;      // boundary number: window (b,j) <-> wf0[b] + b + j
+	for (uint64_t blk = blockIdx.x; blk * 255 < s_wf0[NR] + NR; blk += gridDim.x) {   // grid stride (a sharded rank launches fewer blocks than its upper bound)
+	if (blk != blockIdx.x) __syncthreads();                     // s_q of the previous chunk is done with
+	const uint64_t gid = blk * 255 + threadIdx.x;               // boundary number: window (b,j) <-> wf0[b] + b + j
 	const bool ok = gid < s_wf0[NR] + NR;
 	int b = 0; uint64_t j = 0; uint32_t q = 0;
 	if (ok) {
@@ -752,7 +775,7 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	}
 	s_q[threadIdx.x] = q;
 	__syncthreads();
-	if (!ok || threadIdx.x == 255 || j >= s_wf0[b+1] - s_wf0[b]) return;   // the closing boundary of a piece is no window
+	if (!ok || threadIdx.x == 255 || j >= s_wf0[b+1] - s_wf0[b]) continue;   // the closing boundary of a piece is no window
 	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
 	const uint32_t q1 = s_q[threadIdx.x + 1];
 	const uint64_t o0 = j * WIN, i0 = o0 - q;
@@ -764,6 +787,7 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	d.ni = (uint16_t)(q1 - q);
 	d.nvalid = (uint16_t)min((uint64_t)WIN, nrp.n - o0);
 	LD[s_wf0[b] + j] = d;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -775,11 +799,21 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ void part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap);
+
 __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
 {
+	const uint32_t ntiles = ctl->seg[side].tile0[NR];
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
+		if (tile != blockIdx.x) __syncthreads();
+		part_sparse_tile(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap);
+	}
+}
+
+__device__ __forceinline__ void part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
+{
 	__shared__ uint64_t s_gl[STILE + 1];
-	const TileFix &tfx = tf[blockIdx.x];
-	if (blockIdx.x >= ctl->seg[side].tile0[NR]) return;
+	const TileFix &tfx = tf[tile];
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	const RopeDesc &rp = ctl->rope[side][t.b];
@@ -1035,9 +1069,9 @@ namespace rb2 {
 __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, int sparse)
 {
 	const int ln = lane_id();
-	const uint64_t sb = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2 + (ln >> 5);
 	const uint64_t nsb = ctl->nsb_total;
-	if (sb - (ln >> 5) >= nsb) return;                        // wave-uniform
+	for (uint64_t sbw = ((uint64_t)blockIdx.x * 4 + wave_id()) * 2; sbw < nsb; sbw += (uint64_t)gridDim.x * 8) {   // grid stride (a sharded rank launches fewer waves than its upper bound)
+	const uint64_t sb = sbw + (ln >> 5);
 	const bool live = sb < nsb;
 	const uint64_t gl = sb * SB + (ln & 31);
 	// sub-ropes start on superblock boundaries, in ascending order: the one that owns a superblock is the
@@ -1075,6 +1109,7 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 		SbTot c;
 		c.p01 = s01; c.p23 = s23; c.p45 = s45; c.pad = 0;
 		sbtot[sb] = c;
+	}
 	}
 }
 
@@ -1145,17 +1180,32 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const SbTot 
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
+template <bool AE, bool SPARSE> __device__ __forceinline__ void advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+		const uint64_t *START, const uint8_t *A, const TileFix *tf,
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
+
 template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
-	__shared__ GroupLds G;
-	const TileFix &tfx = tf[blockIdx.x];                        // issued together with the mode and tile-count loads
-	const SegDesc &sg = ctl->seg[side];
+	const uint32_t ntiles = ctl->seg[side].tile0[NR];
 	if ((ctl->ne[round & 1] == 0) != AE) return;
 	if (SPARSE && ctl->overflow) return;                       // void round: the host redoes it on the dense layout
-	if (blockIdx.x >= sg.tile0[NR]) return;
+	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
+		if (tile != blockIdx.x) __syncthreads();
+		advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, ID, W, L2, U2, ID2, W2, send, RKLEAF);
+	}
+}
+
+template <bool AE, bool SPARSE> __device__ __forceinline__ void advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+		const uint64_t *START, const uint8_t *A, const TileFix *tf,
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+{
+	__shared__ GroupLds G;
+	const TileFix &tfx = tf[tile];
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
@@ -1166,7 +1216,7 @@ template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k
 		id2[h] = 0; w2[h] = 0; l2[h] = 0;
 		if (k < t.segend) { id2[h] = ID[k]; w2[h] = send ? 0 : W[k]; l2[h] = L[k]; }   // sharded: W is rebuilt on arrival (k_unpack)
 	}
-	group_setup(G, t, A, tf, sym2, flag2);
+	group_setup(G, t, A, tf, tile, sym2, flag2);
 	uint32_t nz = 0;
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };

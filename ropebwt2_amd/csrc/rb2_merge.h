@@ -214,11 +214,15 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
 	uint32_t *LF = (uint32_t*)(lds[wv] + 2 * NXW + 8);          // NXW flag words of 32 bits
 	const int ln = lane_id();
-	const uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
-	const LeafDesc d = LD[gw];                                  // LD holds an entry for every window of the grid: both loads issue together
-	if (gw >= ctl->wf0[NR]) return;
-	if (d.nvalid == WIN) merge_window<true, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
-	else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+	const uint64_t nwin = ctl->wf0[NR];
+	// one window per wave; a rank of a sharded index launches fewer waves than the upper bound of its windows (the host does not
+	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows
+	for (uint64_t gw = (uint64_t)blockIdx.x * MW + wv; gw < nwin; gw += (uint64_t)gridDim.x * MW) {
+		const LeafDesc d = LD[gw];
+		if (d.nvalid == WIN) merge_window<true, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		if (gw + (uint64_t)gridDim.x * MW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
+	}
 }
 
 // Sparse rounds keep the rank directory current themselves (the dense rounds rebuild it, k_meta_sb): the directory of a
@@ -326,7 +330,8 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
-	const uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LPWV;
+	const uint64_t stride = (uint64_t)gridDim.x * MW * LPWV;
+	for (uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LPWV; ; g0 += stride) {   // grid stride: a sharded rank launches waves for about twice its fair share of the batch
 	LeafDesc d[LPWV];
 	LeafJob J[LPWV];
 #pragma unroll
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 		dir_add_packed(pool, sbtot, d[k].gl, ln, dd[0], dd[1], dd[2]);
 		merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
+	}
 	}
 }
 

@@ -54,6 +54,30 @@ __global__ __launch_bounds__(256) void k_mreduce(MPtrs rows, int n, uint64_t *ou
 //   off   place in s's send buffer: entries of the same source in (d, r2, r) order            (== shard_layout())
 //   vsrc  place in d's receive order: entries of the same destination in (s, r2, r) order      (the RCCL receive buffer)
 //   dst   place in d's next string arrays: entries of the same destination in (r2, r) order    (== k_setup's seg.start + dest)
+struct MPlan { uint64_t off, vsrc, dst, cnt; uint32_t pidx; int s, d, r, a; };
+// entry t = (r, a) of the plan; g = the global count matrix, own = the owner map.  Host and device run the same code
+// (rb2_hip_multi_plan_host lets the CPU tests check it against a simulation of the exchange).
+__host__ __device__ inline MPlan mplan_entry(const uint64_t *g, const uint8_t *own, int t)
+{
+	MPlan P;
+	const int r = t / 5, a = 1 + t % 5;
+	const int r2 = rope_of(a, rope_sym(r)), s = own[r], d = own[r2];
+	uint64_t off = 0, vsrc = 0, dst = 0; uint32_t pidx = 0;
+	for (int t2 = 0; t2 < NR * 5; ++t2) {
+		const int rr = t2 / 5, aa = 1 + t2 % 5;
+		const int rr2 = rope_of(aa, rope_sym(rr)), ss = own[rr], dd = own[rr2];
+		const uint64_t v = g[rr * 6 + aa];
+		const bool lt = rr2 < r2 || (rr2 == r2 && rr < r);
+		if (ss == s && (dd < d || (dd == d && lt))) off += v;
+		if (dd == d) {
+			if (ss < s || (ss == s && lt)) { vsrc += v; pidx += v != 0; }
+			if (lt) dst += v;
+		}
+	}
+	P.off = off; P.vsrc = vsrc; P.dst = dst; P.cnt = g[r * 6 + a]; P.pidx = pidx; P.s = s; P.d = d; P.r = r; P.a = a;
+	return P;
+}
+
 __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in, MOwner ow, int me, int peer, MPtrs srcs, const ShardRec *recv, MTab *tab)
 {
 	__shared__ uint64_t g[NR * 6];
@@ -64,28 +88,14 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 	__syncthreads();
 	const int t = threadIdx.x;
 	if (t < NR * 5) {
-		const int r = t / 5, a = 1 + t % 5;
-		const int r2 = rope_of(a, rope_sym(r)), s = ow.o[r], d = ow.o[r2];
-		const uint64_t gv = g[r * 6 + a];
-		uint64_t off = 0, vsrc = 0, dst = 0; uint32_t pidx = 0;
-		for (int t2 = 0; t2 < NR * 5; ++t2) {
-			const int rr = t2 / 5, aa = 1 + t2 % 5;
-			const int rr2 = rope_of(aa, rope_sym(rr)), ss = ow.o[rr], dd = ow.o[rr2];
-			const uint64_t v = g[rr * 6 + aa];
-			const bool lt = rr2 < r2 || (rr2 == r2 && rr < r);
-			if (ss == s && (dd < d || (dd == d && lt))) off += v;
-			if (dd == d) {
-				if (ss < s || (ss == s && lt)) { vsrc += v; pidx += v != 0; }
-				if (lt) dst += v;
-			}
-		}
-		if (s == me) ctl->sdest[r][a] = off;
-		if (d == me && gv) {
+		const MPlan P = mplan_entry(g, ow.o, t);
+		if (P.s == me) ctl->sdest[P.r][P.a] = P.off;
+		if (P.d == me && P.cnt) {
 			MPiece p;
-			p.vsrc = vsrc; p.dst = dst; p.cnt = gv;
-			p.src = peer ? (const ShardRec*)srcs.p[s] + off : recv + vsrc;
-			tab->pc[pidx] = p;
-			atomicAdd(&s_tot, (unsigned long long)gv); atomicAdd(&s_np, 1u);
+			p.vsrc = P.vsrc; p.dst = P.dst; p.cnt = P.cnt;
+			p.src = peer ? (const ShardRec*)srcs.p[P.s] + P.off : recv + P.vsrc;
+			tab->pc[P.pidx] = p;
+			atomicAdd(&s_tot, (unsigned long long)P.cnt); atomicAdd(&s_np, 1u);
 		}
 	}
 	__syncthreads();
@@ -94,15 +104,13 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 
 // records -> next round's SoA arrays in bucket order (k_unpack's job), fetched from wherever k_mlayout says they are: the
 // senders' buffers (PEER: loads over xGMI, 16 bytes per lane, coalesced per piece) or the local receive buffer (RCCL).
-// The grid is sized for the batch (the host does not know how many strings arrive); blocks behind the end return at once.
+// The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
 __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, const uint64_t *START, uint32_t round,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
 {
 	const uint64_t total = tab->total;
-	if ((uint64_t)blockIdx.x * 256 >= total) return;
-	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	bool nonempty = false;
-	if (i < total) {
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {   // grid stride: the host sizes the grid for about twice the rank's fair share
 		int lo = 0, hi = (int)tab->npieces - 1;                  // last piece with vsrc <= i (pieces tile the receive order)
 		while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab->pc[mid].vsrc <= i) lo = mid; else hi = mid - 1; }
 		const MPiece &pc = tab->pc[lo];
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab
 		const uint32_t id = (uint32_t)r.b;
 		L2[d] = l; U2[d] = l + size; ID2[d] = id;
 		W2[d] = pack16(s, ctl->len, START[id] + round + 1);
-		nonempty = size != 0;
+		nonempty |= size != 0;
 	}
 	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
 }
@@ -239,7 +247,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	MPtrs rows, sends[2];
 	memset(&rows, 0, sizeof(rows)); memset(sends, 0, sizeof(sends));
 	if (peer) for (int p = 0; p < m->n; ++p) { rows.p[p] = m->rk[p].gloc; sends[0].p[p] = m->rk[p].send[0]; sends[1].p[p] = m->rk[p].send[1]; }
-	const unsigned grid_m = cdiv(B.m, 256);
+	const unsigned grid_m = cdiv(rank_share(h, B.m), 256);
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                 // one round per string position (mrope.c:299-342)
 		h->gcnt = R.gloc;
 		round_counts(h, B, r);
@@ -539,6 +547,30 @@ uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b)
 		acc = hash_mix(acc, piece_hash(m->rk[o].h, r), m->rk[o].h->h_rope[r].n);
 	}
 	return acc;
+}
+
+/* the exchange plan of one round as rank `me` sees it, computed on the HOST by the very function k_mlayout runs per entry
+ * (mplan_entry): sdest[r*6+a] = where `me` writes the records of (r,a) in its send buffer (-1: not its entry); pieces[i] =
+ * {source rank, offset in that rank's send buffer, offset in me's receive order, offset in me's next string arrays, records}
+ * for the i-th piece `me` receives; returns their number, *total = records received.  No device needed (CPU tests). */
+int rb2_hip_multi_plan_host(const int *owner, int nranks, const int64_t *g, int me, int64_t *sdest, int64_t (*pieces)[5], int64_t *total)
+{
+	uint8_t own[32];
+	int np = 0;
+	(void)nranks;
+	for (int r = 0; r < NR; ++r) own[r] = (uint8_t)owner[r];
+	for (int i = 0; i < NR * 6; ++i) sdest[i] = -1;
+	*total = 0;
+	for (int t = 0; t < NR * 5; ++t) {
+		const MPlan P = mplan_entry((const uint64_t*)g, own, t);
+		if (P.s == me) sdest[P.r * 6 + P.a] = (int64_t)P.off;
+		if (P.d == me && P.cnt) {
+			int64_t *q = pieces[P.pidx];
+			q[0] = P.s; q[1] = (int64_t)P.off; q[2] = (int64_t)P.vsrc; q[3] = (int64_t)P.dst; q[4] = (int64_t)P.cnt;
+			*total += (int64_t)P.cnt; ++np;
+		}
+	}
+	return np;
 }
 
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6])

@@ -33,6 +33,8 @@ def load_hip_lib():
         "rb2_hip_reset": (None, [vp]),
         "rb2_hip_insert_multi": (None, [vp, i64, vp]),
         "rb2_hip_insert_multi_dev": (None, [vp, i64, vp]),
+        "rb2_hip_prefetch": (None, [vp, vp, i64, i64]),
+        "rb2_hip_mem_info": (None, [i32, vp, vp]),
         "rb2_hip_get_counts": (None, [vp, vp]),
         "rb2_hip_rope_bytes": (i64, [vp, i32]),
         "rb2_hip_download_rope": (i64, [vp, i32, vp]),
@@ -84,6 +86,7 @@ def load_hip_lib():
         "rb2_hip_multi_rank1a": (None, [vp, i32, i64, vp]),
         "rb2_hip_multi_stats": (None, [vp, vp]),
         "rb2_hip_multi_rope_hash": (u64, [vp, i32]),
+        "rb2_hip_multi_plan_host": (i32, [vp, i32, vp, i32, vp, vp, vp]),
         "rb2_hip_rope_hash": (u64, [vp, i32]),
     }
     for name, (res, args) in sig.items():
@@ -96,7 +99,7 @@ def load_hip_lib():
 
 ABI_SYMBOLS = [
     "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
-    "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
+    "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
@@ -105,7 +108,7 @@ ABI_SYMBOLS = [
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
     "rb2_hip_multi_get_counts", "rb2_hip_multi_rope_bytes", "rb2_hip_multi_download_rope", "rb2_hip_multi_stream_rope",
-    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
+    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_plan_host", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
 ]
 
 
@@ -170,6 +173,10 @@ class HipBwt:
 
     def insert_multi_dev(self, dev_ptr, nbytes):
         self.L.rb2_hip_insert_multi_dev(self.h, nbytes, dev_ptr)
+
+    def prefetch(self, buf, n_final, capacity=0):
+        """start uploading buf[:n_final] for a later insert_multi(buf[:len]) (rb2_hip_prefetch); buf must stay alive and in place"""
+        self.L.rb2_hip_prefetch(self.h, buf.ctypes.data, n_final, capacity or len(buf))
 
     # -- state ----------------------------------------------------------------------------
     def counts(self):

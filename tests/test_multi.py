@@ -25,6 +25,81 @@ def test_default_owners_match_python_driver():
         assert MultiBwt.default_owners(n) == default_owners(n)
 
 
+def _plan(owner, n, g, me):
+    """rb2_hip_multi_plan_host: the per-entry function of k_mlayout, run on the host"""
+    from ropebwt2_amd import load_hip_lib
+    L = load_hip_lib()
+    own = (C.c_int * 31)(*owner)
+    gg = np.ascontiguousarray(g, dtype=np.int64).reshape(-1)
+    sd = np.zeros(31 * 6, np.int64)
+    pcs = np.zeros((31 * 6, 5), np.int64)
+    tot = C.c_int64(0)
+    k = L.rb2_hip_multi_plan_host(own, n, gg.ctypes.data, me, sd.ctypes.data, pcs.ctypes.data, C.byref(tot))
+    return sd.reshape(31, 6), pcs[:k], int(tot.value)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 16, 20])
+def test_device_exchange_plan_against_a_simulated_exchange(n):
+    """k_mlayout's plan (where every rank writes its records, which pieces every rank fetches from whom, where they land) against
+    a literal simulation: the strings of bucket (a,b) of the next round are the members of the pieces (b,x), x = $ACGTN in order,
+    that inserted a, in their old order (the stable scatter of mrope.c:303-309) -- for the default and for random owner maps"""
+    from ropebwt2_amd import MultiBwt, build_all
+    from ropebwt2_amd.sharded import NR, rope_sym, rope_prev, rope_of, exchange_layout
+    build_all()
+    rng = np.random.RandomState(n)
+    for trial in range(6):
+        owner = MultiBwt.default_owners(n) if trial < 2 else [int(x) for x in rng.randint(0, n, size=NR)]
+        g = rng.randint(0, 9, size=(NR, 6)).astype(np.int64)
+        g[rng.rand(NR, 6) < 0.3] = 0
+        for r in range(NR):
+            if rope_sym(r) == 0 and r != 0:
+                g[r] = 0
+        # every rank fills its send buffer: entry (r, a) at sdest, records tagged (r, a, i)
+        send = []
+        for s_ in range(n):
+            sd, _, _ = _plan(owner, n, g, s_)
+            per = exchange_layout(owner, n, s_, g)
+            buf = [None] * sum(per)
+            for r in range(NR):
+                for a in range(1, 6):
+                    if owner[r] == s_:
+                        assert sd[r, a] >= 0
+                        for i in range(int(g[r, a])):
+                            assert buf[sd[r, a] + i] is None
+                            buf[sd[r, a] + i] = (r, a, i)
+                    else:
+                        assert sd[r, a] == -1
+            assert all(x is not None for x in buf)
+            send.append(buf)
+        for d in range(n):
+            _, pcs, tot = _plan(owner, n, g, d)
+            nxt, recv_order = {}, []
+            for (src, off, vsrc, dst, cnt) in pcs.tolist():
+                assert vsrc == len(recv_order)                        # pieces tile the receive order
+                for i in range(cnt):
+                    rec = send[src][off + i]
+                    recv_order.append(rec)
+                    assert dst + i not in nxt
+                    nxt[dst + i] = rec
+            assert tot == len(recv_order) == len(nxt)
+            want = []                                                 # next arrays of rank d: its pieces ascending; inside (a,b): sources (b,x) by x, old order
+            for r2 in range(1, NR):
+                if owner[r2] != d:
+                    continue
+                a, b = rope_sym(r2), rope_prev(r2)
+                for r in range(NR):
+                    if rope_sym(r) == b:
+                        want += [(r, a, i) for i in range(int(g[r, a]))]
+            assert [nxt[i] for i in range(len(want))] == want and len(nxt) == len(want)
+            # the RCCL receive buffer: blocks by source rank, each in the sender's order for this destination
+            blocks = []
+            for s_ in range(n):
+                per = exchange_layout(owner, n, s_, g)
+                st = sum(per[:d])
+                blocks += send[s_][st:st + per[d]]
+            assert recv_order == blocks
+
+
 def _gpu_count():
     try:
         import torch
