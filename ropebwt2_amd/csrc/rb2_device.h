@@ -297,8 +297,7 @@ __device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, 
 {
 	const uint4 *q = (const uint4*)dir_row(pv, sb, row);
 	uint32_t acc = 0;                                          // two 16-bit sums side by side (<= 16 * LEAF each)
-#pragma unroll
-	for (int i = 0; i < SB / 8; ++i) {                           // all 32 slots: splits fill the reserve behind the first SP_USED
+	auto add8 = [&](int i) {
 		const uint4 v = q[i];
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -306,7 +305,10 @@ __device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, 
 			const uint32_t s0 = (uint32_t)(8 * i + 2 * j);      // the word holds slots s0, s0 + 1
 			acc += w[j] & (k > s0 + 1 ? 0xffffffffu : (k == s0 + 1 ? 0xffffu : 0u));
 		}
-	}
+	};
+#pragma unroll
+	for (int i = 0; i < SP_USED / 8; ++i) add8(i);
+	if (k > (uint32_t)SP_USED) add8(SP_USED / 8);               // reserve slots: only for a leaf that sits in one
 	return (acc & 0xffffu) + (acc >> 16);
 }
 
@@ -345,8 +347,7 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 	// inside the superblock: the fills of its slots are one 48-byte read (dir_row 0); unused slots (n == 0) trail the used ones
 	const uint4 *q = (const uint4*)dir_row(pv, rp.sb0 + lo, 0);
 	uint32_t run = 0, klo = 0, pre = 0, nk = 0;
-#pragma unroll
-	for (int i = 0; i < SB / 8; ++i) {
+	auto scan8 = [&](int i) {
 		const uint4 v = q[i];
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
@@ -355,7 +356,10 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 			if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = n; }
 			run += n;
 		}
-	}
+	};
+#pragma unroll
+	for (int i = 0; i < SP_USED / 8; ++i) scan8(i);             // the slots a re-layout fills: three 16-byte loads, issued together
+	if (run <= rel) scan8(SP_USED / 8);                        // the reserve slots (leaf splits): only when the position lies behind the first 24
 	r.gl = l0 + klo; r.s = sbs + pre; r.n = nk;
 	return r;
 }

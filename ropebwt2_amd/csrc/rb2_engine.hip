@@ -240,6 +240,8 @@ inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b
 // (weak scaling, 327 M strings) 640 k workgroups per tile kernel of which 80 k find a tile -- empty workgroups alone then cost
 // more than a millisecond per round.  The kernels walk their work with a grid stride, so the grid is a hint: twice the fair
 // share (+ slack); a rank that holds more than that loops.  One GPU: the exact upper bound, one tile per block as before.
+// launch KERNEL<..., STRIDE> with STRIDE = (this handle is a rank of a sharded index)
+#define RB2_LAUNCH_STRIDE(h, KT, KF, ...) do { if ((h)->nranks > 1) hipLaunchKernelGGL(KT, __VA_ARGS__); else hipLaunchKernelGGL(KF, __VA_ARGS__); } while (0)
 inline uint64_t rank_share(const rb2_hip_t *h, uint64_t whole)
 {
 	if (h->nranks <= 1) return whole;
@@ -256,7 +258,7 @@ void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays 
 	PoolView pv = h->pool[pool].view();
 	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
 	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
-	if (!leaves_done) hipLaunchKernelGGL(k_meta_sb, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
+	if (!leaves_done) RB2_LAUNCH_STRIDE(h, k_meta_sb<true>, k_meta_sb<false>, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
 	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
 	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);
@@ -364,7 +366,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
 	const int64_t units = (int64_t)B.m;
 	h->cur_round = (int)r;
 	{ Scope sc(h, RB2_K_SYM, units);
-	  hipLaunchKernelGGL(k_sym, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
+	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
 	if (B.nst_ub <= 4 * SCHUNK) {                              // few tiles (long reads): one single-block launch instead of five
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  hipLaunchKernelGGL(k_tscan_fused, dim3(1), dim3(SCHUNK), 0, st, (const Ctl*)h->ctl, sd, (const TileRec*)h->trec.p, h->tsc.p, h->tfix.p, h->gcnt);
@@ -394,20 +396,20 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true>), (k_prep<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  hipLaunchKernelGGL((k_prep<true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true>), (k_prep<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part, dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
+	  RB2_LAUNCH_STRIDE(h, k_part<true>, k_part<false>, dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge, dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
+	  RB2_LAUNCH_STRIDE(h, k_merge<true>, k_merge<false>, dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true>), (k_advance<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
-	  hipLaunchKernelGGL((k_advance<true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true>), (k_advance<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
@@ -475,24 +477,24 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_prep<false, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true>), (k_prep<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  hipLaunchKernelGGL((k_prep<true, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true>), (k_prep<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  hipLaunchKernelGGL(k_part_sparse, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
+	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  RB2_LAUNCH_STRIDE(h, k_merge_leaf<true>, k_merge_leaf<false>, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) hipLaunchKernelGGL((k_advance<false, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true>), (k_advance<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
-	  hipLaunchKernelGGL((k_advance<true, true>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true>), (k_advance<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
-	{ Scope sc(h, RB2_K_MERGE, 0);
-	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch); }
+	{ Scope sc(h, RB2_K_SPLIT, 0);
+	  hipLaunchKernelGGL(k_split, dim3(1024), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch); }
 	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
 	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
 	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
@@ -1258,7 +1260,7 @@ void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[
 
 const char *rb2_hip_kernel_name(int k)
 {
-	static const char *nm[RB2_K_COUNT] = {"k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout"};
+	static const char *nm[RB2_K_COUNT] = {"k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout", "k_split"};
 	return (k >= 0 && k < RB2_K_COUNT) ? nm[k] : "?";
 }
 

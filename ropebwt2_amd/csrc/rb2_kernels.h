@@ -193,14 +193,15 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // tile the round can have and a block runs one; a rank of a sharded index launches about twice its fair share of the batch's
 // tiles (the host cannot know how many strings the rank holds this round without asking the device) and a block takes more
 // tiles when the rank holds more -- an upper-bound grid of N times the work would cost more in empty workgroups than the work itself.
-__global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
+// STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
+// with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
 		uint8_t *A, TileRec *trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
-	const uint32_t ntiles = ctl->seg[side].tile0[NR];
-	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-	if (tile != blockIdx.x) __syncthreads();                    // the LDS tables of the previous tile are done with
+	for (uint32_t tile = blockIdx.x; ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
+	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], tile, t)) return;
 	const int ln = lane_id(), w = wave_id();
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, 
 		r.hist[s] = run; r.fhpre[s] = fhpre; r.lhpre[s] = lhpre;
 		if (s == 0) { r.fh = fh; r.lh = lh; }
 	}
+	if (!STRIDE) return;
 	}
 }
 
@@ -626,28 +628,34 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	return m;
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, const PoolView &oldp,
+template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
-		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE);
+		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE);                      // false: nothing (more) to do for this block
 
-template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
+template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
-	const uint32_t ntiles = ctl->seg[side].tile0[NR];
-	if ((ctl->ne[par] == 0) != AE) return;
-	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
-		if (tile != blockIdx.x) __syncthreads();
-		prep_tile<AE, SPARSE>(tile, ctl, side, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE);
+	// the first tile exactly as a one-tile-per-block kernel would run it (its loads are issued before anything is waited for);
+	// further tiles only when the grid is smaller than the number of tiles (grid stride: see k_sym)
+	for (uint32_t tile = blockIdx.x; ; ) {
+		if (!prep_tile<AE, SPARSE>(tile, ctl, side, par, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE)) return;
+		if (!STRIDE) return;
+		tile += gridDim.x;
+		if (tile >= ctl->seg[side].tile0[NR]) return;
+		__syncthreads();
 	}
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, const PoolView &oldp,
+template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
 		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
 		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
 {
 	__shared__ GroupLds G;
-	const TileFix &tfx = tf[tile];
+	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
+	const SegDesc &sg = ctl->seg[side];
+	if ((ctl->ne[par] == 0) != AE) return false;
+	if (tile >= sg.tile0[NR]) return false;
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
@@ -672,7 +680,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const 
 			INS_E[t.segstart + m.slot] = l2[h] - m.F;          // empty interval: the new symbol goes to l (pre-round coordinates)
 			INS_A[t.segstart + m.slot] = (uint8_t)a;
 		}
-		return;
+		return true;
 	}
 	// Non-empty intervals: the members of a group share [l, u) (mrope.c:192-202), so rope_rank2a is evaluated once per
 	// group and tile -- by the group's first member inside the tile -- and handed to the others through LDS.
@@ -739,6 +747,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const 
 		INS_E[t.segstart + mm[h].slot] = e;
 		INS_A[t.segstart + mm[h].slot] = (uint8_t)a;
 	}
+	return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -749,14 +758,14 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ void prep_tile(const 
 // A block covers 256 boundaries = 255 windows (boundaries overlap by one between blocks).
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, LeafDesc *LD)
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, LeafDesc *LD)
 {
 	__shared__ uint64_t s_wf0[NR + 1];
 	__shared__ uint32_t s_q[256];
 	if (threadIdx.x <= NR) s_wf0[threadIdx.x] = ctl->wf0[threadIdx.x];
 	__syncthreads();
 	for (uint64_t blk = blockIdx.x; blk * 255 < s_wf0[NR] + NR; blk += gridDim.x) {   // grid stride (a sharded rank launches fewer blocks than its upper bound)
-	if (blk != blockIdx.x) __syncthreads();                     // s_q of the previous chunk is done with
+	if (STRIDE && blk != blockIdx.x) __syncthreads();           // s_q of the previous chunk is done with
 	const uint64_t gid = blk * 255 + threadIdx.x;               // boundary number: window (b,j) <-> wf0[b] + b + j
 	const bool ok = gid < s_wf0[NR] + NR;
 	int b = 0; uint64_t j = 0; uint32_t q = 0;
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	}
 	s_q[threadIdx.x] = q;
 	__syncthreads();
-	if (!ok || threadIdx.x == 255 || j >= s_wf0[b+1] - s_wf0[b]) continue;   // the closing boundary of a piece is no window
+	if (!ok || threadIdx.x == 255 || j >= s_wf0[b+1] - s_wf0[b]) { if (!STRIDE) return; continue; }   // the closing boundary of a piece is no window
 	const RopeDesc &orp = ctl->rope[side][b], &nrp = ctl->rope[side ^ 1][b];
 	const uint32_t q1 = s_q[threadIdx.x + 1];
 	const uint64_t o0 = j * WIN, i0 = o0 - q;
@@ -787,6 +796,7 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 	d.ni = (uint16_t)(q1 - q);
 	d.nvalid = (uint16_t)min((uint64_t)WIN, nrp.n - o0);
 	LD[s_wf0[b] + j] = d;
+	if (!STRIDE) return;
 	}
 }
 
@@ -799,21 +809,24 @@ __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const ui
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap);
+__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap);
 
-__global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
 {
-	const uint32_t ntiles = ctl->seg[side].tile0[NR];
-	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
-		if (tile != blockIdx.x) __syncthreads();
-		part_sparse_tile(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap);
+	for (uint32_t tile = blockIdx.x; ; ) {                      // (first tile as ever, then a grid stride: see k_prep)
+		if (!part_sparse_tile(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap)) return;
+		if (!STRIDE) return;
+		tile += gridDim.x;
+		if (tile >= ctl->seg[side].tile0[NR]) return;
+		__syncthreads();
 	}
 }
 
-__device__ __forceinline__ void part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
+__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	__shared__ uint64_t s_gl[STILE + 1];
 	const TileFix &tfx = tf[tile];
+	if (tile >= ctl->seg[side].tile0[NR]) return false;
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	const RopeDesc &rp = ctl->rope[side][t.b];
@@ -868,6 +881,7 @@ __device__ __forceinline__ void part_sparse_tile(const uint32_t tile, Ctl *ctl, 
 		}
 		LD[off++] = d;
 	}
+	return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1015,16 +1029,22 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 			for (int r = 0; r < 7; ++r) R[r][nj] = v[r];
 		}
 		uint64_t *leaves = (uint64_t*)pool.data + sb * SB * LEAFW;
-		for (int k = (int)used - 1; k >= (int)first; --k) {      // from the last slot down: a target slot has always been read already
-			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
-			const bool split = (marked >> k) & 1u;
-			if (!split && nk == (uint32_t)k) continue;
-			const uint64_t w = leaves[(uint64_t)k * LEAFW + ln];
-			if (!split) { leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
-			uint32_t n = 0, ck[6];
-			n = (uint32_t)__shfl((int)v[0], k);
+		// every leaf from the first split one on moves (or splits): all of them are LOADED first, back to back (lane = word, up to 32
+		// words per lane in registers), then stored at their new slots -- one round trip to memory for the whole superblock instead
+		// of one per slot (a wave that moved slot after slot spent 60 us on a full superblock: 31 dependent load -> store pairs)
+		uint64_t W[SB];
 #pragma unroll
-			for (int s = 0; s < 6; ++s) ck[s] = (uint32_t)__shfl((int)v[1 + s], k);
+		for (int k = 0; k < SB; ++k) W[k] = ((uint32_t)k >= first && (uint32_t)k < used) ? leaves[(uint64_t)k * LEAFW + ln] : 0ull;
+#pragma unroll
+		for (int k = 0; k < SB; ++k) {
+			if ((uint32_t)k < first || (uint32_t)k >= used) continue;   // wave-uniform
+			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
+			const uint64_t w = W[k];
+			if (!((marked >> k) & 1u)) { if (nk != (uint32_t)k) leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
+			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)v[0], k);
+			uint32_t ck[6];
+#pragma unroll
+			for (int s = 0; s < 6; ++s) ck[s] = (uint32_t)__builtin_amdgcn_readlane((int)v[1 + s], k);
 			const uint32_t hw = (n / 2) / SPW, h = hw * SPW;        // the first hw words stay
 			NibAcc A;
 			nib_acc(A, w, (uint32_t)ln < hw ? MLOW : 0ull);
@@ -1066,7 +1086,7 @@ namespace rb2 {
 // Runs after every kernel that rewrites whole pieces (k_merge, k_relayout, the loader).  sparse: the pool is in the sparse layout --
 // its directory holds own counts by rows (dir_row, rb2_device.h), so this is a transposition of own[]; the in-place rounds
 // that follow keep rows and totals current themselves (dir_put, rb2_merge.h).
-__global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, int sparse)
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, PoolView newp, SbTot *sbtot, int sparse)
 {
 	const int ln = lane_id();
 	const uint64_t nsb = ctl->nsb_total;
@@ -1110,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_meta_sb(const Ctl *ctl, int nside, Pool
 		c.p01 = s01; c.p23 = s23; c.p45 = s45; c.pad = 0;
 		sbtot[sb] = c;
 	}
+	if (!STRIDE) return;
 	}
 }
 
@@ -1180,32 +1201,36 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const SbTot 
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ void advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
 
-template <bool AE, bool SPARSE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
+template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
-	const uint32_t ntiles = ctl->seg[side].tile0[NR];
-	if ((ctl->ne[round & 1] == 0) != AE) return;
-	if (SPARSE && ctl->overflow) return;                       // void round: the host redoes it on the dense layout
-	for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {   // (grid stride: see k_sym)
-		if (tile != blockIdx.x) __syncthreads();
-		advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, ID, W, L2, U2, ID2, W2, send, RKLEAF);
+	for (uint32_t tile = blockIdx.x; ; ) {                      // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
+		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, ID, W, L2, U2, ID2, W2, send, RKLEAF)) return;
+		if (!STRIDE) return;
+		tile += gridDim.x;
+		if (tile >= ctl->seg[side].tile0[NR]) return;
+		__syncthreads();
 	}
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ void advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	__shared__ GroupLds G;
-	const TileFix &tfx = tf[tile];
+	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
+	const SegDesc &sg = ctl->seg[side];
+	if ((ctl->ne[round & 1] == 0) != AE) return false;
+	if (SPARSE && ctl->overflow) return false;                 // void round: the host redoes it on the dense layout
+	if (tile >= sg.tile0[NR]) return false;
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
@@ -1255,6 +1280,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ void advance_tile(con
 	if (!AE && !send) {                                        // does the next round see a non-empty interval?  (a flag: plain store, no atomic)
 		if (__any(nz != 0) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;
 	}
+	return true;
 }
 
 // sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order; the symbol

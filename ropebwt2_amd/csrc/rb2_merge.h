@@ -206,7 +206,7 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 	}
 }
 
-__global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
 	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8 + NXW / 2];
@@ -214,13 +214,16 @@ __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *_
 	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
 	uint32_t *LF = (uint32_t*)(lds[wv] + 2 * NXW + 8);          // NXW flag words of 32 bits
 	const int ln = lane_id();
-	const uint64_t nwin = ctl->wf0[NR];
 	// one window per wave; a rank of a sharded index launches fewer waves than the upper bound of its windows (the host does not
-	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows
-	for (uint64_t gw = (uint64_t)blockIdx.x * MW + wv; gw < nwin; gw += (uint64_t)gridDim.x * MW) {
-		const LeafDesc d = LD[gw];
+	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows.  The first window's
+	// work order is loaded together with the window count (LD holds an entry for every window a grid can name).
+	uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	LeafDesc d = LD[gw];
+	const uint64_t nwin = ctl->wf0[NR];
+	for (; gw < nwin; gw += (uint64_t)gridDim.x * MW, d = LD[gw < nwin ? gw : 0]) {
 		if (d.nvalid == WIN) merge_window<true, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
 		else merge_window<false, WPL, false>(d, LX, LF, LO, ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		if (!STRIDE) return;                                    // (one GPU: the grid covers every window; no loop, no extra registers)
 		if (gw + (uint64_t)gridDim.x * MW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
 	}
 }
@@ -324,7 +327,7 @@ __device__ __forceinline__ void leaf_job_run(const LeafDesc &d, const int ln, co
 // sparse rounds: one wave per LPWV TOUCHED leaves (work orders appended by k_part_sparse, any order), rewritten in place --
 // rope_insert_run's descent ends here (rope.c:136-141) and this is rle_insert_cached (rle.c:10-89) for all the inserts a
 // leaf receives this round at once.  Untouched leaves keep their bytes.  A round that set ctl->overflow is void.
-__global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
 		const uint64_t *INS_E, const uint8_t *INS_A /* not __restrict__: see the barrier below */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
 	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 		merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
 	}
+	if (!STRIDE) return;
 	}
 }
 

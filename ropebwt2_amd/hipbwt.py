@@ -11,7 +11,7 @@ import numpy as np
 
 from .build import lib_path
 
-K_NAMES = ["k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout"]
+K_NAMES = ["k_sym", "k_tscan", "k_prep", "k_part", "k_merge", "k_meta", "k_advance", "k_init", "k_relayout", "k_split"]
 _lib = None
 
 
@@ -20,7 +20,7 @@ def load_hip_lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = lib_path("librb2hip.so")
+    path = os.environ.get("RB2_HIP_LIB") or lib_path("librb2hip.so")      # (RB2_HIP_LIB: A/B runs of two builds on one box)
     if not os.path.exists(path):
         raise RuntimeError("%s missing: run `python -m ropebwt2_amd.build` (hipcc, gfx950) first" % path)
     L = C.CDLL(path)
@@ -90,7 +90,12 @@ def load_hip_lib():
         "rb2_hip_rope_hash": (u64, [vp, i32]),
     }
     for name, (res, args) in sig.items():
-        f = getattr(L, name)
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            if os.environ.get("RB2_HIP_LIB"):                  # an older build in an A/B run: what it lacks is simply not callable
+                continue
+            raise
         f.restype = res
         f.argtypes = args
     _lib = L

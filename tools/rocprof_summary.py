@@ -16,7 +16,7 @@ with open(sys.argv[2], "w", newline="") as f:
     for name, calls, tot, avg, pct in rows:
         w.writerow([name.split("(")[0], calls, "%.1f" % tot, "%.2f" % avg, "%.3f" % pct])
     if n_timed:
-        d = [(e - s) / 1e3 for s, e in db.execute("select start, end from kernels where name like '%k_merge(%' or name like '%k_merge' order by start")]
+        d = [(e - s) / 1e3 for s, e in db.execute("select start, end from kernels where name like '%k_merge(%' or name like '%k_merge<%' or name like '%k_merge' order by start")]
         d = d[-n_timed:]
         if d:
             w.writerow(["rb2::k_merge [the %d launches of the timed region only]" % len(d), len(d), "%.1f" % sum(d), "%.2f" % (sum(d) / len(d)), ""])
