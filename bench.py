@@ -21,7 +21,7 @@ in HBM.  Beside it the line reports
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: ONE index, its 31 sub-ropes sharded over the ranks (rb2_hip_default_owners), per round a sum of the
-31x6 count matrix and an exchange of 16-byte string records.  The round loop runs INSIDE librb2hip.so
+31x6 count matrix and an exchange of 24-byte string records.  The round loop runs INSIDE librb2hip.so
 (rb2_hip_multi_*, csrc/rb2_multi.h) -- Python only hands over one batch at a time:
   under torch.distributed.run  one process per GPU; every process is one rank of an RCCL group
                                (rb2_hip_multi_create_rank; the ncclUniqueId travels through torch.distributed):
@@ -523,7 +523,7 @@ def main():
                    "reads_per_job": reads_job * (1 if (sharded or n_ranks == 1) else n_gpus), "jobs": args.steps / nb,
                    "symbols": total_symbols, "symbols_per_gpu": symbols // (n_gpus if sharded else 1),
                    "parallelism": "1 GPU" if n_ranks == 1 else
-                                  ("31 sub-ropes (b,x) sharded over %d of %d ranks on %d GPU(s) (owner map %s); per round: sum of the 31x6 count matrix + exchange of 16 B string records"
+                                  ("31 sub-ropes (b,x) sharded over %d of %d ranks on %d GPU(s) (owner map %s); per round: sum of the 31x6 count matrix + exchange of 24 B string records"
                                    % (active, n_ranks, n_gpus, owners)) if sharded else "independent BWT per GPU (read stream sliced by rank)",
                    "driver": driver, "multi_stats": mstats,
                    "counts_ok": bool(ok_counts)},

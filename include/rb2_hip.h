@@ -129,7 +129,7 @@ uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b);
  *   rounds = rb2_hip_shard_begin(h, len, s_dev)
  *   for r in 0..rounds-1:
  *       rb2_hip_shard_counts(h, r, local)              ->  global = all_reduce_sum(local)
- *       rb2_hip_shard_merge(h, r, global, send, nsend) ->  recv = all_to_all(send, nsend)   (16-byte records)
+ *       rb2_hip_shard_merge(h, r, global, send, nsend) ->  recv = all_to_all(send, nsend)   (24-byte records)
  *       rb2_hip_shard_finish(h, r, global, recv, nrecv)
  *   rb2_hip_shard_end(h)
  */

@@ -103,12 +103,13 @@ struct Ctl {
 	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
 };
 
-// one string's state on the wire (16 B): a = l (48 bits) | size[15:0] << 48;  b = id | size[47:16] << 32.
-// The 16-symbol cursor W does not travel: every rank holds the batch text and rebuilds it on arrival.
-struct ShardRec { uint64_t a, b; };
-__host__ __device__ inline ShardRec shard_pack(uint64_t l, uint64_t size, uint32_t id)
+// one string's state on the wire (24 B): a = l (48 bits) | size[15:0] << 48;  b = id | size[47:16] << 32;  w = the symbol cursor.
+// (Rounds 1-2 sent 16 bytes and rebuilt the cursor on arrival from the batch text every rank holds: a 20-byte random gather per
+// string and round on the receiver, ~100 B of HBM traffic to save 8 B on the wire -- and pure loss between ranks of one device.)
+struct ShardRec { uint64_t a, b, w; };
+__host__ __device__ inline ShardRec shard_pack(uint64_t l, uint64_t size, uint32_t id, uint64_t w)
 {
-	ShardRec r; r.a = (l & 0xffffffffffffull) | (size & 0xffffull) << 48; r.b = (uint64_t)id | (size >> 16) << 32; return r;
+	ShardRec r; r.a = (l & 0xffffffffffffull) | (size & 0xffffull) << 48; r.b = (uint64_t)id | (size >> 16) << 32; r.w = w; return r;
 }
 struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 

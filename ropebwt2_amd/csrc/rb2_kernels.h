@@ -1239,7 +1239,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		id2[h] = 0; w2[h] = 0; l2[h] = 0;
-		if (k < t.segend) { id2[h] = ID[k]; w2[h] = send ? 0 : W[k]; l2[h] = L[k]; }   // sharded: W is rebuilt on arrival (k_unpack)
+		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; l2[h] = L[k]; }
 	}
 	group_setup(G, t, A, tf, tile, sym2, flag2);
 	uint32_t nz = 0;
@@ -1269,9 +1269,9 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
 		const uint32_t id = id2[h];
 		uint64_t wv = w2[h] >> 4;
-		if (!send && ((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
-		if (send) {                                            // sharded: the string travels to the owner of piece (a, b)
-			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id);
+		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
+		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
+			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id, wv);
 		} else {
 			L2[d] = l; ID2[d] = id; W2[d] = wv;
 			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
@@ -1283,8 +1283,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 	return true;
 }
 
-// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order; the symbol
-// cursor W is rebuilt from the batch text (one 20-byte gather per string)
+// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
 __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
 		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
 {
@@ -1298,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *
 	const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
 	const uint32_t id = (uint32_t)r.b;
 	L2[d] = l; U2[d] = l + size; ID2[d] = id;
-	W2[d] = pack16(s, ctl->len, START[id] + round + 1);
+	W2[d] = r.w;
 	nonempty = size != 0;
 	}
 	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne

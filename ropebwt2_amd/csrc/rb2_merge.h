@@ -34,6 +34,12 @@ namespace rb2 {
 #ifndef RB2_KMAX
 #define RB2_KMAX 5
 #endif
+#ifndef RB2_LO_PAD
+#define RB2_LO_PAD 0            // LDS layout experiments of merge_window (see there)
+#endif
+#ifndef RB2_LX_LANEMAJOR
+#define RB2_LX_LANEMAJOR 1
+#endif
 constexpr int NXW = 64 * WPL;               // words per window (dense merge)
 
 __device__ __forceinline__ uint64_t nib_eq(uint64_t w, uint32_t a)   // bit 3i set: symbol i of w == a
@@ -50,6 +56,14 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
 {
 	constexpr int WPL = WPL_, NXW = 64 * WPL_, LPW = 64 / WPL_, WIN = WPL_ * LEAF;   // shadow the dense constants
+	// LDS layout.  A lane owns WPL consecutive words of the window; laid out position-major (word pw at index pw) the lanes of a
+	// wave touch addresses 8 * WPL bytes apart: with WPL = 4 only 8 of the 64 banks, a 4-way conflict on every access (PMC, round 3:
+	// SQ_LDS_BANK_CONFLICT = 60 % of SQ_LDS_IDX_ACTIVE in k_merge).  LX, LF and the prefix table LP are therefore kept LANE-major --
+	// word pw lives at (pw % WPL) * 64 + pw / WPL, so lane ln's w-th word is at w * 64 + ln --, the stage of old words LO, which
+	// is read at data-dependent offsets of about WPL * ln, gets one pad word per 32.  WPL = 1 (in-place leaf merge): both are the identity.
+	auto SX = [](uint32_t pw) -> uint32_t { return (WPL == 1 || !RB2_LX_LANEMAJOR) ? pw : (pw % WPL) * 64u + pw / WPL; };
+	auto LM = [](int w, int lane) -> int { return (WPL == 1 || !RB2_LX_LANEMAJOR) ? WPL * lane + w : 64 * w + lane; };   // index of lane's w-th word
+	auto SO = [](uint32_t i) -> uint32_t { return (WPL == 1 || !RB2_LO_PAD) ? i : i + (i >> 5); };
 	const int nvalid = FULL ? WIN : d.nvalid, ni = d.ni;
 	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
 	const uint64_t w0i = INPLACE ? 0 : d.i0 / SPW;              // old word that holds the first of them
@@ -73,14 +87,14 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 		if (jj == ln) { p_first = p; a_first = (uint32_t)a; }
 		const uint32_t pw = p / SPW, ps = (p - pw * SPW) * SBITS;
 		const uint64_t sv = a << ps;                              // 32-bit LDS atomics: a 3-bit field may straddle bit 32
-		uint32_t *x32 = (uint32_t*)LX + 2 * pw;
+		uint32_t *x32 = (uint32_t*)LX + 2 * SX(pw);
 		if ((uint32_t)sv) atomicOr(x32, (uint32_t)sv);
 		if ((uint32_t)(sv >> 32)) atomicOr(x32 + 1, (uint32_t)(sv >> 32));
-		atomicOr(LF + pw, 1u << (p - pw * SPW));                   // flags: one bit per position, 21 per word
+		atomicOr(LF + SX(pw), 1u << (p - pw * SPW));               // flags: one bit per position, 21 per word
 	}
 #pragma unroll
-	for (int w = 0; w < WPL; ++w) LO[ln + 64 * w] = wa[w];
-	if (ln < 2) LO[NXW + ln] = wt;
+	for (int w = 0; w < WPL; ++w) LO[SO((uint32_t)(ln + 64 * w))] = wa[w];
+	if (ln < 2) LO[SO((uint32_t)(NXW + ln))] = wt;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 
 	// ---- 2. what does each lane consume
@@ -90,8 +104,8 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 	const int p0 = ln * SPW * WPL;
 #pragma unroll
 	for (int w = 0; w < WPL; ++w) {
-		X[w] = LX[WPL * ln + w];
-		F[w] = LF[WPL * ln + w];                                // bit i: position i holds a new symbol
+		X[w] = LX[LM(w, ln)];                                   // = SX(WPL * ln + w)
+		F[w] = LF[LM(w, ln)];                                   // bit i: position i holds a new symbol
 		const int v = FULL ? SPW : min(SPW, max(0, nvalid - p0 - SPW * w));
 		VM[w] = FULL ? MALL : nib_below((uint32_t)v);           // all bits of the valid positions
 		kin[w] = (uint32_t)__popc(F[w]);
@@ -105,7 +119,7 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 		uint32_t k = op / SPW, sh = (op - k * SPW) * SBITS;
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
-			const uint64_t w0 = LO[k], w1 = LO[k + 1];           // k + 1 <= NXW + 1
+			const uint64_t w0 = LO[SO(k)], w1 = LO[SO(k + 1)];   // k + 1 <= NXW + 1
 			out[w] = ((w0 >> sh) | (w1 << (63 - sh))) & MALL;     // 63 payload bits per word; sh == 0: the second term lands on bit 63
 			sh += SBITS * non[w];                                  // non <= SPW: at most one word further
 			if (sh >= 63) { sh -= 63; ++k; }
@@ -166,8 +180,8 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 	// publish my words and my exclusive prefixes (the old-word stage is dead by now)
 	uint32_t *LP = (uint32_t*)LO;
 #pragma unroll
-	for (int w = 0; w < WPL; ++w) LX[WPL * ln + w] = out[w];
-	LP[4 * ln + 0] = s01 - e01; LP[4 * ln + 1] = s23 - e23; LP[4 * ln + 2] = s45 - e45;
+	for (int w = 0; w < WPL; ++w) LX[LM(w, ln)] = out[w];
+	LP[ln] = s01 - e01; LP[64 + ln] = s23 - e23; LP[128 + ln] = s45 - e45;   // lane-major too: LP[q * 64 + lane]
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 
 	// ---- 5. leaf-relative rank of every new symbol, one per lane
@@ -180,18 +194,18 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 		const uint32_t pw = p / SPW, lo = pw / WPL, wi = pw - lo * WPL, below = (p - pw * SPW) * SBITS;
 		const uint32_t bl = (p / LEAF) * LPW;                    // first lane of its leaf
 		const uint32_t sh = (a & 1) * 16;
-		uint32_t r = ((LP[4 * lo + (a >> 1)] >> sh) & 0xffffu) - ((LP[4 * bl + (a >> 1)] >> sh) & 0xffffu);
+		uint32_t r = ((LP[64 * (a >> 1) + lo] >> sh) & 0xffffu) - ((LP[64 * (a >> 1) + bl] >> sh) & 0xffffu);
 #pragma unroll
 		for (int w = 0; w < WPL; ++w) {
 			const uint64_t m = (uint32_t)w < wi ? ~0ull : ((uint32_t)w == wi ? (1ull << below) - 1ull : 0ull);
-			r += (uint32_t)__popcll(nib_eq(LX[WPL * lo + w], a) & m);
+			r += (uint32_t)__popcll(nib_eq(LX[LM(w, (int)lo)], a) & m);
 		}
 		RKREL[d.ins0 + jj] = (uint16_t)r;
 		if (INPLACE) RKLEAF[d.ins0 + jj] = (uint32_t)d.gl;
 	}
 	if (!INPLACE && (ln % LPW) == LPW - 1 && (ln / LPW) * LEAF < nvalid) {   // last lane of a leaf that exists (in place: the directory is kept by dir_add)
 		const uint32_t bl = (uint32_t)(ln / LPW) * LPW;
-		const uint32_t t01 = s01 - LP[4 * bl + 0], t23 = s23 - LP[4 * bl + 1], t45 = s45 - LP[4 * bl + 2];
+		const uint32_t t01 = s01 - LP[bl], t23 = s23 - LP[64 + bl], t45 = s45 - LP[128 + bl];
 		LeafMeta m;
 		m.c[0] = (uint16_t)t01; m.c[1] = (uint16_t)(t01 >> 16); m.c[2] = (uint16_t)t23; m.c[3] = (uint16_t)(t23 >> 16);
 		m.c[4] = (uint16_t)t45; m.c[5] = (uint16_t)(t45 >> 16);
@@ -209,10 +223,10 @@ template <bool FULL, int WPL_, bool INPLACE> __device__ __forceinline__ void mer
 template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
-	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 8 + NXW / 2];
+	__shared__ __align__(16) uint64_t lds[MW][2 * NXW + 16 + NXW / 2];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words used
-	uint32_t *LF = (uint32_t*)(lds[wv] + 2 * NXW + 8);          // NXW flag words of 32 bits
+	uint64_t *LX = lds[wv], *LO = lds[wv] + NXW;                // LO: NXW + 2 words + one pad word per 32 (SO)
+	uint32_t *LF = (uint32_t*)(lds[wv] + 2 * NXW + 16);         // NXW flag words of 32 bits
 	const int ln = lane_id();
 	// one window per wave; a rank of a sharded index launches fewer waves than the upper bound of its windows (the host does not
 	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows.  The first window's

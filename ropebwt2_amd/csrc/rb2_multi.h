@@ -12,7 +12,7 @@
 //   layout     k_mlayout (one block, on every rank, from the summed matrix and the owner map): where this rank's k_advance
 //              writes the records it sends (Ctl::sdest) and the list of pieces k_munpack fetches (MTab) -- the host never
 //              needs the matrix for that
-//   records    16-byte ShardRec {l, size, id} per surviving string, from the owner of piece (b,x) to the owner of (a,b)
+//   records    24-byte ShardRec {l, size, id, symbol cursor} per surviving string, from the owner of piece (b,x) to the owner of (a,b)
 //              PEER: the receiver's k_munpack reads them from the senders' buffers, RCCL: grouped ncclSend / ncclRecv
 //
 // Ordering between ranks on the PEER transport is by device events (hipStreamWaitEvent), two per round and rank; the host
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 }
 
 // records -> next round's SoA arrays in bucket order (k_unpack's job), fetched from wherever k_mlayout says they are: the
-// senders' buffers (PEER: loads over xGMI, 16 bytes per lane, coalesced per piece) or the local receive buffer (RCCL).
+// senders' buffers (PEER: loads over xGMI, 24 bytes per lane, consecutive per piece) or the local receive buffer (RCCL).
 // The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
 __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, const uint64_t *START, uint32_t round,
 		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab
 		const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
 		const uint32_t id = (uint32_t)r.b;
 		L2[d] = l; U2[d] = l + size; ID2[d] = id;
-		W2[d] = pack16(s, ctl->len, START[id] + round + 1);
+		W2[d] = r.w;
 		nonempty |= size != 0;
 	}
 	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
@@ -291,8 +291,8 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 				if (p == R.grank && !(m->rccl_self && R.comm)) {     // own block: a device copy, not a message (RB2_RCCL_SELF=1: through RCCL all the same)
 					if (nsend) HIPCHK(hipMemcpyAsync(R.recv + rbase, R.send[r & 1] + start[p], (size_t)nsend * sizeof(ShardRec), hipMemcpyDeviceToDevice, st));
 				} else {
-					if (nsend) NCCLCHK(N.Send(R.send[r & 1] + start[p], (size_t)nsend * 2, ncclUint64, p, R.comm, st));
-					if (nrecv) NCCLCHK(N.Recv(R.recv + rbase, (size_t)nrecv * 2, ncclUint64, p, R.comm, st));
+					if (nsend) NCCLCHK(N.Send(R.send[r & 1] + start[p], (size_t)nsend * (sizeof(ShardRec) / 8), ncclUint64, p, R.comm, st));
+					if (nrecv) NCCLCHK(N.Recv(R.recv + rbase, (size_t)nrecv * (sizeof(ShardRec) / 8), ncclUint64, p, R.comm, st));
 				}
 				rbase += nrecv;
 			}

@@ -10,7 +10,7 @@ rounds
 * every rank needs the NR x 6 matrix "members of bucket r that insert a" (the reference's master reads
   ``r[b]->c[]`` of all ropes, mrope.c:332-340)          -> ``all_reduce`` of 186 int64;
 * a string in piece (b,x) that inserted a moves to the owner of piece (a,b) (the stable scatter of
-  mrope.c:303-309)                                      -> ``all_to_all_single`` of 16-byte records.
+  mrope.c:303-309)                                      -> ``all_to_all_single`` of 24-byte records.
 
 The GPU work of each phase is in librb2hip.so (``rb2_hip_shard_*``); this module only moves the two
 buffers.  The per-batch protocol is written once, as a generator that yields at every
@@ -25,7 +25,7 @@ import numpy as np
 
 from .hipbwt import HipBwt, load_hip_lib
 
-REC_BYTES = 16          # sizeof(ShardRec), rb2_device.h: {l:48, size:48, id:32}; the symbol cursor is rebuilt on arrival
+REC_BYTES = 24          # sizeof(ShardRec), rb2_device.h: {l:48, size:48, id:32, symbol cursor:64}
 NR = 31                 # sub-ropes, rb2_device.h (checked against the library in ShardedBwt)
 
 
@@ -160,7 +160,7 @@ class TorchComm:
         self.EPR = REC_BYTES // 8                 # int64 elements per record
 
     def _ensure(self, n_records):
-        """exchange buffers as int64 tensors (2 elements per 16-byte record): element counts stay small even for
+        """exchange buffers as int64 tensors (3 elements per 24-byte record): element counts stay small even for
         multi-GB exchanges"""
         if n_records <= self.cap:
             return
@@ -370,9 +370,10 @@ class StreamOrderedCluster(VirtualCluster):
         rounds = [L.rb2_hip_shard_begin(r.h, nbytes, dev_ptr) for r in self.ranks]
         assert len(set(rounds)) == 1
         cap = max(L.rb2_hip_shard_capacity(r.h) for r in self.ranks)
-        if self.tx is None or self.tx[0].numel() < cap * 2:
-            self.tx = [torch.empty(max(1, cap) * 2, dtype=torch.int64, device=self.dev) for _ in range(n)]
-            self.rx = [torch.empty(max(1, cap) * 2, dtype=torch.int64, device=self.dev) for _ in range(n)]
+        E = REC_BYTES // 8
+        if self.tx is None or self.tx[0].numel() < cap * E:
+            self.tx = [torch.empty(max(1, cap) * E, dtype=torch.int64, device=self.dev) for _ in range(n)]
+            self.rx = [torch.empty(max(1, cap) * E, dtype=torch.int64, device=self.dev) for _ in range(n)]
         xt = self.ranks[0].xt
         for rd in range(rounds[0]):
             for r in self.ranks:
@@ -392,7 +393,7 @@ class StreamOrderedCluster(VirtualCluster):
                     c = int(cnt[s_, d])
                     if c:
                         so = int(cnt[s_, :d].sum())
-                        self.rx[d][off * 2:(off + c) * 2].copy_(self.tx[s_][so * 2:(so + c) * 2])
+                        self.rx[d][off * E:(off + c) * E].copy_(self.tx[s_][so * E:(so + c) * E])
                     off += c
             for k, r in enumerate(self.ranks):
                 nrecv = (C.c_int64 * n)(*[int(x) for x in cnt[:, k]])

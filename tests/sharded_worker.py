@@ -130,8 +130,8 @@ def main():
                     tot = yield ("allreduce", loc.reshape(-1).copy())
                     assert np.array_equal(tot.reshape(NR, 6), g)
                     recs = [(rnd,) + t for d in range(n) for t in plan(rank, d, g)]
-                    arr = np.zeros((len(recs), 2), np.int64)           # 16-byte records: (round << 32 | r, a << 32 | index)
-                    if recs: arr[:] = [(t[0] << 32 | t[1], t[2] << 32 | t[3]) for t in recs]
+                    arr = np.zeros((len(recs), sharded.REC_BYTES // 8), np.int64)   # records: (round << 32 | r, a << 32 | index, 0...)
+                    if recs: arr[:, :2] = [(t[0] << 32 | t[1], t[2] << 32 | t[3]) for t in recs]
                     raw = arr.view(np.uint8).reshape(-1)
                     ctypes.memmove(sp, raw.ctypes.data, len(raw)) if len(raw) else None
                     sc = sharded.exchange_layout(owner, n, rank, g)
@@ -139,10 +139,10 @@ def main():
                     assert sc == [len(plan(rank, d, g)) for d in range(n)]
                     yield ("alltoall", sc, rc, int(g[:, 1:].sum()))
                     tot_r = sum(rc)
-                    got = np.zeros((tot_r, 2), np.int64)
+                    got = np.zeros((tot_r, sharded.REC_BYTES // 8), np.int64)
                     if tot_r: ctypes.memmove(got.ctypes.data, rp, tot_r * sharded.REC_BYTES)
                     want = [(rnd,) + t for s in range(n) for t in plan(s, rank, g)]
-                    assert got.tolist() == [[w[0] << 32 | w[1], w[2] << 32 | w[3]] for w in want], "round %d: records out of place" % rnd
+                    assert got[:, :2].tolist() == [[w[0] << 32 | w[1], w[2] << 32 | w[3]] for w in want], "round %d: records out of place" % rnd
 
         toy = Toy()
         comm = sharded.TorchComm(toy)

@@ -27,5 +27,6 @@ for j in bench long; do
 	B=$(ls $O/*${j}B*counter_collection.csv $O/*/*${j}B*counter_collection.csv 2>/dev/null | head -1)
 	[ -n "$A$B" ] && python $R/tools/pmc_summary.py $A $B > $S/${TAG}_${j}_sq_counters.csv
 done
+# the raw per-dispatch CSVs are hundreds of MB: only the summaries travel back
+find $O -maxdepth 2 -type f ! -path "$S/*" ! -name "sq_counters.txt" -delete 2>/dev/null
 head -12 $S/*_sq_counters.csv | cut -c1-400
-tail -3 $O/benchB.log
