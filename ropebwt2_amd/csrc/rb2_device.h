@@ -23,7 +23,7 @@
 //                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
 //   pool          two sides (ping-pong); each round the merge kernel streams side -> side^1.
 //   strings       SoA per-string state (reference triple64_t, mrope.c:174-178): L, U (interval in
-//                 the reference's own coordinates), ID, W (next 16 symbols, 4 bit each).
+//                 the reference's own coordinates), W (string id + the next 10 symbols, 3 bits each).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

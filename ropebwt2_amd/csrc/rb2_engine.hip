@@ -170,7 +170,6 @@ struct rb2_hip_s {
 	int64_t n_respread = 0;
 	DevBuf<uint64_t> qbuf;              // rank queries and their answers
 	uint64_t sp_nsb = 0;                // superblocks of the sparse pool (upper bound)
-	DevBuf<uint32_t> ID[2];
 	DevBuf<LeafDesc> LD;
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	// rb2_hip_prefetch: the NEXT batch travels to the device (second text buffer, copy stream) while the current one is inserted
@@ -284,7 +283,7 @@ struct BatchState {
 // per-string arrays + tile tables for batches of up to m strings
 void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
-	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); h->ID[i].ensure(m); }
+	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); }
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
@@ -331,7 +330,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		Scope sc(h, RB2_K_INIT, 0);
 		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len, is_srt);
 		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
-				h->L[0].p, h->U[0].p, h->ID[0].p, h->W[0].p);
+				h->L[0].p, h->U[0].p, h->W[0].p);
 	}
 	HIPCHK(hipMemcpyAsync(&B.max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -408,9 +407,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true>), (k_advance<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true>), (k_advance<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
@@ -489,9 +488,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true>), (k_advance<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true>), (k_advance<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->ID[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->ID[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
+			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
 	  hipLaunchKernelGGL(k_split, dim3(1024), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch); }
@@ -652,7 +651,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	if (!h) return;
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
-	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); h->ID[i].release(); }
+	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
 	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
@@ -1105,7 +1104,7 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 		HIPCHK(hipMemcpyAsync(h->pieces.p, src, pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
 		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
 		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->START.p, (uint32_t)round,
-				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
+				h->L[cur].p, h->U[cur].p, h->W[cur].p);
 	}
 	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));
 }

@@ -106,34 +106,39 @@ __global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t
 	}
 }
 
-// the next 16 symbols of a string, 4 bits each: s[p .. p+16) (bytes past the end of the batch read as 0).
-// Five aligned dword loads + funnel shifts instead of 16 byte loads (the batch buffer is 16-byte aligned).
-__device__ __forceinline__ uint32_t nib4(uint32_t x)      // low nibbles of 4 bytes -> 16 bits
+// The per-string cursor word W that rides through the partition of every round: string id (high 32 bits) + the next CUR_SYMS
+// symbols, 3 bits each (low 30 bits).  (Rounds 1-2: a 16-symbol cursor of 4-bit codes + a separate 32-bit id array -- 12 bytes
+// read and 12 written per string and round in k_advance; one word now, refilled every 10 rounds instead of every 16.)
+constexpr int CUR_SYMS = 10;
+__device__ __forceinline__ uint32_t tri4(uint32_t x)      // low 3 bits of 4 bytes -> 12 bits
 {
-	x &= 0x0f0f0f0fu;
-	x = (x | x >> 4) & 0x00ff00ffu;
-	return (x | x >> 8) & 0xffffu;
+	x &= 0x07070707u;
+	x = (x | x >> 5) & 0x003f003fu;
+	return (x | x >> 10) & 0xfffu;
 }
-__device__ __forceinline__ uint64_t pack16(const uint8_t *s, uint64_t len, uint64_t p)
+__device__ __forceinline__ uint32_t pack10(const uint8_t *s, uint64_t len, uint64_t p)   // s[p .. p+10) as 30 bits (bytes past the end read as 0)
 {
-	if (p + 20 <= len) {
+	if (p + 16 <= len) {
 		const uint32_t *q = (const uint32_t*)(s + (p & ~3ull));
 		const uint32_t sh = (uint32_t)(p & 3) * 8;
-		const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-		const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh);
-		const uint32_t w2 = __builtin_amdgcn_alignbit(d3, d2, sh), w3 = __builtin_amdgcn_alignbit(d4, d3, sh);
-		return (uint64_t)(nib4(w0) | nib4(w1) << 16) | (uint64_t)(nib4(w2) | nib4(w3) << 16) << 32;
+		const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+		const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+		return tri4(w0) | tri4(w1) << 12 | (tri4(w2) & 0x3fu) << 24;
 	}
-	uint64_t w = 0;
-	for (int i = 0; i < 16; ++i) {
+	uint32_t w = 0;
+	for (int i = 0; i < CUR_SYMS; ++i) {
 		const uint64_t q = p + i;
-		w |= (uint64_t)(q < len ? (s[q] & 15) : 0) << (4*i);
+		w |= (uint32_t)(q < len ? (s[q] & 7) : 0) << (3 * i);
 	}
 	return w;
 }
+__device__ __forceinline__ uint64_t cur_make(uint32_t id, uint32_t syms) { return (uint64_t)id << 32 | syms; }
+__device__ __forceinline__ uint32_t cur_id(uint64_t w) { return (uint32_t)(w >> 32); }
+__device__ __forceinline__ int cur_sym(uint64_t w) { return (int)(w & 7); }
+__device__ __forceinline__ uint64_t cur_next(uint64_t w) { return (w & 0xffffffff00000000ull) | ((uint32_t)w >> 3); }   // one symbol consumed
 
 __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
-		uint64_t *L, uint64_t *U, uint32_t *ID, uint64_t *W)
+		uint64_t *L, uint64_t *U, uint64_t *W)
 {
 	__shared__ int s_wm[4];
 	const uint64_t m = ctl->n_strings, k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -143,8 +148,7 @@ __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, cons
 		ln = START[k+1] - 1 - st;
 		L[k] = is_srt ? 0 : n0 + k;                 // mrope.c:280-283
 		U[k] = is_srt ? n0 : n0 + k;
-		ID[k] = (uint32_t)k;
-		W[k] = pack16(s, ctl->len, st);
+		W[k] = cur_make((uint32_t)k, pack10(s, ctl->len, st));
 	}
 	// block max of the lengths -> ctl->max_len
 	unsigned long long v = ln;
@@ -211,7 +215,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *c
 		const uint64_t k = t.base + pos;
 		int sym = 7; bool head = false;
 		if (k < t.segend) {
-			sym = (int)(W[k] & 15);
+			sym = cur_sym(W[k]);
 			head = (k == t.segstart) || (U[k] != U[k-1]);
 			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
 		}
@@ -1203,16 +1207,16 @@ __global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const SbTot 
 
 template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
-		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, ID, W, L2, U2, ID2, W2, send, RKLEAF)) return;
+		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1222,8 +1226,8 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch
 
 template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		const uint64_t *START, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint32_t *ID, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
+		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
@@ -1234,12 +1238,12 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
-	uint32_t id2[2]; uint64_t w2[2], l2[2];                    // issued before the barriers of group_setup
+	uint64_t w2[2], l2[2];                                     // issued before the barriers of group_setup
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		id2[h] = 0; w2[h] = 0; l2[h] = 0;
-		if (k < t.segend) { id2[h] = ID[k]; w2[h] = W[k]; l2[h] = L[k]; }
+		w2[h] = 0; l2[h] = 0;
+		if (k < t.segend) { w2[h] = W[k]; l2[h] = L[k]; }
 	}
 	group_setup(G, t, A, tf, tile, sym2, flag2);
 	uint32_t nz = 0;
@@ -1267,13 +1271,13 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
-		const uint32_t id = id2[h];
-		uint64_t wv = w2[h] >> 4;
-		if (((round + 1) & 15) == 0) wv = pack16(s, ctl->len, START[id] + round + 1);
+		const uint32_t id = cur_id(w2[h]);
+		uint64_t wv = cur_next(w2[h]);
+		if ((round + 1) % CUR_SYMS == 0) wv = cur_make(id, pack10(s, ctl->len, START[id] + round + 1));
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id, wv);
 		} else {
-			L2[d] = l; ID2[d] = id; W2[d] = wv;
+			L2[d] = l; W2[d] = wv;
 			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}
@@ -1285,7 +1289,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 
 // sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
 __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
-		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint64_t *W2)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	bool nonempty = false;
@@ -1295,8 +1299,7 @@ __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *
 	const ShardRec r = recv[i];
 	const uint64_t d = pc[lo].dst + (i - pc[lo].src);
 	const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
-	const uint32_t id = (uint32_t)r.b;
-	L2[d] = l; U2[d] = l + size; ID2[d] = id;
+	L2[d] = l; U2[d] = l + size;
 	W2[d] = r.w;
 	nonempty = size != 0;
 	}

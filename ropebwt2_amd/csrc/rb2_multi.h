@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 // senders' buffers (PEER: loads over xGMI, 24 bytes per lane, consecutive per piece) or the local receive buffer (RCCL).
 // The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
 __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, const uint64_t *START, uint32_t round,
-		uint64_t *L2, uint64_t *U2, uint32_t *ID2, uint64_t *W2)
+		uint64_t *L2, uint64_t *U2, uint64_t *W2)
 {
 	const uint64_t total = tab->total;
 	bool nonempty = false;
@@ -117,8 +117,7 @@ __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab
 		const ShardRec r = pc.src[i - pc.vsrc];
 		const uint64_t d = pc.dst + (i - pc.vsrc);
 		const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
-		const uint32_t id = (uint32_t)r.b;
-		L2[d] = l; U2[d] = l + size; ID2[d] = id;
+		L2[d] = l; U2[d] = l + size;
 		W2[d] = r.w;
 		nonempty |= size != 0;
 	}
@@ -300,7 +299,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 		}
 		const int cur = B.cur;
 		hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, (const uint64_t*)h->START.p, (uint32_t)r,
-				h->L[cur].p, h->U[cur].p, h->ID[cur].p, h->W[cur].p);
+				h->L[cur].p, h->U[cur].p, h->W[cur].p);
 		HIPCHK(hipGetLastError());
 	}
 	h->gcnt = R.gloc;
@@ -464,7 +463,7 @@ void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8
 void rb2_hip_multi_insert_multi(rb2_hip_multi_t *m, int64_t len, const uint8_t *s)
 {
 	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
-	// one copy of the batch text per DEVICE (every rank reads all of it: the 16-symbol cursor refills), uploaded by the first rank on it
+	// one copy of the batch text per DEVICE (every rank reads all of it: the cursor refills every 10 rounds), uploaded by the first rank on it
 	std::vector<const uint8_t*> ptr(m->n, nullptr);
 	multi_each(m, [&](int k) {
 		MRank &R = m->rk[k];
