@@ -346,17 +346,63 @@ static int usage(int block_len, int max_nodes)
  * size when the batch starts, and an append that would outgrow it (one giant record) cancels the announcements first. ---- */
 #define PF_STEP ((size_t)256 << 20)
 static struct { size_t sent; int on; int64_t cap; } PF = { 0, 0, 0 };
+/* the copies themselves are issued by a thread of their own: a pageable host-to-device copy keeps its caller busy for the time of
+ * the copy, and the reader is the wall-clock of a whole run (on the reader's thread the announcements cost configs[1] 0.3 s) */
+static struct {
+	pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+	mrope_t *mr; const uint8_t *s; int64_t n, cap; int pending, busy, quit, started;
+} UP = { .mu = PTHREAD_MUTEX_INITIALIZER, .cv = PTHREAD_COND_INITIALIZER };
+
+static void *up_worker(void *arg)
+{
+	(void)arg;
+	pthread_mutex_lock(&UP.mu);
+	for (;;) {
+		while (!UP.pending && !UP.quit) pthread_cond_wait(&UP.cv, &UP.mu);
+		if (!UP.pending) break;
+		{
+			mrope_t *mr = UP.mr; const uint8_t *s = UP.s; const int64_t n = UP.n, cap = UP.cap;
+			UP.pending = 0; UP.busy = 1;
+			pthread_mutex_unlock(&UP.mu);
+			mr_prefetch(mr, s, n, cap);
+			pthread_mutex_lock(&UP.mu);
+			UP.busy = 0;
+			pthread_cond_broadcast(&UP.cv);
+		}
+	}
+	pthread_mutex_unlock(&UP.mu);
+	return 0;
+}
+static void up_drain(void)                                   /* nothing announced is still waiting or being copied */
+{
+	if (!UP.started) return;
+	pthread_mutex_lock(&UP.mu);
+	while (UP.pending || UP.busy) pthread_cond_wait(&UP.cv, &UP.mu);
+	pthread_mutex_unlock(&UP.mu);
+}
+static void up_stop(void)
+{
+	if (!UP.started) return;
+	up_drain();
+	pthread_mutex_lock(&UP.mu); UP.quit = 1; pthread_cond_broadcast(&UP.cv); pthread_mutex_unlock(&UP.mu);
+	pthread_join(UP.th, 0);
+	UP.started = 0; UP.quit = 0;
+}
 
 static void batch_room(mrope_t *mr, str_t *buf, int64_t m, size_t add)
 {
 	if (!PF.on) return;
-	if (buf->l == 0 && buf->m < (size_t)m + (64 << 20)) { mr_prefetch(mr, 0, 0, 0); str_reserve(buf, (size_t)m + (64 << 20)); PF.sent = 0; }
-	if (buf->l + add + 1 > buf->m) { mr_prefetch(mr, 0, 0, 0); PF.sent = (size_t)-1; }      /* it will move: no announcements for the rest of this batch */
+	if (buf->l == 0 && buf->m < (size_t)m + (64 << 20)) { up_drain(); mr_prefetch(mr, 0, 0, 0); str_reserve(buf, (size_t)m + (64 << 20)); PF.sent = 0; }
+	if (buf->l + add + 1 > buf->m) { up_drain(); mr_prefetch(mr, 0, 0, 0); PF.sent = (size_t)-1; }      /* it will move: no announcements for the rest of this batch */
 }
 static void batch_announce(mrope_t *mr, str_t *buf)
 {
 	if (!PF.on || PF.sent == (size_t)-1 || buf->l < PF.sent + PF_STEP) return;
-	mr_prefetch(mr, (const uint8_t*)buf->s, (int64_t)buf->l, (int64_t)buf->m);
+	if (!UP.started) { UP.started = 1; pthread_create(&UP.th, 0, up_worker, 0); }
+	pthread_mutex_lock(&UP.mu);
+	UP.mr = mr; UP.s = (const uint8_t*)buf->s; UP.n = (int64_t)buf->l; UP.cap = (int64_t)buf->m; UP.pending = 1;   /* (a later announcement replaces one not yet taken) */
+	pthread_cond_broadcast(&UP.cv);
+	pthread_mutex_unlock(&UP.mu);
 	PF.sent = buf->l;
 }
 
@@ -410,6 +456,7 @@ static void flush_wait(void)                                /* every batch hande
 
 static void flush_done(void)
 {
+	up_stop();
 	if (!AF.started) return;
 	flush_wait();
 	pthread_mutex_lock(&AF.mu);
@@ -426,6 +473,7 @@ static void flush_batch(mrope_t *mr, str_t *buf, int flag, int verbose)
 	str_t t;
 	if (getenv("RB2_DUMP_BATCHES") || getenv("RB2_SYNC_INSERT")) { flush_batch_now(mr, buf, flag, verbose); return; }
 	if (!AF.started) { AF.started = 1; pthread_create(&AF.th, 0, aflush_worker, 0); }
+	up_drain();                                                /* what was announced of this batch is on its way before the inserter takes the buffer */
 	pthread_mutex_lock(&AF.mu);
 	while (AF.busy) pthread_cond_wait(&AF.cv, &AF.mu);       /* the batch before this one */
 	t = AF.job; AF.job = *buf; *buf = t;                       /* the reader goes on in the buffer the inserter is done with */

@@ -3,7 +3,7 @@
 #   usage: collect_longreads_profile.sh [tag] [reads]      summaries in gpurun_out/prof_<tag>/summary/
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02_long}
+TAG=${1:-r03_long}
 READS=${2:-1000000}
 O=$R/gpurun_out/prof_$TAG
 S=$O/summary
@@ -18,6 +18,7 @@ DB=$(ls $O/*ktrace*results.db $O/*/*ktrace*results.db 2>/dev/null | head -1)
 F=$(ls $O/*fetch*counter_collection.csv $O/*/*fetch*counter_collection.csv 2>/dev/null | head -1)
 W=$(ls $O/*write*counter_collection.csv $O/*/*write*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python $R/tools/traffic_summary.py $F $W $S/${TAG}_hbm_traffic.csv $S/${TAG}_k_merge_traffic.json "python tools/scale_check.py --reads $READS --read-len 10000 --order io --seed 44"
+find $O -maxdepth 2 -type f ! -path "$S/*" ! -name "*.log" -delete 2>/dev/null
 tail -2 $O/ktrace.log | cut -c1-400
 head -14 $S/${TAG}_kernel_stats.csv
 head -12 $S/${TAG}_hbm_traffic.csv

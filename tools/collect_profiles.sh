@@ -5,7 +5,7 @@
 # only the host-API / CLI / CPU-reference legs that follow it are skipped.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 STEPS=${STEPS:-20}
 WARM=${WARM:-5}
 O=$R/gpurun_out/prof_$TAG
@@ -26,5 +26,7 @@ DB=$(ls $O/*ktrace*results.db $O/*/*ktrace*results.db 2>/dev/null | head -1)
 F=$(ls $O/*fetch*counter_collection.csv $O/*/*fetch*counter_collection.csv 2>/dev/null | head -1)
 W=$(ls $O/*write*counter_collection.csv $O/*/*write*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python $R/tools/traffic_summary.py $F $W $S/${TAG}_hbm_traffic.csv $S/k_merge_traffic.json "python bench.py --steps $STEPS --warmup 0 --no-cpu-baseline --no-extras"
+# only the summaries travel back (gpurun merges at most 64 MiB)
+find $O -maxdepth 2 -type f ! -path "$S/*" ! -name "bench.json" ! -name "*.log" -delete 2>/dev/null
 ls -la $O $S | head -40
 tail -1 $O/bench.json | cut -c1-1500
