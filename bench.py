@@ -124,7 +124,10 @@ def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
     for k, a in enumerate(host):
         th = None
         if k + 1 < len(host):
-            th = threading.Thread(target=b.prefetch, args=(host[k + 1], len(host[k + 1]), len(host[k + 1])))
+            def announce(a=host[k + 1]):                   # in 256 MB steps, as the CLI's reader announces a batch it is assembling
+                for o in range(256 << 20, len(a) + (256 << 20), 256 << 20):
+                    b.prefetch(a, min(o, len(a)), len(a))
+            th = threading.Thread(target=announce)
             th.start()
         b.insert_multi(a)
         if th is not None:

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <mutex>
+#include <condition_variable>
 #include "rb2_hip.h"
 #include "rb2_kernels.h"
 
@@ -174,6 +175,7 @@ struct rb2_hip_s {
 	DevBuf<uint8_t> A, INS_A, sbuf;
 	// rb2_hip_prefetch: the NEXT batch travels to the device (second text buffer, copy stream) while the current one is inserted
 	DevBuf<uint8_t> sbuf2; hipStream_t st_copy = nullptr; const uint8_t *pf_host = nullptr; size_t pf_done = 0; std::mutex pf_mu;
+	bool pf_busy = false; std::condition_variable pf_cv;        // a prefetch copy is running (outside the lock: an insert of ANOTHER buffer must not wait for it)
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<TileFix> tfix; DevBuf<ChunkPart> cpart;
 	DevBuf<SbTot> sbtot; DevBuf<Cnt6> sbpart;
 	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
@@ -700,8 +702,9 @@ void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
  * between the first prefetch and the insert.  Entirely optional: an insert of a buffer that was not prefetched uploads all of it. */
 void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t capacity)
 {
-	std::lock_guard<std::mutex> lk(h->pf_mu);
+	std::unique_lock<std::mutex> lk(h->pf_mu);
 	HIPCHK(hipSetDevice(h->dev));
+	h->pf_cv.wait(lk, [h] { return !h->pf_busy; });             // one copy at a time
 	if (!h->st_copy) HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
 	if (s == nullptr) {                                          // cancel: the caller is about to move or free the buffer -- no copy may still read it
 		HIPCHK(hipStreamSynchronize(h->st_copy));
@@ -711,13 +714,15 @@ void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t c
 	if (h->pf_host != s) { h->pf_host = s; h->pf_done = 0; }
 	if (n_final <= (int64_t)h->pf_done) return;
 	const size_t need = (size_t)std::max(n_final, capacity) + 64;
-	if (need > h->sbuf2.cap) {                                  // (first call of a batch, normally; a moved buffer starts over)
-		HIPCHK(hipStreamSynchronize(h->st_copy));
-		h->sbuf2.ensure(need);
-		h->pf_done = 0;
-	}
-	HIPCHK(hipMemcpyAsync(h->sbuf2.p + h->pf_done, s + h->pf_done, (size_t)n_final - h->pf_done, hipMemcpyHostToDevice, h->st_copy));
+	const size_t from = need > h->sbuf2.cap ? 0 : h->pf_done;  // (first call of a batch, normally; a buffer that has to grow starts over)
+	h->pf_busy = true;
+	lk.unlock();                                                 // the copy keeps this thread busy for its whole duration (pageable memory): not under the lock
+	if (need > h->sbuf2.cap) { HIPCHK(hipStreamSynchronize(h->st_copy)); h->sbuf2.ensure(need); }
+	HIPCHK(hipMemcpyAsync(h->sbuf2.p + from, s + from, (size_t)n_final - from, hipMemcpyHostToDevice, h->st_copy));
+	lk.lock();
 	h->pf_done = (size_t)n_final;
+	h->pf_busy = false;
+	h->pf_cv.notify_all();
 }
 
 void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
@@ -734,6 +739,7 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
 	{	// (most of) the batch is on the device already?  (rb2_hip_prefetch)
 		std::unique_lock<std::mutex> lk(h->pf_mu);
+		if (h->pf_host == s) h->pf_cv.wait(lk, [h] { return !h->pf_busy; });   // a copy of THIS batch is running: it is what we are about to use
 		if (h->pf_host == s && h->pf_done > 0 && (int64_t)h->pf_done <= len && h->sbuf2.cap >= (size_t)len + 64) {
 			if ((size_t)len > h->pf_done) HIPCHK(hipMemcpyAsync(h->sbuf2.p + h->pf_done, s + h->pf_done, (size_t)len - h->pf_done, hipMemcpyHostToDevice, h->st_copy));
 			HIPCHK(hipStreamSynchronize(h->st_copy));
