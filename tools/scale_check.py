@@ -64,7 +64,11 @@ def main():
             r = bwt.rank1a(b, int(x))
             ok_rank &= int(r.sum()) == int(x) and bool(np.all(r >= prev))
             prev = r
-    extra = {"layout": bwt.sparse_stats(), "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default")}
+    try:
+        lay = bwt.layout_stats()                      # (+ re-spreads and leaf splits; an older library in an A/B run has only the four)
+    except Exception:  # noqa: BLE001
+        lay = bwt.sparse_stats()
+    extra = {"layout": lay, "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default"), "library": os.environ.get("RB2_HIP_LIB", "this build")}
     if args.profile:
         extra["kernels_ms"] = {k: round(v["ms"], 2) for k, v in bwt.profile_get().items()}
     bwt.dev_free(buf)
