@@ -155,6 +155,7 @@ struct rb2_hip_s {
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
 	int sp_head = 8;                    // dense rounds at the start of a batch while the index is sparse (see insert_dev)
 	int sp_maxpen = 6;                  // at most 64 dense rounds between two attempts (a failed attempt costs about four dense rounds)
+	int leaf_pipe = 0;                  // > 0: in-place rounds use the persistent, software-pipelined k_merge_leaf_pipe with this many workgroups (RB2_LEAF_PIPE)
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
@@ -485,7 +486,8 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  RB2_LAUNCH_STRIDE(h, k_merge_leaf<true>, k_merge_leaf<false>, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  if (h->leaf_pipe > 0) hipLaunchKernelGGL(k_merge_leaf_pipe, dim3(std::min<unsigned>(cdiv(rank_share(h, B.m), MW * LPWP), (unsigned)h->leaf_pipe)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p);
+	  else RB2_LAUNCH_STRIDE(h, k_merge_leaf<true>, k_merge_leaf<false>, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -631,6 +633,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	h->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	if (getenv("RB2_SPARSE_LAMBDA")) h->sp_lambda = atof(getenv("RB2_SPARSE_LAMBDA"));   // 0: never leave the dense layout
 	if (getenv("RB2_SPARSE_HEAD")) h->sp_head = atoi(getenv("RB2_SPARSE_HEAD"));
+	if (getenv("RB2_LEAF_PIPE")) h->leaf_pipe = atoi(getenv("RB2_LEAF_PIPE"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));

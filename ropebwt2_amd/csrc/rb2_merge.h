@@ -381,6 +381,64 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge_leaf(const
 	}
 }
 
+// The same work as a PERSISTENT, software-pipelined kernel: a wave walks the work list with a grid stride and keeps three groups
+// of LPWP orders going at once -- the group it is inserting into, the group whose leaf words and insert records are in flight,
+// and the group whose work orders (scalar loads) are in flight.  k_merge_leaf above starts a wave per group: every wave pays the
+// chain order -> leaf + inserts -> stores once, and what hides it is only the other waves of the SIMD (8 at most).  Here the
+// chain of the NEXT group runs beside the shifts of the current one.
+constexpr int LPWP = 2;
+__global__ __launch_bounds__(256) void k_merge_leaf_pipe(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
+		const uint64_t *INS_E, const uint8_t *INS_A, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
+{
+	__shared__ __align__(16) uint64_t lds[MW][64 + 136 + 32];
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int ln = lane_id();
+	const uint64_t stride = (uint64_t)gridDim.x * MW * LPWP;
+	uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LPWP;
+	const uint32_t nwork = ctl->nwork;
+	if (ctl->overflow || g0 >= nwork) return;
+	auto ld_desc = [&](uint64_t g, LeafDesc *d) {                // orders g .. g + LPWP - 1 (behind the end: a duplicate of the group's first, loaded but never run)
+#pragma unroll
+		for (int k = 0; k < LPWP; ++k) d[k] = LD[g + k < nwork ? g + k : g];
+	};
+	LeafDesc d[LPWP], dn[LPWP], dnn[LPWP];
+	LeafJob J[LPWP], Jn[LPWP];
+	ld_desc(g0, dn);
+	if (g0 + stride < nwork) ld_desc(g0 + stride, dnn); else ld_desc(g0, dnn);
+#pragma unroll
+	for (int k = 0; k < LPWP; ++k) leaf_job_load(dn[k], ln, pool, INS_E, INS_A, Jn[k]);
+	for (;;) {
+#pragma unroll
+		for (int k = 0; k < LPWP; ++k) { d[k] = dn[k]; J[k] = Jn[k]; dn[k] = dnn[k]; }
+		const uint64_t g1 = g0 + stride, g2 = g1 + stride;
+		const bool more = g1 < nwork;
+		if (more) {
+#pragma unroll
+			for (int k = 0; k < LPWP; ++k) leaf_job_load(dn[k], ln, pool, INS_E, INS_A, Jn[k]);   // next group: in flight while this one is worked on
+			ld_desc(g2 < nwork ? g2 : g1, dnn);
+		}
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int k = 0; k < LPWP; ++k) {
+			if (g0 + k >= nwork) break;
+			if (d[k].ni <= LIGHT_NI) { leaf_job_run(d[k], ln, pool, J[k], RKREL, RKLEAF, sbtot); continue; }
+			uint64_t *LX = lds[wv], *LO = lds[wv] + 64;
+			uint32_t *LF = (uint32_t*)(lds[wv] + 64 + 136);
+			uint32_t dd[3] = {0, 0, 0};
+			for (int j0 = 0; j0 < (int)d[k].ni; j0 += 64) {
+				const uint32_t a = j0 + ln < (int)d[k].ni ? (uint32_t)INS_A[d[k].ins0 + j0 + ln] : 7u;
+#pragma unroll
+				for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(a == (uint32_t)sy)) << (16 * (sy & 1));
+			}
+			dir_add_packed(pool, sbtot, d[k].gl, ln, dd[0], dd[1], dd[2]);
+			merge_window<false, 1, true>(d[k], LX, LF, LO, ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+		}
+		if (!more) return;
+		g0 = g1;
+	}
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_export: chunks [c0, c0+nc) of XCHUNK symbols of one sub-rope -> run-length bytes of ropebwt2's 43+3 codec, one
 // byte per run of <= 15 symbols (rle_enc1's 1-byte form, rle.h:55-57), runs cut at chunk ends.  A sub-rope is a flat
