@@ -155,7 +155,8 @@ struct rb2_hip_s {
 	int sp_backoff = 0, sp_penalty = 0; // after a void sparse round: dense rounds to run before trying again / its growth
 	int sp_head = 8;                    // dense rounds at the start of a batch while the index is sparse (see insert_dev)
 	int sp_maxpen = 6;                  // at most 64 dense rounds between two attempts (a failed attempt costs about four dense rounds)
-	int leaf_pipe = 0;                  // > 0: in-place rounds use the persistent, software-pipelined k_merge_leaf_pipe with this many workgroups (RB2_LEAF_PIPE)
+	int leaf_pipe = 8192;               // in-place rounds use the software-pipelined k_merge_leaf_pipe with at most this many workgroups (RB2_LEAF_PIPE; 0: one wave per
+	                                    // four work orders, k_merge_leaf).  1 M inserts per round: 232 us with k_merge_leaf, 259 / 228 / 212 / 207 / 212 us with 1024 / 1536 / 4096 / 8192 / 16384
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
