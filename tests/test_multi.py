@@ -174,6 +174,52 @@ def test_peer_random_owner_maps(hip, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_peer_fuzz_jobs(hip, seed):
+    """random jobs: number of ranks, owner map, order, strands, read shapes, batch cuts, and the leaf layout forced sparse in half
+    of them -- ropes and count matrix against the oracle after every batch"""
+    from ropebwt2_amd import MultiBwt
+    rng = np.random.RandomState(1000 + seed)
+    n = int(rng.randint(1, 10))
+    owners = None if rng.rand() < 0.5 else [int(x) for x in rng.randint(0, n, size=31)]
+    so = int(rng.randint(0, 3))
+    reads = []
+    for _ in range(int(rng.randint(2, 5))):
+        kind = rng.randint(0, 3)
+        if kind == 0:
+            reads += H.repetitive_reads(int(rng.randint(50, 1500)), seed=int(rng.randint(1 << 30)), genome_len=int(rng.randint(60, 2000)), max_len=int(rng.randint(5, 300)))
+        elif kind == 1:
+            reads += list(H.splitmix_bases(int(rng.randint(10, 3000)), int(rng.randint(1, 250)), seed=int(rng.randint(1 << 30))))
+        else:
+            reads += [[int(rng.randint(1, 5))] * int(rng.randint(1, 3000))] * int(rng.randint(1, 40))     # homopolymers, duplicates
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    cuts = sorted(set([0, len(reads)] + [int(x) for x in rng.randint(0, len(reads) + 1, size=int(rng.randint(0, 4)))]))
+    env = {"RB2_SPARSE_LAMBDA": "1e18", "RB2_SPARSE_MAXPEN": "0"} if seed % 2 else {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        o = H.Oracle(so)
+        m = MultiBwt(so, [0] * n, "peer", owners=owners)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if a == b:
+                continue
+            buf = H.encode_batch(reads[a:b], True, bool(rng.rand() < 0.4))
+            o.insert_multi(buf)
+            m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts()), "counts (seed %d, %d ranks)" % (seed, n)
+        for b in range(6):
+            assert np.array_equal(m.rope(b), o.rope(b)), "rope %d (seed %d, %d ranks, so %d)" % (b, seed, n, so)
+        m.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
 def test_peer_edge_batches(hip):
     """empty strings, one string, a batch of sentinels only, strings of very different lengths"""
     from ropebwt2_amd import MultiBwt
