@@ -53,6 +53,13 @@ typedef struct rb2_hip_s rb2_hip_t;
 #define RB2_SO_RLO  1
 #define RB2_SO_RCLO 2
 
+/* Fatal errors (a HIP call that fails, a missing GPU, a malformed batch, out of device memory): a message on stderr, then abort() --
+ * the reference's own convention on this path (asserts and unchecked mallocs).  A host program that wants a say
+ * installs a handler: it is called with the message before abort() and may log, release what it holds, or leave through longjmp /
+ * exit (the handle that failed must not be used again; others may). */
+typedef void (*rb2_hip_fatal_cb)(void *user, const char *message);
+void rb2_hip_set_fatal_handler(rb2_hip_fatal_cb cb, void *user);
+
 /* number of visible HIP devices (0 when there is no GPU; never aborts) */
 int rb2_hip_device_count(void);
 

@@ -18,8 +18,25 @@
 
 using namespace rb2;
 
+// Fatal errors.  The reference has no error convention on this path (asserts, unchecked mallocs: SURVEY.md 8b); the engine keeps that
+// -- a message on stderr, then abort() -- but a host program can ask to be told first (rb2_hip_set_fatal_handler): it may log, clean up,
+// or leave by longjmp / exit; if the handler returns, abort() follows.
+static rb2_hip_fatal_cb g_fatal_cb = nullptr;
+static void *g_fatal_user = nullptr;
+#include <cstdarg>
+[[noreturn]] static void rb2_fatal(const char *fmt, ...)
+{
+	char msg[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(msg, sizeof(msg), fmt, ap);
+	va_end(ap);
+	fputs(msg, stderr);
+	if (g_fatal_cb) g_fatal_cb(g_fatal_user, msg);
+	abort();
+}
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
-	fprintf(stderr, "[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); abort(); } } while (0)
+	rb2_fatal("[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, hipGetErrorString(e_)); } } while (0)
 
 namespace {
 
@@ -112,9 +129,8 @@ template <typename T> struct DevBuf {
 		if (e_ != hipSuccess) {                                    // tell the caller how much was needed (a 288 GB part can run out: both strands of 1.2 B reads)
 			size_t fr = 0, tot = 0;
 			(void)hipMemGetInfo(&fr, &tot);
-			fprintf(stderr, "[rb2_hip] out of device memory: a buffer of %.2f GB was needed (it held %.2f GB before), %.2f of %.2f GB are free; "
+			rb2_fatal("[rb2_hip] out of device memory: a buffer of %.2f GB was needed (it held %.2f GB before), %.2f of %.2f GB are free; "
 					"use smaller batches (-m) or shard the index over more GPUs\n", ncap * sizeof(T) / 1e9, cap * sizeof(T) / 1e9, fr / 1e9, tot / 1e9);
-			abort();
 		}
 		if (keep && p && cap) { HIPCHK(hipMemcpyAsync(q, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
 		if (p) { if (vm_res) vm_release(); else HIPCHK(hipFree(p)); }
@@ -217,7 +233,7 @@ struct Scope {          // times everything enqueued between construction and de
 		HIPCHK(hipEventRecord(r.a, h->st));
 	}
 	~Scope() {
-		if (h->debug) { hipError_t e = hipStreamSynchronize(h->st); if (e != hipSuccess) { fprintf(stderr, "[rb2_hip] kernel group %s failed: %s\n", rb2_hip_kernel_name(k), hipGetErrorString(e)); abort(); } }
+		if (h->debug) { hipError_t e = hipStreamSynchronize(h->st); if (e != hipSuccess) { rb2_fatal("[rb2_hip] kernel group %s failed: %s\n", rb2_hip_kernel_name(k), hipGetErrorString(e)); } }
 		if (!h->prof) return;
 		HIPCHK(hipEventRecord(r.b, h->st));
 		h->recs.push_back(r);
@@ -312,8 +328,8 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		HIPCHK(hipMemcpyAsync(res, h->zblk.p + nzb, 16, hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		m = res[0];
-		if (res[1]) { fprintf(stderr, "[rb2_hip] the batch contains bytes that are not nt6 codes 0..5 ($ACGTN)\n"); abort(); }
-		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { fprintf(stderr, "[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); abort(); }
+		if (res[1]) { rb2_fatal("[rb2_hip] the batch contains bytes that are not nt6 codes 0..5 ($ACGTN)\n"); }
+		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { rb2_fatal("[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); }
 		h->START.ensure(m + 1);
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
 	}
@@ -395,7 +411,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
 	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);      // string tiles / output windows this handle launches blocks for (rank_share)
 	const unsigned wg = cdiv(B.n_tot + rank_share(h, std::min<uint64_t>(B.len, (r + 1) * B.m)), WIN) + NR;
-	if ((uint64_t)nlf * 64 >= (1ull << 32)) { fprintf(stderr, "[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); abort(); }
+	if ((uint64_t)nlf * 64 >= (1ull << 32)) { rb2_fatal("[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); }
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -577,7 +593,7 @@ void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bo
 
 void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 {
-	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); abort(); }
+	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); }
 	BatchState B;
 	batch_begin(h, B, len64, s);
 	// The first rounds of a batch are hot spots by construction: round 0 puts every string into rope $ (at its end in input order,
@@ -601,7 +617,7 @@ void check_last_byte(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 	uint8_t last = 1;
 	HIPCHK(hipMemcpyAsync(&last, s_dev + len - 1, 1, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
-	if (last != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }
+	if (last != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }
 }
 
 } // namespace
@@ -611,6 +627,8 @@ void check_last_byte(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 // =============================================================================================
 
 extern "C" {
+
+void rb2_hip_set_fatal_handler(rb2_hip_fatal_cb cb, void *user) { g_fatal_cb = cb; g_fatal_user = user; }
 
 int rb2_hip_device_count(void)
 {
@@ -623,10 +641,9 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 {
 	int n = rb2_hip_device_count();
 	if (n <= 0 || device < 0 || device >= n) {
-		fprintf(stderr, "[rb2_hip] no usable HIP device (requested %d, visible %d); this engine has no CPU fallback\n", device, n);
-		abort();
+		rb2_fatal("[rb2_hip] no usable HIP device (requested %d, visible %d); this engine has no CPU fallback\n", device, n);
 	}
-	if (sorting_order < 0 || sorting_order > 2) { fprintf(stderr, "[rb2_hip] bad sorting order %d\n", sorting_order); abort(); }   // mrope.c:18
+	if (sorting_order < 0 || sorting_order > 2) { rb2_fatal("[rb2_hip] bad sorting order %d\n", sorting_order); }   // mrope.c:18
 	HIPCHK(hipSetDevice(device));
 	rb2_hip_t *h = new rb2_hip_s();
 	h->dev = device; h->so = sorting_order;
@@ -678,7 +695,7 @@ int rb2_hip_sorting_order(const rb2_hip_t *h) { return h->so; }
 void rb2_hip_reset(rb2_hip_t *h)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (h->batch) { fprintf(stderr, "[rb2_hip] reset inside a sharded batch\n"); abort(); }
+	if (h->batch) { rb2_fatal("[rb2_hip] reset inside a sharded batch\n"); }
 	memset(h->h_rope, 0, sizeof(h->h_rope));
 	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;
 	HIPCHK(hipMemsetAsync(&h->ctl->rope[0][0], 0, sizeof(RopeDesc) * 2 * NR, h->st));
@@ -688,7 +705,7 @@ void rb2_hip_reset(rb2_hip_t *h)
 void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (len <= 0) { fprintf(stderr, "[rb2_hip] insert_multi: len must be > 0\n"); abort(); }   // mrope.c:268
+	if (len <= 0) { rb2_fatal("[rb2_hip] insert_multi: len must be > 0\n"); }   // mrope.c:268
 	check_last_byte(h, len, s_dev);
 	if (((uintptr_t)s_dev & 15) != 0) {              // kernels use 16-byte loads
 		h->sbuf.ensure((size_t)len + 64);
@@ -740,7 +757,7 @@ void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
 void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
+	if (len <= 0 || s[len - 1] != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }   // mrope.c:268
 	{	// (most of) the batch is on the device already?  (rb2_hip_prefetch)
 		std::unique_lock<std::mutex> lk(h->pf_mu);
 		if (h->pf_host == s) h->pf_cv.wait(lk, [h] { return !h->pf_busy; });   // a copy of THIS batch is running: it is what we are about to use
@@ -878,7 +895,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 	HIPCHK(hipMemcpyAsync(tot_h, cnt.p, sizeof(tot_h), hipMemcpyDeviceToHost, st));
 	HIPCHK(hipMemcpyAsync(flag_h, flag.p, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
-	if (flag_h[0]) { fprintf(stderr, "[rb2_hip] load_ropes: not run-length bytes of ropebwt2's codec (bad symbol or truncated run)\n"); abort(); }
+	if (flag_h[0]) { rb2_fatal("[rb2_hip] load_ropes: not run-length bytes of ropebwt2's codec (bad symbol or truncated run)\n"); }
 	// piece (b,x) of rope b has as many rows as rope x has b's; rope $ is one piece
 	uint64_t tot[6][6];
 	for (int b = 0; b < 6; ++b) for (int a = 0; a < 6; ++a) tot[b][a] = tot_h[b * 6 + a];
@@ -906,8 +923,8 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 			leaf += (d.nleaves + SB - 1) / SB * SB;
 		}
 		t.q[t.np] = want;
-		if (have < want) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); abort(); }
-		if (have > want) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); abort(); }
+		if (have < want) { rb2_fatal("[rb2_hip] load_ropes: rope %d is shorter than the symbol counts of the other ropes imply\n", b); }
+		if (have > want) { rb2_fatal("[rb2_hip] load_ropes: rope %d is longer than the symbol counts of the other ropes imply (not a BWT of complete strings?)\n", b); }
 	}
 	const int sd = h->side, ps = h->pside;
 	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;      /* what is loaded is the dense layout */
@@ -931,8 +948,8 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 		hipLaunchKernelGGL(k_ld_long, dim3(1024), dim3(256), 0, st, (const LdLong*)longs.p, (const uint32_t*)(flag.p + 1), long_cap, (uint64_t*)pv.data);
 		HIPCHK(hipMemcpyAsync(flag_h, flag.p, 8, hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));                      // (off is reused; the long-run list is per rope)
-		if (flag_h[0]) { fprintf(stderr, "[rb2_hip] load_ropes: rope %d does not match the symbol counts of the other ropes\n", b); abort(); }
-		if (flag_h[1] > long_cap) { fprintf(stderr, "[rb2_hip] load_ropes: more than %u runs longer than %u symbols in rope %d\n", long_cap, LD_LONG, b); abort(); }
+		if (flag_h[0]) { rb2_fatal("[rb2_hip] load_ropes: rope %d does not match the symbol counts of the other ropes\n", b); }
+		if (flag_h[1] > long_cap) { rb2_fatal("[rb2_hip] load_ropes: more than %u runs longer than %u symbols in rope %d\n", long_cap, LD_LONG, b); }
 		HIPCHK(hipMemsetAsync(flag.p + 1, 0, 4, st));
 	}
 	unsigned long long pc_h[NR * 6];
@@ -957,12 +974,12 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (nranks < 1 || rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] bad shard rank %d/%d\n", rank, nranks); abort(); }
+	if (nranks < 1 || rank < 0 || rank >= nranks) { rb2_fatal("[rb2_hip] bad shard rank %d/%d\n", rank, nranks); }
 	ensure_dense(h);
 	uint32_t own[NR + 1];
 	memset(own, 0, sizeof(own));
 	for (int r = 0; r < NR; ++r) {
-		if (owner[r] < 0 || owner[r] >= nranks) { fprintf(stderr, "[rb2_hip] bad owner of sub-rope %d\n", r); abort(); }
+		if (owner[r] < 0 || owner[r] >= nranks) { rb2_fatal("[rb2_hip] bad owner of sub-rope %d\n", r); }
 		h->owner[r] = owner[r]; own[r] = owner[r] == rank;
 	}
 	h->rank = rank; h->nranks = nranks;
@@ -976,7 +993,7 @@ int rb2_hip_num_subropes(void) { return NR; }
 int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (len <= 0 || ((uintptr_t)s_dev & 15)) { fprintf(stderr, "[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); abort(); }
+	if (len <= 0 || ((uintptr_t)s_dev & 15)) { rb2_fatal("[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); }
 	check_last_byte(h, len, s_dev);
 	ensure_dense(h);                                           /* the protocol below runs dense rounds (k_part / k_merge): a handle that went sparse through rb2_hip_insert_multi is converted first */
 	BatchState *B = new BatchState();
@@ -1056,7 +1073,7 @@ void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt,
 	BatchState &B = *(BatchState*)h->batch;
 	int64_t off[NR][6], start[64];
 	memset(off, 0, sizeof(off));
-	if (h->nranks > 64) { fprintf(stderr, "[rb2_hip] too many ranks\n"); abort(); }
+	if (h->nranks > 64) { rb2_fatal("[rb2_hip] too many ranks\n"); }
 	shard_layout(h->owner, h->nranks, h->rank, global_cnt, off, send_counts, start);
 	uint64_t sd_stack[NR][6];
 	uint64_t (*sd)[6] = h->async_proto ? (uint64_t (*)[6])(h->pin_sd + (round & 1) * NR * 6) : sd_stack;   /* async: the copy outlives this call */
@@ -1087,7 +1104,7 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 		int64_t off[NR][6], per[64], start[64];
 		memset(off, 0, sizeof(off));
 		shard_layout(h->owner, h->nranks, s, global_cnt, off, per, start);
-		if (per[h->rank] != recv_counts[s]) { fprintf(stderr, "[rb2_hip] shard_finish: rank %d expected %lld records from rank %d, caller says %lld\n", h->rank, (long long)per[h->rank], s, (long long)recv_counts[s]); abort(); }
+		if (per[h->rank] != recv_counts[s]) { rb2_fatal("[rb2_hip] shard_finish: rank %d expected %lld records from rank %d, caller says %lld\n", h->rank, (long long)per[h->rank], s, (long long)recv_counts[s]); }
 		for (int r2 = 1; r2 < NR; ++r2) {
 			if (h->owner[r2] != h->rank) continue;
 			const int a = rope_sym(r2), b = rope_prev(r2);
@@ -1105,7 +1122,7 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 		std::sort(pcs.begin(), pcs.end(), [](const ShardPiece &x, const ShardPiece &y) { return x.src < y.src; });
 		const ShardPiece *src = pcs.data();
 		if (h->async_proto) {                                   /* the copy outlives this call: stage in pinned memory, and never reallocate the device list mid-batch */
-			if (pcs.size() > (size_t)64 * NR * 6) { fprintf(stderr, "[rb2_hip] shard_finish: too many exchange pieces\n"); abort(); }
+			if (pcs.size() > (size_t)64 * NR * 6) { rb2_fatal("[rb2_hip] shard_finish: too many exchange pieces\n"); }
 			ShardPiece *pin = h->pin_pcs + (round & 1) * 64 * NR * 6;
 			memcpy(pin, pcs.data(), pcs.size() * sizeof(ShardPiece));
 			src = pin;
@@ -1140,9 +1157,9 @@ void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int
 void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_t *out)
 {
 	HIPCHK(hipSetDevice(h->dev));
-	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rank: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n"); abort(); }
+	if (h->nranks > 1) rb2_fatal("[rb2_hip] rank: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n");
 	if (n <= 0) return;
-	if (b < 0 || b > 5) { fprintf(stderr, "[rb2_hip] rank: bad rope %d\n", b); abort(); }
+	if (b < 0 || b > 5) { rb2_fatal("[rb2_hip] rank: bad rope %d\n", b); }
 	const int64_t CH = 1 << 24;                                  // queries per launch (one wave each; a launch is capped at 2^32 threads)
 	h->qbuf.ensure((size_t)std::min(n, CH) * 7);
 	for (int64_t i0 = 0; i0 < n; i0 += CH) {
@@ -1185,7 +1202,7 @@ static uint64_t hash_mix(uint64_t acc, uint64_t piece, uint64_t n)      /* piece
 uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b)
 {
 	uint64_t acc = 0;
-	if (h->nranks > 1) { fprintf(stderr, "[rb2_hip] rope_hash: this handle holds only its own sub-ropes of a sharded index (use rb2_hip_multi_rope_hash)\n"); abort(); }
+	if (h->nranks > 1) { rb2_fatal("[rb2_hip] rope_hash: this handle holds only its own sub-ropes of a sharded index (use rb2_hip_multi_rope_hash)\n"); }
 	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) acc = hash_mix(acc, piece_hash(h, r), h->h_rope[r].n);
 	return acc;
 }
@@ -1216,8 +1233,8 @@ void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read,
 	HIPCHK(hipSetDevice(h->dev));
 	const uint64_t total = (uint64_t)n_reads * (read_len + 1) * (strand ? 2 : 1);
 	if (total == 0) return;
-	if ((uintptr_t)dst_dev & 15) { fprintf(stderr, "[rb2_hip] synth_reads: destination must be 16-byte aligned\n"); abort(); }
-	if (genome_len != 0 && genome_len < read_len) { fprintf(stderr, "[rb2_hip] synth_reads: genome shorter than a read\n"); abort(); }
+	if ((uintptr_t)dst_dev & 15) { rb2_fatal("[rb2_hip] synth_reads: destination must be 16-byte aligned\n"); }
+	if (genome_len != 0 && genome_len < read_len) { rb2_fatal("[rb2_hip] synth_reads: genome shorter than a read\n"); }
 	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256 * 16)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand, (uint64_t)genome_len);
 	HIPCHK(hipGetLastError());
 }

@@ -154,10 +154,10 @@ RcclApi &rccl()
 	if (dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) lib = dlopen(nullptr, RTLD_NOW);
 	for (int i = 0; !lib && i < 4; ++i) lib = dlopen(cand[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
 	for (int i = 0; !lib && i < 4; ++i) lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
-	if (!lib) { fprintf(stderr, "[rb2_hip] the RCCL transport was asked for but librccl cannot be loaded (%s)\n", dlerror()); abort(); }
+	if (!lib) { rb2_fatal("[rb2_hip] the RCCL transport was asked for but librccl cannot be loaded (%s)\n", dlerror()); }
 	RcclApi &R = g_rccl;
 	R.lib = lib;
-#define RB2_NCCL_SYM(field, name) do { *(void**)&R.field = dlsym(lib, name); if (!R.field) { fprintf(stderr, "[rb2_hip] librccl has no %s\n", name); abort(); } } while (0)
+#define RB2_NCCL_SYM(field, name) do { *(void**)&R.field = dlsym(lib, name); if (!R.field) { rb2_fatal("[rb2_hip] librccl has no %s\n", name); } } while (0)
 	RB2_NCCL_SYM(GetUniqueId, "ncclGetUniqueId"); RB2_NCCL_SYM(CommInitRank, "ncclCommInitRank"); RB2_NCCL_SYM(CommInitAll, "ncclCommInitAll");
 	RB2_NCCL_SYM(CommDestroy, "ncclCommDestroy"); RB2_NCCL_SYM(AllReduce, "ncclAllReduce"); RB2_NCCL_SYM(Send, "ncclSend"); RB2_NCCL_SYM(Recv, "ncclRecv");
 	RB2_NCCL_SYM(GroupStart, "ncclGroupStart"); RB2_NCCL_SYM(GroupEnd, "ncclGroupEnd"); RB2_NCCL_SYM(GetErrorString, "ncclGetErrorString");
@@ -165,7 +165,7 @@ RcclApi &rccl()
 	return R;
 }
 #define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
-	fprintf(stderr, "[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, rccl().GetErrorString(r_)); abort(); } } while (0)
+	rb2_fatal("[rb2_hip] %s failed at %s:%d: %s\n", #expr, __FILE__, __LINE__, rccl().GetErrorString(r_)); } } while (0)
 
 // the host threads of the local ranks meet here (never the devices): sense-reversing, spins briefly, then yields
 struct SpinBarrier {
@@ -318,14 +318,14 @@ void multi_run(rb2_hip_multi_t *m, int64_t len)
 
 rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int so, int transport, const int *owner)
 {
-	if (n < 1 || world < n || world > RB2_MULTI_MAX_RANKS) { fprintf(stderr, "[rb2_hip] multi: bad number of ranks (%d local of %d, at most %d)\n", n, world, RB2_MULTI_MAX_RANKS); abort(); }
-	if (transport != RB2_TRANSPORT_PEER && transport != RB2_TRANSPORT_RCCL) { fprintf(stderr, "[rb2_hip] multi: unknown transport %d\n", transport); abort(); }
+	if (n < 1 || world < n || world > RB2_MULTI_MAX_RANKS) { rb2_fatal("[rb2_hip] multi: bad number of ranks (%d local of %d, at most %d)\n", n, world, RB2_MULTI_MAX_RANKS); }
+	if (transport != RB2_TRANSPORT_PEER && transport != RB2_TRANSPORT_RCCL) { rb2_fatal("[rb2_hip] multi: unknown transport %d\n", transport); }
 	rb2_hip_multi_t *m = new rb2_hip_multi_s();
 	m->n = n; m->world = world; m->rank0 = rank0; m->transport = transport; m->so = so;
 	m->trace = getenv("RB2_HIP_TRACE") ? atoi(getenv("RB2_HIP_TRACE")) : 0;
 	m->rccl_self = getenv("RB2_RCCL_SELF") ? atoi(getenv("RB2_RCCL_SELF")) : 0;
 	if (owner) { for (int r = 0; r < NR; ++r) m->owner[r] = owner[r]; } else rb2_hip_default_owners(world, m->owner);
-	for (int r = 0; r < NR; ++r) if (m->owner[r] < 0 || m->owner[r] >= world) { fprintf(stderr, "[rb2_hip] multi: bad owner of sub-rope %d\n", r); abort(); }
+	for (int r = 0; r < NR; ++r) if (m->owner[r] < 0 || m->owner[r] >= world) { rb2_fatal("[rb2_hip] multi: bad owner of sub-rope %d\n", r); }
 	{ bool seen[RB2_MULTI_MAX_RANKS] = {false}; m->active = 0; for (int r = 1; r < NR; ++r) if (!seen[m->owner[r]]) { seen[m->owner[r]] = true; ++m->active; } }
 	m->bar.n = n;
 	m->rk.resize(n);
@@ -350,7 +350,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 			if (m->rk[k].dev == m->rk[p].dev) continue;
 			int can = 0;
 			HIPCHK(hipDeviceCanAccessPeer(&can, m->rk[k].dev, m->rk[p].dev));
-			if (!can) { fprintf(stderr, "[rb2_hip] multi: device %d cannot access device %d (no peer access): use the RCCL transport\n", m->rk[k].dev, m->rk[p].dev); abort(); }
+			if (!can) { rb2_fatal("[rb2_hip] multi: device %d cannot access device %d (no peer access): use the RCCL transport\n", m->rk[k].dev, m->rk[p].dev); }
 			HIPCHK(hipSetDevice(m->rk[k].dev));
 			const hipError_t e = hipDeviceEnablePeerAccess(m->rk[p].dev, 0);
 			if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIPCHK(e);
@@ -391,7 +391,7 @@ rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_ord
 	rb2_hip_multi_t *m = multi_new(n, devices, n, 0, sorting_order, transport, owner);
 	if (transport == RB2_TRANSPORT_RCCL && n > 1) {
 		for (int k = 0; k < n; ++k) for (int p = 0; p < k; ++p)
-			if (devices[k] == devices[p]) { fprintf(stderr, "[rb2_hip] multi: RCCL needs one device per rank (device %d is listed twice); several ranks on one device run on the PEER transport\n", devices[k]); abort(); }
+			if (devices[k] == devices[p]) rb2_fatal("[rb2_hip] multi: RCCL needs one device per rank (device %d is listed twice); several ranks on one device run on the PEER transport\n", devices[k]);
 		std::vector<ncclComm_t> comms(n);
 		NCCLCHK(rccl().CommInitAll(comms.data(), n, devices));
 		for (int k = 0; k < n; ++k) m->rk[k].comm = comms[k];
@@ -414,12 +414,12 @@ void rb2_hip_multi_unique_id(void *id128)
 
 rb2_hip_multi_t *rb2_hip_multi_create_rank(int device, int rank, int nranks, const void *nccl_id, int sorting_order, const int *owner)
 {
-	if (rank < 0 || rank >= nranks) { fprintf(stderr, "[rb2_hip] multi: bad rank %d of %d\n", rank, nranks); abort(); }
+	if (rank < 0 || rank >= nranks) { rb2_fatal("[rb2_hip] multi: bad rank %d of %d\n", rank, nranks); }
 	rb2_hip_multi_t *m = multi_new(1, &device, nranks, rank, sorting_order, RB2_TRANSPORT_RCCL, owner);
 	ncclUniqueId id;
 	if (nccl_id) memcpy(&id, nccl_id, sizeof(id));
 	else if (nranks == 1) NCCLCHK(rccl().GetUniqueId(&id));
-	else { fprintf(stderr, "[rb2_hip] multi: a group of %d ranks needs the id of rb2_hip_multi_unique_id() from rank 0\n", nranks); abort(); }
+	else { rb2_fatal("[rb2_hip] multi: a group of %d ranks needs the id of rb2_hip_multi_unique_id() from rank 0\n", nranks); }
 	HIPCHK(hipSetDevice(device));
 	NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, nranks, id, rank));
 	return m;
@@ -450,9 +450,9 @@ rb2_hip_t *rb2_hip_multi_engine(rb2_hip_multi_t *m, int k) { return (k >= 0 && k
 
 void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8_t *const *s_dev)
 {
-	if (len <= 0) { fprintf(stderr, "[rb2_hip] insert_multi: len must be > 0\n"); abort(); }   // mrope.c:268
+	if (len <= 0) { rb2_fatal("[rb2_hip] insert_multi: len must be > 0\n"); }   // mrope.c:268
 	for (int k = 0; k < m->n; ++k) {
-		if ((uintptr_t)s_dev[k] & 15) { fprintf(stderr, "[rb2_hip] multi insert: the device buffers must be 16-byte aligned\n"); abort(); }
+		if ((uintptr_t)s_dev[k] & 15) { rb2_fatal("[rb2_hip] multi insert: the device buffers must be 16-byte aligned\n"); }
 		m->rk[k].s_dev = s_dev[k];
 	}
 	HIPCHK(hipSetDevice(m->rk[0].dev));
@@ -462,7 +462,7 @@ void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8
 
 void rb2_hip_multi_insert_multi(rb2_hip_multi_t *m, int64_t len, const uint8_t *s)
 {
-	if (len <= 0 || s[len - 1] != 0) { fprintf(stderr, "[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); abort(); }   // mrope.c:268
+	if (len <= 0 || s[len - 1] != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }   // mrope.c:268
 	// one copy of the batch text per DEVICE (every rank reads all of it: the cursor refills every 10 rounds), uploaded by the first rank on it
 	std::vector<const uint8_t*> ptr(m->n, nullptr);
 	multi_each(m, [&](int k) {
@@ -527,7 +527,7 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6])
 		for (int a = 0; a < 6; ++a) n += hr[r].cnt[a];
 		if (p >= n) { for (int a = 0; a < 6; ++a) cx[a] += (int64_t)hr[r].cnt[a]; p -= n; continue; }
 		const int o = m->owner[r] - m->rank0;
-		if (o < 0 || o >= m->n) { fprintf(stderr, "[rb2_hip] multi rank: piece %d lives in another process\n", r); abort(); }
+		if (o < 0 || o >= m->n) { rb2_fatal("[rb2_hip] multi rank: piece %d lives in another process\n", r); }
 		int64_t c[6];
 		rank_piece(m->rk[o].h, r, (int64_t)p, c);
 		for (int a = 0; a < 6; ++a) cx[a] += c[a];
@@ -542,7 +542,7 @@ uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b)
 	for (int r = 0; r < NR; ++r) {
 		if (rope_sym(r) != b) continue;
 		const int o = m->owner[r] - m->rank0;
-		if (o < 0 || o >= m->n) { fprintf(stderr, "[rb2_hip] multi rope_hash: piece %d lives in another process\n", r); abort(); }
+		if (o < 0 || o >= m->n) { rb2_fatal("[rb2_hip] multi rope_hash: piece %d lives in another process\n", r); }
 		acc = hash_mix(acc, piece_hash(m->rk[o].h, r), m->rk[o].h->h_rope[r].n);
 	}
 	return acc;

@@ -27,6 +27,7 @@ def load_hip_lib():
     vp, i64, i32, u64 = C.c_void_p, C.c_int64, C.c_int, C.c_uint64
     sig = {
         "rb2_hip_device_count": (i32, []),
+        "rb2_hip_set_fatal_handler": (None, [vp, vp]),
         "rb2_hip_create": (vp, [i32, i32]),
         "rb2_hip_destroy": (None, [vp]),
         "rb2_hip_sorting_order": (i32, [vp]),
@@ -103,7 +104,7 @@ def load_hip_lib():
 
 
 ABI_SYMBOLS = [
-    "rb2_hip_device_count", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
+    "rb2_hip_device_count", "rb2_hip_set_fatal_handler", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",

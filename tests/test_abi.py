@@ -78,3 +78,22 @@ def test_product_never_touches_oracle():
                     if re.search(r"liboracle|bcr_oracle|oracle/_ref|orc_insert", t):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_fatal_handler_is_called_before_abort(lib):
+    """rb2_hip_set_fatal_handler: a host program is told (with the message) before the engine gives up, and may leave its own way"""
+    if lib.rb2_hip_device_count() > 0:
+        code_tail = "L.rb2_hip_create(99, 0)\n"                  # no such device
+    else:
+        code_tail = "L.rb2_hip_create(0, 0)\n"
+    code = ("import sys, os, ctypes as C; sys.path.insert(0, %r)\n"
+            "from ropebwt2_amd.hipbwt import load_hip_lib\n"
+            "L = load_hip_lib()\n"
+            "CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)\n"
+            "def h(user, msg):\n"
+            "    sys.stdout.write('handler: ' + msg.decode()); sys.stdout.flush(); os._exit(7)\n"
+            "cb = CB(h)\n"
+            "L.rb2_hip_set_fatal_handler(cb, None)\n") % ROOT + code_tail
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 7, (p.returncode, p.stderr.decode()[-300:])
+    assert b"handler: [rb2_hip] no usable HIP device" in p.stdout
