@@ -35,13 +35,29 @@ static void str_append(str_t *s, const char *p, size_t n) { str_reserve(s, s->l 
  * in -L mode; sequence lines are taken raw (embedded blanks become N), a trailing CR is dropped; a FASTQ record
  * whose quality string is shorter than its sequence ends the input (kseq_read's -2). */
 #define RD_BUF 16384
-typedef struct { gzFile fp; unsigned char buf[RD_BUF]; int beg, end, eof, last; str_t seq, qual; } reader_t;
+typedef struct {
+	gzFile fp; unsigned char buf[RD_BUF]; int beg, end, eof, last; str_t seq, qual;
+	/* raw blocks to be read BEFORE the stream goes on (the threaded FASTQ reader hands its unparsed blocks back when the input
+	 * turns out not to be strict four-line FASTQ); pos = stream offset of the next refill: refills stay on multiples of RD_BUF,
+	 * as in a run that read the stream sequentially from its start */
+	const uint8_t **mem; const int64_t *mem_n; int nmem, imem; int64_t mem_off, pos;
+} reader_t;
 
 static int rd_fill(reader_t *r)               /* 0: nothing more to read */
 {
-	r->beg = 0; r->end = gzread(r->fp, r->buf, RD_BUF);
-	if (r->end < 0) r->end = 0;
-	if (r->end < RD_BUF) r->eof = 1;
+	const int want = RD_BUF - (int)(r->pos % RD_BUF);
+	int got = 0;
+	r->beg = 0;
+	while (got < want && r->imem < r->nmem) {
+		int64_t k = r->mem_n[r->imem] - r->mem_off;
+		if (k > want - got) k = want - got;
+		memcpy(r->buf + got, r->mem[r->imem] + r->mem_off, (size_t)k);
+		got += (int)k; r->mem_off += k;
+		if (r->mem_off == r->mem_n[r->imem]) { ++r->imem; r->mem_off = 0; }
+	}
+	if (got < want) { const int k = gzread(r->fp, r->buf + got, (unsigned)(want - got)); if (k > 0) got += k; }
+	r->end = got; r->pos += got;
+	if (r->end < want) r->eof = 1;
 	return r->end > 0;
 }
 static int rd_getc(reader_t *r)
@@ -214,12 +230,15 @@ typedef struct {
 	uint8_t *in; int64_t n_in, m_in; int extra_empty;    /* whole lines (the last one may lack its newline) + kseq's phantom empty line */
 	str_t out; uint32_t *rec_end; size_t n_rec, m_rec;   /* encoded strings; out offset after every record */
 	int state;                                           /* 0 free, 1 queued, 2 done */
+	int at_eof, failed; int64_t stream_off;              /* FASTQ mode: last block of the input; not strict four-line FASTQ (in[] untouched); offset of in[0] in the stream */
 } pjob_t;
 typedef struct {
 	enc_cfg_t cfg; pjob_t *job; int njob;
 	int64_t next_work, n_queued; int closing;
 	int64_t consumed; int eof;                                  /* blocks the main thread has taken over; the reader thread saw the end of the input */
 	gzFile fp; int64_t chunk;                                   /* the reader thread's input */
+	int fastq, stop;                                            /* blocks of whole four-line records instead of whole lines; the consumer asks the reader to stop (fallback) */
+	uint8_t *carry; int64_t n_carry, total;                     /* what the reader thread held back when it stopped, and how far it had read */
 	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
 } pparse_t;
 
@@ -248,6 +267,46 @@ static void pjob_encode(const enc_cfg_t *cfg, pjob_t *jb)
 	}
 }
 
+/* ---- FASTQ in batch mode, threaded.  Real inputs are FASTQ; kseq's grammar (multi-line sequences and qualities, '@' and '>' are
+ * only special at the start of a line, a quality string is as long as its sequence says) is sequential in general -- but a file of
+ * strict FOUR-LINE records is not: blocks cut after a multiple of four lines start at a record, and every record can be checked
+ * on its own to be one that kseq reads exactly like four lines (header starts with '@', third line with '+', the sequence line
+ * does not start with '+', '@' or '>', quality as long as the sequence).  Workers verify while they encode and never write to the
+ * block; the first block that is NOT strict sends the consumer back to the sequential reader, which takes the raw blocks from
+ * that one on and then the rest of the stream -- so the result is kseq's for every input, and four-line FASTQ is parsed by all cores. */
+static int pjob_encode_fastq(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
+{
+	const uint8_t *p = jb->in, *end = jb->in + jb->n_in;
+	jb->out.l = 0; jb->n_rec = 0;
+	str_reserve(&jb->out, (size_t)jb->n_in / 2 * (((cfg->flag & F_FOR) ? 1 : 0) + ((cfg->flag & F_REV) ? 1 : 0)) + 64);
+	while (p < end) {
+		const uint8_t *ln[4]; int64_t len[4]; int i, sl, ql, l;
+		for (i = 0; i < 4; ++i) {
+			const uint8_t *nl;
+			if (p >= end) return 0;                              /* fewer than four lines left */
+			nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+			if (!nl) { if (!(jb->at_eof && i == 3)) return 0; nl = end; }   /* only the very last line of the input may lack its newline */
+			ln[i] = p; len[i] = nl - p; p = nl < end ? nl + 1 : end;
+		}
+		if (len[0] < 1 || ln[0][0] != '@') return 0;
+		if (len[2] < 1 || ln[2][0] != '+') return 0;
+		if (len[1] > 0 && (ln[1][0] == '+' || ln[1][0] == '@' || ln[1][0] == '>')) return 0;
+		if (len[1] > 0x3fffffff) return 0;
+		sl = (int)len[1]; if (sl > 1 && ln[1][sl-1] == '\r') --sl;   /* kseq.h:136, as rd_until does */
+		ql = (int)len[3]; if (ql > 1 && ln[3][ql-1] == '\r') --ql;
+		if (ql != sl) return 0;                                /* shorter: kseq reads on; longer: kseq gives up -- the sequential reader does either */
+		str_reserve(tmp, (size_t)sl + 2);
+		memcpy(tmp->s, ln[1], (size_t)sl);
+		l = prepare_record(cfg, (uint8_t*)tmp->s, sl, (const char*)ln[3], ql);
+		if (l >= 0) {
+			append_strands(cfg, (uint8_t*)tmp->s, l, &jb->out);
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
+		}
+	}
+	return 1;
+}
+
 static void *pparse_worker(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
@@ -258,7 +317,8 @@ static void *pparse_worker(void *arg)
 		if (pp->next_work >= pp->n_queued) break;
 		jb = &pp->job[pp->next_work++ % pp->njob];
 		pthread_mutex_unlock(&pp->mu);
-		pjob_encode(&pp->cfg, jb);
+		if (pp->fastq) { str_t tmp = { 0, 0, 0 }; jb->failed = !pjob_encode_fastq(&pp->cfg, jb, &tmp); free(tmp.s); }
+		else pjob_encode(&pp->cfg, jb);
 		pthread_mutex_lock(&pp->mu);
 		jb->state = 2;
 		pthread_cond_broadcast(&pp->cv_done);
@@ -280,9 +340,11 @@ static void *pparse_reader(void *arg)
 		pjob_t *jb;
 		int64_t got = 0, cut;
 		pthread_mutex_lock(&pp->mu);
-		while (pp->n_queued - pp->consumed >= pp->njob) pthread_cond_wait(&pp->cv_space, &pp->mu);
+		while (pp->n_queued - pp->consumed >= pp->njob && !pp->stop) pthread_cond_wait(&pp->cv_space, &pp->mu);
+		if (pp->stop) { pthread_mutex_unlock(&pp->mu); break; }  /* the consumer goes back to the sequential reader: what is held back here is its to read */
 		jb = &pp->job[pp->n_queued % pp->njob];                /* free: taken over by the main thread already */
 		pthread_mutex_unlock(&pp->mu);
+		jb->stream_off = total - n_carry; jb->failed = 0;
 		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
 		memcpy(jb->in, carry, n_carry);
 		while (got < CHUNK) {                                 /* gzread may return short counts on pipes */
@@ -293,8 +355,15 @@ static void *pparse_reader(void *arg)
 		total += got;
 		if (got) last_byte = jb->in[n_carry + got - 1];
 		jb->n_in = n_carry + got;
+		jb->at_eof = eof;
 		if (!eof) {                                           /* keep the unfinished last line for the next block */
 			for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
+			if (pp->fastq && cut > 0) {                         /* ... and, for FASTQ, the lines behind the last multiple of four: a block holds whole records */
+				int64_t nl = 0, i;
+				int back;
+				for (i = 0; i < cut; ++i) nl += jb->in[i] == '\n';
+				for (back = (int)(nl & 3); back > 0; --back) for (--cut; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
+			}
 			n_carry = jb->n_in - cut;                           /* (cut == 0: one line longer than a block -- everything is carried on) */
 			if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)realloc(carry, m_carry); }
 			memcpy(carry, jb->in + cut, n_carry);
@@ -312,7 +381,11 @@ static void *pparse_reader(void *arg)
 		pthread_cond_broadcast(&pp->cv_done);                  /* (the main thread also waits for blocks to exist) */
 		pthread_mutex_unlock(&pp->mu);
 	}
-	free(carry);
+	pthread_mutex_lock(&pp->mu);
+	pp->carry = carry; pp->n_carry = n_carry; pp->total = total;   /* (freed by the main thread) */
+	if (!eof) pp->eof = 1;
+	pthread_cond_broadcast(&pp->cv_done);
+	pthread_mutex_unlock(&pp->mu);
 	return 0;
 }
 
@@ -572,14 +645,26 @@ int main(int argc, char *argv[])
 	PF.on = m >= (int64_t)(2 * PF_STEP) && !getenv("RB2_DUMP_BATCHES") && !getenv("RB2_SYNC_INSERT") && !getenv("RB2_NO_PREFETCH");   /* batches worth announcing */
 	if (getenv("RB2_PARSE_THREADS")) pthr = atol(getenv("RB2_PARSE_THREADS"));
 	if (pthr > 16) pthr = 16;
-	if ((flag & F_LINE) && m && pthr > 1) {                 /* -L in batch mode: blocks of whole lines encoded by worker threads */
+	{
+	int par = 0, need_seq = 1;                              /* 1: -L, blocks of whole lines; 2: FASTQ, blocks of whole four-line records (pjob_encode_fastq) */
+	pparse_t pp;
+	const uint8_t *fb_mem[64]; int64_t fb_n[64];              /* raw blocks handed back to the sequential reader (FASTQ fallback) */
+	memset(&pp, 0, sizeof(pp));
+	if (m && pthr > 1) {
+		if (flag & F_LINE) par = 1;
+		else if (!getenv("RB2_SEQ_FASTX")) {                  /* a file that starts with '@' is taken for four-line FASTQ until a block says otherwise */
+			const int c0 = gzgetc(rd->fp);
+			if (c0 >= 0) gzungetc(c0, rd->fp);
+			if (c0 == '@') par = 2;
+		}
+	}
+	if (par) {
 		const int64_t CHUNK = getenv("RB2_PARSE_CHUNK") ? atol(getenv("RB2_PARSE_CHUNK")) : 16 << 20;
-		pparse_t pp;
 		pthread_t *th = (pthread_t*)calloc(pthr, sizeof(pthread_t)), reader;
-		int k;
-		memset(&pp, 0, sizeof(pp));
-		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
-		pp.fp = rd->fp; pp.chunk = CHUNK;
+		int k, fell_back = 0;
+		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; if (pp.njob > 62) pp.njob = 62;
+		pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
+		pp.fp = rd->fp; pp.chunk = CHUNK; pp.fastq = par == 2;
 		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0); pthread_cond_init(&pp.cv_space, 0);
 		for (k = 0; k < pthr; ++k) pthread_create(&th[k], 0, pparse_worker, &pp);
 		pthread_create(&reader, 0, pparse_reader, &pp);
@@ -591,6 +676,12 @@ int main(int argc, char *argv[])
 			if (pp.consumed >= pp.n_queued) { pthread_mutex_unlock(&pp.mu); break; }   /* end of input, everything taken over */
 			jb = &pp.job[pp.consumed % pp.njob];
 			while (jb->state != 2) pthread_cond_wait(&pp.cv_done, &pp.mu);
+			if (pp.fastq && jb->failed) {                       /* not strict four-line FASTQ from here on: stop the reader, keep the raw blocks */
+				pp.stop = 1; fell_back = 1;
+				pthread_cond_broadcast(&pp.cv_space);
+				pthread_mutex_unlock(&pp.mu);
+				break;
+			}
 			pthread_mutex_unlock(&pp.mu);
 			while (done < jb->out.l) {                          /* same flush points as the sequential loop: after the record that fills the batch */
 				size_t lo = r0, hi = jb->n_rec;                 /* first record whose end reaches the threshold */
@@ -611,10 +702,21 @@ int main(int argc, char *argv[])
 		pthread_join(reader, 0);
 		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_mutex_unlock(&pp.mu);
 		for (k = 0; k < pthr; ++k) pthread_join(th[k], 0);
-		for (k = 0; k < pp.njob; ++k) { free(pp.job[k].in); free(pp.job[k].out.s); free(pp.job[k].rec_end); }
-		free(pp.job); free(th);
-		pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done); pthread_cond_destroy(&pp.cv_space);
-	} else
+		free(th);
+		need_seq = fell_back;
+		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
+		if (fell_back) {                                        /* the blocks from the failed one on, what the reader held back, then the stream itself */
+			int64_t q;
+			int n = 0;
+			for (q = pp.consumed; q < pp.n_queued; ++q) { pjob_t *jb = &pp.job[q % pp.njob]; fb_mem[n] = jb->in; fb_n[n] = jb->n_in; ++n; }
+			if (pp.n_carry > 0) { fb_mem[n] = pp.carry; fb_n[n] = pp.n_carry; ++n; }
+			rd->mem = fb_mem; rd->mem_n = fb_n; rd->nmem = n; rd->imem = 0; rd->mem_off = 0;
+			rd->pos = pp.job[pp.consumed % pp.njob].stream_off;
+			rd->beg = rd->end = 0; rd->eof = 0; rd->last = 0;
+			if (verbose >= 3) fprintf(stderr, "[M::%s] the input is not four-line FASTQ from byte %ld on: sequential reader\n", "main_ropebwt2", (long)rd->pos);
+		}
+	}
+	if (need_seq)
 	while ((flag & F_LINE ? read_line_record(rd) : read_fastx_record(rd)) >= 0) {
 		uint8_t *s = (uint8_t*)rd->seq.s;
 		int l = prepare_record(&cfg, s, (int)rd->seq.l, rd->qual.s, (int)rd->qual.l);
@@ -628,6 +730,13 @@ int main(int argc, char *argv[])
 			if (flag & F_FOR) mr_insert1(mr, s);
 			if (flag & F_REV) { revcomp_in_place(s, l); mr_insert1(mr, s); }
 		}
+	}
+	if (par) {
+		int k;
+		for (k = 0; k < pp.njob; ++k) { free(pp.job[k].in); free(pp.job[k].out.s); free(pp.job[k].rec_end); }
+		free(pp.job); free(pp.carry);
+		pthread_mutex_destroy(&pp.mu); pthread_cond_destroy(&pp.cv_work); pthread_cond_destroy(&pp.cv_done); pthread_cond_destroy(&pp.cv_space);
+	}
 	}
 	}
 	if (m && buf.l) flush_batch(mr, &buf, flag, verbose);

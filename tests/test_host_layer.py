@@ -372,6 +372,71 @@ def test_line_reader_batches_match_python_model(tmp_path):
     assert got[8:] == want and int.from_bytes(got[:8], "little") == len(want)
 
 
+# ---- the FASTQ reader in batch mode: blocks of whole four-line records parsed by worker threads; anything that is not strict
+# ---- four-line FASTQ sends the rest of the input back to the sequential (kseq-exact) reader ------------------------------------
+
+def _fastq_inputs():
+    rng = np.random.RandomState(12)
+    recs = []
+    for i in range(1500):
+        L = int(rng.choice([0, 1, 2, 30, 101, 250], p=[.04, .04, .06, .3, .46, .1]))
+        s = "".join(rng.choice(list("ACGTNacgtn"), size=L, p=[.22, .22, .22, .22, .03, .02, .02, .02, .02, .01]))
+        if rng.rand() < 0.05 and L >= 2 and L % 2 == 0:
+            h = s[:L // 2].upper().replace("N", "A")
+            s = h + h[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        q = "".join(chr(33 + int(x)) for x in rng.randint(0, 42, size=L))        # '@' (33+31), '+' and '>' occur inside quality strings
+        recs.append((s, q))
+    def fq(recs, eol="\n", last_nl=True):
+        t = "".join("@r%d some comment%s%s%s+%s%s%s" % (i, eol, s, eol, "" if i % 3 else "r%d" % i, eol, q + eol) for i, (s, q) in enumerate(recs))
+        return (t if last_nl else t[:-len(eol)]).encode()
+    strict = fq(recs)
+    out = {"strict": strict, "strict_crlf": fq(recs, "\r\n"), "strict_no_final_newline": fq(recs, last_nl=False), "empty": b"", "one": fq(recs[:1]),
+           "header_only": b"@x\n", "truncated_record": strict[:len(strict) // 2]}
+    # not strict somewhere in the middle: a sequence wrapped over two lines (quality too), a FASTA record, a blank line, qualities too short / too long
+    k = len(recs) // 2
+    s0, q0 = "ACGTACGTAC", "IIIIIIIIII"
+    mid = {"multiline": "@m\n%s\n%s\n+\n%s\n%s\n" % (s0[:4], s0[4:], q0[:7], q0[7:]), "fasta": ">f\nACGTTTGA\nCCA\n", "blank": "\n",
+           "qual_short": "@s\nACGTAC\n+\nIII\n", "qual_long": "@l\nACG\n+\nIIIII\n", "seq_starts_with_plus": "@p\n+CGT\n+\nIIII\n"}
+    for name, frag in mid.items():
+        out["mid_" + name] = fq(recs[:k]) + frag.encode() + fq(recs[k:])
+    out["starts_with_garbage"] = b"xx\n" + strict
+    out["starts_with_fasta"] = b">f\nACGT\n" + strict
+    return out
+
+
+@pytest.mark.parametrize("flags", [["-R"], [], ["-F"], ["-N"], ["-q", "20"], ["-x", "5", "-q", "15"], ["-C"], ["-s", "-R"]])
+def test_parallel_fastq_reader_equals_sequential(flags, tmp_path):
+    """the threaded FASTQ reader (blocks of whole four-line records, verified record by record) gives the batch stream of the
+    sequential kseq-exact reader for strict inputs AND for inputs that stop being strict somewhere (fallback to the sequential reader
+    from the failing block on), for block sizes down to 64 bytes"""
+    for name, data in _fastq_inputs().items():
+        for m in ("-m30k", "-m1g"):
+            want = _dump_batches(flags + [m], data, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq")
+            for chunk, thr in (("64", "3"), ("1500", "2"), ("100000", "5"), ("0", "4")):
+                env = {"RB2_PARSE_THREADS": thr}
+                if chunk != "0":
+                    env["RB2_PARSE_CHUNK"] = chunk
+                got = _dump_batches(flags + [m], data, env, tmp_path, "par")
+                assert got == want, (name, flags, m, chunk, thr, len(data), len(got), len(want))
+
+
+def test_parallel_fastq_reader_really_runs_and_falls_back(tmp_path):
+    """the strict input is parsed by the workers (no fallback message), the broken one reports where it went sequential"""
+    ins = _fastq_inputs()
+    for name, expect in (("strict", False), ("mid_multiline", True), ("starts_with_fasta", False)):
+        f = tmp_path / "b.bin"
+        p = subprocess.run([CLI, "-R", "-m1g", "-"], input=ins[name], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, RB2_DUMP_BATCHES=str(f), RB2_PARSE_THREADS="4", RB2_PARSE_CHUNK="4096", RB2_PARSE_TRACE="1"))
+        assert p.returncode == 0
+        assert (b"not four-line FASTQ" in p.stderr) == expect, (name, p.stderr.decode()[-300:])
+        if name == "strict":
+            import re
+            mm = re.search(rb"(\d+) blocks of four-line FASTQ records parsed by 4 threads", p.stderr)
+            assert mm and int(mm.group(1)) > 10 and b"then the sequential" not in p.stderr, p.stderr.decode()[-300:]
+        if name == "starts_with_fasta":
+            assert b"parsed by" not in p.stderr                      # does not start with '@': sequential from the first byte
+
+
 def test_fmr_dump_to_a_file_equals_dump_to_a_pipe(golden, tmp_path):
     """mr_dump writes the six ropes of a regular file from six threads (pwrite at known offsets); a pipe -- and
     RB2_DUMP_SEQUENTIAL=1 -- takes the reference's sequential fwrite path.  Same bytes, and the reference restores them."""

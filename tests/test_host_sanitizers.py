@@ -139,3 +139,15 @@ def test_sanitized_parallel_loader_growing_canonical_form(san_cli, tmp_path):
         ours = run(san_cli, ["-d", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": "4", "RB2_LOAD_MIN_SEG": "500"})
         if ref.returncode == 0:
             assert ours == ref.stdout
+
+
+def test_sanitized_parallel_fastq_reader(san_cli, tmp_path):
+    """the threaded FASTQ reader and its fallback to the sequential reader (raw blocks handed back) under ASan/UBSan"""
+    from test_host_layer import _fastq_inputs
+    ins = _fastq_inputs()
+    dump = tmp_path / "b.bin"
+    for name in ("strict", "strict_crlf", "strict_no_final_newline", "mid_multiline", "mid_qual_long", "mid_blank", "truncated_record", "header_only", "empty"):
+        for chunk in ("64", "3000", "1000000"):
+            if dump.exists():
+                dump.unlink()
+            run(san_cli, ["-m40k", "-q", "10", "-C"], ins[name], env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})
