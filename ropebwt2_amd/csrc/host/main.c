@@ -7,6 +7,7 @@
  * provided.
  */
 #include <zlib.h>
+#include <fcntl.h>
 #include <ctype.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -237,6 +238,7 @@ typedef struct {
 	int64_t next_work, n_queued; int closing;
 	int64_t consumed; int eof;                                  /* blocks the main thread has taken over; the reader thread saw the end of the input */
 	gzFile fp; int64_t chunk;                                   /* the reader thread's input */
+	int fd;                                                     /* >= 0: the input is a plain (uncompressed) regular file -- read(2) it directly; zlib's transparent mode copies every byte twice */
 	int fastq, stop;                                            /* blocks of whole four-line records instead of whole lines; the consumer asks the reader to stop (fallback) */
 	uint8_t *carry; int64_t n_carry, total;                     /* what the reader thread held back when it stopped, and how far it had read */
 	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
@@ -330,6 +332,24 @@ static void *pparse_worker(void *arg)
 /* The reader of the parallel -L path, a thread of its own: reads the next block, cuts it behind its last newline (the unfinished
  * line is carried into the next block) and queues it for the encoders.  The main thread only takes the encoded blocks over, in
  * order -- with both in one thread, reading 10 GB and appending 10 GB were 3+ s of configs[1]'s whole process. */
+static int64_t count_newlines(const uint8_t *p, int64_t n)   /* eight bytes per step (the reader thread is the wall-clock of a FASTQ run) */
+{
+	int64_t c = 0, i = 0;
+	const uint64_t K = 0x0a0a0a0a0a0a0a0aull, L7 = 0x7f7f7f7f7f7f7f7full;
+	for (; i + 32 <= n; i += 32) {
+		int k;
+		for (k = 0; k < 4; ++k) {
+			uint64_t x;
+			memcpy(&x, p + i + 8 * k, 8);
+			x ^= K;                                               /* bytes equal to '\n' are zero now */
+			x = ~(((x & L7) + L7) | x | L7);                      /* 0x80 in every zero byte, exact */
+			c += __builtin_popcountll(x);
+		}
+	}
+	for (; i < n; ++i) c += p[i] == '\n';
+	return c;
+}
+
 static void *pparse_reader(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
@@ -348,7 +368,8 @@ static void *pparse_reader(void *arg)
 		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
 		memcpy(jb->in, carry, n_carry);
 		while (got < CHUNK) {                                 /* gzread may return short counts on pipes */
-			const int r = gzread(pp->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
+			const int64_t r = pp->fd >= 0 ? (int64_t)read(pp->fd, jb->in + n_carry + got, (size_t)(CHUNK - got))
+			                              : (int64_t)gzread(pp->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
 			if (r <= 0) { eof = 1; break; }
 			got += r;
 		}
@@ -359,9 +380,8 @@ static void *pparse_reader(void *arg)
 		if (!eof) {                                           /* keep the unfinished last line for the next block */
 			for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
 			if (pp->fastq && cut > 0) {                         /* ... and, for FASTQ, the lines behind the last multiple of four: a block holds whole records */
-				int64_t nl = 0, i;
+				const int64_t nl = count_newlines(jb->in, cut);
 				int back;
-				for (i = 0; i < cut; ++i) nl += jb->in[i] == '\n';
 				for (back = (int)(nl & 3); back > 0; --back) for (--cut; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
 			}
 			n_carry = jb->n_in - cut;                           /* (cut == 0: one line longer than a block -- everything is carried on) */
@@ -665,6 +685,11 @@ int main(int argc, char *argv[])
 		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; if (pp.njob > 62) pp.njob = 62;
 		pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
 		pp.fp = rd->fp; pp.chunk = CHUNK; pp.fastq = par == 2;
+		pp.fd = -1;
+		if (optind < argc && strcmp(argv[optind], "-") && gzdirect(rd->fp) == 1 && !getenv("RB2_NO_DIRECT_READ")) {   /* a plain file: bypass zlib */
+			struct stat st;
+			if (stat(argv[optind], &st) == 0 && S_ISREG(st.st_mode)) pp.fd = open(argv[optind], O_RDONLY);
+		}
 		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0); pthread_cond_init(&pp.cv_space, 0);
 		for (k = 0; k < pthr; ++k) pthread_create(&th[k], 0, pparse_worker, &pp);
 		pthread_create(&reader, 0, pparse_reader, &pp);
@@ -703,6 +728,7 @@ int main(int argc, char *argv[])
 		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_mutex_unlock(&pp.mu);
 		for (k = 0; k < pthr; ++k) pthread_join(th[k], 0);
 		free(th);
+		if (pp.fd >= 0) close(pp.fd);
 		need_seq = fell_back;
 		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
 		if (fell_back) {                                        /* the blocks from the failed one on, what the reader held back, then the stream itself */
@@ -713,6 +739,7 @@ int main(int argc, char *argv[])
 			rd->mem = fb_mem; rd->mem_n = fb_n; rd->nmem = n; rd->imem = 0; rd->mem_off = 0;
 			rd->pos = pp.job[pp.consumed % pp.njob].stream_off;
 			rd->beg = rd->end = 0; rd->eof = 0; rd->last = 0;
+			if (pp.fd >= 0) gzseek(rd->fp, (z_off_t)pp.total, SEEK_SET);   /* the reader thread read the file itself: the stream goes on where it stopped */
 			if (verbose >= 3) fprintf(stderr, "[M::%s] the input is not four-line FASTQ from byte %ld on: sequential reader\n", "main_ropebwt2", (long)rd->pos);
 		}
 	}

@@ -420,6 +420,33 @@ def test_parallel_fastq_reader_equals_sequential(flags, tmp_path):
                 assert got == want, (name, flags, m, chunk, thr, len(data), len(got), len(want))
 
 
+def test_named_files_plain_and_gz(tmp_path):
+    """a named plain file is read with read(2) by the reader thread (zlib bypassed), a .gz through zlib; the fallback of the FASTQ
+    reader continues the plain file from where the reader thread stopped -- same batches as the sequential reader in all cases"""
+    import gzip
+    ins = _fastq_inputs()
+    lines = H.reads_to_text(H.splitmix_bases(4000, 60, seed=8))
+    cases = [("strict", ins["strict"], ["-R"]), ("mid_multiline", ins["mid_multiline"], ["-R"]), ("mid_fasta", ins["mid_fasta"], []), ("lines", lines, ["-L", "-R"])]
+    for name, data, flags in cases:
+        plain = tmp_path / (name + ".txt")
+        plain.write_bytes(data)
+        gz = tmp_path / (name + ".txt.gz")
+        with gzip.open(gz, "wb") as fp:
+            fp.write(data)
+        outs = []
+        for path in (plain, gz):
+            for thr, extra in (("1", {}), ("4", {"RB2_PARSE_CHUNK": "3000"}), ("4", {"RB2_PARSE_CHUNK": "3000", "RB2_NO_DIRECT_READ": "1"})):
+                f = tmp_path / "o.bin"
+                if f.exists():
+                    f.unlink()
+                e = dict(os.environ, RB2_DUMP_BATCHES=str(f), RB2_NO_RESERVE="1", RB2_PARSE_THREADS=thr)
+                e.update(extra)
+                p = subprocess.run([CLI] + flags + ["-m25k", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+                assert p.returncode == 0, p.stderr.decode()[-300:]
+                outs.append(f.read_bytes())
+        assert all(o == outs[0] for o in outs), name
+
+
 def test_parallel_fastq_reader_really_runs_and_falls_back(tmp_path):
     """the strict input is parsed by the workers (no fallback message), the broken one reports where it went sequential"""
     ins = _fastq_inputs()

@@ -1,7 +1,8 @@
 /* tools/synth_reads.c -- input generator for tests and bench.py (built to ropebwt2_amd/bin/synth_reads).
  * Deterministic synthetic read generator: base j of read i is
  * "ACGT"[splitmix64_output(seed, i*L+j+1) >> 62], one read per line.
- *   usage: synth_reads <n_reads> <read_len> [seed=42] [first_read=0] [genome_len=0]  > reads.txt
+ *   usage: synth_reads <n_reads> <read_len> [seed=42] [first_read=0] [genome_len=0] [fastq=0]  > reads.txt
+ * fastq = 1: the same reads as four-line FASTQ records ("@r<i>", bases, "+", a constant quality string of 'I')
  * genome_len > 0: read i is the window of a random genome (base p = "ACGT"[sm64(seed, p) >> 62]) that starts at
  * sm64(seed ^ COV_SALT, i) % (genome_len - L + 1) -- overlapping reads, the same stream as rb2_hip_synth_reads_cov.
  */
@@ -24,17 +25,22 @@ int main(int argc, char **argv)
 	uint64_t seed = argc > 3 ? strtoull(argv[3], 0, 10) : 42;
 	uint64_t first = argc > 4 ? strtoull(argv[4], 0, 10) : 0;
 	uint64_t glen = argc > 5 ? strtoull(argv[5], 0, 10) : 0;
+	const int fastq = argc > 6 ? atoi(argv[6]) : 0;
 	const uint64_t COV_SALT = 0x5bd1e995c0f3a1d7ULL;
 	if (glen && glen < L) { fprintf(stderr, "genome shorter than a read\n"); return 1; }
-	char *line = (char*)malloc(L + 2);
+	char *line = (char*)malloc(L + 2), *qual = (char*)malloc(L + 4);
+	for (uint64_t j = 0; j < L; ++j) qual[j] = 'I';
+	qual[L] = '\n';
 	static char obuf[1 << 20];
 	setvbuf(stdout, obuf, _IOFBF, sizeof obuf);
 	for (uint64_t i = first; i < first + n; ++i) {
 		const uint64_t base = glen ? sm64(seed ^ COV_SALT, i) % (glen - L + 1) : i * L;
 		for (uint64_t j = 0; j < L; ++j) line[j] = "ACGT"[sm64(seed, base + j) >> 62];
 		line[L] = '\n';
+		if (fastq) printf("@r%llu\n", (unsigned long long)i);
 		fwrite(line, 1, L + 1, stdout);
+		if (fastq) { fwrite("+\n", 1, 2, stdout); fwrite(qual, 1, L + 1, stdout); }
 	}
-	free(line);
+	free(line); free(qual);
 	return 0;
 }
