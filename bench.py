@@ -384,7 +384,10 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    # RB2_BENCH_FORCE_MULTI=1: run the multi-GPU code path (process group, ncclUniqueId through torch.distributed, one rank of an RCCL
+    # group per process, the round loop inside librb2hip.so) even with ONE process -- how that path is exercised on a one-GPU box
+    force_multi = bool(os.environ.get("RB2_BENCH_FORCE_MULTI")) and "RANK" in os.environ
+    if world > 1 or force_multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # test hook for single-GPU boxes: RB2_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages
@@ -402,7 +405,7 @@ def main():
         build_all()
     if dist is not None:
         dist.barrier()
-    sharded = n_ranks > 1 and args.mode in ("weak", "strong")
+    sharded = (n_ranks > 1 or force_multi) and args.mode in ("weak", "strong")
     if sharded and args.mode == "weak":                 # per-GPU work fixed: N times the reads, N times the batch
         args.reads *= n_gpus
         args.batch *= n_gpus
@@ -411,13 +414,15 @@ def main():
     L = args.read_len
     per_batch = batch_reads(args.batch * 1024 ** 3, L)
     dev = local_rank if world > 1 else 0
-    py_driver = world > 1 and (os.environ.get("RB2_BENCH_DRIVER") == "python" or os.environ.get("RB2_BENCH_BACKEND") == "gloo")
+    py_driver = (world > 1 or force_multi) and (os.environ.get("RB2_BENCH_DRIVER") == "python" or os.environ.get("RB2_BENCH_BACKEND") == "gloo")
     driver = "single engine"
-    nccl_id = None
-    if sharded and world > 1 and not py_driver:          # the RCCL group of the C-level driver: rank 0's id, through torch.distributed
+
+    def fresh_nccl_id():
+        """every RCCL communicator needs an id of its own (the warm-up handle and the measured one are two communicators):
+        rank 0 makes one, torch.distributed hands it round"""
         box = [MultiBwt.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        nccl_id = box[0]
+        return box[0]
 
     def barrier():
         if dist is not None:
@@ -443,9 +448,9 @@ def main():
         if py_driver:
             driver = "python round loop (sharded.py) over %s" % dist.get_backend()
             return PyDriver(so_, dev_)
-        if world > 1:
+        if world > 1 or force_multi:
             driver = "librb2hip round loop, one process per GPU, RCCL C API (ncclAllReduce + grouped ncclSend/ncclRecv)"
-            return Multi(so_, [dev_], "rccl", rank=rank, nranks=world, nccl_id=nccl_id)
+            return Multi(so_, [dev_], "rccl", rank=rank, nranks=world, nccl_id=fresh_nccl_id())
         tr = os.environ.get("RB2_BENCH_TRANSPORT", "peer")
         driver = "librb2hip round loop, one process, %d ranks on devices %s, %s transport" % (len(local_devices), local_devices, tr.upper())
         return Multi(so_, local_devices, tr)

@@ -344,6 +344,23 @@ def test_one_process_group_over_rccl_c_driver(hip):
     assert "C-level RCCL driver ok" in out, out
 
 
+@pytest.mark.gpu
+def test_bench_multi_gpu_code_path_with_one_process(hip):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one process per GPU, RCCL group driven inside the
+    library, a fresh ncclUniqueId per communicator: warm-up handle and measured handle), with N = 1 forced onto that path"""
+    import json
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RB2_BENCH_FORCE_MULTI="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29771",
+           os.path.join(H.ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--reads", "3000000", "--batch", "0.1", "--no-extras", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["config"]["counts_ok"] is True and "RCCL C API" in d["config"]["driver"], d["config"]
+    assert d["config"]["multi_stats"]["rounds"] > 100 and d["value"] > 0
+
+
 # ---- through the drop-in boundary: the CLI and the mrope C API with RB2_HIP_DEVICES ---------------------------------------
 
 def _cli_env(flags, data, devices, transport=None, extra_env=None):
