@@ -115,31 +115,11 @@ def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
     dt = time.perf_counter() - t0
     ok = int(b.counts().sum()) == sum(sizes)
     b.close()
-    # the same, with the NEXT batch announced (rb2_hip_prefetch, from a second thread -- what the CLI's reader does) while the
-    # current one is inserted: its PCIe crossing hides behind the insertion; only the first batch of the job pays for its upload
-    import threading
-    b = HipBwt(so, dev)
-    b.sync()
-    t0 = time.perf_counter()
-    for k, a in enumerate(host):
-        th = None
-        if k + 1 < len(host):
-            def announce(a=host[k + 1]):                   # in 256 MB steps, as the CLI's reader announces a batch it is assembling
-                for o in range(256 << 20, len(a) + (256 << 20), 256 << 20):
-                    b.prefetch(a, min(o, len(a)), len(a))
-            th = threading.Thread(target=announce)
-            th.start()
-        b.insert_multi(a)
-        if th is not None:
-            th.join()
-    b.sync()
-    dtp = time.perf_counter() - t0
-    okp = int(b.counts().sum()) == sum(sizes)
-    b.close()
+    # (rb2_hip_prefetch does not help THIS pattern -- batches fired back to back from pageable memory: a copy that runs beside the
+    # insert kernels takes twice as long and slows them, tools/prefetch_probe.py; it pays where a batch is assembled over seconds,
+    # as in the CLI: profiles/r03_configs2_full_cli_1gpu.txt)
     return {"value": sum(sizes) / dt / 1e9, "unit": "Gsymbols/s", "seconds": dt, "counts_ok": ok,
-            "what": "one configs[1] job through rb2_hip_insert_multi on pageable host buffers, no rb2_hip_reserve: PCIe-inclusive",
-            "with_prefetch": {"value": sum(sizes) / dtp / 1e9, "seconds": dtp, "counts_ok": okp,
-                              "what": "the same calls, the next batch announced with rb2_hip_prefetch from a second thread while the current one is inserted"}}
+            "what": "one configs[1] job through rb2_hip_insert_multi on pageable host buffers, no rb2_hip_reserve: PCIe-inclusive"}
 
 
 def whole_process(reads, read_len, so_flag, batch_gib):
