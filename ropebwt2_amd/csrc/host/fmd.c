@@ -17,6 +17,7 @@
 #include <pthread.h>
 #include "rb2_fmd.h"
 #include "rle.h"
+#include "rb2_parcopy.h"
 
 #define BLK_WORDS   8                    /* 1 << sbits, sbits = 3 */
 #define SYM_BITS    3                    /* ilog2(asize) + 1 */
@@ -546,7 +547,7 @@ void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n)
 			while (take > 0 && (runs[take] & 0xC0) == 0x80) --take;
 			if (take == 0) { queue_fill(p); continue; }
 		}
-		memcpy(sg->runs + sg->n, runs, (size_t)take); sg->n += take;
+		rb2_par_memcpy(sg->runs + sg->n, runs, take); sg->n += take;   /* (four threads: this copy was the producer's whole time) */
 		runs += take; n -= take;
 		if (sg->n >= p->seg_bytes) queue_fill(p);
 	}

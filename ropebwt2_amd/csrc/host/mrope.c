@@ -24,6 +24,7 @@
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_hip.h"
+#include "rb2_parcopy.h"
 
 typedef struct {
 	mrope_t pub;            /* must stay first: callers hold mrope_t* */
@@ -163,30 +164,11 @@ int64_t mr_auto_batch_bytes(mrope_t *mr)
 /* device -> host ropes: stream each rope's run bytes off the device ONCE into a growing buffer (the size is only known
  * after the export; asking for it first would run the export kernel twice) and bulk-load a fresh B+ tree */
 typedef struct { uint8_t *p; int64_t n, m; } runbuf_t;
-/* one thread copies ~6 GB/s out of the pinned staging buffer: at configs[2] size (88 GB of run bytes) that alone was 15 s of
- * mr_sync_host -- the pieces (up to 32 MiB each) are copied by four threads */
-typedef struct { uint8_t *d; const uint8_t *s; size_t n; } cpjob_t;
-static void *cp_worker(void *a) { cpjob_t *j = (cpjob_t*)a; memcpy(j->d, j->s, j->n); return 0; }
-static void par_memcpy(uint8_t *d, const uint8_t *s, int64_t n)
-{
-	enum { T = 4 };
-	cpjob_t job[T]; pthread_t th[T]; int k, started = 0;
-	const int64_t part = (n / T + 63) & ~(int64_t)63;
-	if (n < (8 << 20)) { memcpy(d, s, (size_t)n); return; }
-	for (k = 0; k < T; ++k) {
-		const int64_t o = k * part, len = o >= n ? 0 : (n - o < part || k == T - 1 ? n - o : part);
-		job[k].d = d + o; job[k].s = s + o; job[k].n = (size_t)len;
-		if (k > 0 && len > 0 && pthread_create(&th[k], 0, cp_worker, &job[k]) == 0) started |= 1 << k;
-		else if (k > 0 && len > 0) cp_worker(&job[k]);
-	}
-	cp_worker(&job[0]);
-	for (k = 1; k < T; ++k) if (started >> k & 1) pthread_join(th[k], 0);
-}
 static void runbuf_add(void *user, const uint8_t *q, int64_t n)
 {
 	runbuf_t *b = (runbuf_t*)user;
 	if (b->n + n > b->m) { b->m = (b->n + n) + ((b->n + n) >> 1) + (1 << 20); b->p = (uint8_t*)realloc(b->p, b->m); }
-	par_memcpy(b->p + b->n, q, n); b->n += n;
+	rb2_par_memcpy(b->p + b->n, q, n); b->n += n;              /* (four threads: rb2_parcopy.h) */
 }
 
 typedef struct { rope_t *r; runbuf_t rb; } load_job_t;
