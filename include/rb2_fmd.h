@@ -31,6 +31,11 @@ typedef struct rb2_fmdp_s rb2_fmdp_t;
 rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t segment_bytes /* 0: default */);
 void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n_bytes);
 rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p);
+/* Stream the encoded words to `fd` (a regular file, not O_APPEND; the .fmd starts at byte `offset`) while they are produced;
+ * rb2_fmd_write() on the finished index then adds header, tail and rank frames and leaves its FILE (same descriptor) positioned
+ * behind the index.  Returns -1 (nothing changes, rb2_fmd_write writes everything) when fd cannot be written at offsets.
+ * Call before the first rb2_fmdp_push_runs.  The file is byte-identical either way (rld_dump, rld0.c:207-229). */
+int rb2_fmdp_set_output(rb2_fmdp_t *p, int fd, int64_t offset);
 
 #ifdef __cplusplus
 }

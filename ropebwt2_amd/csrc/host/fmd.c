@@ -15,6 +15,12 @@
 #include <string.h>
 #include <assert.h>
 #include <pthread.h>
+#include <stdio.h>
+#include <errno.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <sys/types.h>
+#include <sys/stat.h>
 #include "rb2_fmd.h"
 #include "rle.h"
 #include "rb2_parcopy.h"
@@ -38,6 +44,9 @@ struct rb2_fmd_s {
 	uint32_t *start; uint8_t *type; size_t nblk, cap_blk;   /* start[k], type[k] of block k; block nblk is the one being filled */
 	uint32_t run_pos;                                       /* offset of the run being encoded */
 	int64_t pend_seg;                                       /* true orbit of the parallel writer: segment in which the pending run starts */
+	/* streamed output (rb2_fmdp_set_output): words [0, out_done) are already in the file at out_base + 80; wmu keeps the
+	 * writer thread's pwrite and reserve()'s realloc apart */
+	int out_fd; int64_t out_base; size_t out_done; pthread_mutex_t *wmu; int out_err;
 };
 
 static const int hdr_words[3] = { 2, 4, 7 };   /* (7*16+63)/64, (7*32+63)/64, 7 */
@@ -49,7 +58,10 @@ static void reserve(rb2_fmd_t *f, size_t n_words)
 	if (n_words <= f->cap) return;
 	size_t nc = f->cap ? f->cap : 1 << 16;
 	while (nc < n_words) nc += nc >> 1;
+	if (f->wmu) pthread_mutex_lock(f->wmu);
 	f->w = (uint64_t*)realloc(f->w, nc * 8);
+	if (f->wmu) pthread_mutex_unlock(f->wmu);
+	if (!f->w) { fprintf(stderr, "[rb2_fmd] out of memory (%zu words)\n", nc); abort(); }
 	memset(f->w + f->cap, 0, (nc - f->cap) * 8);
 	f->cap = nc;
 }
@@ -67,6 +79,7 @@ rb2_fmd_t *rb2_fmd_init(void)
 	reserve(f, 2 * BLK_WORDS);
 	f->head = 0; f->p = hdr_words[0]; f->tail = block_tail(0); f->r = 64;
 	f->pend_c = -1;
+	f->out_fd = -1;
 	return f;
 }
 
@@ -233,11 +246,42 @@ static void fmd_index_mt(rb2_fmd_t *f, int nthr)
 
 static void fmd_index(rb2_fmd_t *f) { fmd_index_mt(f, 1); }
 
+static int pwrite_all(int fd, const void *buf, size_t n, int64_t off)
+{
+	const char *q = (const char*)buf;
+	while (n > 0) {
+		const ssize_t k = pwrite(fd, q, n > ((size_t)1 << 30) ? (size_t)1 << 30 : n, (off_t)off);
+		if (k < 0) { if (errno == EINTR) continue; return -1; }
+		q += k; n -= (size_t)k; off += k;
+	}
+	return 0;
+}
+
+/* the stream was written to out_fd while it was produced (rb2_fmdp_set_output): header, the words that became final after the
+ * writer thread stopped, and the rank frames; fp (the FILE on the same descriptor) is left positioned behind the file */
+static int fmd_write_rest(const rb2_fmd_t *f, FILE *fp)
+{
+	const uint32_t a = 6u << 16 | 3u;
+	uint8_t hdr[80];
+	const size_t nw = f->n_bytes / 8;
+	int r = f->out_err ? -1 : 0;
+	memset(hdr, 0, sizeof(hdr));
+	memcpy(hdr, "RLD\3", 4); memcpy(hdr + 4, &a, 4);
+	memcpy(hdr + 16, &f->n_bytes, 8); memcpy(hdr + 24, &f->n_frames, 8); memcpy(hdr + 32, f->mcnt + 1, 48);
+	if (fflush(fp) != 0) r = -1;
+	if (pwrite_all(f->out_fd, hdr, 80, f->out_base) != 0) r = -1;
+	if (f->out_done < nw && pwrite_all(f->out_fd, f->w + f->out_done, (nw - f->out_done) * 8, f->out_base + 80 + (int64_t)f->out_done * 8) != 0) r = -1;
+	if (pwrite_all(f->out_fd, f->frame, f->n_frames * 8 * N_FIELDS, f->out_base + 80 + (int64_t)nw * 8) != 0) r = -1;
+	if (fseeko(fp, (off_t)(f->out_base + 80 + (int64_t)nw * 8 + (int64_t)f->n_frames * 8 * N_FIELDS), SEEK_SET) != 0) r = -1;
+	return r;
+}
+
 int rb2_fmd_write(const rb2_fmd_t *f, FILE *fp)
 {
 	const uint32_t a = 6u << 16 | 3u;
 	const uint64_t zero = 0;
 	if (!f->finished) return -1;
+	if (f->out_fd >= 0) return fmd_write_rest(f, fp);
 	fwrite("RLD\3", 1, 4, fp);
 	fwrite(&a, 4, 1, fp);
 	fwrite(&zero, 8, 1, fp);
@@ -297,6 +341,9 @@ typedef struct {
 
 struct rb2_fmdp_s {
 	rb2_fmd_t *f;                    /* the true stream */
+	/* streamed output: the writer thread puts the words below pub_head (final: the true orbit has left those blocks) into the file */
+	pthread_t writer; int writer_on, writer_quit; size_t pub_head;
+	pthread_mutex_t wmu, pmu; pthread_cond_t pcv;
 	fseg_t **seg; int64_t nseg, cap_seg, seg_bytes;          /* segments are allocated one by one: workers keep pointers to them */
 	int64_t n_queued, next_work;     /* segments handed to the workers / next one a worker takes */
 	int64_t cur_seg, cur_pos;        /* input cursor of the true orbit */
@@ -528,6 +575,12 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 		}
 		free(sg->runs); sg->runs = 0;
 		free(sg->sp->w); free(sg->sp->start); free(sg->sp->type); free(sg->sp); sg->sp = 0;
+		if (p->writer_on) {                                   /* everything below the block being filled is final */
+			pthread_mutex_lock(&p->pmu);
+			p->pub_head = f->head;
+			pthread_cond_signal(&p->pcv);
+			pthread_mutex_unlock(&p->pmu);
+		}
 		pthread_mutex_lock(&p->mu);
 		++p->cur_seg; p->cur_pos = 0;                        /* (the fseg_t itself stays: the next segment reads prev_sym_out) */
 		pthread_cond_broadcast(&p->cv_space);
@@ -536,6 +589,50 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 }
 
 static void *fmdp_stitcher(void *arg) { stitch((rb2_fmdp_t*)arg); return 0; }
+
+static size_t out_step_words(void)                            /* the writer thread moves at least 32 MiB per pwrite (RB2_FMD_OUT_STEP: words, tests) */
+{
+	const char *e = getenv("RB2_FMD_OUT_STEP");
+	const long v = e ? atol(e) : 0;
+	return v > 0 ? (size_t)v : (size_t)4 << 20;
+}
+
+static void *fmdp_writer(void *arg)
+{
+	rb2_fmdp_t *p = (rb2_fmdp_t*)arg;
+	rb2_fmd_t *f = p->f;
+	const size_t OUT_STEP_WORDS = out_step_words();
+	for (;;) {
+		size_t upto; int quit;
+		pthread_mutex_lock(&p->pmu);
+		while (p->pub_head < f->out_done + OUT_STEP_WORDS && !p->writer_quit) pthread_cond_wait(&p->pcv, &p->pmu);
+		upto = p->pub_head; quit = p->writer_quit;
+		pthread_mutex_unlock(&p->pmu);
+		if (upto > f->out_done && !f->out_err) {
+			pthread_mutex_lock(&p->wmu);                       /* f->w does not move while it is being read */
+			if (pwrite_all(f->out_fd, f->w + f->out_done, (upto - f->out_done) * 8, f->out_base + 80 + (int64_t)f->out_done * 8) != 0) f->out_err = 1;
+			pthread_mutex_unlock(&p->wmu);
+			f->out_done = upto;
+		}
+		if (quit) return 0;
+	}
+}
+
+/* Stream the .fmd to fd while it is being encoded: the file starts at byte `offset` of fd (a regular file opened without
+ * O_APPEND; returns -1 and changes nothing otherwise).  rb2_fmd_write() on the finished index then only adds the header, the
+ * tail of the stream and the rank frames.  Call it before the first rb2_fmdp_push_runs. */
+int rb2_fmdp_set_output(rb2_fmdp_t *p, int fd, int64_t offset)
+{
+	struct stat st;
+	const int fl = fcntl(fd, F_GETFL);
+	if (p->writer_on || fl < 0 || (fl & O_APPEND) || (fl & O_ACCMODE) == O_RDONLY) return -1;
+	if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || offset < 0) return -1;
+	pthread_mutex_init(&p->wmu, 0); pthread_mutex_init(&p->pmu, 0); pthread_cond_init(&p->pcv, 0);
+	p->f->out_fd = fd; p->f->out_base = offset; p->f->out_done = 0; p->f->wmu = &p->wmu;
+	p->writer_on = 1;
+	pthread_create(&p->writer, 0, fmdp_writer, p);
+	return 0;
+}
 
 void rb2_fmdp_push_runs(rb2_fmdp_t *p, const uint8_t *runs, int64_t n)
 {
@@ -563,6 +660,15 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
 	pthread_cond_broadcast(&p->cv_done);
 	pthread_mutex_unlock(&p->mu);
 	pthread_join(p->stitcher, 0);
+	if (p->writer_on) {                                       /* the writer drains what is published and stops; the rest goes out with rb2_fmd_write */
+		pthread_mutex_lock(&p->pmu);
+		p->writer_quit = 1;
+		pthread_cond_signal(&p->pcv);
+		pthread_mutex_unlock(&p->pmu);
+		pthread_join(p->writer, 0);
+		f->wmu = 0;
+		pthread_mutex_destroy(&p->wmu); pthread_mutex_destroy(&p->pmu); pthread_cond_destroy(&p->pcv);
+	}
 	pthread_mutex_lock(&p->mu);
 	p->closing = 1;
 	pthread_cond_broadcast(&p->cv_work);

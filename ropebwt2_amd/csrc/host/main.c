@@ -797,6 +797,12 @@ int main(int argc, char *argv[])
 			long nt = sysconf(_SC_NPROCESSORS_ONLN) - 1;
 			if (getenv("RB2_FMD_THREADS")) nt = atol(getenv("RB2_FMD_THREADS"));
 			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 24 ? 24 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
+			if (!getenv("RB2_FMD_NO_STREAM")) {                 /* -o file / a redirected stdout: the index goes out while it is encoded */
+				fflush(stdout);
+				const off_t at = ftello(stdout);
+				if (at >= 0 && rb2_fmdp_set_output(fmdp, fileno(stdout), (int64_t)at) == 0 && verbose >= 4)
+					fprintf(stderr, "[M::%s] the .fmd is written while it is encoded\n", "main_ropebwt2");
+			}
 		}
 		const double ts0 = realtime();
 		mr_stream_runs(mr, emit_runs, fmdp);                   /* the reference walks mr_itr_next_block here (main.c:288-305) */
@@ -808,7 +814,7 @@ int main(int argc, char *argv[])
 			rb2_fmd_counts(fmd, cc);
 			fprintf(stderr, "[M::%s] rld: (tot, $, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
 					(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5], (long)cc[6]);
-			rb2_fmd_write(fmd, stdout);
+			if (rb2_fmd_write(fmd, stdout) != 0) { fprintf(stderr, "[E::%s] failed to write the index\n", "main_ropebwt2"); ret = 1; }
 			rb2_fmd_destroy(fmd);
 		} else putchar('\n');
 	}

@@ -312,6 +312,89 @@ def test_parallel_fmd_writer_crosses_a_chunk_border(tmp_path):
     assert len(a) > (1 << 26) + 4096 and a == b
 
 
+@pytest.mark.parametrize("n,step,offset", [(0, 1, 0), (40, 1, 0), (300000, 64, 13), (3000000, 1024, 0), (3000000, 0, 4096)])
+def test_fmd_streamed_to_the_file_while_encoded(n, step, offset, tmp_path):
+    """rb2_fmdp_set_output: a writer thread pwrites the final words while the stitcher is still working (step: words per write,
+    0 = the 32 MiB default, i.e. everything left to rb2_fmd_write); the file equals the sequential writer's, also behind other bytes"""
+    L = _fmd_lib()
+    L.rb2_fmdp_set_output.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    libc = C.CDLL(None)
+    libc.fdopen.restype = C.c_void_p; libc.fdopen.argtypes = [C.c_int, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    libc.ftello.argtypes = [C.c_void_p]; libc.ftello.restype = C.c_int64
+    libc.fseeko.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.rb2_fmd_write.argtypes = [C.c_void_p, C.c_void_p]
+    rng = np.random.RandomState(n % 89)
+    runs = (rng.choice([1, 1, 2, 3, 9, 15], size=n).astype(np.uint8) << 3 | rng.randint(0, 6, size=n).astype(np.uint8)).astype(np.uint8)
+    chunks = [runs[i:i + 5000] for i in range(0, n, 5000)]
+    f = L.rb2_fmd_init()
+    for r in chunks:
+        L.rb2_fmd_push_runs(f, r.ctypes.data, len(r))
+    L.rb2_fmd_finish(f)
+    a = str(tmp_path / "seq.fmd").encode()
+    assert L.rb2_fmd_write_path(f, a) == 0
+    L.rb2_fmd_destroy(f)
+    want = open(a, "rb").read()
+    if step:
+        os.environ["RB2_FMD_OUT_STEP"] = str(step)
+    try:
+        out = tmp_path / "streamed.fmd"
+        fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        fp = libc.fdopen(fd, b"wb")
+        os.write(fd, b"x" * offset)
+        libc.fseeko(fp, offset, 0)
+        p = L.rb2_fmdp_init(4, 4096)
+        assert L.rb2_fmdp_set_output(p, fd, offset) == 0
+        for r in chunks:
+            L.rb2_fmdp_push_runs(p, r.ctypes.data, len(r))
+        f = L.rb2_fmdp_finish(p)
+        assert L.rb2_fmd_write(f, fp) == 0
+        assert libc.ftello(fp) == offset + len(want)                    # the FILE continues behind the index
+        L.rb2_fmd_destroy(f)
+        libc.fclose(fp)
+    finally:
+        os.environ.pop("RB2_FMD_OUT_STEP", None)
+    got = out.read_bytes()
+    assert got[:offset] == b"x" * offset and got[offset:] == want
+
+
+def test_fmd_streaming_is_refused_where_offsets_do_not_work(tmp_path):
+    """pipes and O_APPEND files keep the one-shot writer"""
+    L = _fmd_lib()
+    L.rb2_fmdp_set_output.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    p = L.rb2_fmdp_init(2, 0)
+    r, w = os.pipe()
+    assert L.rb2_fmdp_set_output(p, w, 0) == -1
+    fd = os.open(tmp_path / "a", os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+    assert L.rb2_fmdp_set_output(p, fd, 0) == -1
+    fd2 = os.open(tmp_path / "a", os.O_RDONLY)
+    assert L.rb2_fmdp_set_output(p, fd2, 0) == -1
+    f = L.rb2_fmdp_finish(p)
+    assert L.rb2_fmd_write_path(f, str(tmp_path / "b").encode()) == 0
+    L.rb2_fmd_destroy(f)
+    for x in (r, w, fd, fd2):
+        os.close(x)
+
+
+def test_cli_fmd_to_a_file_is_streamed_and_identical(golden, tmp_path):
+    """-o FILE and a redirected stdout take the streamed path; same bytes as through a pipe"""
+    g = golden["sets"]["10k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    for mode in ("-o", ">", "no_stream"):
+        out = tmp_path / ("o_%s.fmd" % mode.strip("->"))
+        env = dict(os.environ, RB2_FMD_SEGMENT="3000", RB2_FMD_OUT_STEP="256")
+        if mode == "no_stream":
+            env["RB2_FMD_NO_STREAM"] = "1"
+        if mode == ">":
+            with open(out, "wb") as fo:
+                p = subprocess.run([CLI, "-LRsd", "-m0", "-v4", "-"], input=text, stdout=fo, stderr=subprocess.PIPE, env=env)
+        else:
+            p = subprocess.run([CLI, "-LRsd", "-m0", "-v4", "-o", str(out), "-"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-400:]
+        assert (b"written while it is encoded" in p.stderr) == (mode != "no_stream")
+        assert H.md5(out.read_bytes()) == g["fmd_md5"]["-LRsd"], mode
+
+
 def test_cli_fmd_small_segments_m0(golden):
     """the CLI's .fmd through the parallel writer with segments far smaller than a leaf chunk and with one thread"""
     g = golden["sets"]["10k_x_101"]

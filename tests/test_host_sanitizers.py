@@ -57,6 +57,10 @@ def test_sanitized_host_layer_m0(san_cli, golden, tmp_path):
     # small leaves / buckets: splits at every level; the parallel .fmd writer with tiny segments and several threads
     b = run(san_cli, ["-LRsd", "-m0", "-l", "32", "-n", "4"], text, env={"RB2_FMD_SEGMENT": "300", "RB2_FMD_THREADS": "3"})
     assert a == b
+    # the same streamed to a regular file by the writer thread while the stitcher works (tiny write steps)
+    out = tmp_path / "streamed.fmd"
+    run(san_cli, ["-LRsd", "-m0", "-o", str(out)], text, env={"RB2_FMD_SEGMENT": "300", "RB2_FMD_THREADS": "3", "RB2_FMD_OUT_STEP": "16"})
+    assert out.read_bytes() == a
     fmr = tmp_path / "x.fmr"
     fmr.write_bytes(run(san_cli, ["-LRsb", "-m0", "-l", "64", "-n", "6"], text))
     more = H.reads_to_text(H.splitmix_bases(500, 60, 9))
