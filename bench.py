@@ -150,11 +150,11 @@ def whole_process(reads, read_len, so_flag, batch_gib):
         pf = subprocess.run([CLI] + fflags + ["-o", out, txt], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
         dtf = time.perf_counter() - t1
         ef = pf.stderr.decode()
-        mh = re.search(r"moved into host ropes in ([0-9.]+) sec, \.fmr written in ([0-9.]+) sec", ef)
+        mh = re.search(r"written as \.fmr in ([0-9.]+) sec", ef)
         mcf = re.search(r"constructed FM-index in ([0-9.]+) sec", ef)
         if pf.returncode == 0 and os.path.exists(out):
-            fmr = {"real_s": dtf, "read_parse_insert_s": float(mcf.group(1)) if mcf else None, "to_host_ropes_s": float(mh.group(1)) if mh else None,
-                   "write_s": float(mh.group(2)) if mh else None, "fmr_bytes": os.path.getsize(out), "flags": " ".join(fflags)}
+            fmr = {"real_s": dtf, "read_parse_insert_s": float(mcf.group(1)) if mcf else None, "device_to_fmr_file_s": float(mh.group(1)) if mh else None,
+                   "fmr_bytes": os.path.getsize(out), "flags": " ".join(fflags)}
     except Exception as e:  # noqa: BLE001
         sys.stderr.write("[bench] whole-process leg: %r; using a pipe from the generator\n" % (e,))
         mode, fmd_bytes = "pipe", None

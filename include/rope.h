@@ -71,6 +71,13 @@ rope_t *rope_restore(FILE *fp);                                                 
 /* replace the content of an EMPTY rope by the symbols of a 43+3 run stream (bulk load) */
 void    rope_load_runs(rope_t *rope, const uint8_t *rle, int64_t n_bytes);
 void    rope_load_runs_mt(rope_t *rope, const uint8_t *rle, int64_t n_bytes, int n_threads);   /* rb2 extension: the same tree, byte for byte, built by several threads */
+/* rb2 extension: rope_dump()'s bytes of the tree rope_load_runs_mt(max_nodes, block_len) would build from the run stream, without
+ * building it: prepare (canonical stream + leaf boundaries: the size is known), then write at an offset of a regular file
+ * (pwrite, n_threads; frees the handle; 0 = ok).  The stream must stay valid until prepare returns. */
+typedef struct rope_rdump_s rope_rdump_t;
+rope_rdump_t *rope_rdump_prepare(const uint8_t *rle, int64_t n_bytes, int max_nodes, int block_len, int n_threads);
+int64_t rope_rdump_size(const rope_rdump_t *d);
+int     rope_rdump_write(rope_rdump_t *d, int fd, int64_t off);
 /* append all run bytes of the rope to a malloc'ed buffer; returns the byte count */
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out);
 

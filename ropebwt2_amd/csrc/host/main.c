@@ -781,12 +781,9 @@ int main(int argc, char *argv[])
 	{ static char obuf[4 << 20]; fflush(stdout); setvbuf(stdout, obuf, _IOFBF, sizeof(obuf)); }   /* .fmr dumps are millions of small fwrites */
 	if (flag & F_BIN) {
 		const double td0 = realtime();
-		double td1;
-		mr_sync_host(mr);                                       /* device -> six host ropes (one loader thread per rope) */
-		td1 = realtime();
-		mr_dump(mr, stdout);
+		mr_dump(mr, stdout);                                    /* a regular file: leaf records straight from the device's run bytes, no host trees (mrope.c) */
 		fflush(stdout);
-		if (verbose >= 3) fprintf(stderr, "[M::%s] BWT moved into host ropes in %.3f sec, .fmr written in %.3f sec\n", "main_ropebwt2", td1 - td0, realtime() - td1);
+		if (verbose >= 3) fprintf(stderr, "[M::%s] BWT off the device and written as .fmr in %.3f sec\n", "main_ropebwt2", realtime() - td0);
 	}
 	else if (flag & F_TREE) mr_print_tree(mr);
 	else {

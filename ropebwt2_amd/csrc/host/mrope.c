@@ -393,13 +393,85 @@ static void *dump_pool_worker(void *arg)
 	return 0;
 }
 
+/* The dump of an index whose host trees do not exist (it lives on the device, or it was restored as run bytes and never used
+ * on the host): rope_dump's bytes follow from the run bytes alone (rope_rdump_*, rope.c), so every rope's run stream goes from
+ * the device into a buffer once, a thread per rope brings it into canonical form and finds the leaf boundaries -- which gives the
+ * size of its dump and so the file offset of the next rope -- and then writes its leaf records straight into the file, while the
+ * next rope is streaming off the device.  No B+ trees: at configs[2] size they were 92 GB of host memory and 30 s.
+ * Regular files only (pwrite); the bytes are those of the tree path (tests/test_host_layer.py, tests/test_cli_gpu.py). */
+typedef struct {
+	runbuf_t rb; int keep_rb;
+	int max_nodes, block_len, nthr, fd, a, err;
+	int64_t *off;                                              /* off[a]: start of rope a in the file, valid once off_ok > a */
+	int *off_ok; pthread_mutex_t *mu; pthread_cond_t *cv;
+} rdump_rope_t;
+
+static void *rdump_rope_worker(void *arg)
+{
+	rdump_rope_t *j = (rdump_rope_t*)arg;
+	rope_rdump_t *d = rope_rdump_prepare(j->rb.p, j->rb.n, j->max_nodes, j->block_len, j->nthr);
+	int64_t at;
+	if (!j->keep_rb) { free(j->rb.p); j->rb.p = 0; }
+	pthread_mutex_lock(j->mu);
+	while (*j->off_ok <= j->a) pthread_cond_wait(j->cv, j->mu);
+	at = j->off[j->a];
+	j->off[j->a + 1] = at + rope_rdump_size(d);
+	*j->off_ok = j->a + 2;
+	pthread_cond_broadcast(j->cv);
+	pthread_mutex_unlock(j->mu);
+	if (rope_rdump_write(d, j->fd, at) != 0) j->err = 1;
+	return 0;
+}
+
+static int dump_without_trees(mrope_t *mr, FILE *fp)
+{
+	mrx_t *x = X(mr);
+	rdump_rope_t job[6];
+	pthread_t th[6];
+	pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+	pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+	int64_t off[7];
+	int a, off_ok = 1, err = 0, nthr;
+	const int on_dev = has_dev(x) && x->dev_ok, trace = getenv("RB2_SYNC_TRACE") != 0;
+	if (getenv("RB2_LOAD_THREADS")) nthr = atoi(getenv("RB2_LOAD_THREADS"));
+	else { const long nc = sysconf(_SC_NPROCESSORS_ONLN); nthr = nc >= 80 ? 16 : (nc >= 40 ? 8 : 4); }
+	if (fflush(fp) != 0 || (off[0] = (int64_t)ftello(fp)) < 0) return -1;
+	for (a = 0; a < 6; ++a) {
+		struct timespec t0, t1;
+		memset(&job[a], 0, sizeof(job[a]));
+		job[a].max_nodes = x->max_nodes; job[a].block_len = x->block_len; job[a].nthr = nthr; job[a].fd = fileno(fp); job[a].a = a;
+		job[a].off = off; job[a].off_ok = &off_ok; job[a].mu = &mu; job[a].cv = &cv;
+		if (on_dev) {
+			int64_t c[36], ub = 1 << 20; int b;                    /* (as mr_sync_host: the symbols of the rope bound its run bytes) */
+			dev_get_counts(x, c);
+			for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
+			job[a].rb.p = (uint8_t*)malloc((size_t)ub);
+			job[a].rb.m = job[a].rb.p ? ub : 0;
+			clock_gettime(CLOCK_MONOTONIC, &t0);
+			dev_stream_rope(x, a, runbuf_add, &job[a].rb);
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if (trace) fprintf(stderr, "[mr_dump] rope %d: %.2f GB of runs off the device in %.3f s\n", a, job[a].rb.n / 1e9, (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9);
+		} else { job[a].rb.p = x->raw[a]; job[a].rb.n = x->raw_n[a]; job[a].keep_rb = 1; }
+		pthread_create(&th[a], 0, rdump_rope_worker, &job[a]);
+	}
+	for (a = 0; a < 6; ++a) { pthread_join(th[a], 0); err |= job[a].err; }
+	if (err) { fprintf(stderr, "[E::%s] write error\n", "mr_dump"); exit(1); }
+	if (fseeko(fp, (off_t)off[6], SEEK_SET) != 0) { fprintf(stderr, "[E::%s] cannot seek behind the dump\n", "mr_dump"); exit(1); }
+	return 0;
+}
+
 void mr_dump(mrope_t *mr, FILE *fp)
 {
 	int a;
 	struct stat st;
-	mr_sync_host(mr);
+	mrx_t *xx = X(mr);
 	fwrite("RB\2", 1, 3, fp);                                    /* magic; byte 3 = sorting order (mrope.c:139-140) */
 	fwrite(&mr->so, 1, 1, fp);
+	if (!xx->host_ok && ((has_dev(xx) && xx->dev_ok) || xx->raw_ok) && !getenv("RB2_DUMP_VIA_TREES")) {
+		const int fl = fflush(fp) == 0 ? fcntl(fileno(fp), F_GETFL) : -1;
+		if (fl >= 0 && !(fl & O_APPEND) && fstat(fileno(fp), &st) == 0 && S_ISREG(st.st_mode) && dump_without_trees(mr, fp) == 0) return;
+	}
+	mr_sync_host(mr);
 	/* a regular file: the dump is cut into parts -- per rope the header and one part per subtree of the root -- that are sized,
 	 * given their offsets, and written with pwrite by a pool of threads (the bytes are those of rope_dump, mrope.c:141; the
 	 * reference writes them one fwrite after the other).  Pipes and terminals take the sequential path. */

@@ -649,50 +649,25 @@ static void *fill_worker(void *arg)
 	return 0;
 }
 
+static int canon_stream(const uint8_t *rle, int64_t n_bytes, int nthr, canon_job_t *seg, int64_t *pre);
+static int64_t leaf_starts(const canon_job_t *seg, const int64_t *pre, int nseg, int fill, int64_t **pstart);
+
 void rope_load_runs_mt(rope_t *rope, const uint8_t *rle, int64_t n_bytes, int nthr)
 {
 	const int fill = rope->block_len - RLE_MIN_SPACE - 2;
 	canon_job_t seg[16];
 	fill_job_t fj[16];
 	pthread_t th[16];
-	int64_t pre[17], *start = 0, nl = 0, ml = 0, total, pos;
+	int64_t pre[17], *start = 0, nl = 0, total, pos;
 	entvec_t lv = { 0, 0, 0 };
 	int t, nseg = 0, a;
 	if (nthr > 16) nthr = 16;
 	if (nthr < 2 || n_bytes < (int64_t)nthr * (getenv("RB2_LOAD_MIN_SEG") ? atol(getenv("RB2_LOAD_MIN_SEG")) : 8 << 20)) { rope_load_runs(rope, rle, n_bytes); return; }
-	/* 1. cut points: the first place at or behind k * n / nthr where two one-byte runs of different symbols meet */
-	{
-		int64_t from = 0;
-		for (t = 1; t <= nthr; ++t) {
-			int64_t cut = t == nthr ? n_bytes : n_bytes / nthr * t;
-			if (t < nthr) {
-				if (cut <= from) continue;
-				while (cut < n_bytes && !(!(rle[cut - 1] & 0x80) && (rle[cut - 1] & 0x78) && !(rle[cut] & 0x80) && (rle[cut] & 0x78) && ((rle[cut - 1] ^ rle[cut]) & 7))) ++cut;
-				if (cut >= n_bytes) continue;                     /* no such place in this stretch: it joins the next one */
-			}
-			seg[nseg].in = rle + from; seg[nseg].n = cut - from; seg[nseg].out = 0; seg[nseg].out_n = 0;
-			++nseg; from = cut;
-		}
-	}
-	for (t = 0; t < nseg; ++t) pthread_create(&th[t], 0, canon_worker, &seg[t]);
-	for (t = 0; t < nseg; ++t) pthread_join(th[t], 0);
-	for (t = 0, pre[0] = 0; t < nseg; ++t) pre[t + 1] = pre[t] + seg[t].out_n;
+	nseg = canon_stream(rle, n_bytes, nthr, seg, pre);            /* 1. canonical form, segment by segment */
 	total = pre[nseg];
 	rope_reset(rope);
 	if (total == 0) { for (t = 0; t < nseg; ++t) free(seg[t].out); return; }
-	/* 2. leaf starts */
-	for (pos = 0; pos < total; ) {
-		int64_t nxt = pos + fill;
-		if (nl == ml) { ml = ml ? ml * 2 : 1 << 16; start = (int64_t*)realloc(start, (size_t)ml * sizeof(int64_t)); }
-		start[nl++] = pos;
-		if (nxt >= total) break;
-		for (;;) {                                             /* back to the head of the run that does not fit any more */
-			const int sg = vseg(pre, nseg, nxt);
-			if ((seg[sg].out[nxt - pre[sg]] & 0xC0) != 0x80) break;
-			--nxt;
-		}
-		pos = nxt;
-	}
+	nl = leaf_starts(seg, pre, nseg, fill, &start);               /* 2. leaf starts */
 	/* 3. leaves: allocated here (the arena is not shared), filled by the threads */
 	lv.n = lv.m = (size_t)nl;
 	lv.v = (rpnode_t*)calloc((size_t)nl, sizeof(rpnode_t));
@@ -707,6 +682,183 @@ void rope_load_runs_mt(rope_t *rope, const uint8_t *rle, int64_t n_bytes, int nt
 	for (t = 0; t < nseg; ++t) free(seg[t].out);
 	free(start);
 	build_upper_levels(rope, &lv);
+}
+
+/* ---- the dump of that tree without the tree (rb2 extension; mr_dump of an index that lives on the device) ---------------------
+ * rope_dump's bytes (rope.c:253-275) depend only on the leaves in order: the levels above pack `fan` entries per bucket
+ * (build_upper_levels), so a bucket of level v (0 = bottom) starts at every leaf k with k % fan^(v+1) == 0, and the pre-order
+ * dump is the leaf records in order with the 3-byte headers of the buckets that start at a leaf in front of it, top level
+ * first.  Steps 1 and 2 of rope_load_runs_mt (canonical stream, leaf starts) give the size of the dump; the leaf records
+ * (48 bytes of counts, u16 length, run bytes) are then assembled by the threads, each a contiguous range of leaves, and written
+ * with pwrite -- no arena, no nodes, no second pass over the leaves. */
+#define RDUMP_MAX_LEVELS 40
+struct rope_rdump_s {
+	canon_job_t seg[16]; int64_t pre[17]; int nseg;
+	int64_t *start, nl, total;
+	int max_nodes, block_len, fan, nlev, nthr;
+	int64_t cnt[RDUMP_MAX_LEVELS], span[RDUMP_MAX_LEVELS];      /* level v: entries of all its buckets together; leaves below one bucket */
+	int64_t size;
+};
+
+static int canon_stream(const uint8_t *rle, int64_t n_bytes, int nthr, canon_job_t *seg, int64_t *pre)
+{
+	pthread_t th[16];
+	int t, nseg = 0;
+	int64_t from = 0;
+	if (nthr > 16) nthr = 16;
+	if (nthr < 1) nthr = 1;
+	for (t = 1; t <= nthr; ++t) {                              /* cut points: the first place at or behind k * n / nthr where two one-byte runs of different symbols meet */
+		int64_t cut = t == nthr ? n_bytes : n_bytes / nthr * t;
+		if (t < nthr) {
+			if (cut <= from) continue;
+			while (cut < n_bytes && !(!(rle[cut - 1] & 0x80) && (rle[cut - 1] & 0x78) && !(rle[cut] & 0x80) && (rle[cut] & 0x78) && ((rle[cut - 1] ^ rle[cut]) & 7))) ++cut;
+			if (cut >= n_bytes) continue;                         /* no such place in this stretch: it joins the next one */
+		}
+		seg[nseg].in = rle + from; seg[nseg].n = cut - from; seg[nseg].out = 0; seg[nseg].out_n = 0;
+		++nseg; from = cut;
+	}
+	if (nseg == 1) canon_worker(&seg[0]);
+	else {
+		for (t = 0; t < nseg; ++t) pthread_create(&th[t], 0, canon_worker, &seg[t]);
+		for (t = 0; t < nseg; ++t) pthread_join(th[t], 0);
+	}
+	for (t = 0, pre[0] = 0; t < nseg; ++t) pre[t + 1] = pre[t] + seg[t].out_n;
+	return nseg;
+}
+
+static int64_t leaf_starts(const canon_job_t *seg, const int64_t *pre, int nseg, int fill, int64_t **pstart)
+{
+	const int64_t total = pre[nseg];
+	int64_t *start = 0, nl = 0, ml = 0, pos;
+	for (pos = 0; pos < total; ) {
+		int64_t nxt = pos + fill;
+		if (nl == ml) {
+			ml = ml ? ml * 2 : 1 << 16; start = (int64_t*)realloc(start, (size_t)ml * sizeof(int64_t));
+			if (start == 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(1); }
+		}
+		start[nl++] = pos;
+		if (nxt >= total) break;
+		for (;;) {                                             /* back to the head of the run that does not fit any more */
+			const int sg = vseg(pre, nseg, nxt);
+			if ((seg[sg].out[nxt - pre[sg]] & 0xC0) != 0x80) break;
+			--nxt;
+		}
+		pos = nxt;
+	}
+	*pstart = start;
+	return nl;
+}
+
+rope_rdump_t *rope_rdump_prepare(const uint8_t *rle, int64_t n_bytes, int max_nodes, int block_len, int nthr)
+{
+	rope_rdump_t *d = (rope_rdump_t*)calloc(1, sizeof(rope_rdump_t));
+	int64_t c, nbuckets = 0;
+	int v;
+	if (d == 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(1); }
+	if (block_len < 32) block_len = 32;                        /* as rope_init */
+	d->max_nodes = (max_nodes + 1) / 2 * 2;
+	if (d->max_nodes < 4) d->max_nodes = 4;
+	d->block_len = (block_len + 7) / 8 * 8;
+	d->fan = d->max_nodes > 4 ? d->max_nodes - 2 : d->max_nodes / 2;
+	d->nthr = nthr < 1 ? 1 : nthr > 16 ? 16 : nthr;
+	if (n_bytes < 0) n_bytes = 0;
+	{	/* threads that have at least 1 MiB of the stream each (RB2_LOAD_MIN_SEG: bytes, tests) */
+		const int64_t min_seg = getenv("RB2_LOAD_MIN_SEG") ? atol(getenv("RB2_LOAD_MIN_SEG")) : 1 << 20;
+		const int64_t fit = n_bytes / (min_seg > 0 ? min_seg : 1);
+		d->nseg = canon_stream(rle, n_bytes, fit < 1 ? 1 : fit < d->nthr ? (int)fit : d->nthr, d->seg, d->pre);
+	}
+	d->total = d->pre[d->nseg];
+	d->nl = leaf_starts(d->seg, d->pre, d->nseg, d->block_len - RLE_MIN_SPACE - 2, &d->start);
+	/* levels, as build_upper_levels packs them (an empty stream is the reset rope: one empty leaf in a bottom root) */
+	for (c = d->nl > 0 ? d->nl : 1, v = 0; ; ++v) {
+		const int64_t nbk = (c + d->fan - 1) / d->fan;
+		d->cnt[v] = c;
+		d->span[v] = v == 0 ? d->fan : (d->span[v - 1] > INT64_MAX / d->fan ? INT64_MAX : d->span[v - 1] * d->fan);
+		nbuckets += nbk;
+		if (nbk == 1) break;
+		c = nbk;
+	}
+	d->nlev = v + 1;
+	d->size = 8 + 3 * nbuckets + 50 * (d->nl > 0 ? d->nl : 1) + d->total;
+	return d;
+}
+
+int64_t rope_rdump_size(const rope_rdump_t *d) { return d->size; }
+
+typedef struct { const rope_rdump_t *d; int64_t k0, k1; int fd; int64_t off; int err; } rdump_job_t;
+
+static void *rdump_worker(void *arg)
+{
+	rdump_job_t *j = (rdump_job_t*)arg;
+	const rope_rdump_t *d = j->d;
+	fill_job_t f;
+	dumpw_t w;
+	uint8_t blk[2 + 65536 + 8];
+	int64_t k, o = j->off + 8 + 50 * j->k0 + d->start[j->k0];
+	int v;
+	for (v = 0; v < d->nlev; ++v) o += 3 * ((j->k0 + d->span[v] - 1) / d->span[v]);   /* headers of the buckets that start in front of leaf k0 */
+	memset(&f, 0, sizeof(f));
+	f.seg = d->seg; f.pre = d->pre; f.nseg = d->nseg;
+	w.fd = j->fd; w.off = o; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.buf = (uint8_t*)malloc((size_t)w.cap);
+	if (w.buf == 0) { j->err = 1; return 0; }
+	for (k = j->k0; k < j->k1; ++k) {
+		const int64_t s = d->start[k], e = k + 1 < d->nl ? d->start[k + 1] : d->total, nb = e - s;
+		int64_t cc[6] = { 0, 0, 0, 0, 0, 0 }, i;
+		uint8_t *b = blk + 2;
+		int wide = 0;
+		for (v = d->nlev - 1; v >= 0; --v)
+			if (k % d->span[v] == 0) {
+				const int64_t idx = k / d->span[v], left = d->cnt[v] - idx * d->fan;
+				const uint8_t isb = v == 0;
+				const int16_t n = (int16_t)(left < d->fan ? left : d->fan);
+				dumpw_put(&w, &isb, 1);
+				dumpw_put(&w, &n, 2);
+			}
+		vcopy(&f, b, s, nb);
+		*(uint16_t*)blk = (uint16_t)nb;
+		for (i = 0; i < nb; ++i) wide |= b[i];
+		if (!(wide & 0x80)) count_plain_runs(b, nb, cc);
+		else {
+			const uint8_t *q = b, *end = b + nb;
+			while (q < end) { int c; int64_t l; q += rle_dec1_fn(q, &c, &l); if (c < 6) cc[c] += l; }
+		}
+		dumpw_put(&w, cc, 48);
+		dumpw_put(&w, blk, 2 + nb);
+	}
+	if (dumpw_finish(&w) != 0) j->err = 1;
+	return 0;
+}
+
+/* writes the dump at offset off of fd (a regular file) and frees d; 0 = ok */
+int rope_rdump_write(rope_rdump_t *d, int fd, int64_t off)
+{
+	int t, err = 0;
+	{
+		uint8_t head[8 + 3 + 50];
+		int n = 8;
+		memcpy(head, &d->max_nodes, 4); memcpy(head + 4, &d->block_len, 4);
+		if (d->nl == 0) { memset(head + 8, 0, 3 + 50); head[8] = 1; head[9] = 1; n = 8 + 3 + 50; }   /* bottom root, one empty leaf */
+		{
+			int64_t done = 0;
+			while (done < n) { const ssize_t k = pwrite(fd, head + done, (size_t)(n - done), (off_t)(off + done)); if (k <= 0) { err = 1; break; } done += k; }
+		}
+	}
+	if (d->nl > 0) {
+		rdump_job_t job[16];
+		pthread_t th[16];
+		const int nthr = d->nl / 64 < 1 ? 1 : d->nl / 64 < d->nthr ? (int)(d->nl / 64) : d->nthr;   /* 64 leaves or more per thread */
+		for (t = 0; t < nthr; ++t) {
+			job[t].d = d; job[t].fd = fd; job[t].off = off; job[t].err = 0;
+			job[t].k0 = d->nl / nthr * t; job[t].k1 = t == nthr - 1 ? d->nl : d->nl / nthr * (t + 1);
+			if (nthr > 1) pthread_create(&th[t], 0, rdump_worker, &job[t]);
+			else rdump_worker(&job[t]);
+		}
+		for (t = 0; t < nthr; ++t) { if (nthr > 1) pthread_join(th[t], 0); err |= job[t].err; }
+	}
+	for (t = 0; t < d->nseg; ++t) free(d->seg[t].out);
+	free(d->start); free(d);
+	return err ? -1 : 0;
 }
 
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out)

@@ -118,6 +118,26 @@ def test_incremental_build(golden, so_flag, tmp_path):
     assert H.md5(out) == g["fmd_md5"]["-LR" + so_flag + "d"]
 
 
+@pytest.mark.parametrize("so_flag,extra", [("", []), ("s", ["-l", "64", "-n", "6"]), ("r", ["-m", "300k"])])
+def test_fmr_straight_from_the_device_equals_the_dump_of_the_host_trees(golden, so_flag, extra, tmp_path):
+    """-b -o FILE on a device-built index: run bytes off the device -> leaf records in the file, no host B+ trees
+    (dump_without_trees, mrope.c); the same bytes as device -> trees -> rope_dump (RB2_DUMP_VIA_TREES=1 and the piped path),
+    and -i of it + nothing reproduces the .fmd golden"""
+    g = golden["sets"]["100k_x_101"]
+    text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
+    piped = cli(["-LRb" + so_flag] + extra, text)
+    outs = []
+    for env in ({}, {"RB2_DUMP_VIA_TREES": "1"}, {"RB2_LOAD_THREADS": "3"}):
+        f = tmp_path / ("o%d.fmr" % len(outs))
+        p = subprocess.run([CLI, "-LRb" + so_flag] + extra + ["-o", str(f), "-"], input=text, stderr=subprocess.PIPE, env=dict(os.environ, RB2_SYNC_TRACE="1", **env))
+        assert p.returncode == 0, p.stderr.decode()[-400:]
+        assert (b"[mr_dump] rope" in p.stderr) == ("RB2_DUMP_VIA_TREES" not in env)
+        outs.append(f.read_bytes())
+    assert outs[0] == outs[1] == outs[2] == piped
+    out = subprocess.run([CLI, "-d", "-m0", "-i", str(tmp_path / "o0.fmr"), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout
+    assert H.md5(out) == g["fmd_md5"]["-LR" + so_flag + "d"]
+
+
 @pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
 def test_our_fmr_restores_in_reference(golden, tmp_path):
     g = golden["sets"]["100k_x_101"]

@@ -656,3 +656,92 @@ def test_bulk_loader_threads_build_the_same_tree(hostlib, tmp_path, seed):
         assert f.read_bytes() == outs[2]
     finally:
         del os.environ["RB2_LOAD_MIN_SEG"]
+
+
+def _mixed_run_stream(seed, n):
+    from ropebwt2_amd.hipbwt import encode_runs
+    rng = np.random.RandomState(seed)
+    if n == 0:
+        return b""
+    sym = rng.randint(0, 6, size=n).astype(np.uint8)
+    ln = rng.randint(1, 16, size=n).astype(np.uint8)
+    same = rng.rand(n) < 0.02
+    sym[1:][same[1:]] = sym[:-1][same[1:]]
+    ln[rng.rand(n) < 0.003] = 0
+    plain = (ln << 3 | sym).astype(np.uint8)
+    parts, at = [], 0
+    for cut in sorted(rng.randint(0, n, size=min(30, n))):
+        parts.append(plain[at:cut].tobytes())
+        parts.append(encode_runs(np.repeat(np.uint8(rng.randint(0, 6)), int(rng.choice([20, 300, 70_000, 600_000])))))
+        at = cut
+    parts.append(plain[at:].tobytes())
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("n,max_nodes,block_len,thr", [(0, 64, 512, 4), (1, 64, 512, 1), (300, 64, 512, 3), (40_000, 64, 512, 4), (40_000, 6, 64, 5), (40_000, 4, 32, 2),
+                                                        (2_500_000, 64, 512, 16), (2_500_000, 10, 96, 7), (2_500_000, 5, 30, 3)])
+def test_dump_without_trees_equals_the_dump_of_the_tree(hostlib, tmp_path, n, max_nodes, block_len, thr):
+    """rope_rdump_*: rope_dump's bytes straight from the run stream (no arena, no nodes) -- header positions follow from the leaf
+    count alone.  Against rope_load_runs + rope_dump for empty streams, one leaf, one bucket, and 2-14 levels of buckets."""
+    L = hostlib
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.rope_init.restype = C.c_void_p; L.rope_init.argtypes = [C.c_int, C.c_int]
+    L.rope_load_runs.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.rope_dump.argtypes = [C.c_void_p, C.c_void_p]
+    L.rope_destroy.argtypes = [C.c_void_p]
+    L.rope_rdump_prepare.restype = C.c_void_p; L.rope_rdump_prepare.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.c_int, C.c_int]
+    L.rope_rdump_size.restype = C.c_int64; L.rope_rdump_size.argtypes = [C.c_void_p]
+    L.rope_rdump_write.argtypes = [C.c_void_p, C.c_int, C.c_int64]
+    stream = _mixed_run_stream(n % 7 + thr, n)
+    r = L.rope_init(max_nodes, block_len)
+    L.rope_load_runs(r, stream, len(stream))
+    f = tmp_path / "tree.bin"
+    fp = libc.fopen(str(f).encode(), b"wb"); L.rope_dump(r, fp); libc.fclose(fp); L.rope_destroy(r)
+    want = f.read_bytes()
+    d = L.rope_rdump_prepare(stream, len(stream), max_nodes, block_len, thr)
+    assert L.rope_rdump_size(d) == len(want)
+    g = tmp_path / "direct.bin"
+    fd = os.open(g, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    os.write(fd, b"#" * 11)
+    assert L.rope_rdump_write(d, fd, 11) == 0
+    os.close(fd)
+    assert g.read_bytes() == b"#" * 11 + want
+
+
+def test_mr_dump_of_restored_run_bytes_needs_no_trees(hostlib, tmp_path):
+    """mr_restore_runs + mr_dump to a regular file: the run bytes go straight into leaf records (dump_without_trees); the same
+    bytes as through the host trees (RB2_DUMP_VIA_TREES=1), and the index still answers rank queries afterwards"""
+    L = hostlib
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.mr_restore_runs.restype = C.c_void_p; L.mr_restore_runs.argtypes = [C.c_void_p]
+    L.mr_rank2a.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.mr_dump.argtypes = [C.c_void_p, C.c_void_p]
+    L.mr_destroy.argtypes = [C.c_void_p]
+    text = H.reads_to_text(H.splitmix_bases(4000, 101, 11)) + b"A" * 90 + b"\n" + (b"C" * 70 + b"\n") * 300
+    for so, extra in (("", []), ("s", ["-l", "64", "-n", "6"])):
+        f = tmp_path / ("in%s.fmr" % so)
+        f.write_bytes(cli(["-LRb" + so, "-m0"] + extra, text))
+        outs = {}
+        for mode in ("direct", "trees"):
+            if mode == "trees":
+                os.environ["RB2_DUMP_VIA_TREES"] = "1"
+            try:
+                fp = libc.fopen(str(f).encode(), b"rb")
+                mr = L.mr_restore_runs(fp)
+                libc.fclose(fp)
+                g = tmp_path / ("%s%s.fmr" % (mode, so))
+                fo = libc.fopen(str(g).encode(), b"wb")
+                L.mr_dump(mr, fo)
+                libc.fclose(fo)
+                cx = (C.c_int64 * 6)()
+                L.mr_rank2a(mr, 5000, -1, cx, None)
+                outs[mode] = (g.read_bytes(), list(cx))
+                L.mr_destroy(mr)
+            finally:
+                os.environ.pop("RB2_DUMP_VIA_TREES", None)
+        assert outs["direct"] == outs["trees"]
+        assert cli(["-m0", "-i", str(tmp_path / ("direct%s.fmr" % so))], b"") == cli(["-m0", "-i", str(f)], b"")

@@ -138,6 +138,9 @@ def test_sanitized_parallel_loader_growing_canonical_form(san_cli, tmp_path):
     for thr in ("2", "4", "8"):
         par = run(san_cli, ["-b", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": thr, "RB2_LOAD_MIN_SEG": "500"})
         assert par == seq
+        g = tmp_path / ("direct%s.fmr" % thr)                # to a regular file: leaf records straight from the run bytes, no trees (rope_rdump_*)
+        run(san_cli, ["-b", "-i", str(f), "-o", str(g)], b"", env={"RB2_LOAD_THREADS": thr, "RB2_LOAD_MIN_SEG": "500"})
+        assert g.read_bytes() == seq
     if H.have_ref():
         ref = subprocess.run([H.REF_BIN, "-d", "-i", str(f), "/dev/null"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         ours = run(san_cli, ["-d", "-i", str(f)], b"", env={"RB2_LOAD_THREADS": "4", "RB2_LOAD_MIN_SEG": "500"})

@@ -5,9 +5,9 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 N=${1:-1200000000}
-for M in 10g auto; do
+for M in ${2:-10g auto}; do
 	echo "== synth_reads $N 101 42 | ropebwt2 -LRbr -m$M -o /dev/shm/c2.fmr -"
-	( time ( $R/ropebwt2_amd/bin/synth_reads $N 101 42 | $R/ropebwt2_amd/bin/ropebwt2 -LRbr -m$M -o /dev/shm/c2.fmr - ) ) 2>&1 | grep -E "inserted|constructed|auto|moved|Real|real|symbol counts"
+	( time ( $R/ropebwt2_amd/bin/synth_reads $N 101 42 | RB2_SYNC_TRACE=1 $R/ropebwt2_amd/bin/ropebwt2 -LRbr -m$M -o /dev/shm/c2.fmr - ) ) 2>&1 | grep -E "inserted|constructed|auto|written as|mr_dump|Real|real|symbol counts"
 	md5sum /dev/shm/c2.fmr | cut -c1-32
 	rm -f /dev/shm/c2.fmr
 done
