@@ -21,6 +21,7 @@
 #include <fcntl.h>
 #include <sys/types.h>
 #include <sys/stat.h>
+#include <time.h>
 #include "rb2_fmd.h"
 #include "rle.h"
 #include "rb2_parcopy.h"
@@ -62,8 +63,7 @@ static void reserve(rb2_fmd_t *f, size_t n_words)
 	f->w = (uint64_t*)realloc(f->w, nc * 8);
 	if (f->wmu) pthread_mutex_unlock(f->wmu);
 	if (!f->w) { fprintf(stderr, "[rb2_fmd] out of memory (%zu words)\n", nc); abort(); }
-	memset(f->w + f->cap, 0, (nc - f->cap) * 8);
-	f->cap = nc;
+	f->cap = nc;                                              /* (not zeroed: every block is zeroed when it is opened -- most blocks of the parallel writer are copied over whole) */
 }
 
 static size_t block_tail(size_t head)
@@ -77,6 +77,7 @@ rb2_fmd_t *rb2_fmd_init(void)
 {
 	rb2_fmd_t *f = (rb2_fmd_t*)calloc(1, sizeof(rb2_fmd_t));
 	reserve(f, 2 * BLK_WORDS);
+	memset(f->w, 0, BLK_WORDS * 8);
 	f->head = 0; f->p = hdr_words[0]; f->tail = block_tail(0); f->r = 64;
 	f->pend_c = -1;
 	f->out_fd = -1;
@@ -90,6 +91,7 @@ static void open_next_block(rb2_fmd_t *f)
 	const int64_t tot = f->cnt[0] - f->mcnt[0];
 	f->head += BLK_WORDS;
 	reserve(f, f->head + 2 * BLK_WORDS);
+	memset(f->w + f->head, 0, BLK_WORDS * 8);
 	type = tot < 0x4000 ? 0 : tot < 0x40000000 ? 1 : 2;
 	for (i = 0; i < N_FIELDS; ++i) {
 		const uint64_t v = (uint64_t)(f->cnt[i] - f->mcnt[i]);
@@ -349,6 +351,8 @@ struct rb2_fmdp_s {
 	int64_t cur_seg, cur_pos;        /* input cursor of the true orbit */
 	int64_t tot[N_FIELDS];
 	int64_t n_copied_blocks, n_true_blocks;
+	double t_stitch_wait, t_stitch_work, t_push_wait;        /* RB2_FMD_STATS: who waited for whom */
+	int stats;
 	pthread_t *thr; int nthr, closing;
 	pthread_t stitcher; int no_more;   /* the true orbit has a thread of its own: it copies every coupled block (6 GB at configs[1]) while the producer copies run bytes into segments */
 	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
@@ -390,6 +394,7 @@ static void spec_encode(fseg_t *sg)
 	reserve(f, (size_t)(n / 4 + 4 * BLK_WORDS));             /* ~5 bits per run byte on random reads; grows when needed */
 	f->cap_blk = (size_t)(n / 256 + 1024);
 	f->start = (uint32_t*)malloc(f->cap_blk * 4); f->type = (uint8_t*)malloc(f->cap_blk);
+	memset(f->w, 0, BLK_WORDS * 8);                           /* (reserve does not zero: blocks are zeroed as they are opened) */
 	f->head = 0; f->p = hdr_words[0]; f->tail = block_tail_of(f, 0); f->r = 64;
 	memset(sg->sum, 0, sizeof(sg->sum));
 	while (i < n) {                                           /* the straddling run belongs to the true orbit: skip it (but count it) */
@@ -433,6 +438,7 @@ static void *fmdp_worker(void *arg)
 }
 
 static void *fmdp_stitcher(void *arg);
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + t.tv_nsec * 1e-9; }
 
 rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t seg_bytes)
 {
@@ -442,6 +448,7 @@ rb2_fmdp_t *rb2_fmdp_init(int n_threads, int64_t seg_bytes)
 	p->seg_bytes = seg_bytes > 0 ? seg_bytes : 16 << 20;
 	if (p->seg_bytes > 0x7fffffff) p->seg_bytes = 0x7fffffff;     /* offsets inside a segment are 32 bit */
 	p->nthr = n_threads > 0 ? n_threads : 1;
+	p->stats = getenv("RB2_FMD_STATS") != 0;
 	pthread_mutex_init(&p->mu, 0); pthread_cond_init(&p->cv_work, 0); pthread_cond_init(&p->cv_done, 0);
 	p->thr = (pthread_t*)calloc(p->nthr, sizeof(pthread_t));
 	for (i = 0; i < p->nthr; ++i) pthread_create(&p->thr[i], 0, fmdp_worker, p);
@@ -485,7 +492,11 @@ static void queue_fill(rb2_fmdp_t *p)                          /* hand the segme
 	p->n_queued = p->nseg;
 	pthread_cond_signal(&p->cv_work);
 	pthread_cond_broadcast(&p->cv_done);                       /* (the stitcher also waits for segments to exist) */
-	while (p->n_queued - p->cur_seg > 4 * p->nthr + 8) pthread_cond_wait(&p->cv_space, &p->mu);   /* backlog: let workers and stitcher catch up */
+	if (p->n_queued - p->cur_seg > 4 * p->nthr + 8) {          /* backlog: let workers and stitcher catch up */
+		const double t0 = p->stats ? now_s() : 0;
+		while (p->n_queued - p->cur_seg > 4 * p->nthr + 8) pthread_cond_wait(&p->cv_space, &p->mu);
+		if (p->stats) p->t_push_wait += now_s() - t0;
+	}
 	pthread_mutex_unlock(&p->mu);
 }
 
@@ -522,7 +533,7 @@ static int64_t try_couple(rb2_fmdp_t *p, fseg_t *sg, int64_t pos)
 	reserve(f, f->head + (e - j + 2) * BLK_WORDS);
 	k = hdr_words[sp->type[j]];
 	memcpy(f->w + f->head + k, sp->w + j * BLK_WORDS + k, (BLK_WORDS - k) * 8);      /* body of block j behind the true header */
-	if (e > j + 1) memcpy(f->w + f->head + BLK_WORDS, sp->w + (j + 1) * BLK_WORDS, (e - j - 1) * BLK_WORDS * 8);
+	if (e > j + 1) rb2_par_memcpy((uint8_t*)(f->w + f->head + BLK_WORDS), (const uint8_t*)(sp->w + (j + 1) * BLK_WORDS), (int64_t)((e - j - 1) * BLK_WORDS * 8));   /* (fresh pages: four threads fault them in) */
 	p->n_copied_blocks += (int64_t)(e - j);
 	/* state: block e-1 is complete; its counts are in the speculative header of block e */
 	hdr_counts(sp->w + e * BLK_WORDS, prev);
@@ -540,12 +551,16 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 		fseg_t *sg;
 		const uint8_t *q;
 		int64_t i, n;
+		const double tw0 = p->stats ? now_s() : 0;
+		double tw1;
 		pthread_mutex_lock(&p->mu);
 		while (p->cur_seg >= p->n_queued && !p->no_more) pthread_cond_wait(&p->cv_done, &p->mu);
 		if (p->cur_seg >= p->n_queued) { pthread_mutex_unlock(&p->mu); return; }
 		sg = p->seg[p->cur_seg];
 		while (sg->state != 3) pthread_cond_wait(&p->cv_done, &p->mu);
 		pthread_mutex_unlock(&p->mu);
+		tw1 = p->stats ? now_s() : 0;
+		p->t_stitch_wait += tw1 - tw0;
 		q = sg->runs; n = sg->n; i = p->cur_pos;
 		if (i == 0) { int k; for (k = 0; k < N_FIELDS; ++k) p->tot[k] += sg->sum[k]; }
 		if (p->cur_seg == 0 && i == 0 && sg->sp->nblk > 0 && f->p == (size_t)hdr_words[0] && f->r == 64) {
@@ -573,6 +588,7 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 			f->pend_c = c; f->pend_l = l; f->run_pos = (uint32_t)i; f->pend_seg = p->cur_seg;
 			i += nb;
 		}
+		if (p->stats) p->t_stitch_work += now_s() - tw1;
 		free(sg->runs); sg->runs = 0;
 		free(sg->sp->w); free(sg->sp->start); free(sg->sp->type); free(sg->sp); sg->sp = 0;
 		if (p->writer_on) {                                   /* everything below the block being filled is final */
@@ -680,8 +696,9 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p)
 	open_next_block(f);
 	memcpy(f->mcnt, p->tot, sizeof(p->tot)); memcpy(f->cnt, p->tot, sizeof(p->tot));
 	fmd_index_mt(f, p->nthr);
-	if (getenv("RB2_FMD_STATS")) fprintf(stderr, "[rb2_fmdp] %lld segments, %lld blocks copied from the speculative encodings, %lld encoded by the true orbit\n",
-			(long long)p->nseg, (long long)p->n_copied_blocks, (long long)p->n_true_blocks);
+	if (p->stats) fprintf(stderr, "[rb2_fmdp] %lld segments, %lld blocks copied from the speculative encodings, %lld encoded by the true orbit; "
+			"stitcher: %.3f s working, %.3f s waiting for segments; producer: %.3f s waiting for room (%d workers)\n",
+			(long long)p->nseg, (long long)p->n_copied_blocks, (long long)p->n_true_blocks, p->t_stitch_work, p->t_stitch_wait, p->t_push_wait, p->nthr);
 	pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->cv_work); pthread_cond_destroy(&p->cv_done); pthread_cond_destroy(&p->cv_space);
 	{ int64_t k; for (k = 0; k < p->nseg; ++k) free(p->seg[k]); }
 	free(p->thr); free(p->seg); free(p);

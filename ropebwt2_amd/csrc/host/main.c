@@ -792,8 +792,9 @@ int main(int argc, char *argv[])
 		rb2_fmdp_t *fmdp = 0;
 		if (flag & F_RLD) {
 			long nt = sysconf(_SC_NPROCESSORS_ONLN) - 1;
+			if (nt > 24) nt = 24;
 			if (getenv("RB2_FMD_THREADS")) nt = atol(getenv("RB2_FMD_THREADS"));
-			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 24 ? 24 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
+			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 64 ? 64 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
 			if (!getenv("RB2_FMD_NO_STREAM")) {                 /* -o file / a redirected stdout: the index goes out while it is encoded */
 				fflush(stdout);
 				const off_t at = ftello(stdout);
