@@ -35,7 +35,7 @@ def main():
     total = args.reads * per_read
     bwt.reserve(per_batch * per_read, per_batch * (2 if args.both_strands else 1), total)
     buf = bwt.dev_alloc(per_batch * per_read + 64)
-    done, times = 0, []
+    done, times, per_batch_ms, prev_ms = 0, [], [], {}
     while done < args.reads:
         n = min(per_batch, args.reads - done)
         bwt.synth_reads(buf, done, n, L, seed=args.seed, strand=1 if args.both_strands else 0, genome_len=args.genome_len)
@@ -45,6 +45,10 @@ def main():
         bwt.sync()
         times.append(time.perf_counter() - t0)
         done += n
+        if args.profile:                                          # kernel time of THIS batch (the counters are cumulative)
+            now = {k: v["ms"] for k, v in bwt.profile_get().items()}
+            per_batch_ms.append({k: round(v - prev_ms.get(k, 0.0), 1) for k, v in now.items() if v - prev_ms.get(k, 0.0) >= 0.05})
+            prev_ms = now
         sys.stderr.write("[scale] %d / %d reads, batch %.2f s (%.2f Gsym/s)\n" % (done, args.reads, times[-1], n * per_read / times[-1] / 1e9))
     c = bwt.counts()
     n_str = args.reads * (2 if args.both_strands else 1)
@@ -71,6 +75,7 @@ def main():
     extra = {"layout": lay, "sparse_lambda": os.environ.get("RB2_SPARSE_LAMBDA", "default"), "library": os.environ.get("RB2_HIP_LIB", "this build")}
     if args.profile:
         extra["kernels_ms"] = {k: round(v["ms"], 2) for k, v in bwt.profile_get().items()}
+        extra["kernels_ms_per_batch"] = per_batch_ms
     bwt.dev_free(buf)
     bwt.close()
     print(json.dumps({**extra, "reads": args.reads, "read_len": L, "order": args.order, "both_strands": args.both_strands, "genome_len": args.genome_len, "batch_gib": args.batch,
