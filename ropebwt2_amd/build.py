@@ -60,12 +60,12 @@ def build_host(force=False):
     hdrs = [os.path.join(INC, f) for f in os.listdir(INC)] + [os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h")]
     out = lib_path("libropebwt2.so")
     if force or not _newer(out, csrcs + hdrs + [lib_path("librb2hip.so")]):
-        _run(["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-fPIC", "-shared", "-I" + INC, "-I" + host, "-o", out] + csrcs +
+        _run(["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration", "-fPIC", "-shared", "-I" + INC, "-I" + host, "-o", out] + csrcs +
              ["-L" + LIBDIR, "-lrb2hip", "-Wl,-rpath,$ORIGIN", "-lpthread"])
     main_c = os.path.join(host, "main.c")
     exe = os.path.join(BINDIR, "ropebwt2")
     if os.path.exists(main_c) and (force or not _newer(exe, [main_c, out] + hdrs)):
-        _run(["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-I" + INC, "-I" + host, "-o", exe, main_c,
+        _run(["gcc", "-O2", "-g", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration", "-I" + INC, "-I" + host, "-o", exe, main_c,
               "-L" + LIBDIR, "-lropebwt2", "-lrb2hip", "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"])
     gen_c = os.path.join(ROOT, "tools", "synth_reads.c")      # synthetic read generator (SURVEY.md 8c stream) for tests / bench
     gen = os.path.join(BINDIR, "synth_reads")

@@ -6,6 +6,7 @@
  * writers (plain text, FMR, FMD).  The undocumented CRLF output (-B) of the reference is not
  * provided.
  */
+#define _GNU_SOURCE                  /* memrchr */
 #include <zlib.h>
 #include <fcntl.h>
 #include <ctype.h>
@@ -239,7 +240,7 @@ typedef struct {
 	int64_t consumed; int eof;                                  /* blocks the main thread has taken over; the reader thread saw the end of the input */
 	gzFile fp; int64_t chunk;                                   /* the reader thread's input */
 	int fd;                                                     /* >= 0: the input is a plain (uncompressed) regular file -- read(2) it directly; zlib's transparent mode copies every byte twice */
-	int fastq, stop;                                            /* blocks of whole four-line records instead of whole lines; the consumer asks the reader to stop (fallback) */
+	int fastq, stop;                                            /* 1: blocks of whole four-line FASTQ records, 2: of whole FASTA records, instead of whole lines; the consumer asks the reader to stop (fallback) */
 	uint8_t *carry; int64_t n_carry, total;                     /* what the reader thread held back when it stopped, and how far it had read */
 	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
 } pparse_t;
@@ -309,6 +310,50 @@ static int pjob_encode_fastq(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
 	return 1;
 }
 
+/* ---- FASTA in batch mode, threaded (long reads and assemblies come as FASTA).  '>' is only special at the start of a line, and a
+ * sequence line cannot start with it: a block cut in front of a line that starts with '>' starts at a record.  Workers read the
+ * plain case -- header line, then sequence lines (concatenated, empty ones skipped: kseq.h:190-196) up to the next '>' line -- and
+ * hand everything else back to the sequential kseq-exact reader like the FASTQ workers do: a line that starts with '+' or '@'
+ * (kseq reads a quality string / a new record there), a carriage return (kseq strips it depending on what it has gathered so far),
+ * a last line without its newline. */
+static int pjob_encode_fasta(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
+{
+	const uint8_t *p = jb->in, *end = jb->in + jb->n_in;
+	jb->out.l = 0; jb->n_rec = 0;
+	str_reserve(&jb->out, (size_t)jb->n_in * (((cfg->flag & F_FOR) ? 1 : 0) + ((cfg->flag & F_REV) ? 1 : 0)) + 64);
+	if (p < end && end[-1] != '\n') return 0;
+	while (p < end) {
+		const uint8_t *nl;
+		int64_t sl = 0;
+		int l;
+		if (*p != '>') return 0;
+		nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));   /* header: name and comment are not used */
+		p = nl + 1;                                              /* (the block ends with a newline) */
+		while (p < end && *p != '>') {
+			int64_t len;
+			nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+			len = nl - p;
+			if (len > 0) {
+				if (*p == '+' || *p == '@' || memchr(p, '\r', (size_t)len)) return 0;
+				if (sl + len > 0x3fffffff) return 0;
+				str_reserve(tmp, (size_t)(sl + len) + 2);
+				memcpy(tmp->s + sl, p, (size_t)len); sl += len;
+			}
+			p = nl + 1;
+		}
+		str_reserve(tmp, (size_t)sl + 2);
+		l = prepare_record(cfg, (uint8_t*)tmp->s, (int)sl, 0, 0);
+		if (l >= 0) {
+			const size_t before = jb->out.l;
+			append_strands(cfg, (uint8_t*)tmp->s, l, &jb->out);
+			if (jb->out.l > 0xffffffffu) { jb->out.l = before; return 0; }   /* rec_end is 32 bit: a block of > 4 GB of codes (one huge record, both strands) */
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
+		}
+	}
+	return 1;
+}
+
 static void *pparse_worker(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
@@ -319,7 +364,7 @@ static void *pparse_worker(void *arg)
 		if (pp->next_work >= pp->n_queued) break;
 		jb = &pp->job[pp->next_work++ % pp->njob];
 		pthread_mutex_unlock(&pp->mu);
-		if (pp->fastq) { str_t tmp = { 0, 0, 0 }; jb->failed = !pjob_encode_fastq(&pp->cfg, jb, &tmp); free(tmp.s); }
+		if (pp->fastq) { str_t tmp = { 0, 0, 0 }; jb->failed = !(pp->fastq == 2 ? pjob_encode_fasta(&pp->cfg, jb, &tmp) : pjob_encode_fastq(&pp->cfg, jb, &tmp)); free(tmp.s); }
 		else pjob_encode(&pp->cfg, jb);
 		pthread_mutex_lock(&pp->mu);
 		jb->state = 2;
@@ -378,8 +423,15 @@ static void *pparse_reader(void *arg)
 		jb->n_in = n_carry + got;
 		jb->at_eof = eof;
 		if (!eof) {                                           /* keep the unfinished last line for the next block */
+			if (pp->fastq == 2) {                               /* FASTA: in front of the last line that starts with '>' (0: one record longer than the block) */
+				const uint8_t *q = jb->in + jb->n_in;
+				cut = 0;
+				while (q > jb->in + 1 && (q = (const uint8_t*)memrchr(jb->in + 1, '>', (size_t)(q - jb->in - 1))) != 0) {
+					if (q[-1] == '\n') { cut = q - jb->in; break; }
+				}
+			} else
 			for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
-			if (pp->fastq && cut > 0) {                         /* ... and, for FASTQ, the lines behind the last multiple of four: a block holds whole records */
+			if (pp->fastq == 1 && cut > 0) {                         /* ... and, for FASTQ, the lines behind the last multiple of four: a block holds whole records */
 				const int64_t nl = count_newlines(jb->in, cut);
 				int back;
 				for (back = (int)(nl & 3); back > 0; --back) for (--cut; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
@@ -676,6 +728,7 @@ int main(int argc, char *argv[])
 			const int c0 = gzgetc(rd->fp);
 			if (c0 >= 0) gzungetc(c0, rd->fp);
 			if (c0 == '@') par = 2;
+			else if (c0 == '>') par = 3;                         /* ... one that starts with '>' for plain FASTA (pjob_encode_fasta) */
 		}
 	}
 	if (par) {
@@ -684,7 +737,7 @@ int main(int argc, char *argv[])
 		int k, fell_back = 0;
 		pp.cfg = cfg; pp.njob = (int)pthr * 2 + 2; if (pp.njob > 62) pp.njob = 62;
 		pp.job = (pjob_t*)calloc(pp.njob, sizeof(pjob_t));
-		pp.fp = rd->fp; pp.chunk = CHUNK; pp.fastq = par == 2;
+		pp.fp = rd->fp; pp.chunk = CHUNK; pp.fastq = par == 2 ? 1 : par == 3 ? 2 : 0;
 		pp.fd = -1;
 		if (optind < argc && strcmp(argv[optind], "-") && gzdirect(rd->fp) == 1 && !getenv("RB2_NO_DIRECT_READ")) {   /* a plain file: bypass zlib */
 			struct stat st;
@@ -730,7 +783,7 @@ int main(int argc, char *argv[])
 		free(th);
 		if (pp.fd >= 0) close(pp.fd);
 		need_seq = fell_back;
-		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
+		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : par == 3 ? "FASTA records" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
 		if (fell_back) {                                        /* the blocks from the failed one on, what the reader held back, then the stream itself */
 			int64_t q;
 			int n = 0;
@@ -740,7 +793,7 @@ int main(int argc, char *argv[])
 			rd->pos = pp.job[pp.consumed % pp.njob].stream_off;
 			rd->beg = rd->end = 0; rd->eof = 0; rd->last = 0;
 			if (pp.fd >= 0) gzseek(rd->fp, (z_off_t)pp.total, SEEK_SET);   /* the reader thread read the file itself: the stream goes on where it stopped */
-			if (verbose >= 3) fprintf(stderr, "[M::%s] the input is not four-line FASTQ from byte %ld on: sequential reader\n", "main_ropebwt2", (long)rd->pos);
+			if (verbose >= 3) fprintf(stderr, "[M::%s] the input is not %s from byte %ld on: sequential reader\n", "main_ropebwt2", par == 2 ? "four-line FASTQ" : "plain FASTA", (long)rd->pos);
 		}
 	}
 	if (need_seq)

@@ -503,13 +503,82 @@ def test_parallel_fastq_reader_equals_sequential(flags, tmp_path):
                 assert got == want, (name, flags, m, chunk, thr, len(data), len(got), len(want))
 
 
+def _fasta_inputs():
+    rng = np.random.RandomState(21)
+    recs = []
+    for i in range(900):
+        L = int(rng.choice([0, 1, 2, 30, 101, 400, 3000], p=[.04, .04, .06, .3, .36, .15, .05]))
+        recs.append("".join(rng.choice(list("ACGTNacgtn"), size=L, p=[.22, .22, .22, .22, .03, .02, .02, .02, .02, .01])))
+    def fa(recs, width=0, eol="\n", last_nl=True, blank=False):
+        out = []
+        for i, s in enumerate(recs):
+            out.append(">r%d%s" % (i, " a comment > with marks @ +" if i % 4 == 0 else "") + eol)
+            if width:
+                for k in range(0, len(s), width):
+                    out.append(s[k:k + width] + eol)
+                    if blank and k % (3 * width) == 0:
+                        out.append(eol)
+            else:
+                out.append(s + eol)
+        t = "".join(out)
+        return (t if last_nl else t[:-len(eol)]).encode()
+    plain = fa(recs)
+    out = {"one_line": plain, "wrapped60": fa(recs, 60), "wrapped7_blank_lines": fa(recs, 7, blank=True), "crlf": fa(recs[:300], 60, "\r\n"),
+           "no_final_newline": fa(recs, 60, last_nl=False), "one": fa(recs[:1]), "header_only": b">x\n", "header_no_newline": b">x", "two_headers": b">a\n>b\nACGT\n",
+           "one_record_longer_than_many_blocks": fa(["".join(rng.choice(list("ACGT"), size=50_000))], 80) + fa(recs[:50], 60),
+           "truncated": plain[:len(plain) // 2]}
+    k = len(recs) // 2
+    mid = {"fastq": "@q\nACGTAC\n+\nIIIIII\n", "plus_line": ">p\nACGT\n+\nIIII\n", "at_line": ">p\nACGT\n@x\nAC\n+\nII\n", "cr_inside": ">c\nAC\rGT\nA\r\nC\n",
+           "spaces_and_tabs": ">s t\nAC GT\n\tA C\n", "gt_inside_a_line": ">g\nAC>GT\nAC\n"}
+    for name, frag in mid.items():
+        out["mid_" + name] = fa(recs[:k], 60) + frag.encode() + fa(recs[k:], 60)
+    out["starts_with_garbage"] = b"xx\n" + plain
+    out["starts_with_newline"] = b"\n" + plain
+    return out
+
+
+@pytest.mark.parametrize("flags", [["-R"], [], ["-F"], ["-N"], ["-x", "5"], ["-C"], ["-s", "-R"]])
+def test_parallel_fasta_reader_equals_sequential(flags, tmp_path):
+    """the threaded FASTA reader (blocks cut in front of a '>' line; header, then sequence lines concatenated) gives the batch stream
+    of the sequential kseq-exact reader -- wrapped and blank lines, records longer than many blocks, header-only records -- and
+    hands over to it (from the failing block on) where kseq's grammar does more: '+' / '@' lines, carriage returns, an unterminated
+    last line"""
+    for name, data in _fasta_inputs().items():
+        for m in ("-m30k", "-m1g"):
+            want = _dump_batches(flags + [m], data, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq")
+            for chunk, thr in (("64", "3"), ("1500", "2"), ("100000", "5"), ("0", "4")):
+                env = {"RB2_PARSE_THREADS": thr}
+                if chunk != "0":
+                    env["RB2_PARSE_CHUNK"] = chunk
+                got = _dump_batches(flags + [m], data, env, tmp_path, "par")
+                assert got == want, (name, flags, m, chunk, thr, len(data), len(got), len(want))
+
+
+def test_parallel_fasta_reader_really_runs_and_falls_back(tmp_path):
+    ins = _fasta_inputs()
+    for name, expect in (("wrapped60", False), ("mid_plus_line", True), ("crlf", True), ("starts_with_garbage", False)):
+        f = tmp_path / "b.bin"
+        p = subprocess.run([CLI, "-R", "-m1g", "-"], input=ins[name], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, RB2_DUMP_BATCHES=str(f), RB2_PARSE_THREADS="4", RB2_PARSE_CHUNK="4096", RB2_PARSE_TRACE="1"))
+        assert p.returncode == 0
+        assert (b"not plain FASTA" in p.stderr) == expect, (name, p.stderr.decode()[-300:])
+        if name == "wrapped60":
+            import re
+            mm = re.search(rb"(\d+) blocks of FASTA records parsed by 4 threads", p.stderr)
+            assert mm and int(mm.group(1)) > 10 and b"then the sequential" not in p.stderr, p.stderr.decode()[-300:]
+        if name == "starts_with_garbage":
+            assert b"parsed by" not in p.stderr
+
+
 def test_named_files_plain_and_gz(tmp_path):
     """a named plain file is read with read(2) by the reader thread (zlib bypassed), a .gz through zlib; the fallback of the FASTQ
     reader continues the plain file from where the reader thread stopped -- same batches as the sequential reader in all cases"""
     import gzip
     ins = _fastq_inputs()
     lines = H.reads_to_text(H.splitmix_bases(4000, 60, seed=8))
-    cases = [("strict", ins["strict"], ["-R"]), ("mid_multiline", ins["mid_multiline"], ["-R"]), ("mid_fasta", ins["mid_fasta"], []), ("lines", lines, ["-L", "-R"])]
+    fas = _fasta_inputs()
+    cases = [("strict", ins["strict"], ["-R"]), ("mid_multiline", ins["mid_multiline"], ["-R"]), ("mid_fasta", ins["mid_fasta"], []), ("lines", lines, ["-L", "-R"]),
+             ("fasta", fas["wrapped60"], ["-R"]), ("fasta_mid_plus", fas["mid_plus_line"], [])]
     for name, data, flags in cases:
         plain = tmp_path / (name + ".txt")
         plain.write_bytes(data)

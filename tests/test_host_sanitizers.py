@@ -158,3 +158,16 @@ def test_sanitized_parallel_fastq_reader(san_cli, tmp_path):
             if dump.exists():
                 dump.unlink()
             run(san_cli, ["-m40k", "-q", "10", "-C"], ins[name], env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})
+
+
+def test_sanitized_parallel_fasta_reader(san_cli, tmp_path):
+    """the threaded FASTA reader (blocks cut in front of '>' lines, carried-over records longer than a block) and its fallback under ASan/UBSan"""
+    from test_host_layer import _fasta_inputs
+    ins = _fasta_inputs()
+    dump = tmp_path / "b.bin"
+    for name in ("wrapped60", "wrapped7_blank_lines", "crlf", "no_final_newline", "header_only", "header_no_newline", "two_headers", "one_record_longer_than_many_blocks",
+                 "truncated", "mid_fastq", "mid_cr_inside", "mid_gt_inside_a_line"):
+        for chunk in ("64", "3000", "1000000"):
+            if dump.exists():
+                dump.unlink()
+            run(san_cli, ["-m40k", "-C"], ins[name], env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})

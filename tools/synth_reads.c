@@ -3,6 +3,7 @@
  * "ACGT"[splitmix64_output(seed, i*L+j+1) >> 62], one read per line.
  *   usage: synth_reads <n_reads> <read_len> [seed=42] [first_read=0] [genome_len=0] [fastq=0]  > reads.txt
  * fastq = 1: the same reads as four-line FASTQ records ("@r<i>", bases, "+", a constant quality string of 'I')
+ * fastq = 2: as FASTA records (">r<i>", bases wrapped at 80 columns)
  * genome_len > 0: read i is the window of a random genome (base p = "ACGT"[sm64(seed, p) >> 62]) that starts at
  * sm64(seed ^ COV_SALT, i) % (genome_len - L + 1) -- overlapping reads, the same stream as rb2_hip_synth_reads_cov.
  */
@@ -37,6 +38,11 @@ int main(int argc, char **argv)
 		const uint64_t base = glen ? sm64(seed ^ COV_SALT, i) % (glen - L + 1) : i * L;
 		for (uint64_t j = 0; j < L; ++j) line[j] = "ACGT"[sm64(seed, base + j) >> 62];
 		line[L] = '\n';
+		if (fastq == 2) {
+			printf(">r%llu\n", (unsigned long long)i);
+			for (uint64_t j = 0; j < L; j += 80) { fwrite(line + j, 1, L - j < 80 ? L - j : 80, stdout); fputc('\n', stdout); }
+			continue;
+		}
 		if (fastq) printf("@r%llu\n", (unsigned long long)i);
 		fwrite(line, 1, L + 1, stdout);
 		if (fastq) { fwrite("+\n", 1, 2, stdout); fwrite(qual, 1, L + 1, stdout); }
