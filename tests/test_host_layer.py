@@ -612,8 +612,8 @@ def test_parallel_fastq_reader_really_runs_and_falls_back(tmp_path):
             import re
             mm = re.search(rb"(\d+) blocks of four-line FASTQ records parsed by 4 threads", p.stderr)
             assert mm and int(mm.group(1)) > 10 and b"then the sequential" not in p.stderr, p.stderr.decode()[-300:]
-        if name == "starts_with_fasta":
-            assert b"parsed by" not in p.stderr                      # does not start with '@': sequential from the first byte
+        if name == "starts_with_fasta":                               # starts with '>': the FASTA workers take it, and hand over at the first '@' line
+            assert b"not plain FASTA" in p.stderr and b"then the sequential reader" in p.stderr
 
 
 def test_fmr_dump_to_a_file_equals_dump_to_a_pipe(golden, tmp_path):
