@@ -57,6 +57,7 @@ void    *mr_hip_handle(mrope_t *mr);
 /* ... or the rb2_hip_multi_t, when RB2_HIP_DEVICES lists several devices: the index is then sharded over them and
  * mr_insert_multi drives all of them inside the call, as the reference drives its worker threads (mrope.c:287-296, 312-329) */
 void    *mr_hip_multi_handle(mrope_t *mr);
+void     mr_wait(mrope_t *mr);                         /* rb2 extension: mr_insert_multi may return while the GPU is still inserting (rb2_hip.h: rb2_hip_set_lazy); wait for it -- only needed to time it */
 void     mr_prefetch(mrope_t *mr, const uint8_t *s, int64_t n_final, int64_t capacity);   /* rb2 extension: start uploading the batch that is being assembled (rb2_hip_prefetch) */
 int64_t  mr_auto_batch_bytes(mrope_t *mr);                                              /* rb2 extension: batch size for `-m auto`, from the device's free memory */
 void     mr_reserve(mrope_t *mr, int64_t batch_bytes, int64_t total_symbols);       /* rb2 extension: capacity hint (rb2_hip_reserve); 0 = unknown */

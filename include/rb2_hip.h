@@ -74,6 +74,16 @@ void rb2_hip_reset(rb2_hip_t *h);
  * 0-terminated, nt6 codes 0..5, s[len-1]==0).  `s` is a host buffer, borrowed for the call. */
 void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s);
 
+/* rb2_hip_insert_multi may return as soon as the batch text is on the device and its rounds are queued (default; RB2_HIP_LAZY_INSERT=0
+ * or rb2_hip_set_lazy(h, 0): only when the device is done): `s` is the caller's again, and what it does next -- parse the next batch,
+ * upload it (the text goes to a second device buffer on a copy stream) -- runs beside the kernels.  Every other entry point waits for
+ * the queued rounds before it looks at the index; rb2_hip_wait does only that.  rb2_hip_last_batch_counts: what that batch adds to
+ * the count matrix (layout of rb2_hip_get_counts), computed from its text alone and valid at once -- how mr_insert_multi keeps
+ * mr_get_c() truthful (mrope.c:332-340) without waiting; returns 0 when the last insert was not a host-buffer one. */
+void rb2_hip_set_lazy(rb2_hip_t *h, int on);
+void rb2_hip_wait(rb2_hip_t *h);
+int  rb2_hip_last_batch_counts(rb2_hip_t *h, int64_t d[36]);
+
 /* optional: bytes [0, n_final) of the buffer a LATER rb2_hip_insert_multi(h, len >= n_final, s) will pass are final -- start
  * uploading them now (copy stream, second text buffer), concurrently with an insert running on another thread.  capacity = the
  * largest len that call may have.  `s` must stay where it is until that call; s == NULL cancels (waits for copies in flight:

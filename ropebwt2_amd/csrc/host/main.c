@@ -562,6 +562,7 @@ static void flush_batch_now(mrope_t *mr, str_t *buf, int flag, int verbose)
 		return;
 	}
 	mr_insert_multi(mr, (int64_t)buf->l, (const uint8_t*)buf->s, flag & F_THR);
+	mr_wait(mr);                                             /* (the call may return with the GPU still inserting; this line reports the insert, and the CLI overlaps its reading on threads of its own) */
 	if (verbose >= 3) fprintf(stderr, "[M::%s] inserted %ld symbols in %.3f sec, %.3f CPU sec\n", "main_ropebwt2", (long)buf->l, realtime() - r0, cputime() - c0);
 	buf->l = 0;
 }

@@ -123,6 +123,7 @@ int mr_thr_min(mrope_t *mr, int thr_min)
 }
 
 void *mr_hip_handle(mrope_t *mr) { return X(mr)->dev; }
+void mr_wait(mrope_t *mr) { if (X(mr)->dev) rb2_hip_wait((rb2_hip_t*)X(mr)->dev); }
 void *mr_hip_multi_handle(mrope_t *mr) { return X(mr)->mdev; }
 
 /* rb2 extension: what the caller knows about the job ahead (the size of one batch buffer, the symbols the finished index will
@@ -281,9 +282,17 @@ void mr_insert_multi(mrope_t *mr, int64_t len, const uint8_t *s, int is_thr)
 	sync_dev(mr);
 	if (x->mdev) rb2_hip_multi_insert_multi(x->mdev, len, s);   /* N GPUs: the round loop, the count matrix and the exchange of the strings all run inside this call */
 	else rb2_hip_insert_multi(x->dev, len, s);
+	/* keep mr_get_c()/mr_get_ac() truthful.  One GPU: the call above may have returned with the rounds still running on the device
+	 * (rb2_hip.h); what the batch adds to the counts follows from its text alone and is here already -- asking for the counts
+	 * themselves would wait for the device, and a caller that parses its next batch now would not overlap with it */
+	if (!x->mdev && rb2_hip_last_batch_counts(x->dev, c)) {
+		for (a = 0; a < 6; ++a)
+			for (b = 0; b < 6; ++b) mr->r[a]->c[b] += c[a*6+b];
+	} else {
 	dev_get_counts(x, c);
 	for (a = 0; a < 6; ++a)
-		for (b = 0; b < 6; ++b) mr->r[a]->c[b] = c[a*6+b];      /* keep mr_get_c()/mr_get_ac() truthful */
+		for (b = 0; b < 6; ++b) mr->r[a]->c[b] = c[a*6+b];
+	}
 	x->host_ok = 0;
 }
 

@@ -176,6 +176,10 @@ struct rb2_hip_s {
 	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
+	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
+	bool pair_valid = false;
+	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
+	int lazy_insert = 1;                // RB2_HIP_LAZY_INSERT=0 / rb2_hip_set_lazy(h, 0): every insert returns only when the device is done
 	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
 	Ctl *ctl = nullptr;                 // device
 	RopeDesc h_rope[NR];                // host mirror of ctl->rope[side] (sub-ropes)
@@ -591,7 +595,25 @@ void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bo
 	round_merge(h, B, r, send);
 }
 
-void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
+void batch_trace(rb2_hip_t *h)
+{
+	if (h->trace) fprintf(stderr, "[rb2_hip] batch done: layout %s, relayouts %lld (of them re-spreads %lld), void sparse rounds %lld, sparse rounds %lld\n", h->sparse ? "sparse" : "dense",
+			(long long)h->n_relayout, (long long)h->n_respread, (long long)h->n_void, (long long)h->n_sparse_rounds);
+}
+
+// A host-buffer insert may return as soon as its text is on the device and its rounds are queued (`lazy`): the caller gets its buffer
+// back, and what it does next -- parse the next batch, upload it -- runs beside the kernels.  Every entry point that looks at the
+// handle's state waits for them first (finish_pending).
+void finish_pending(rb2_hip_t *h)
+{
+	if (!h || !h->pending_end) return;
+	h->pending_end = false;
+	HIPCHK(hipSetDevice(h->dev));
+	batch_end(h);
+	batch_trace(h);
+}
+
+void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false)
 {
 	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); }
 	BatchState B;
@@ -606,9 +628,9 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s)
 		if (B.counted != r) round_counts(h, B, r);
 		round_merge_any(h, B, r, nullptr, true);
 	}
+	if (lazy && h->lazy_insert && !h->prof && !h->debug) { h->cur_round = -1; HIPCHK(hipGetLastError()); h->pending_end = true; return; }
 	batch_end(h);
-	if (h->trace) fprintf(stderr, "[rb2_hip] batch done: layout %s, relayouts %lld (of them re-spreads %lld), void sparse rounds %lld, sparse rounds %lld\n", h->sparse ? "sparse" : "dense",
-			(long long)h->n_relayout, (long long)h->n_respread, (long long)h->n_void, (long long)h->n_sparse_rounds);
+	batch_trace(h);
 }
 
 // the batch must end with a sentinel (mrope.c:268): bytes after the last 0 would be sized for but never inserted
@@ -652,6 +674,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	if (getenv("RB2_SPARSE_LAMBDA")) h->sp_lambda = atof(getenv("RB2_SPARSE_LAMBDA"));   // 0: never leave the dense layout
 	if (getenv("RB2_SPARSE_HEAD")) h->sp_head = atoi(getenv("RB2_SPARSE_HEAD"));
 	if (getenv("RB2_LEAF_PIPE")) h->leaf_pipe = atoi(getenv("RB2_LEAF_PIPE"));
+	if (getenv("RB2_HIP_LAZY_INSERT")) h->lazy_insert = atoi(getenv("RB2_HIP_LAZY_INSERT"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -670,7 +693,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 }
 
 void rb2_hip_destroy(rb2_hip_t *h)
-{
+{ finish_pending(h);
 	if (!h) return;
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
@@ -681,6 +704,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
+	if (h->pair_d) { HIPCHK(hipFree(h->pair_d)); HIPCHK(hipHostFree(h->pair_h)); }
 	if (h->gcnt_own) h->gcnt = h->gcnt_own;
 	if (h->pin_sd) { HIPCHK(hipHostFree(h->pin_sd)); HIPCHK(hipHostFree(h->pin_pcs)); }
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
@@ -693,7 +717,7 @@ int rb2_hip_sorting_order(const rb2_hip_t *h) { return h->so; }
 
 /* back to the empty index of rb2_hip_create; buffers, shard ownership and profiling state are kept */
 void rb2_hip_reset(rb2_hip_t *h)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->batch) { rb2_fatal("[rb2_hip] reset inside a sharded batch\n"); }
 	memset(h->h_rope, 0, sizeof(h->h_rope));
@@ -703,7 +727,7 @@ void rb2_hip_reset(rb2_hip_t *h)
 }
 
 void rb2_hip_insert_multi_dev(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
-{
+{ finish_pending(h); h->pair_valid = false;
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0) { rb2_fatal("[rb2_hip] insert_multi: len must be > 0\n"); }   // mrope.c:268
 	check_last_byte(h, len, s_dev);
@@ -758,27 +782,49 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || s[len - 1] != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }   // mrope.c:268
-	{	// (most of) the batch is on the device already?  (rb2_hip_prefetch)
+	// The text goes into the SECOND text buffer on the copy stream -- the first may still be read by the rounds of the previous
+	// insert, which was allowed to return before they were done (finish_pending): a caller that inserts batch after batch has batch
+	// k + 1 cross PCIe while batch k is being inserted.  Whatever rb2_hip_prefetch has brought over already is not sent again.
+	{
 		std::unique_lock<std::mutex> lk(h->pf_mu);
-		if (h->pf_host == s) h->pf_cv.wait(lk, [h] { return !h->pf_busy; });   // a copy of THIS batch is running: it is what we are about to use
-		if (h->pf_host == s && h->pf_done > 0 && (int64_t)h->pf_done <= len && h->sbuf2.cap >= (size_t)len + 64) {
-			if ((size_t)len > h->pf_done) HIPCHK(hipMemcpyAsync(h->sbuf2.p + h->pf_done, s + h->pf_done, (size_t)len - h->pf_done, hipMemcpyHostToDevice, h->st_copy));
-			HIPCHK(hipStreamSynchronize(h->st_copy));
-			std::swap(h->sbuf, h->sbuf2);                           // the previous batch's text is dead: it becomes the target of the next prefetch
-			h->pf_host = nullptr; h->pf_done = 0;
-			lk.unlock();
-			insert_dev(h, len, h->sbuf.p);
-			return;
-		}
-		if (h->pf_host == s) { h->pf_host = nullptr; h->pf_done = 0; }
+		if (!h->st_copy) HIPCHK(hipStreamCreateWithFlags(&h->st_copy, hipStreamNonBlocking));
+		h->pf_cv.wait(lk, [h] { return !h->pf_busy; });          // a prefetch copy is running (of this batch, or a stale one): it owns sbuf2 until it is done
+		size_t have = 0;
+		if (h->pf_host == s && h->pf_done > 0 && (int64_t)h->pf_done <= len && h->sbuf2.cap >= (size_t)len + 64) have = h->pf_done;
+		h->pf_host = nullptr; h->pf_done = 0;
+		h->pf_busy = true;                                       // (keeps a concurrent rb2_hip_prefetch of the NEXT batch out of sbuf2 until the buffers are swapped)
+		lk.unlock();
+		if (h->sbuf2.cap < (size_t)len + 64) { HIPCHK(hipStreamSynchronize(h->st_copy)); h->sbuf2.ensure((size_t)len + 64); have = 0; }
+		if ((size_t)len > have) HIPCHK(hipMemcpyAsync(h->sbuf2.p + have, s + have, (size_t)len - have, hipMemcpyHostToDevice, h->st_copy));
+		if (!h->pair_d) { HIPCHK(hipMalloc((void**)&h->pair_d, 36 * 8)); HIPCHK(hipHostMalloc((void**)&h->pair_h, 36 * 8, hipHostMallocDefault)); }
+		HIPCHK(hipMemsetAsync(h->pair_d, 0, 36 * 8, h->st_copy));  // the count matrix of the batch, from its text alone (rb2_hip_last_batch_counts)
+		hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)std::min<uint64_t>(((uint64_t)len + 4095) / 4096, 8192)), dim3(256), 0, h->st_copy, (const uint8_t*)h->sbuf2.p, (uint64_t)len, h->pair_d);
+		HIPCHK(hipMemcpyAsync(h->pair_h, h->pair_d, 36 * 8, hipMemcpyDeviceToHost, h->st_copy));
+		HIPCHK(hipStreamSynchronize(h->st_copy));
+		h->pair_valid = true;
+		finish_pending(h);                                       // the previous batch is done with sbuf: it becomes the target of the next upload
+		lk.lock();
+		std::swap(h->sbuf, h->sbuf2);
+		h->pf_busy = false;
+		h->pf_cv.notify_all();
 	}
-	h->sbuf.ensure((size_t)len + 64);
-	HIPCHK(hipMemcpyAsync(h->sbuf.p, s, (size_t)len, hipMemcpyHostToDevice, h->st));
-	insert_dev(h, len, h->sbuf.p);
+	insert_dev(h, len, h->sbuf.p, true);
 }
 
-void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
+/* what the last rb2_hip_insert_multi adds to the count matrix (d[b*6+a], layout of rb2_hip_get_counts), computed from the text of the
+ * batch alone: available as soon as that call returns, without waiting for its rounds.  0 if the last insert was not a host-buffer one. */
+int rb2_hip_last_batch_counts(rb2_hip_t *h, int64_t d[36])
 {
+	if (!h->pair_valid) return 0;
+	for (int i = 0; i < 36; ++i) d[i] = (int64_t)h->pair_h[i];
+	return 1;
+}
+
+void rb2_hip_set_lazy(rb2_hip_t *h, int on) { finish_pending(h); h->lazy_insert = on; }
+void rb2_hip_wait(rb2_hip_t *h) { finish_pending(h); }
+
+void rb2_hip_get_counts(rb2_hip_t *h, int64_t c[36])
+{ finish_pending(h);
 	for (int i = 0; i < 36; ++i) c[i] = 0;
 	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) c[rope_sym(r) * 6 + a] += (int64_t)h->h_rope[r].cnt[a];   // rope b = its pieces (b,x)
 }
@@ -841,7 +887,7 @@ static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb
 }
 
 int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	ensure_dense(h);
 	int64_t k = 0;
@@ -851,7 +897,7 @@ int64_t rb2_hip_stream_rope(rb2_hip_t *h, int b, rb2_hip_run_cb cb, void *user)
 
 /* rope b = its pieces (b,x) in the order x = $,A,C,G,T,N (rb2_device.h) */
 int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	ensure_dense(h);
 	int64_t t = 0;
@@ -860,7 +906,7 @@ int64_t rb2_hip_rope_bytes(rb2_hip_t *h, int b)
 }
 
 int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	ensure_dense(h);
 	int64_t k = 0;
@@ -869,7 +915,7 @@ int64_t rb2_hip_download_rope(rb2_hip_t *h, int b, uint8_t *dst)
 }
 
 void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t n_bytes[6])
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	hipStream_t st = h->st;
 	// The run bytes go to the device as they are and are decoded there (k_ld_*, rb2_kernels.h): at configs[4] size -- an index of
@@ -972,7 +1018,7 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 /* ---- rope sharding across GPUs ------------------------------------------- */
 
 void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (nranks < 1 || rank < 0 || rank >= nranks) { rb2_fatal("[rb2_hip] bad shard rank %d/%d\n", rank, nranks); }
 	ensure_dense(h);
@@ -991,7 +1037,7 @@ void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 int rb2_hip_num_subropes(void) { return NR; }
 
 int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || ((uintptr_t)s_dev & 15)) { rb2_fatal("[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); }
 	check_last_byte(h, len, s_dev);
@@ -1022,7 +1068,7 @@ void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt)
  * (its host copy is only used to lay out the exchange); shard_merge / shard_finish return without waiting for the device.
  * One host synchronisation per round remains: the caller reading the reduced matrix to size the uneven all-to-all. */
 void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (!h->own_stream && h->st == (hipStream_t)hip_stream) return;            /* bound already */
 	if (h->own_stream) { HIPCHK(hipStreamSynchronize(h->st)); HIPCHK(hipStreamDestroy(h->st)); h->own_stream = false; }
@@ -1031,7 +1077,7 @@ void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
 }
 
 void rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipStreamSynchronize(h->st));
 	if (gcnt_dev) {
@@ -1146,7 +1192,7 @@ void rb2_hip_shard_end(rb2_hip_t *h)
 
 /* plain copies for callers that stage exchange buffers themselves: kind 0 host->device, 1 device->host, 2 device->device */
 void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (bytes <= 0) return;
 	HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->st));
@@ -1155,7 +1201,7 @@ void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int
 
 /* n rank queries against rope b in one launch: one wave per query (k_rank_batch / wave_rank_all) */
 void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_t *out)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->nranks > 1) rb2_fatal("[rb2_hip] rank: this handle holds only its own sub-ropes of a sharded index; ask the owner of the piece\n");
 	if (n <= 0) return;
@@ -1174,7 +1220,7 @@ void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_
 }
 
 void rb2_hip_rank1a(rb2_hip_t *h, int b, int64_t x, int64_t cx[6])
-{
+{ finish_pending(h);
 	if (x < 0) x = 0;
 	rb2_hip_rank_batch(h, b, 1, &x, cx);
 }
@@ -1200,7 +1246,7 @@ static uint64_t hash_mix(uint64_t acc, uint64_t piece, uint64_t n)      /* piece
 	return (acc ^ n) * 0xBF58476D1CE4E5B9ull;
 }
 uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b)
-{
+{ finish_pending(h);
 	uint64_t acc = 0;
 	if (h->nranks > 1) { rb2_fatal("[rb2_hip] rope_hash: this handle holds only its own sub-ropes of a sharded index (use rb2_hip_multi_rope_hash)\n"); }
 	for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) acc = hash_mix(acc, piece_hash(h, r), h->h_rope[r].n);
@@ -1226,10 +1272,10 @@ void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)
 	return p;
 }
 
-void rb2_hip_dev_free(rb2_hip_t *h, void *p) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipFree(p)); }
+void rb2_hip_dev_free(rb2_hip_t *h, void *p) { finish_pending(h); HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipFree(p)); }
 
 void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand, int64_t genome_len)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	const uint64_t total = (uint64_t)n_reads * (read_len + 1) * (strand ? 2 : 1);
 	if (total == 0) return;
@@ -1245,7 +1291,7 @@ void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int
 }
 
 void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, int64_t total_symbols)
-{
+{ finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (batch_bytes > 0) h->zblk.ensure(cdiv((uint64_t)batch_bytes, ZBLOCK) + 2);
 	if (batch_strings > 0) ensure_strings(h, (uint64_t)batch_strings);
@@ -1260,12 +1306,12 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 }
 
 void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4])
-{
+{ finish_pending(h);
 	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
 }
 
 void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
-{
+{ finish_pending(h);
 	uint64_t ns = 0;
 	HIPCHK(hipSetDevice(h->dev));
 	HIPCHK(hipMemcpyAsync(&ns, &h->ctl->nsplit_total, 8, hipMemcpyDeviceToHost, h->st));
@@ -1274,12 +1320,12 @@ void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
 	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = out[7] = 0;
 }
 
-void rb2_hip_sync(rb2_hip_t *h) { HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }
+void rb2_hip_sync(rb2_hip_t *h) { finish_pending(h); HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }
 
-void rb2_hip_profile(rb2_hip_t *h, int enable) { h->prof = enable; }
+void rb2_hip_profile(rb2_hip_t *h, int enable) { finish_pending(h); h->prof = enable; }
 
 void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[RB2_K_COUNT], int64_t units[RB2_K_COUNT], int reset)
-{
+{ finish_pending(h);
 	for (int k = 0; k < RB2_K_COUNT; ++k) { launches[k] = h->p_launch[k]; ms[k] = h->p_ms[k]; units[k] = h->p_units[k]; }
 	if (reset) { memset(h->p_launch, 0, sizeof(h->p_launch)); memset(h->p_ms, 0, sizeof(h->p_ms)); memset(h->p_units, 0, sizeof(h->p_units)); }
 }

@@ -70,6 +70,48 @@ __global__ __launch_bounds__(256) void k_count_zeros(const uint8_t *s, uint64_t 
 	if (bad) *bad_flag = 1;
 }
 
+// What a batch adds to the count matrix, known before a single round has run: symbol t[i] of the batch text goes into the rope of
+// the symbol inserted before it -- t[i-1], and rope $ for the first symbol of a string, which follows the sentinel 0 of the string
+// in front of it (mrope.c:299-342) -- so c[a][b] grows by the number of adjacent pairs (a, b) of the text, with t[-1] = 0.  A host
+// that only wants mr_get_c() / mr_get_ac() to be truthful after mr_insert_multi need not wait for the rounds.  out[a*6+b].
+__global__ __launch_bounds__(256) void k_pair_hist(const uint8_t *s /* 16-byte aligned */, uint64_t len, unsigned long long *out)
+{
+	__shared__ uint32_t h[36];
+	if (threadIdx.x < 36) h[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t loc[36];
+#pragma unroll
+	for (int i = 0; i < 36; ++i) loc[i] = 0;
+	const uint64_t K = 0x0101010101010101ull, L7 = 0x7f7f7f7f7f7f7f7full;
+	auto eq = [&](uint64_t x, uint32_t v) -> uint64_t { const uint64_t t = x ^ (K * v); return ~(((t & L7) + L7) | t | L7); };   // 0x80 in every byte of x that equals v
+	for (uint64_t p = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; p < len; p += (uint64_t)gridDim.x * 256 * 16) {
+		uint64_t w[2];
+		if (p + 16 <= len) { const uint4 v = *(const uint4*)(s + p); w[0] = v.x | (uint64_t)v.y << 32; w[1] = v.z | (uint64_t)v.w << 32; }
+		else { w[0] = w[1] = 0x0707070707070707ull; for (uint64_t q = p; q < len; ++q) { uint64_t &d = w[(q - p) >> 3]; const int sh = 8 * (int)((q - p) & 7); d = (d & ~(0xffull << sh)) | (uint64_t)s[q] << sh; } }   // 7: no symbol
+		uint64_t prev = p ? s[p - 1] : 0ull;
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint64_t cur = w[k], pw = cur << 8 | prev;      // byte i of pw = the byte in front of byte i of cur
+			prev = cur >> 56;
+			uint64_t mp[6], mc[6];
+#pragma unroll
+			for (int v = 0; v < 6; ++v) { mp[v] = eq(pw, v); mc[v] = eq(cur, v); }
+#pragma unroll
+			for (int a = 0; a < 6; ++a)
+#pragma unroll
+				for (int b = 0; b < 6; ++b) loc[a * 6 + b] += (uint32_t)__popcll(mp[a] & mc[b]);
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < 36; ++i) {                             // wave sum, one LDS atomic per wave and counter
+		uint32_t v = loc[i];
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor((int)v, o);
+		if (lane_id() == 0 && v) atomicAdd(&h[i], v);
+	}
+	__syncthreads();
+	if (threadIdx.x < 36 && h[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
 // in-place exclusive scan of the per-block sentinel counts (one block); blk[n] = total = number of strings
 __global__ __launch_bounds__(SCHUNK) void k_zscan(uint64_t *blk, uint32_t n)
 {

@@ -35,6 +35,9 @@ def load_hip_lib():
         "rb2_hip_insert_multi": (None, [vp, i64, vp]),
         "rb2_hip_insert_multi_dev": (None, [vp, i64, vp]),
         "rb2_hip_prefetch": (None, [vp, vp, i64, i64]),
+        "rb2_hip_set_lazy": (None, [vp, C.c_int]),
+        "rb2_hip_wait": (None, [vp]),
+        "rb2_hip_last_batch_counts": (C.c_int, [vp, vp]),
         "rb2_hip_mem_info": (None, [i32, vp, vp]),
         "rb2_hip_get_counts": (None, [vp, vp]),
         "rb2_hip_rope_bytes": (i64, [vp, i32]),
@@ -105,7 +108,7 @@ def load_hip_lib():
 
 ABI_SYMBOLS = [
     "rb2_hip_device_count", "rb2_hip_set_fatal_handler", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
-    "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
+    "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_set_lazy", "rb2_hip_wait", "rb2_hip_last_batch_counts", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
@@ -179,6 +182,18 @@ class HipBwt:
 
     def insert_multi_dev(self, dev_ptr, nbytes):
         self.L.rb2_hip_insert_multi_dev(self.h, nbytes, dev_ptr)
+
+    def set_lazy(self, on):
+        """rb2_hip_set_lazy: may insert_multi return before the device is done with the batch (default: yes)"""
+        self.L.rb2_hip_set_lazy(self.h, int(on))
+
+    def wait(self):
+        self.L.rb2_hip_wait(self.h)
+
+    def last_batch_counts(self):
+        """what the last insert_multi adds to counts(), from the text of the batch alone (None if it was not a host-buffer insert)"""
+        d = np.zeros(36, np.int64)
+        return d.reshape(6, 6) if self.L.rb2_hip_last_batch_counts(self.h, d.ctypes.data) else None
 
     def prefetch(self, buf, n_final, capacity=0):
         """start uploading buf[:n_final] for a later insert_multi(buf[:len]) (rb2_hip_prefetch); buf must stay alive and in place"""

@@ -583,3 +583,39 @@ def test_fuzz_medium_jobs_with_layout_changes(hip, seed, lam):
         assert np.array_equal(dev.rope(r), o.rope(r)), "rope %d (so %d strand %d L %d cov %g, %s)" % (r, so, strand, L, cov, st)
     assert st["sparse_rounds"] > 0, st
     dev.dev_free(p)
+
+
+def test_lazy_host_insert_overlaps_and_stays_exact(hip):
+    """rb2_hip_insert_multi may return while its rounds run (rb2_hip_set_lazy, the default): batches fired back to back -- the next
+    text is uploaded to the second device buffer beside the kernels --, queries in between (every entry point waits first), the count
+    matrix of a batch from its text alone (rb2_hip_last_batch_counts = what mr_insert_multi adds to mr_get_c), all against the oracle"""
+    import helpers as H
+    for so in (0, 1, 2):
+        o = H.Oracle(so)
+        dev = hip.HipBwt(so)
+        sync = hip.HipBwt(so)
+        sync.set_lazy(0)
+        bufs = [H.encode_batch_fixed(H.splitmix_bases(3000, 80, seed=11)), H.encode_batch(H.repetitive_reads(1500, seed=5, genome_len=700, max_len=90), True, so == 2),
+                H.encode_batch([[1, 2, 3], [], [4] * 50, [5, 5]]), H.encode_batch_fixed(H.splitmix_bases(2000, 101, seed=12))]
+        for i, buf in enumerate(bufs):
+            before = o.counts().copy()
+            o.insert_multi(buf)
+            keep = buf.copy()
+            dev.insert_multi(buf)
+            d = dev.last_batch_counts()
+            assert d is not None and np.array_equal(d, o.counts() - before), i        # valid at once, no wait
+            buf[:] = 0                                                                 # the buffer is the caller's again
+            sync.insert_multi(keep)
+            if i == 1:                                                                 # a query in between sees the finished batch
+                assert np.array_equal(dev.counts(), o.counts())
+                assert np.array_equal(dev.rank1a(2, 17), np.bincount(o.rope(2)[:17], minlength=6))
+        assert np.array_equal(dev.counts(), o.counts()) and np.array_equal(sync.counts(), o.counts())
+        for b in range(6):
+            assert np.array_equal(dev.rope(b), o.rope(b)) and np.array_equal(sync.rope(b), o.rope(b)), (so, b)
+        # a device-buffer insert invalidates the per-batch matrix
+        p = dev.dev_alloc(64)
+        z = np.zeros(3, np.uint8); z[:2] = (1, 2)
+        dev.L.rb2_hip_memcpy(dev.h, p, z.ctypes.data, 3, 0)
+        dev.insert_multi_dev(p, 3)
+        assert dev.last_batch_counts() is None
+        dev.dev_free(p); dev.close(); sync.close()
