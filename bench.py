@@ -328,6 +328,34 @@ def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.
                                   % (reads, L, so_name.upper(), batch_gib, len(times), total / 1e9)}
 
 
+def secondary_configs3(reads=1_000_000, L=10_000, batch_gib=10.0):
+    """BASELINE.json configs[3]'s shape at one tenth on ONE GPU (1 M x 10 kbp, input order, forward strand, -m10g: one batch of
+    10,001 rounds of a million symbols each -- the latency-bound regime; the full config is ten such batches on a growing index,
+    profiles/r03_configs3_full_1gpu.json).  Inputs generated on the device, the insert timed; checked through the count matrix."""
+    from ropebwt2_amd import HipBwt
+    b = HipBwt(0, 0)
+    try:
+        total = reads * (L + 1)
+        b.reserve(total, reads, total)
+        buf = b.dev_alloc(total + 64)
+        b.synth_reads(buf, 0, reads, L, seed=44)
+        b.sync()
+        t0 = time.perf_counter()
+        b.insert_multi_dev(buf, total)
+        b.sync()
+        dt = time.perf_counter() - t0
+        c = b.counts()
+        sizes, occ = c.sum(axis=1), c.sum(axis=0)
+        ok = int(c.sum()) == total and int(c[:, 0].sum()) == reads and all(int(sizes[a]) == int(occ[a]) for a in range(1, 6))
+        st = b.layout_stats()
+        b.dev_free(buf)
+    finally:
+        b.close()
+    return {"value": total / dt / 1e9, "unit": "Gsymbols/s", "insert_s": dt, "rounds": L + 1, "us_per_round": dt / (L + 1) * 1e6, "counts_ok": bool(ok), "layout": st,
+            "what": "configs[3] shape at one tenth on 1 GPU: %d x %d bp, input order, forward strand, one -m10g batch (%.1f G symbols), inputs generated on the device, insert timed"
+                    % (reads, L, total / 1e9)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -575,6 +603,10 @@ def main():
                 out["secondary"] = {"configs2_shape_1gpu": secondary_configs2()}
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("[bench] secondary leg failed: %r\n" % (e,))
+            try:
+                out.setdefault("secondary", {})["configs3_shape_tenth_1gpu"] = secondary_configs3()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("[bench] secondary long-read leg failed: %r\n" % (e,))
     if not args.no_cpu_baseline and n_ranks == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
     print(json.dumps(out))
