@@ -36,6 +36,9 @@ rb2_fmd_t *rb2_fmdp_finish(rb2_fmdp_t *p);
  * behind the index.  Returns -1 (nothing changes, rb2_fmd_write writes everything) when fd cannot be written at offsets.
  * Call before the first rb2_fmdp_push_runs.  The file is byte-identical either way (rld_dump, rld0.c:207-229). */
 int rb2_fmdp_set_output(rb2_fmdp_t *p, int fd, int64_t offset);
+/* optional: the stream will hold n_symbols symbols -- the output array is sized once (and backed by huge pages where the host has
+ * them) instead of growing as it fills.  Call before the first rb2_fmdp_push_runs. */
+void rb2_fmdp_expect(rb2_fmdp_t *p, int64_t n_symbols);
 
 #ifdef __cplusplus
 }

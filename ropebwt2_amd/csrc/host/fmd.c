@@ -24,6 +24,7 @@
 #include <time.h>
 #include "rb2_fmd.h"
 #include "rle.h"
+#define RB2_THP_WHICH 2
 #include "rb2_parcopy.h"
 
 #define BLK_WORDS   8                    /* 1 << sbits, sbits = 3 */
@@ -605,6 +606,17 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 }
 
 static void *fmdp_stitcher(void *arg) { stitch((rb2_fmdp_t*)arg); return 0; }
+
+/* The index will hold n_symbols symbols: size the output array once (a run of one symbol costs 4 bits -- Elias delta of 1 is one
+ * bit -- and a block spends 2 of its 8 words on counts: at most 0.67 bytes per symbol; pages that are never written are never
+ * backed) instead of growing it by half again and again, and ask for huge pages: the stitcher faults all of it in.  Call before the
+ * first rb2_fmdp_push_runs; without it the array grows on demand as before. */
+void rb2_fmdp_expect(rb2_fmdp_t *p, int64_t n_symbols)
+{
+	if (n_symbols <= 0 || p->f->head != 0) return;
+	reserve(p->f, (size_t)(n_symbols / 8 * 0.7) + (1 << 16));
+	rb2_hint_huge_which(p->f->w, p->f->cap * 8, 8);
+}
 
 static size_t out_step_words(void)                            /* the writer thread moves at least 32 MiB per pwrite (RB2_FMD_OUT_STEP: words, tests) */
 {

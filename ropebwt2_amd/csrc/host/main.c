@@ -21,12 +21,14 @@
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_fmd.h"
+#define RB2_THP_WHICH 1
+#include "rb2_parcopy.h"
 
 #define RB2_VERSION "r187-hip1"
 
 /* ---- tiny growable byte string ---------------------------------------------------------------- */
 typedef struct { size_t l, m; char *s; } str_t;
-static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need + (need >> 1) + 64; s->s = (char*)realloc(s->s, s->m); } }
+static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need + (need >> 1) + 64; s->s = (char*)realloc(s->s, s->m); rb2_hint_huge(s->s, s->m); } }
 static void str_putc(str_t *s, int c) { str_reserve(s, s->l + 2); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
 static void str_append(str_t *s, const char *p, size_t n) { str_reserve(s, s->l + n + 1); memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0; }
 
@@ -710,6 +712,7 @@ int main(int argc, char *argv[])
 		}
 	}
 	ct = cputime(); rt = realtime();
+	if (verbose >= 4) fprintf(stderr, "[M::%s] set up (options, index, device buffers) in %.3f sec\n", "main_ropebwt2", rt - t0);
 
 	{
 	enc_cfg_t cfg;
@@ -829,7 +832,8 @@ int main(int argc, char *argv[])
 		fprintf(stderr, "[M::%s] symbol counts: ($, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
 				(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5]);
 	}
-	free(buf.s); gzclose(rd->fp); free(rd->seq.s); free(rd->qual.s); free(rd);
+	{ const double tf = realtime(); free(buf.s); gzclose(rd->fp); free(rd->seq.s); free(rd->qual.s); free(rd);
+	  if (verbose >= 4) fprintf(stderr, "[M::%s] batch buffers and reader released in %.3f sec\n", "main_ropebwt2", realtime() - tf); }
 
 	if (out != stdout) { fflush(stdout); if (dup2(fileno(out), fileno(stdout)) < 0) return 1; }   /* mr_print_tree writes to stdout */
 	{ static char obuf[4 << 20]; fflush(stdout); setvbuf(stdout, obuf, _IOFBF, sizeof(obuf)); }   /* .fmr dumps are millions of small fwrites */
@@ -849,6 +853,7 @@ int main(int argc, char *argv[])
 			if (nt > 24) nt = 24;
 			if (getenv("RB2_FMD_THREADS")) nt = atol(getenv("RB2_FMD_THREADS"));
 			fmdp = rb2_fmdp_init(nt < 1 ? 1 : nt > 64 ? 64 : (int)nt, getenv("RB2_FMD_SEGMENT") ? atol(getenv("RB2_FMD_SEGMENT")) : 0);
+			{ int64_t cc[6], tot = 0; int a; mr_get_c(mr, cc); for (a = 0; a < 6; ++a) tot += cc[a]; rb2_fmdp_expect(fmdp, tot); }
 			if (!getenv("RB2_FMD_NO_STREAM")) {                 /* -o file / a redirected stdout: the index goes out while it is encoded */
 				fflush(stdout);
 				const off_t at = ftello(stdout);
@@ -866,12 +871,15 @@ int main(int argc, char *argv[])
 			rb2_fmd_counts(fmd, cc);
 			fprintf(stderr, "[M::%s] rld: (tot, $, A, C, G, T, N) = (%ld, %ld, %ld, %ld, %ld, %ld, %ld)\n", "main_ropebwt2",
 					(long)cc[0], (long)cc[1], (long)cc[2], (long)cc[3], (long)cc[4], (long)cc[5], (long)cc[6]);
-			if (rb2_fmd_write(fmd, stdout) != 0) { fprintf(stderr, "[E::%s] failed to write the index\n", "main_ropebwt2"); ret = 1; }
-			rb2_fmd_destroy(fmd);
+			{ const double tw = realtime(); double tw1;
+			  if (rb2_fmd_write(fmd, stdout) != 0) { fprintf(stderr, "[E::%s] failed to write the index\n", "main_ropebwt2"); ret = 1; }
+			  tw1 = realtime();
+			  rb2_fmd_destroy(fmd);
+			  if (verbose >= 4) fprintf(stderr, "[M::%s] rest of the .fmd written in %.3f sec, encoder released in %.3f sec\n", "main_ropebwt2", tw1 - tw, realtime() - tw1); }
 		} else putchar('\n');
 	}
 	fflush(stdout);
-	mr_destroy(mr);
+	{ const double td = realtime(); mr_destroy(mr); if (verbose >= 4) fprintf(stderr, "[M::%s] index and device released in %.3f sec\n", "main_ropebwt2", realtime() - td); }
 	fprintf(stderr, "[M::%s] Version: %s\n[M::%s] CMD:", "main", RB2_VERSION, "main");
 	for (i = 0; i < argc; ++i) fprintf(stderr, " %s", argv[i]);
 	fprintf(stderr, "\n[M::%s] Real time: %.3f sec; CPU: %.3f sec\n", "main", realtime() - t0, cputime());

@@ -24,6 +24,7 @@
 #include "mrope.h"
 #include "rle.h"
 #include "rb2_hip.h"
+#define RB2_THP_WHICH 4
 #include "rb2_parcopy.h"
 
 typedef struct {
@@ -218,6 +219,7 @@ void mr_sync_host(mrope_t *mr)
 			for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
 			job[a].rb.p = (uint8_t*)malloc((size_t)ub);
 			job[a].rb.m = job[a].rb.p ? ub : 0;
+			rb2_hint_huge(job[a].rb.p, (size_t)ub);
 		}
 		clock_gettime(CLOCK_MONOTONIC, &t0);
 		dev_stream_rope(x, a, runbuf_add, &job[a].rb);
@@ -456,6 +458,7 @@ static int dump_without_trees(mrope_t *mr, FILE *fp)
 			for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
 			job[a].rb.p = (uint8_t*)malloc((size_t)ub);
 			job[a].rb.m = job[a].rb.p ? ub : 0;
+			rb2_hint_huge(job[a].rb.p, (size_t)ub);
 			clock_gettime(CLOCK_MONOTONIC, &t0);
 			dev_stream_rope(x, a, runbuf_add, &job[a].rb);
 			clock_gettime(CLOCK_MONOTONIC, &t1);

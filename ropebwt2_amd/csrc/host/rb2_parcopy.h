@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 typedef struct { uint8_t *d; const uint8_t *s; size_t n; } rb2_cpjob_t;
-static void *rb2_cp_worker(void *a) { rb2_cpjob_t *j = (rb2_cpjob_t*)a; memcpy(j->d, j->s, j->n); return 0; }
+static __attribute__((unused)) void *rb2_cp_worker(void *a) { rb2_cpjob_t *j = (rb2_cpjob_t*)a; memcpy(j->d, j->s, j->n); return 0; }
 static inline void rb2_par_memcpy(uint8_t *d, const uint8_t *s, int64_t n)
 {
 	enum { T = 4 };
@@ -23,4 +23,24 @@ static inline void rb2_par_memcpy(uint8_t *d, const uint8_t *s, int64_t n)
 	rb2_cp_worker(&job[0]);
 	for (k = 1; k < T; ++k) if (started >> k & 1) pthread_join(th[k], 0);
 }
+/* A large fresh buffer is faulted in 4 KiB at a time: 0.14 s per GB on the MI355X hosts, and as much again to give it back -- the
+ * 6 GB output array of the .fmd coder, the batch buffers and the run-byte buffers of a configs[1] run are 30 GB of that.  With
+ * transparent huge pages (the hosts run THP in `madvise` mode) the same costs 0.04 s per GB (tools/ubench/thp_probe.c).  Call it
+ * on a buffer of tens of MB or more right after (re)allocating it; a no-op where THP is off. */
+#include <sys/mman.h>
+#include <stdlib.h>
+static inline void rb2_hint_huge_which(void *p, size_t n, int which)
+{
+#ifdef MADV_HUGEPAGE
+	static int mask = -1;
+	if (mask < 0) { const char *e = getenv("RB2_THP"); mask = e ? atoi(e) : 15; }   /* 1: batch buffers, 4: run-byte buffers, 8: the .fmd array when its size is known up front */
+	if (!(mask & which)) return;
+	const size_t H = (size_t)2 << 20;
+	const size_t a = ((size_t)p + H - 1) & ~(H - 1), e = ((size_t)p + n) & ~(H - 1);
+	if (p && n >= ((size_t)32 << 20) && e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+#else
+	(void)p; (void)n;
+#endif
+}
+#define rb2_hint_huge(p, n) rb2_hint_huge_which(p, n, RB2_THP_WHICH)
 #endif

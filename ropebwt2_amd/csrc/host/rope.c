@@ -18,6 +18,8 @@
 #include <stdio.h>
 #include "rle.h"
 #include "rope.h"
+#define RB2_THP_WHICH 4
+#include "rb2_parcopy.h"
 
 /* ---------------------------------------------------------------------------------------------
  * arena: fixed-size zeroed items, never freed individually
@@ -600,6 +602,7 @@ static void *canon_worker(void *arg)
 	 * 4-byte run + a 1-byte run that crosses 2^19 an 8-byte one -- at worst 8 bytes out for 5 in.  Twice the input bounds it
 	 * (pages that are never written are never backed). */
 	j->out = (uint8_t*)malloc(2 * (size_t)j->n + 16);
+	rb2_hint_huge(j->out, 2 * (size_t)j->n + 16);
 	if (j->out == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes)\n", __func__, (long long)(2 * j->n + 16)); exit(1); }
 	j->out_n = canon_segment(j->in, j->in + j->n, j->out);
 	return 0;
