@@ -291,16 +291,24 @@ static int64_t bucket_dump_size(const rpnode_t *p)
 
 int64_t rope_dump_size(const rope_t *r) { return 8 + bucket_dump_size(r->root); }
 
-typedef struct { int fd; int64_t off; uint8_t *buf; int64_t n, cap; int err; } dumpw_t;
+typedef struct { int fd; int64_t off; uint8_t *buf; int64_t n, cap; int err; pthread_mutex_t *one; } dumpw_t;
+
+/* one file in tmpfs takes 6 GB/s from ONE writing thread and less from many (tools/ubench/tmpfs_write.c: 5.4 GB/s from 16, 3.8 from
+ * 32 -- the writes of one file serialise on its inode and the threads only add contention): writers that assemble their pieces in
+ * parallel take turns at the file (RB2_DUMP_TURNS=0: all at once) */
+static pthread_mutex_t g_dump_turn = PTHREAD_MUTEX_INITIALIZER;
+static int dump_turns(void) { static int v = -1; if (v < 0) { const char *e = getenv("RB2_DUMP_TURNS"); v = e ? atoi(e) : 1; } return v; }
 
 static void dumpw_flush(dumpw_t *w)
 {
 	int64_t done = 0;
+	if (w->one) pthread_mutex_lock(w->one);
 	while (done < w->n && !w->err) {
 		const ssize_t k = pwrite(w->fd, w->buf + done, (size_t)(w->n - done), (off_t)(w->off + done));
 		if (k <= 0) { w->err = 1; break; }
 		done += k;
 	}
+	if (w->one) pthread_mutex_unlock(w->one);
 	w->off += w->n; w->n = 0;
 }
 
@@ -343,7 +351,7 @@ int rope_dump_part_at(const rope_t *r, int part, int fd, int64_t off)
 {
 	dumpw_t w;
 	if (part == 0 && r->root->is_bottom) return rope_dump_at(r, fd, off);
-	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0; w.one = 0;
 	w.buf = (uint8_t*)malloc((size_t)w.cap);
 	if (w.buf == 0) return -1;
 	if (part == 0) {
@@ -360,7 +368,7 @@ int rope_dump_part_at(const rope_t *r, int part, int fd, int64_t off)
 int rope_dump_at(const rope_t *r, int fd, int64_t off)
 {
 	dumpw_t w;
-	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.fd = fd; w.off = off; w.n = 0; w.cap = 8 << 20; w.err = 0; w.one = 0;
 	w.buf = (uint8_t*)malloc((size_t)w.cap);
 	if (w.buf == 0) return -1;
 	dumpw_put(&w, &r->max_nodes, 4);
@@ -802,7 +810,7 @@ static void *rdump_worker(void *arg)
 	for (v = 0; v < d->nlev; ++v) o += 3 * ((j->k0 + d->span[v] - 1) / d->span[v]);   /* headers of the buckets that start in front of leaf k0 */
 	memset(&f, 0, sizeof(f));
 	f.seg = d->seg; f.pre = d->pre; f.nseg = d->nseg;
-	w.fd = j->fd; w.off = o; w.n = 0; w.cap = 8 << 20; w.err = 0;
+	w.fd = j->fd; w.off = o; w.n = 0; w.cap = 8 << 20; w.err = 0; w.one = dump_turns() ? &g_dump_turn : 0;
 	w.buf = (uint8_t*)malloc((size_t)w.cap);
 	if (w.buf == 0) { j->err = 1; return 0; }
 	for (k = j->k0; k < j->k1; ++k) {
