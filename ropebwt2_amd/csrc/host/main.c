@@ -244,6 +244,7 @@ typedef struct {
 	int fd;                                                     /* >= 0: the input is a plain (uncompressed) regular file -- read(2) it directly; zlib's transparent mode copies every byte twice */
 	int fastq, stop;                                            /* 1: blocks of whole four-line FASTQ records, 2: of whole FASTA records, instead of whole lines; the consumer asks the reader to stop (fallback) */
 	uint8_t *carry; int64_t n_carry, total;                     /* what the reader thread held back when it stopped, and how far it had read */
+	int direct; int64_t fsize; int last_is_nl;                  /* -L on a plain regular file: no reader thread -- block k is the lines that START in bytes [k, k + 1) * chunk, the workers pread them */
 	pthread_mutex_t mu; pthread_cond_t cv_work, cv_done, cv_space;
 } pparse_t;
 
@@ -356,12 +357,63 @@ static int pjob_encode_fasta(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
 	return 1;
 }
 
+/* -L on a plain regular file: the blocks need no reader thread to cut them -- one thread copying the file out of the page cache
+ * (6 GB/s from tmpfs) was the whole "read + parse + insert" time of configs[1] once the parsing was spread over the cores.  Block k is
+ * the lines that START in bytes [k * chunk, (k + 1) * chunk): its worker reads that range (and the byte in front of it, to know
+ * whether a line starts at its first byte), drops the tail of the line that started earlier, and reads on to the end of its last line. */
+static void pjob_fill_direct(pparse_t *pp, pjob_t *jb, int64_t k)
+{
+	const int64_t C = pp->chunk, size = pp->fsize, b0 = k * C, b1 = b0 + C < size ? b0 + C : size, from = b0 > 0 ? b0 - 1 : 0;
+	int64_t have = 0, start, end;
+	jb->stream_off = b0; jb->failed = 0; jb->n_in = 0; jb->at_eof = 0;
+	jb->extra_empty = (k + 1) * C >= size && size % RD_BUF == 0 && pp->last_is_nl;   /* kseq's phantom empty line (see pparse_reader), in the last block */
+	if (jb->m_in < 16) { jb->m_in = 16; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }   /* (pjob_encode may write in[n_in]) */
+	if (b1 <= from) return;
+	if (jb->m_in < (b1 - from) + 2) { jb->m_in = (b1 - from) + C + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+	while (have < b1 - from) {
+		const ssize_t r = pread(pp->fd, jb->in + have, (size_t)(b1 - from - have), (off_t)(from + have));
+		if (r <= 0) break;                                      /* the file shrank under us: what is there is the input */
+		have += r;
+	}
+	if (b0 == 0) start = 0;
+	else { const uint8_t *q = (const uint8_t*)memchr(jb->in, '\n', (size_t)have); start = q ? q - jb->in + 1 : have; }
+	if (start >= have) return;                                 /* no line starts in this block */
+	end = have;
+	while (jb->in[end - 1] != '\n' && from + end < size) {      /* the last line goes on behind the block */
+		const int64_t more = size - (from + end) < C ? size - (from + end) : C;
+		const uint8_t *q;
+		ssize_t r;
+		if (jb->m_in < end + more + 2) { jb->m_in = end + more + C + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+		r = pread(pp->fd, jb->in + end, (size_t)more, (off_t)(from + end));
+		if (r <= 0) break;
+		q = (const uint8_t*)memchr(jb->in + end, '\n', (size_t)r);
+		end = q ? q - jb->in + 1 : end + r;
+	}
+	memmove(jb->in, jb->in + start, (size_t)(end - start));
+	jb->n_in = end - start;
+	jb->at_eof = from + end >= size;
+}
+
 static void *pparse_worker(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
 	pthread_mutex_lock(&pp->mu);
 	for (;;) {
 		pjob_t *jb;
+		if (pp->direct) {                                       /* claim the next block as soon as its slot has been taken over by the consumer */
+			int64_t k;
+			while (pp->next_work < pp->n_queued && pp->next_work - pp->consumed >= pp->njob && !pp->closing) pthread_cond_wait(&pp->cv_space, &pp->mu);
+			if (pp->next_work >= pp->n_queued || pp->closing) break;
+			k = pp->next_work++;
+			jb = &pp->job[k % pp->njob];
+			pthread_mutex_unlock(&pp->mu);
+			pjob_fill_direct(pp, jb, k);
+			pjob_encode(&pp->cfg, jb);
+			pthread_mutex_lock(&pp->mu);
+			jb->state = 2;
+			pthread_cond_broadcast(&pp->cv_done);
+			continue;
+		}
 		while (pp->next_work >= pp->n_queued && !pp->closing) pthread_cond_wait(&pp->cv_work, &pp->mu);
 		if (pp->next_work >= pp->n_queued) break;
 		jb = &pp->job[pp->next_work++ % pp->njob];
@@ -748,8 +800,19 @@ int main(int argc, char *argv[])
 			if (stat(argv[optind], &st) == 0 && S_ISREG(st.st_mode)) pp.fd = open(argv[optind], O_RDONLY);
 		}
 		pthread_mutex_init(&pp.mu, 0); pthread_cond_init(&pp.cv_work, 0); pthread_cond_init(&pp.cv_done, 0); pthread_cond_init(&pp.cv_space, 0);
+		if (par == 1 && pp.fd >= 0 && !getenv("RB2_NO_DIRECT_BLOCKS")) {   /* -L, plain regular file: the workers read their blocks themselves */
+			struct stat st;
+			if (fstat(pp.fd, &st) == 0 && S_ISREG(st.st_mode)) {
+				uint8_t last = '\n';
+				pp.direct = 1; pp.fsize = (int64_t)st.st_size;
+				if (pp.fsize > 0 && pread(pp.fd, &last, 1, (off_t)(pp.fsize - 1)) != 1) last = 0;
+				pp.last_is_nl = last == '\n';
+				pp.n_queued = pp.fsize > 0 ? (pp.fsize + CHUNK - 1) / CHUNK : 1;
+				pp.eof = 1;
+			}
+		}
 		for (k = 0; k < pthr; ++k) pthread_create(&th[k], 0, pparse_worker, &pp);
-		pthread_create(&reader, 0, pparse_reader, &pp);
+		if (!pp.direct) pthread_create(&reader, 0, pparse_reader, &pp);
 		for (;;) {                                              /* take over the finished blocks, in order */
 			pjob_t *jb;
 			size_t done = 0, r0 = 0;
@@ -781,13 +844,13 @@ int main(int argc, char *argv[])
 			pthread_cond_broadcast(&pp.cv_space);
 			pthread_mutex_unlock(&pp.mu);
 		}
-		pthread_join(reader, 0);
-		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_mutex_unlock(&pp.mu);
+		if (!pp.direct) pthread_join(reader, 0);
+		pthread_mutex_lock(&pp.mu); pp.closing = 1; pthread_cond_broadcast(&pp.cv_work); pthread_cond_broadcast(&pp.cv_space); pthread_mutex_unlock(&pp.mu);
 		for (k = 0; k < pthr; ++k) pthread_join(th[k], 0);
 		free(th);
 		if (pp.fd >= 0) close(pp.fd);
 		need_seq = fell_back;
-		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : par == 3 ? "FASTA records" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
+		if (getenv("RB2_PARSE_TRACE")) fprintf(stderr, "[M::%s] %ld blocks of %s parsed by %ld threads%s\n", "main_ropebwt2", (long)pp.consumed, par == 2 ? "four-line FASTQ records" : par == 3 ? "FASTA records" : pp.direct ? "lines (read by the workers)" : "lines", pthr, fell_back ? ", then the sequential reader" : "");
 		if (fell_back) {                                        /* the blocks from the failed one on, what the reader held back, then the stream itself */
 			int64_t q;
 			int n = 0;

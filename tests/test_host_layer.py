@@ -446,6 +446,49 @@ def test_parallel_line_reader_equals_sequential(flags, tmp_path):
                 assert got == want, (flags, m, chunk, thr, len(data), len(got), len(want))
 
 
+def _dump_batches_file(flags, path, env, tmp_path, tag):
+    f = tmp_path / ("batches_%s.bin" % tag)
+    if f.exists():
+        f.unlink()
+    e = dict(os.environ, RB2_DUMP_BATCHES=str(f), RB2_NO_RESERVE="1")
+    e.update(env)
+    p = subprocess.run([CLI] + flags + [str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    return (f.read_bytes() if f.exists() else b""), p.stderr
+
+
+@pytest.mark.parametrize("flags", [["-L", "-R"], ["-L"], ["-L", "-N"], ["-L", "-x", "4", "-C"]])
+def test_line_blocks_read_by_the_workers_equal_sequential(flags, tmp_path):
+    """-L on a named plain file: no reader thread, block k = the lines that START in bytes [k, k + 1) * chunk, pread by its worker
+    (pjob_fill_direct).  Same batch stream as the sequential loop on the same bytes from stdin -- lines that span many blocks, blocks
+    in which no line starts, CR line ends, no final newline, an empty file, files of k x 16384 bytes (kseq's phantom empty line)"""
+    rng = np.random.RandomState(7 + len(" ".join(flags)))
+    lines = []
+    for i in range(3000):
+        L = int(rng.choice([0, 1, 3, 20, 101, 400, 5000], p=[.05, .05, .1, .3, .38, .1, .02]))
+        s = "".join(rng.choice(list("ACGTNacgtn"), size=L, p=[.22, .22, .22, .22, .03, .02, .02, .02, .02, .01]))
+        lines.append(s + ("\r" if rng.rand() < 0.1 else ""))
+    big = "\n".join(lines)
+    pad = lambda t, n: t + "A" * ((-len(t) - 1) % n) + "\n"                 # a multiple of n bytes, newline last
+    cases = {"many": big + "\n", "no_final_newline": big, "empty": "", "newline": "\n", "one": "ACGT", "k16384_nl": pad(big[:40000], 16384), "k16384_no_nl": pad(big[:40000], 16384)[:-1] + "C",
+             "exactly_one_buffer": ("A" * 15 + "\n") * 1024, "one_line_longer_than_all_blocks": "ACGT" * 9000 + "\n" + "GG\n"}
+    for name, data in cases.items():
+        data = data.encode()
+        path = tmp_path / ("%s.txt" % name)
+        path.write_bytes(data)
+        for m in ("-m20k", "-m1g"):
+            want = _dump_batches(flags + [m], data, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq")
+            for chunk, thr in (("64", "3"), ("1000", "2"), ("16384", "4"), ("70000", "5"), ("0", "4")):
+                env = {"RB2_PARSE_THREADS": thr, "RB2_PARSE_TRACE": "1"}
+                if chunk != "0":
+                    env["RB2_PARSE_CHUNK"] = chunk
+                got, err = _dump_batches_file(flags + [m], path, env, tmp_path, "direct")
+                assert b"read by the workers" in err
+                assert got == want, (name, flags, m, chunk, thr, len(data), len(got), len(want))
+        got, err = _dump_batches_file(flags + ["-m1g"], path, {"RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": "1000", "RB2_NO_DIRECT_BLOCKS": "1", "RB2_PARSE_TRACE": "1"}, tmp_path, "reader")
+        assert b"read by the workers" not in err and got == _dump_batches(flags + ["-m1g"], data, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq"), name
+
+
 def test_line_reader_batches_match_python_model(tmp_path):
     """the dumped batch of the threaded reader is what helpers.encode_batch builds (main.c:200-237)"""
     codes = H.splitmix_bases(3000, 50, seed=2)

@@ -171,3 +171,21 @@ def test_sanitized_parallel_fasta_reader(san_cli, tmp_path):
             if dump.exists():
                 dump.unlink()
             run(san_cli, ["-m40k", "-C"], ins[name], env={"RB2_DUMP_BATCHES": str(dump), "RB2_PARSE_THREADS": "4", "RB2_PARSE_CHUNK": chunk})
+
+
+def test_sanitized_line_blocks_read_by_the_workers(san_cli, tmp_path):
+    """-L on a named plain file: the workers pread their own blocks (pjob_fill_direct) -- long lines across blocks, empty file, no final newline -- under ASan/UBSan"""
+    rng = np.random.RandomState(3)
+    lines = ["".join(rng.choice(list("ACGTN"), size=int(rng.choice([0, 1, 50, 101, 3000])))) for _ in range(800)]
+    dump = tmp_path / "b.bin"
+    for name, data in (("many", "\n".join(lines) + "\n"), ("no_nl", "\n".join(lines)), ("empty", ""), ("long", "ACGT" * 5000 + "\nA\n"), ("k16384", ("A" * 15 + "\n") * 1024)):
+        path = tmp_path / (name + ".txt")
+        path.write_bytes(data.encode())
+        for chunk in ("64", "1000", "16384"):
+            if dump.exists():
+                dump.unlink()
+            e = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", RB2_DUMP_BATCHES=str(dump), RB2_PARSE_THREADS="4",
+                     RB2_PARSE_CHUNK=chunk, RB2_NO_RESERVE="1")
+            p = subprocess.run([san_cli, "-L", "-m30k", "-C", str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+            assert p.returncode == 0, p.stderr.decode()[-2000:]
+            assert b"ERROR: AddressSanitizer" not in p.stderr and b"runtime error" not in p.stderr, p.stderr.decode()[-2000:]
