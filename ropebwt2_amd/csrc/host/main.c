@@ -771,8 +771,9 @@ int main(int argc, char *argv[])
 	long pthr = sysconf(_SC_NPROCESSORS_ONLN) - 1;
 	cfg.flag = flag; cfg.min_q = min_q; cfg.min_cut = min_cut; cfg.batch = m != 0;
 	PF.on = m >= (int64_t)(2 * PF_STEP) && !getenv("RB2_DUMP_BATCHES") && !getenv("RB2_SYNC_INSERT") && !getenv("RB2_NO_PREFETCH");   /* batches worth announcing */
-	if (getenv("RB2_PARSE_THREADS")) pthr = atol(getenv("RB2_PARSE_THREADS"));
 	if (pthr > 16) pthr = 16;
+	if (getenv("RB2_PARSE_THREADS")) pthr = atol(getenv("RB2_PARSE_THREADS"));
+	if (pthr > 30) pthr = 30;                                 /* (62 block slots, two per thread) */
 	{
 	int par = 0, need_seq = 1;                              /* 1: -L, blocks of whole lines; 2: FASTQ, blocks of whole four-line records (pjob_encode_fastq) */
 	pparse_t pp;
