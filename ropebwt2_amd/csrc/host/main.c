@@ -466,9 +466,12 @@ static void *pparse_reader(void *arg)
 		jb->stream_off = total - n_carry; jb->failed = 0;
 		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
 		memcpy(jb->in, carry, n_carry);
+		if (pp->fd >= 0) {                                    /* a plain regular file: four threads copy the block out of the page cache */
+			got = rb2_par_pread(pp->fd, jb->in + n_carry, CHUNK, total);
+			if (got < CHUNK) eof = 1;
+		} else
 		while (got < CHUNK) {                                 /* gzread may return short counts on pipes */
-			const int64_t r = pp->fd >= 0 ? (int64_t)read(pp->fd, jb->in + n_carry + got, (size_t)(CHUNK - got))
-			                              : (int64_t)gzread(pp->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
+			const int64_t r = (int64_t)gzread(pp->fp, jb->in + n_carry + got, (unsigned)(CHUNK - got));
 			if (r <= 0) { eof = 1; break; }
 			got += r;
 		}

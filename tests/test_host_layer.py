@@ -642,6 +642,21 @@ def test_named_files_plain_and_gz(tmp_path):
         assert all(o == outs[0] for o in outs), name
 
 
+def test_big_named_fastq_and_fasta_blocks_of_16_mib(tmp_path):
+    """default 16 MiB blocks on files of several blocks: the reader thread fills a block with four preads side by side (rb2_par_pread);
+    same batches as the sequential reader, also when the input stops being strict in the third block"""
+    fq, fa = _fastq_inputs(), _fasta_inputs()
+    big_fq = fq["strict"] * 140                                       # ~45 MB
+    cases = [("fq", big_fq, ["-R"]), ("fq_broken", big_fq[:36 << 20] + b"@m\nACGT\nAC\n+\nIIII\nII\n" + fq["strict"], ["-R"]), ("fa", fa["wrapped60"] * 70, ["-R"])]
+    for name, data, flags in cases:
+        path = tmp_path / (name + ".txt")
+        path.write_bytes(data)
+        want, _ = _dump_batches_file(flags + ["-m8m"], path, {"RB2_PARSE_THREADS": "1"}, tmp_path, "seq")
+        got, err = _dump_batches_file(flags + ["-m8m"], path, {"RB2_PARSE_THREADS": "5", "RB2_PARSE_TRACE": "1"}, tmp_path, "par")
+        assert b"parsed by 5 threads" in err and (b"then the sequential" in err) == (name == "fq_broken"), err.decode()[-300:]
+        assert got == want, name
+
+
 def test_parallel_fastq_reader_really_runs_and_falls_back(tmp_path):
     """the strict input is parsed by the workers (no fallback message), the broken one reports where it went sequential"""
     ins = _fastq_inputs()
