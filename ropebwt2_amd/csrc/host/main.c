@@ -449,6 +449,25 @@ static int64_t count_newlines(const uint8_t *p, int64_t n)   /* eight bytes per 
 	return c;
 }
 
+typedef struct { const uint8_t *p; int64_t n, c; } nljob_t;
+static void *nl_worker(void *a) { nljob_t *j = (nljob_t*)a; j->c = count_newlines(j->p, j->n); return 0; }
+static int64_t count_newlines_par(const uint8_t *p, int64_t n)   /* four threads: at 8 GB/s the count of a 16 MiB block was most of what the FASTQ reader thread did */
+{
+	enum { T = 4 };
+	nljob_t job[T]; pthread_t th[T]; int k, started = 0;
+	int64_t c = 0;
+	if (n < (2 << 20)) return count_newlines(p, n);
+	for (k = 0; k < T; ++k) {
+		const int64_t o = n / T * k;
+		job[k].p = p + o; job[k].n = k == T - 1 ? n - o : n / T; job[k].c = 0;
+		if (k > 0) { if (pthread_create(&th[k], 0, nl_worker, &job[k]) == 0) started |= 1 << k; else nl_worker(&job[k]); }
+	}
+	nl_worker(&job[0]);
+	for (k = 1; k < T; ++k) if (started >> k & 1) pthread_join(th[k], 0);
+	for (k = 0; k < T; ++k) c += job[k].c;
+	return c;
+}
+
 static void *pparse_reader(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
@@ -489,7 +508,7 @@ static void *pparse_reader(void *arg)
 			} else
 			for (cut = jb->n_in; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
 			if (pp->fastq == 1 && cut > 0) {                         /* ... and, for FASTQ, the lines behind the last multiple of four: a block holds whole records */
-				const int64_t nl = count_newlines(jb->in, cut);
+				const int64_t nl = count_newlines_par(jb->in, cut);
 				int back;
 				for (back = (int)(nl & 3); back > 0; --back) for (--cut; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
 			}
