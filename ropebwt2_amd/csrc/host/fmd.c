@@ -64,6 +64,11 @@ static void reserve(rb2_fmd_t *f, size_t n_words)
 	f->w = (uint64_t*)realloc(f->w, nc * 8);
 	if (f->wmu) pthread_mutex_unlock(f->wmu);
 	if (!f->w) { fprintf(stderr, "[rb2_fmd] out of memory (%zu words)\n", nc); abort(); }
+	{	/* tests: fresh words hold garbage, not the zeros a new mapping happens to bring (nothing may rely on them) */
+		static int poison = -1;
+		if (poison < 0) poison = getenv("RB2_FMD_POISON") != 0;
+		if (poison) memset(f->w + f->cap, 0xA5, (nc - f->cap) * 8);
+	}
 	f->cap = nc;                                              /* (not zeroed: every block is zeroed when it is opened -- most blocks of the parallel writer are copied over whole) */
 }
 
@@ -400,12 +405,14 @@ static void spec_encode(fseg_t *sg)
 	memset(sg->sum, 0, sizeof(sg->sum));
 	while (i < n) {                                           /* the straddling run belongs to the true orbit: skip it (but count it) */
 		const int nb = run_at(q + i, &c, &l);
+		if (l == 0) { i += nb; continue; }
 		if (c != sg->prev_sym) break;
 		sg->sum[0] += l; sg->sum[c + 1] += l; i += nb;
 	}
 	f->start[0] = (uint32_t)i; f->type[0] = 0;
 	while (i < n) {
 		const int nb = run_at(q + i, &c, &l);
+		if (l == 0) { i += nb; continue; }
 		sg->sum[0] += l; sg->sum[c + 1] += l;
 		if (c == pc) pl += l;
 		else {
@@ -485,8 +492,14 @@ static void queue_fill(rb2_fmdp_t *p)                          /* hand the segme
 	{	/* symbol of the segment's last run: its head byte is the last byte that is not a continuation byte (rle.h:39-51) */
 		fseg_t *sg = p->seg[p->nseg - 1];
 		int64_t k = sg->n - 1;
-		while (k > 0 && (sg->runs[k] & 0xC0) == 0x80) --k;
-		sg->prev_sym_out = sg->n > 0 ? (sg->runs[k] & 7) : sg->prev_sym;
+		sg->prev_sym_out = sg->prev_sym;
+		while (k >= 0) {                                          /* ... that holds symbols: empty runs do not exist for the coder (rld_enc, rld0.c:155) */
+			int c; int64_t l;
+			while (k > 0 && (sg->runs[k] & 0xC0) == 0x80) --k;
+			run_at(sg->runs + k, &c, &l);
+			if (l > 0) { sg->prev_sym_out = c; break; }
+			--k;
+		}
 	}
 	pthread_mutex_lock(&p->mu);
 	p->seg[p->nseg - 1]->state = 1;
@@ -572,6 +585,7 @@ static void stitch(rb2_fmdp_t *p)                             /* body of the sti
 		while (i < n) {
 			int c, w; int64_t l;
 			const int nb = run_at(q + i, &c, &l);
+			if (l == 0) { i += nb; continue; }                  /* (an empty run is no run: it must not separate two runs of one symbol) */
 			if (c == f->pend_c) { f->pend_l += l; i += nb; continue; }
 			if (f->pend_l) {                                   /* flush the pending maximal run: it started at f->run_pos of segment pend_seg */
 				const uint64_t x = run_code(f->pend_l, f->pend_c, &w);

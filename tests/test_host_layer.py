@@ -302,6 +302,27 @@ def test_parallel_fmd_writer_wide_runs(threads, seg, tmp_path):
     assert a == b
 
 
+@pytest.mark.parametrize("threads,seg", [(1, 256), (3, 2000), (4, 70000), (8, 0)])
+def test_parallel_fmd_writer_ignores_empty_runs_like_the_sequential_one(threads, seg, tmp_path):
+    """zero-length runs (a hand-made .fmr may hold them; the reference's coder drops them, rld0.c:155) must not separate two runs of one
+    symbol -- also not across a segment border --, and fresh words of the output array may hold garbage (RB2_FMD_POISON)"""
+    os.environ["RB2_FMD_POISON"] = "1"
+    try:
+        for seed in (5, 6, 7):
+            stream = np.frombuffer(_mixed_run_stream(seed, 80000), np.uint8)
+            cuts = [0]
+            rng = np.random.RandomState(seed)
+            while cuts[-1] < len(stream):
+                c = min(len(stream), cuts[-1] + int(rng.randint(1, 30000)))
+                while c < len(stream) and (stream[c] & 0xC0) == 0x80:
+                    c += 1
+                cuts.append(c)
+            a, b = _write_both(_fmd_lib(), [stream[x:y] for x, y in zip(cuts[:-1], cuts[1:])], threads, seg, tmp_path)
+            assert a == b, seed
+    finally:
+        del os.environ["RB2_FMD_POISON"]
+
+
 def test_parallel_fmd_writer_crosses_a_chunk_border(tmp_path):
     """more than 64 MiB of output: the last block of a 2^23-word chunk is one word shorter (rld0.h:75), which the speculative
     encodings cannot know -- the stitcher re-encodes from there until it couples again"""
