@@ -13,11 +13,17 @@ from ropebwt2_amd import HipBwt, MultiBwt, build_all
 build_all(); H.build_oracle()
 
 def gen_batch(rng, so):
-    kind = rng.choice(["fixed", "var", "repet", "homo", "tiny", "long"], p=[.3, .2, .2, .1, .1, .1])
+    kind = rng.choice(["fixed", "var", "repet", "homo", "tiny", "long", "big", "cover"], p=[.26, .18, .18, .1, .1, .1, .04, .04])
     both = bool(rng.rand() < 0.4)
     if kind == "fixed":
         codes = H.splitmix_bases(int(rng.randint(1, 6000)), int(rng.choice([1, 2, 17, 50, 101, 150])), seed=int(rng.randint(1, 1 << 30)))
         return H.encode_batch_fixed(codes, True, both)
+    if kind == "big":                                             # enough strings for the dense regime on a grown index, and for several tiles per piece
+        return H.encode_batch_fixed(H.splitmix_bases(int(rng.randint(20000, 60000)), 101, seed=int(rng.randint(1, 1 << 30))), True, both)
+    if kind == "cover":                                           # overlapping reads of one genome: non-empty intervals for many rounds, large groups
+        g = rng.randint(1, 5, size=3000).astype(np.uint8); L = int(rng.choice([50, 101]))
+        st = rng.randint(0, len(g) - L, size=int(rng.randint(3000, 15000)))
+        return H.encode_batch_fixed(np.stack([g[x:x + L] for x in st]), True, both)
     if kind == "var":
         n = int(rng.randint(1, 3000))
         reads = [rng.randint(1, 6, size=int(rng.choice([0, 1, 3, 30, 90, 400], p=[.05, .1, .1, .3, .35, .1]))).astype(np.uint8) for _ in range(n)]
