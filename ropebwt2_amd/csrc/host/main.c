@@ -28,7 +28,14 @@
 
 /* ---- tiny growable byte string ---------------------------------------------------------------- */
 typedef struct { size_t l, m; char *s; } str_t;
-static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need + (need >> 1) + 64; s->s = (char*)realloc(s->s, s->m); rb2_hint_huge(s->s, s->m); } }
+/* the CLI cannot go on without its buffers: say so instead of writing through a null pointer */
+static void *xrealloc(void *p, size_t n)
+{
+	void *q = realloc(p, n ? n : 1);
+	if (q == 0) { fprintf(stderr, "[E::%s] out of memory (%zu bytes)\n", "main_ropebwt2", n); exit(1); }
+	return q;
+}
+static void str_reserve(str_t *s, size_t need) { if (need > s->m) { s->m = need + (need >> 1) + 64; s->s = (char*)xrealloc(s->s, s->m); rb2_hint_huge(s->s, s->m); } }
 static void str_putc(str_t *s, int c) { str_reserve(s, s->l + 2); s->s[s->l++] = (char)c; s->s[s->l] = 0; }
 static void str_append(str_t *s, const char *p, size_t n) { str_reserve(s, s->l + n + 1); memcpy(s->s + s->l, p, n); s->l += n; s->s[s->l] = 0; }
 
@@ -266,7 +273,7 @@ static void pjob_encode(const enc_cfg_t *cfg, pjob_t *jb)
 		l = prepare_record(cfg, p, l, 0, 0);
 		if (l >= 0) {
 			append_strands(cfg, p, l, &jb->out);
-			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)xrealloc(jb->rec_end, jb->m_rec * 4); }
 			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
 		}
 		p = next;
@@ -306,7 +313,7 @@ static int pjob_encode_fastq(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
 		l = prepare_record(cfg, (uint8_t*)tmp->s, sl, (const char*)ln[3], ql);
 		if (l >= 0) {
 			append_strands(cfg, (uint8_t*)tmp->s, l, &jb->out);
-			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)xrealloc(jb->rec_end, jb->m_rec * 4); }
 			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
 		}
 	}
@@ -350,7 +357,7 @@ static int pjob_encode_fasta(const enc_cfg_t *cfg, pjob_t *jb, str_t *tmp)
 			const size_t before = jb->out.l;
 			append_strands(cfg, (uint8_t*)tmp->s, l, &jb->out);
 			if (jb->out.l > 0xffffffffu) { jb->out.l = before; return 0; }   /* rec_end is 32 bit: a block of > 4 GB of codes (one huge record, both strands) */
-			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)realloc(jb->rec_end, jb->m_rec * 4); }
+			if (jb->n_rec == jb->m_rec) { jb->m_rec = jb->m_rec ? jb->m_rec * 2 : 1 << 16; jb->rec_end = (uint32_t*)xrealloc(jb->rec_end, jb->m_rec * 4); }
 			jb->rec_end[jb->n_rec++] = (uint32_t)jb->out.l;
 		}
 	}
@@ -367,9 +374,9 @@ static void pjob_fill_direct(pparse_t *pp, pjob_t *jb, int64_t k)
 	int64_t have = 0, start, end;
 	jb->stream_off = b0; jb->failed = 0; jb->n_in = 0; jb->at_eof = 0;
 	jb->extra_empty = (k + 1) * C >= size && size % RD_BUF == 0 && pp->last_is_nl;   /* kseq's phantom empty line (see pparse_reader), in the last block */
-	if (jb->m_in < 16) { jb->m_in = 16; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }   /* (pjob_encode may write in[n_in]) */
+	if (jb->m_in < 16) { jb->m_in = 16; jb->in = (uint8_t*)xrealloc(jb->in, jb->m_in); }   /* (pjob_encode may write in[n_in]) */
 	if (b1 <= from) return;
-	if (jb->m_in < (b1 - from) + 2) { jb->m_in = (b1 - from) + C + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+	if (jb->m_in < (b1 - from) + 2) { jb->m_in = (b1 - from) + C + 2; jb->in = (uint8_t*)xrealloc(jb->in, jb->m_in); }
 	while (have < b1 - from) {
 		const ssize_t r = pread(pp->fd, jb->in + have, (size_t)(b1 - from - have), (off_t)(from + have));
 		if (r <= 0) break;                                      /* the file shrank under us: what is there is the input */
@@ -383,7 +390,7 @@ static void pjob_fill_direct(pparse_t *pp, pjob_t *jb, int64_t k)
 		const int64_t more = size - (from + end) < C ? size - (from + end) : C;
 		const uint8_t *q;
 		ssize_t r;
-		if (jb->m_in < end + more + 2) { jb->m_in = end + more + C + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+		if (jb->m_in < end + more + 2) { jb->m_in = end + more + C + 2; jb->in = (uint8_t*)xrealloc(jb->in, jb->m_in); }
 		r = pread(pp->fd, jb->in + end, (size_t)more, (off_t)(from + end));
 		if (r <= 0) break;
 		q = (const uint8_t*)memchr(jb->in + end, '\n', (size_t)r);
@@ -472,7 +479,7 @@ static void *pparse_reader(void *arg)
 {
 	pparse_t *pp = (pparse_t*)arg;
 	const int64_t CHUNK = pp->chunk;
-	uint8_t *carry = (uint8_t*)malloc(CHUNK + 16); int64_t n_carry = 0, m_carry = CHUNK + 16, total = 0;
+	uint8_t *carry = (uint8_t*)xrealloc(0, CHUNK + 16); int64_t n_carry = 0, m_carry = CHUNK + 16, total = 0;
 	int last_byte = '\n', eof = 0;
 	while (!eof) {
 		pjob_t *jb;
@@ -483,7 +490,7 @@ static void *pparse_reader(void *arg)
 		jb = &pp->job[pp->n_queued % pp->njob];                /* free: taken over by the main thread already */
 		pthread_mutex_unlock(&pp->mu);
 		jb->stream_off = total - n_carry; jb->failed = 0;
-		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)realloc(jb->in, jb->m_in); }
+		if (jb->m_in < CHUNK + n_carry + 2) { jb->m_in = CHUNK + n_carry + 2; jb->in = (uint8_t*)xrealloc(jb->in, jb->m_in); }
 		memcpy(jb->in, carry, n_carry);
 		if (pp->fd >= 0) {                                    /* a plain regular file: four threads copy the block out of the page cache */
 			got = rb2_par_pread(pp->fd, jb->in + n_carry, CHUNK, total);
@@ -513,7 +520,7 @@ static void *pparse_reader(void *arg)
 				for (back = (int)(nl & 3); back > 0; --back) for (--cut; cut > 0 && jb->in[cut - 1] != '\n'; --cut);
 			}
 			n_carry = jb->n_in - cut;                           /* (cut == 0: one line longer than a block -- everything is carried on) */
-			if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)realloc(carry, m_carry); }
+			if (n_carry > m_carry) { m_carry = n_carry + CHUNK; carry = (uint8_t*)xrealloc(carry, m_carry); }
 			memcpy(carry, jb->in + cut, n_carry);
 			jb->n_in = cut;
 		} else n_carry = 0;

@@ -169,7 +169,10 @@ typedef struct { uint8_t *p; int64_t n, m; } runbuf_t;
 static void runbuf_add(void *user, const uint8_t *q, int64_t n)
 {
 	runbuf_t *b = (runbuf_t*)user;
-	if (b->n + n > b->m) { b->m = (b->n + n) + ((b->n + n) >> 1) + (1 << 20); b->p = (uint8_t*)realloc(b->p, b->m); }
+	if (b->n + n > b->m) {
+		b->m = (b->n + n) + ((b->n + n) >> 1) + (1 << 20); b->p = (uint8_t*)realloc(b->p, b->m);
+		if (b->p == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes of run bytes)\n", "mr_sync_host", (long long)b->m); exit(1); }
+	}
 	rb2_par_memcpy(b->p + b->n, q, n); b->n += n;              /* (four threads: rb2_parcopy.h) */
 }
 
@@ -590,7 +593,10 @@ static void raw_bucket(rawld_t *w, int64_t c[6])
 			memcpy(lc, q, 48);
 			nb = q[48] | q[49] << 8;
 			if (nb + 2 > w->block_len || (q = raw_take(w, nb)) == 0) { w->err = 1; return; }
-			if (w->n + nb > w->m) { w->m = (w->n + nb) + ((w->n + nb) >> 1) + (1 << 20); w->p = (uint8_t*)realloc(w->p, (size_t)w->m); }
+			if (w->n + nb > w->m) {
+				w->m = (w->n + nb) + ((w->n + nb) >> 1) + (1 << 20); w->p = (uint8_t*)realloc(w->p, (size_t)w->m);
+				if (w->p == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes of run bytes)\n", "mr_restore_runs", (long long)w->m); exit(1); }
+			}
 			memcpy(w->p + w->n, q, (size_t)nb);
 			w->n += nb;
 			for (a = 0; a < 6; ++a) c[a] += lc[a];
