@@ -4,11 +4,17 @@
 //
 //   sub-rope      rope b is kept as six independent pieces (b,x), x = the symbol following b in the
 //                 row's suffix; NR = 31 pieces (see below).  A piece is a flat array of 3-bit symbols.
-//   leaf          LEAF symbols of one piece, 3 bits each (LEAFB bytes; symbol i in bits 3(i%21).. of
-//                 64-bit word i/21, bit 63 unused).  Every leaf of a piece holds exactly LEAF symbols except the
-//                 last, so "which leaf holds position p" is p / LEAF -- no B+ tree descent (the
-//                 reference walks rpnode_t buckets, rope.c:119-134).  Run-length coding (rle.h:39-75)
-//                 only happens on export (k_export).
+//   group         GSYM = 64 consecutive symbols as three 64-bit BIT PLANES: bit i of plane k = bit k of symbol i.
+//                 Counting symbols is popcounts of dense words, a symbol compare is two ANDs of XORed planes, and every
+//                 position -> (word, bit) computation is a shift (rounds 1-3 packed 21 three-bit fields into a word:
+//                 divisions by 21 and 1344 everywhere, 22 VALU per 21 symbols for the counts).
+//   leaf          LEAFG = 16 groups = LEAF = 1024 symbols = LEAFW = 48 words = LEAFB = 384 bytes = three 128-byte
+//                 lines, PLANE-MAJOR: word pl * 16 + g holds plane pl of group g.  A leaf is one DPP row of 16 lanes
+//                 (lane = group, the three planes in registers): a wave works on four leaves at once and every
+//                 wave-level load or store moves whole 128-byte lines.
+//                 Dense layout: every leaf of a piece holds exactly LEAF symbols except the last, so "which leaf
+//                 holds position p" is p >> 10 -- no B+ tree descent (the reference walks rpnode_t buckets,
+//                 rope.c:119-134).  Run-length coding (rle.h:39-75) only happens on export (k_export).
 //   LeafMeta      16 B per leaf: per-symbol counts of the preceding leaves of the same superblock
 //                 (u16 x 6), their total (npre) and the leaf's own fill (n).  A second array (`own`)
 //                 holds every leaf's own counts: the merge kernels write it, k_meta_sb turns it into
@@ -16,10 +22,10 @@
 //   sparse layout the same arrays, but leaves carry SLACK (fill <= LEAF, only the first few slots of
 //                 a superblock in use): rounds that touch few leaves insert IN PLACE into the leaves
 //                 they hit (k_merge_leaf) instead of rewriting the piece, and position -> leaf becomes
-//                 a search over sbpos / npre (locate()) instead of a division -- the counterpart of
+//                 a search over sbpos / the fills (locate()) instead of a shift -- the counterpart of
 //                 the reference's B+ tree descent (rope.c:119-134) with its half-full leaves.
 //   superblock    SB consecutive leaves; Cnt6 (6 x u64) exclusive prefix of symbol counts over
-//                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf scan  (rope_rank2a,
+//                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf popcounts  (rope_rank2a,
 //                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
 //   pool          two sides (ping-pong); each round the merge kernel streams side -> side^1.
 //   strings       SoA per-string state (reference triple64_t, mrope.c:174-178): L, U (interval in
@@ -30,13 +36,19 @@
 
 namespace rb2 {
 
-constexpr int SBITS  = 3;              // bits per symbol ($ACGTN = 0..5)
-constexpr int SPW    = 21;             // symbols per 64-bit word (bit 63 unused)
-constexpr int LEAFW  = 64;             // words per leaf: one per lane of a wave
-constexpr int LEAF   = SPW * LEAFW;    // 1344 symbols per leaf
+constexpr int SBITS  = 3;              // bit planes per symbol ($ACGTN = 0..5)
+constexpr int GSYM   = 64;             // symbols per group (one 64-bit word per plane)
+constexpr int LEAFG  = 16;             // groups per leaf: one per lane of a DPP row
+constexpr int LEAFW  = SBITS * LEAFG;  // 48 words per leaf, plane-major: word pl * LEAFG + g
+constexpr int LEAF   = GSYM * LEAFG;   // 1024 symbols per leaf
+constexpr int LEAF_SH = 10;            // log2(LEAF)
 constexpr int SB     = 32;            // leaves per superblock
-constexpr int LEAFB  = LEAFW * 8;      // bytes per leaf
-constexpr int WPL    = 4;              // 64-bit words per lane in k_merge: one wave rewrites WPL consecutive leaves (a window)
+constexpr int LEAFB  = LEAFW * 8;      // 384 bytes per leaf
+#ifndef RB2_GPL
+#define RB2_GPL 1
+#endif
+constexpr int GPL    = RB2_GPL;        // groups per lane in k_merge: one wave rewrites a window of 64 * GPL groups
+constexpr int WPL    = 64 * GPL / LEAFG;   // leaves per window
 constexpr int WIN    = WPL * LEAF;     // symbols per window
 constexpr int STILE  = 512;           // strings per string tile
 constexpr int MW     = 4;             // waves per block in the one-wave-per-leaf / per-window kernels
@@ -54,7 +66,7 @@ __host__ __device__ inline int rope_prev(int r) { return r == 0 ? 0 : (r - 1) % 
 __host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (a - 1) * 6 + b; }
 
 struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: prefixes inside the superblock + own fill; own[]: own counts + own fill
-constexpr int SP_FILL = 1008;          // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 336 inserts)
+constexpr int SP_FILL = 768;           // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 256 inserts)
 constexpr int SP_USED = 24;            // ... leaf slots in use per superblock; the other 8 are the superblock's own reserve: a leaf that comes within
                                        // SP_MARGIN symbols of LEAF is split into one of them at the end of the round (k_split: the counterpart of the
                                        // reference's leaf split, rope.c:143-146 / split_node rope.c:78-112, one level of its B+ tree)
@@ -237,53 +249,41 @@ __device__ __forceinline__ uint64_t lt_mask(int lane) { return lane ? (~0ull >> 
 // RLO / input order: $ A C G T N;  RCLO: $ T G C A N
 __device__ __forceinline__ int sym_ord(int a, int is_comp) { return (is_comp && a >= 1 && a <= 4) ? 5 - a : a; }
 
-// symbol counts of packed 3-bit symbols (21 per word, symbol i in bits 3i..3i+2).  Valid symbols are 0..5 = 000..101,
-// so with the bit planes b0,b1,b2 (one bit per symbol): #3 = |b0&b1|, #2 = |b1|-#3, #5 = |b0&b2|, #4 = |b2|-#5, #1 = |b0|-#3-#5.
-constexpr uint64_t MLOW = 0x1249249249249249ull;           // bit 3i for i = 0..20
-constexpr uint64_t MALL = 0x7fffffffffffffffull;           // the 63 payload bits
-struct NibAcc { uint32_t p0 = 0, p1 = 0, p2 = 0, p01 = 0, p02 = 0; };
-__device__ __forceinline__ void nib_acc(NibAcc &A, uint64_t x, uint64_t M /* bits 3i of the symbols to count */)
+// symbol counts from bit planes.  Valid symbols are 0..5 = 000..101, so with the planes b0,b1,b2 (one bit per symbol, already
+// masked to the symbols to count): #3 = |b0&b1|, #2 = |b1|-#3, #5 = |b0&b2|, #4 = |b2|-#5, #1 = |b0|-#3-#5.
+struct PlAcc { uint32_t p0 = 0, p1 = 0, p2 = 0, p01 = 0, p02 = 0; };
+__device__ __forceinline__ void pl_acc(PlAcc &A, uint64_t b0, uint64_t b1, uint64_t b2, uint64_t M /* the symbols to count */)
 {
-	const uint64_t b0 = x & M, b1 = (x >> 1) & M, b2 = (x >> 2) & M;
+	b0 &= M; b1 &= M; b2 &= M;
 	A.p0 += (uint32_t)__popcll(b0); A.p1 += (uint32_t)__popcll(b1); A.p2 += (uint32_t)__popcll(b2);
 	A.p01 += (uint32_t)__popcll(b0 & b1); A.p02 += (uint32_t)__popcll(b0 & b2);
 }
-__device__ __forceinline__ void nib_finish(const NibAcc &A, uint32_t n, uint32_t c[6])
+__device__ __forceinline__ void pl_finish(const PlAcc &A, uint32_t n, uint32_t c[6])
 {
 	c[3] = A.p01; c[2] = A.p1 - A.p01; c[5] = A.p02; c[4] = A.p2 - A.p02; c[1] = A.p0 - A.p01 - A.p02;
 	c[0] = n - (c[1] + c[2] + c[3] + c[4] + c[5]);
 }
+// bit i set: symbol i of the group equals a
+__device__ __forceinline__ uint64_t pl_eq(uint64_t b0, uint64_t b1, uint64_t b2, uint32_t a)
+{
+	const uint64_t m0 = 0ull - (uint64_t)(~a & 1u), m1 = 0ull - (uint64_t)(~(a >> 1) & 1u), m2 = 0ull - (uint64_t)(~(a >> 2) & 1u);   // all ones where the bit of a is CLEAR
+	return (b0 ^ m0) & (b1 ^ m1) & (b2 ^ m2);
+}
 
-// all bits of the first n symbols of a word
-__device__ __forceinline__ uint64_t nib_below(uint32_t n) { return n >= (uint32_t)SPW ? MALL : (1ull << (SBITS * n)) - 1ull; }
-// accumulate the symbols at [from, to) of one packed leaf (16-byte loads = two words; edge words are masked)
-__device__ inline void leaf_count(const uint4 *q, uint32_t from, uint32_t to, NibAcc &A)
+// the first n positions of a group, n <= 64
+__device__ __forceinline__ uint64_t bits_below(uint32_t n) { return n >= 64u ? ~0ull : (1ull << n) - 1ull; }
+// word pl * LEAFG + g of leaf slot gl
+__device__ __forceinline__ const uint64_t *leaf_words(const uint8_t *data, uint64_t gl) { return (const uint64_t*)data + gl * LEAFW; }
+// accumulate the symbols at [from, to) of one leaf, by one thread: the groups the interval touches, three words each
+__device__ inline void leaf_count(const uint64_t *lw, uint32_t from, uint32_t to, PlAcc &A)
 {
 	if (from >= to) return;
-	const uint32_t c0 = from / (2 * SPW), c1 = (to - 1) / (2 * SPW);
-	auto edge = [&](uint32_t c) {
-		const uint4 v = q[c];
-		const uint64_t x0 = (uint64_t)v.y << 32 | v.x, x1 = (uint64_t)v.w << 32 | v.z;
-		const uint32_t base = c * 2 * SPW;
-		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, (uint32_t)(2 * SPW));      // in-chunk range [lo, hi)
-		nib_acc(A, x0, MLOW & nib_below(min(hi, (uint32_t)SPW)) & ~nib_below(min(lo, (uint32_t)SPW)));
-		nib_acc(A, x1, MLOW & nib_below(hi > SPW ? hi - SPW : 0u) & ~nib_below(lo > SPW ? lo - SPW : 0u));
-	};
-	edge(c0);
-	if (c1 == c0) return;
-	uint32_t c = c0 + 1;
-	for (; c + 4 <= c1; c += 4) {                              // interior chunks, four loads in flight
-		const uint4 v0 = q[c], v1 = q[c + 1], v2 = q[c + 2], v3 = q[c + 3];
-		nib_acc(A, (uint64_t)v0.y << 32 | v0.x, MLOW); nib_acc(A, (uint64_t)v0.w << 32 | v0.z, MLOW);
-		nib_acc(A, (uint64_t)v1.y << 32 | v1.x, MLOW); nib_acc(A, (uint64_t)v1.w << 32 | v1.z, MLOW);
-		nib_acc(A, (uint64_t)v2.y << 32 | v2.x, MLOW); nib_acc(A, (uint64_t)v2.w << 32 | v2.z, MLOW);
-		nib_acc(A, (uint64_t)v3.y << 32 | v3.x, MLOW); nib_acc(A, (uint64_t)v3.w << 32 | v3.z, MLOW);
+	const uint32_t g0 = from >> 6, g1 = (to - 1) >> 6;
+	for (uint32_t g = g0; g <= g1; ++g) {
+		const uint32_t base = g << 6;
+		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, 64u);
+		pl_acc(A, lw[g], lw[LEAFG + g], lw[2 * LEAFG + g], bits_below(hi) & ~bits_below(lo));
 	}
-	for (; c < c1; ++c) {
-		const uint4 v = q[c];
-		nib_acc(A, (uint64_t)v.y << 32 | v.x, MLOW); nib_acc(A, (uint64_t)v.w << 32 | v.z, MLOW);
-	}
-	edge(c1);
 }
 
 // ---- sparse layout: the directory of a superblock ---------------------------------------------
@@ -369,13 +369,13 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 __device__ __forceinline__ Loc locate_dense(const RopeDesc &rp, uint64_t p)
 {
 	Loc r;
-	const uint64_t lf = rp.nleaves ? min(p / LEAF, rp.nleaves - 1) : 0;
-	r.gl = rp.leaf0 + lf; r.s = lf * LEAF; r.n = (uint32_t)min((uint64_t)LEAF, rp.n - r.s);
+	const uint64_t lf = rp.nleaves ? min(p >> LEAF_SH, rp.nleaves - 1) : 0;
+	r.gl = rp.leaf0 + lf; r.s = lf << LEAF_SH; r.n = (uint32_t)min((uint64_t)LEAF, rp.n - r.s);
 	return r;
 }
 
 // counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
-// superblock prefix + leaf-relative prefix + a scan of the packed leaf up to p, 32 symbols per load
+// superblock prefix + leaf-relative prefix + popcounts over the groups of the leaf up to p
 // (the reference walks the runs of one leaf, rle.c:147-158).  SPARSE: leaves carry slack, the leaf is found by locate().
 template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
 {
@@ -386,7 +386,7 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 	}
 	uint64_t gl; uint32_t off;
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
-	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
+	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	uint32_t pc[6];                                            // symbols of the superblock in front of the leaf
 	if (SPARSE) {
@@ -397,10 +397,10 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 #pragma unroll
 		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
 	}
-	NibAcc A;
-	leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), 0, off, A);
+	PlAcc A;
+	leaf_count(leaf_words(pv.data, gl), 0, off, A);
 	uint32_t c[6];
-	nib_finish(A, off, c);
+	pl_finish(A, off, c);
 #pragma unroll
 	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
 }
@@ -412,13 +412,13 @@ template <bool SPARSE = false> __device__ inline void range_counts(const PoolVie
 {
 	uint64_t gl; uint32_t ol; bool one;
 	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
-	else { const uint64_t lf = l / LEAF; gl = rp.leaf0 + lf; ol = (uint32_t)(l - lf * LEAF); one = (u - 1) / LEAF == lf; }
+	else { const uint64_t lf = l >> LEAF_SH; gl = rp.leaf0 + lf; ol = (uint32_t)(l & (LEAF - 1)); one = ((u - 1) >> LEAF_SH) == lf; }
 	if (one) {
-		NibAcc A;
+		PlAcc A;
 		const uint32_t ou = ol + (uint32_t)(u - l);
-		leaf_count((const uint4*)(pv.data + gl * (uint64_t)LEAFB), ol, ou, A);
+		leaf_count(leaf_words(pv.data, gl), ol, ou, A);
 		uint32_t c[6];
-		nib_finish(A, ou - ol, c);
+		pl_finish(A, ou - ol, c);
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {
@@ -460,22 +460,23 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__buil
 
 
 // ---------------------------------------------------------------------------------------------
-// wave-cooperative rank: a leaf is 64 words = one per lane.  One coalesced 512-byte load, per-lane bit-plane popcounts of
-// the lane's share of [from, to), three packed DPP reductions -> the six counts in every lane.  Cost is independent of the
-// interval length (the single-thread scan of leaf_count is linear in it): this is what serves long intervals and intervals
+// wave-cooperative rank: a leaf is 16 groups = one per lane of the first DPP row.  Three coalesced 128-byte loads, per-lane
+// popcounts of the lane's share of [from, to), three packed DPP reductions -> the six counts in every lane.  Cost is independent
+// of the interval length (the single-thread scan of leaf_count is linear in it): this is what serves long intervals and intervals
 // that span leaves in k_prep, and every query of k_rank_batch.  (rle_rank2a, rle.c:134-191; rope_rank2a, rope.c:179-194.)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_leaf_counts(const uint64_t *leaf, uint32_t from, uint32_t to, uint32_t c[6])
 {
-	const uint32_t b = (uint32_t)lane_id() * SPW;
-	const uint64_t w = leaf[lane_id()];
-	const uint32_t lo = from > b ? min(from - b, (uint32_t)SPW) : 0u, hi = to > b ? min(to - b, (uint32_t)SPW) : 0u;   // my symbols [lo, hi)
-	NibAcc A;
-	nib_acc(A, w, MLOW & nib_below(hi) & ~nib_below(lo));
+	const uint32_t g = (uint32_t)lane_id(), b = g << 6;
+	PlAcc A;
+	if (g < (uint32_t)LEAFG) {
+		const uint32_t lo = from > b ? min(from - b, 64u) : 0u, hi = to > b ? min(to - b, 64u) : 0u;   // my symbols [lo, hi)
+		pl_acc(A, leaf[g], leaf[LEAFG + g], leaf[2 * LEAFG + g], bits_below(hi) & ~bits_below(lo));
+	}
 	const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
-	NibAcc T;
+	PlAcc T;
 	T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
-	nib_finish(T, to > from ? to - from : 0u, c);
+	pl_finish(T, to > from ? to - from : 0u, c);
 }
 
 // all 64 lanes call it with the same p
@@ -488,7 +489,7 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 	}
 	uint64_t gl; uint32_t off;
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
-	else { gl = rp.leaf0 + p / LEAF; off = (uint32_t)(p % LEAF); }
+	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
 	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	uint32_t pc[6];
 	if (SPARSE) {                                              // lane j < k holds the counts of slot j: three packed wave sums
@@ -504,7 +505,7 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
 	}
 	uint32_t c[6];
-	wave_leaf_counts((const uint64_t*)pv.data + gl * LEAFW, 0, off, c);
+	wave_leaf_counts(leaf_words(pv.data, gl), 0, off, c);
 #pragma unroll
 	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
 }
@@ -514,10 +515,10 @@ template <bool SPARSE> __device__ __forceinline__ void wave_range_counts(const P
 {
 	uint64_t gl; uint32_t ol; bool one;
 	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
-	else { const uint64_t lf = l / LEAF; gl = rp.leaf0 + lf; ol = (uint32_t)(l - lf * LEAF); one = (u - 1) / LEAF == lf; }
+	else { const uint64_t lf = l >> LEAF_SH; gl = rp.leaf0 + lf; ol = (uint32_t)(l & (LEAF - 1)); one = ((u - 1) >> LEAF_SH) == lf; }
 	if (one) {
 		uint32_t c[6];
-		wave_leaf_counts((const uint64_t*)pv.data + gl * LEAFW, ol, ol + (uint32_t)(u - l), c);
+		wave_leaf_counts(leaf_words(pv.data, gl), ol, ol + (uint32_t)(u - l), c);
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {

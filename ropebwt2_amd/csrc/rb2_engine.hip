@@ -507,8 +507,8 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  if (h->leaf_pipe > 0) hipLaunchKernelGGL(k_merge_leaf_pipe, dim3(std::min<unsigned>(cdiv(rank_share(h, B.m), MW * LPWP), (unsigned)h->leaf_pipe)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p);
-	  else RB2_LAUNCH_STRIDE(h, k_merge_leaf<true>, k_merge_leaf<false>, dim3(cdiv(rank_share(h, B.m), MW * LPWV)), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -554,7 +554,7 @@ void choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
 {
 	const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
 	const double lambda = (double)m_eff / ((double)n_ub / LEAF + 1.0);
-	bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LPWV work orders, 2^32 threads per launch)
+	bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LROWS work orders, 2^32 threads per launch)
 	if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 	if (h->sp_backoff > 0) --h->sp_backoff;
 	if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits

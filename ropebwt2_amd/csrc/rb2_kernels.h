@@ -752,7 +752,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const 
 		mm[h] = group_member(G, t, x, sym2[h], orda);
 		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
-			const bool small = u0[h] - l0[h] <= 4 * 2 * SPW && (SPARSE || (u0[h] - 1) / LEAF == l0[h] / LEAF);
+			const bool small = u0[h] - l0[h] <= 3 * GSYM && (SPARSE || ((u0[h] - 1) >> LEAF_SH) == (l0[h] >> LEAF_SH));
 			s_d[x][0] = l0[h]; s_d[x][1] = u0[h];
 			if (small) s_qs[atomicAdd(&s_ns, 1u)] = (uint16_t)x; else s_qw[atomicAdd(&s_nw, 1u)] = (uint16_t)x;
 		}
@@ -956,16 +956,16 @@ __global__ __launch_bounds__(64) void k_relayout_setup(Ctl *ctl, int side, uint3
 	if (r == 63) ctl->nsb_total = inc / SB;
 }
 
-// one wave per output leaf slot: gathers its symbols from the (one to three) old leaves that hold them -- 3-bit fields ORed into
-// place with LDS atomics --, writes the leaf and its own counts.  Slots that stay empty get zeroed counts.
+// one wave per output leaf slot: gathers its symbols from the (one to three) old leaves that hold them -- lane = old group, its bits
+// ORed into place with LDS atomics, plane by plane --, writes the leaf and its own counts.  Slots that stay empty get zeroed counts.
 __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, PoolView oldp, PoolView newp, uint32_t F, uint32_t K, int old_sparse)
 {
-	__shared__ __align__(16) uint64_t lds[MW][LEAFW + 2];
+	__shared__ __align__(16) uint64_t lds[MW][3 * (LEAFG + 1)];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint64_t *LX = lds[wv];
+	uint64_t *LX = lds[wv];                                     // plane pl of output group g at pl * (LEAFG + 1) + g (+ one spill word per plane)
 	const int ln = lane_id();
-	// grid-stride over the output slots: a launch is capped at 2^32 threads, i.e. 2^26 one-wave slots = 52 G symbols of sparse
-	// layout (found at full configs[3] size: the capped launch was refused and the re-layout silently did nothing)
+	// grid-stride over the output slots: a launch is capped at 2^32 threads, i.e. 2^26 one-wave slots
+	// (found at full configs[3] size: the capped launch was refused and the re-layout silently did nothing)
 	for (uint64_t gl = (uint64_t)blockIdx.x * MW + wv; gl < ctl->nsb_total * SB; gl += (uint64_t)gridDim.x * MW) {
 	// the piece that owns the slot: last one with leaf0 <= gl among those that have slots
 	const uint64_t l0 = ctl->rope[side][ln < NR ? ln : NR - 1].leaf0;
@@ -975,25 +975,26 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 	const uint64_t t = sbi * K + k, p0 = t * F;                 // logical leaf, its first symbol
 	const bool used = k < K && p0 < nrp.n;
 	const uint32_t nvalid = used ? (uint32_t)min((uint64_t)F, nrp.n - p0) : 0u;
-	LX[ln] = 0; if (ln < 2) LX[LEAFW + ln] = 0;
+	if (ln < 3 * (LEAFG + 1)) LX[ln] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	if (nvalid) {
 		Loc lc = old_sparse ? locate(oldp, orp, p0) : locate_dense(orp, p0);   // wave-uniform
 		uint32_t off = (uint32_t)(p0 - lc.s), taken = 0;
 		while (taken < nvalid) {
 			const uint32_t take = min(lc.n - off, nvalid - taken);
-			if (take) {
-				const uint64_t w = ((const uint64_t*)oldp.data)[lc.gl * LEAFW + ln];
-				const uint32_t a = max(off, (uint32_t)(ln * SPW)), b = min(off + take, (uint32_t)((ln + 1) * SPW));   // my symbols [a, b) of the old leaf
+			if (take && ln < LEAFG) {
+				const uint64_t *lw = leaf_words(oldp.data, lc.gl) + ln;
+				const uint32_t a = max(off, (uint32_t)(ln * GSYM)), b = min(off + take, (uint32_t)((ln + 1) * GSYM));   // my symbols [a, b) of the old leaf
 				if (a < b) {
-					const uint64_t bits = (w >> (SBITS * (a - ln * SPW))) & nib_below(b - a);
-					const uint32_t op = taken + (a - off), ow = op / SPW, sh = (op - ow * SPW) * SBITS;
-					const uint64_t lo = (bits << sh) & MALL, hi = sh ? bits >> (63 - sh) : 0ull;   // 63 payload bits per word
-					uint32_t *x32 = (uint32_t*)LX + 2 * ow;
-					if ((uint32_t)lo) atomicOr(x32, (uint32_t)lo);
-					if ((uint32_t)(lo >> 32)) atomicOr(x32 + 1, (uint32_t)(lo >> 32));
-					if ((uint32_t)hi) atomicOr(x32 + 2, (uint32_t)hi);
-					if ((uint32_t)(hi >> 32)) atomicOr(x32 + 3, (uint32_t)(hi >> 32));
+					const uint32_t op = taken + (a - off), og = op >> 6, sh = op & 63;
+					const uint64_t m = bits_below(b - a);
+#pragma unroll
+					for (int pl = 0; pl < 3; ++pl) {
+						const uint64_t bits = (lw[pl * LEAFG] >> (a & 63)) & m;
+						const uint64_t lo = bits << sh, hi = sh ? bits >> (64 - sh) : 0ull;
+						if (lo) atomicOr((unsigned long long*)&LX[pl * (LEAFG + 1) + og], (unsigned long long)lo);
+						if (hi) atomicOr((unsigned long long*)&LX[pl * (LEAFG + 1) + og + 1], (unsigned long long)hi);
+					}
 				}
 			}
 			taken += take; off = 0;
@@ -1011,18 +1012,22 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 		}
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	const uint64_t out = LX[ln];
-	const int v = min(SPW, max(0, (int)nvalid - ln * SPW));
-	NibAcc A;
-	nib_acc(A, out, nib_below((uint32_t)v) & MLOW);
-	uint32_t c[6];
-	nib_finish(A, (uint32_t)v, c);
-	const uint32_t s01 = wave_sum<uint32_t>(c[0] | c[1] << 16), s23 = wave_sum<uint32_t>(c[2] | c[3] << 16), s45 = wave_sum<uint32_t>(c[4] | c[5] << 16);
-	((uint64_t*)newp.data)[gl * LEAFW + ln] = out;
+	PlAcc A;
+	if (ln < LEAFG) {
+		const uint64_t b0 = LX[ln], b1 = LX[(LEAFG + 1) + ln], b2 = LX[2 * (LEAFG + 1) + ln];
+		const int v = min(GSYM, max(0, (int)nvalid - ln * GSYM));
+		pl_acc(A, b0, b1, b2, bits_below((uint32_t)v));
+		uint64_t *dst = (uint64_t*)newp.data + gl * LEAFW + ln;
+		dst[0] = b0; dst[LEAFG] = b1; dst[2 * LEAFG] = b2;
+	}
+	const uint32_t r0 = wave_sum<uint32_t>(A.p0 | A.p1 << 16), r1 = wave_sum<uint32_t>(A.p2 | A.p01 << 16), r2 = wave_sum<uint32_t>(A.p02);
 	if (ln == 0) {
+		PlAcc T;
+		T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
+		uint32_t c[6];
+		pl_finish(T, nvalid, c);
 		LeafMeta m;
-		m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
-		m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
+		for (int sy = 0; sy < 6; ++sy) m.c[sy] = (uint16_t)c[sy];
 		m.npre = 0; m.n = (uint16_t)nvalid;
 		newp.own[gl] = m;
 	}
@@ -1075,33 +1080,39 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 			for (int r = 0; r < 7; ++r) R[r][nj] = v[r];
 		}
 		uint64_t *leaves = (uint64_t*)pool.data + sb * SB * LEAFW;
-		// every leaf from the first split one on moves (or splits): all of them are LOADED first, back to back (lane = word, up to 32
-		// words per lane in registers), then stored at their new slots -- one round trip to memory for the whole superblock instead
-		// of one per slot (a wave that moved slot after slot spent 60 us on a full superblock: 31 dependent load -> store pairs)
+		// every leaf from the first split one on moves (or splits): all of them are LOADED first, back to back (lane = word: plane
+		// ln >> 4 of group ln & 15, up to 32 words per lane in registers), then stored at their new slots -- one round trip to memory
+		// for the whole superblock instead of one per slot (a wave that moved slot after slot spent 60 us on a full superblock)
+		const bool wl = ln < LEAFW;                              // 48 words per leaf
+		const uint32_t gq = (uint32_t)(ln & 15);                 // my group
 		uint64_t W[SB];
 #pragma unroll
-		for (int k = 0; k < SB; ++k) W[k] = ((uint32_t)k >= first && (uint32_t)k < used) ? leaves[(uint64_t)k * LEAFW + ln] : 0ull;
+		for (int k = 0; k < SB; ++k) W[k] = (wl && (uint32_t)k >= first && (uint32_t)k < used) ? leaves[(uint64_t)k * LEAFW + ln] : 0ull;
 #pragma unroll
 		for (int k = 0; k < SB; ++k) {
 			if ((uint32_t)k < first || (uint32_t)k >= used) continue;   // wave-uniform
 			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
 			const uint64_t w = W[k];
-			if (!((marked >> k) & 1u)) { if (nk != (uint32_t)k) leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
+			if (!((marked >> k) & 1u)) { if (nk != (uint32_t)k && wl) leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
 			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)v[0], k);
 			uint32_t ck[6];
 #pragma unroll
 			for (int s = 0; s < 6; ++s) ck[s] = (uint32_t)__builtin_amdgcn_readlane((int)v[1 + s], k);
-			const uint32_t hw = (n / 2) / SPW, h = hw * SPW;        // the first hw words stay
-			NibAcc A;
-			nib_acc(A, w, (uint32_t)ln < hw ? MLOW : 0ull);
+			const uint32_t hg = (n / 2) >> 6, h = hg << 6;           // the first hg groups stay
+			// counts of the part that stays: the three planes of a group sit 16 lanes apart
+			const uint64_t w1 = (uint64_t)__shfl((unsigned long long)w, (ln + 16) & 63), w2 = (uint64_t)__shfl((unsigned long long)w, (ln + 32) & 63);
+			PlAcc A;
+			pl_acc(A, w, w1, w2, (ln < LEAFG && gq < hg) ? ~0ull : 0ull);
 			const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
-			NibAcc T;
+			PlAcc T;
 			T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
 			uint32_t c1[6];
-			nib_finish(T, h, c1);
-			const uint64_t up = (uint64_t)__shfl((unsigned long long)w, (ln + (int)hw) & 63);   // word ln + hw of the old leaf
-			leaves[(uint64_t)(nk + 1) * LEAFW + ln] = (uint32_t)ln + hw < (uint32_t)LEAFW ? up : 0ull;
-			leaves[(uint64_t)nk * LEAFW + ln] = (uint32_t)ln < hw ? w : 0ull;
+			pl_finish(T, h, c1);
+			const uint64_t up = (uint64_t)__shfl((unsigned long long)w, (ln + (int)hg) & 63);   // group g + hg of my plane
+			if (wl) {
+				leaves[(uint64_t)(nk + 1) * LEAFW + ln] = gq + hg < (uint32_t)LEAFG ? up : 0ull;
+				leaves[(uint64_t)nk * LEAFW + ln] = gq < hg ? w : 0ull;
+			}
 			if (ln == 0) {
 				R[0][nk] = (uint16_t)h; R[0][nk + 1] = (uint16_t)(n - h);
 #pragma unroll
@@ -1307,7 +1318,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 		if (SPARSE) gl = RKLEAF[t.segstart + m.slot];          // where k_merge_leaf put my symbol
 		else {
 			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
-			gl = nrp.leaf0 + f / LEAF;
+			gl = nrp.leaf0 + (f >> LEAF_SH);
 		}
 		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
@@ -1410,19 +1421,20 @@ __global__ __launch_bounds__(256) void k_rank_batch(const Ctl *ctl, int side, Po
 	if (lane_id() < 6) { uint64_t v = acc[0]; for (int s = 1; s < 6; ++s) if (lane_id() == s) v = acc[s]; out[i * 6 + lane_id()] = v; }
 }
 
-// position-weighted checksum of the symbols of piece r (dense layout: a flat array of 21-symbol words): sum over its words of
-// word_j * (2j + 1) mod 2^64 -- equal for equal symbol sequences whatever built them (one engine, N ranks, a loaded .fmr),
-// sensitive to order.  Bits behind the last symbol are masked.  *out must be zeroed by the caller.
+// position-weighted checksum of the symbols of piece r (dense layout: a flat array of groups, three plane words each): sum over its
+// plane words of word * (2 * (3 * group + plane) + 1) mod 2^64 -- equal for equal symbol sequences whatever built them (one engine,
+// N ranks, a loaded .fmr), sensitive to order.  Bits behind the last symbol are masked.  *out must be zeroed by the caller.
 __global__ __launch_bounds__(256) void k_piece_hash(const Ctl *ctl, int side, PoolView pv, int r, unsigned long long *out)
 {
 	__shared__ uint64_t s_w[4];
 	const RopeDesc &d = ctl->rope[side][r];
-	const uint64_t nw = (d.n + SPW - 1) / SPW;
+	const uint64_t ng = (d.n + GSYM - 1) / GSYM;                // groups in use
 	const uint64_t *w = (const uint64_t*)pv.data + d.leaf0 * LEAFW;
 	uint64_t acc = 0;
-	for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < nw; j += (uint64_t)gridDim.x * 256) {
-		uint64_t v = w[j] & MALL;
-		if (j == nw - 1) v &= nib_below((uint32_t)(d.n - j * SPW));
+	for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < 3 * ng; j += (uint64_t)gridDim.x * 256) {
+		const uint64_t G = j / 3; const uint32_t pl = (uint32_t)(j - 3 * G);
+		uint64_t v = w[(G >> 4) * LEAFW + pl * LEAFG + (G & 15)];
+		if (G == ng - 1) v &= bits_below((uint32_t)(d.n - G * GSYM));
 		acc += v * (2 * j + 1);
 	}
 	uint64_t tot;
@@ -1529,8 +1541,15 @@ __global__ __launch_bounds__(256) void k_ld_expand(const uint8_t *rle, uint64_t 
 #pragma unroll
 		for (int s = 0; s < 6; ++s) { if (lc[s]) atomicAdd(&s_pc[x][s], (unsigned long long)lc[s]); lc[s] = 0; }
 	};
-	uint64_t cur_w = ~0ull, cur_v = 0;                         // the word being collected
-	auto flush = [&]() { if (cur_w != ~0ull && cur_v) atomicOr((unsigned long long*)&data[cur_w], (unsigned long long)cur_v); cur_v = 0; };
+	uint64_t cur_g = ~0ull, cur_w0 = 0, cur_v[3] = {0, 0, 0};  // the group being collected: its number inside the piece, the piece's first word, its plane bits
+	auto flush = [&]() {
+		if (cur_g != ~0ull) {
+			unsigned long long *q = (unsigned long long*)&data[cur_w0 + (cur_g >> 4) * LEAFW + (cur_g & 15)];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) if (cur_v[pl]) atomicOr(q + pl * LEAFG, (unsigned long long)cur_v[pl]);
+		}
+		cur_v[0] = cur_v[1] = cur_v[2] = 0;
+	};
 	ld_runs(rle, nbytes, o0, bad, [&](uint32_t c, uint64_t l) {
 		while (l > 0) {
 			if (x < tab.np && S >= tab.q[x + 1]) { tally_out(); while (x < tab.np && S >= tab.q[x + 1]) ++x; }
@@ -1543,13 +1562,15 @@ __global__ __launch_bounds__(256) void k_ld_expand(const uint8_t *rle, uint64_t 
 					const uint32_t k = atomicAdd(nlong, 1u);
 					if (k < long_cap) { LdLong e; e.word0 = tab.word0[x]; e.o = o; e.n = part; e.c = c; e.pad = 0; longs[k] = e; }
 				} else {
-					uint64_t wd = tab.word0[x] + o / SPW; uint32_t off = (uint32_t)(o % SPW), t = (uint32_t)part;
+					uint64_t gd = o >> 6; uint32_t off = (uint32_t)(o & 63), t = (uint32_t)part;
 					while (t > 0) {
-						const uint32_t k = min(t, (uint32_t)SPW - off);
-						const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
-						if (wd != cur_w) { flush(); cur_w = wd; }
-						cur_v |= ((uint64_t)c * MLOW & field) << (SBITS * off);
-						t -= k; off = 0; ++wd;
+						const uint32_t k = min(t, (uint32_t)GSYM - off);
+						const uint64_t field = bits_below(k) << off;
+						if (gd != cur_g || tab.word0[x] != cur_w0) { flush(); cur_g = gd; cur_w0 = tab.word0[x]; }
+						if (c & 1u) cur_v[0] |= field;
+						if (c & 2u) cur_v[1] |= field;
+						if (c & 4u) cur_v[2] |= field;
+						t -= k; off = 0; ++gd;
 					}
 				}
 			}
@@ -1570,12 +1591,13 @@ __global__ __launch_bounds__(256) void k_ld_long(const LdLong *longs, const uint
 	const uint32_t n = min(*nlong, long_cap);
 	for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
 		const LdLong L = longs[e];
-		const uint64_t w0 = L.o / SPW, w1 = (L.o + L.n - 1) / SPW;      // words [w0, w1] of the piece
-		for (uint64_t w = w0 + threadIdx.x; w <= w1; w += 256) {
-			const uint64_t lo = max(L.o, w * SPW), hi = min(L.o + L.n, (w + 1) * SPW);   // symbols [lo, hi) of this word
-			const uint32_t off = (uint32_t)(lo - w * SPW), k = (uint32_t)(hi - lo);
-			const uint64_t field = k >= (uint32_t)SPW ? MALL : (1ull << (SBITS * k)) - 1ull;
-			atomicOr((unsigned long long*)&data[L.word0 + w], (unsigned long long)(((uint64_t)L.c * MLOW & field) << (SBITS * off)));
+		const uint64_t g0 = L.o >> 6, g1 = (L.o + L.n - 1) >> 6;        // groups [g0, g1] of the piece
+		for (uint64_t gd = g0 + threadIdx.x; gd <= g1; gd += 256) {
+			const uint64_t lo = max(L.o, gd << 6), hi = min(L.o + L.n, (gd + 1) << 6);   // symbols [lo, hi) of this group
+			const uint64_t field = bits_below((uint32_t)(hi - lo)) << (uint32_t)(lo & 63);
+			unsigned long long *q = (unsigned long long*)&data[L.word0 + (gd >> 4) * LEAFW + (gd & 15)];
+#pragma unroll
+			for (int pl = 0; pl < 3; ++pl) if ((L.c >> pl) & 1u) atomicOr(q + pl * LEAFG, (unsigned long long)field);
 		}
 	}
 }
@@ -1587,7 +1609,7 @@ __global__ __launch_bounds__(256) void k_ld_own(PoolView pv, uint64_t leaf0, uin
 	if (i >= nleaves) return;
 	const uint32_t fill = (uint32_t)min((uint64_t)LEAF, n - i * LEAF);
 	uint32_t c[6];
-	wave_leaf_counts((const uint64_t*)pv.data + (leaf0 + i) * LEAFW, 0, fill, c);
+	wave_leaf_counts(leaf_words(pv.data, leaf0 + i), 0, fill, c);
 	if (lane_id() == 0) {
 		LeafMeta m;
 		for (int s = 0; s < 6; ++s) m.c[s] = (uint16_t)c[s];
