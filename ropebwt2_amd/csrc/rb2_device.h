@@ -70,7 +70,7 @@ constexpr int SP_FILL = 768;           // sparse layout: symbols per leaf after 
 constexpr int SP_USED = 24;            // ... leaf slots in use per superblock; the other 8 are the superblock's own reserve: a leaf that comes within
                                        // SP_MARGIN symbols of LEAF is split into one of them at the end of the round (k_split: the counterpart of the
                                        // reference's leaf split, rope.c:143-146 / split_node rope.c:78-112, one level of its B+ tree)
-constexpr int SP_MARGIN = 128;         // a leaf is split when its fill exceeds LEAF - SP_MARGIN: whatever a round brings, a leaf takes 128 more symbols
+constexpr int SP_MARGIN = 64;          // a leaf is split when its fill exceeds LEAF - SP_MARGIN: whatever a round brings, a leaf takes 64 more symbols
 struct Cnt6 { uint64_t v[6]; };
 struct SbTot { uint32_t p01, p23, p45, pad; };             // symbol counts of one superblock, six 16-bit fields (<= SB * LEAF each)
 
@@ -133,13 +133,31 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 	uint16_t ni, nvalid;    // new symbols / symbols in the window
 };
 
+struct SpOrd {              // work order of one touched leaf in a sparse round, written by k_part_sparse, read by k_merge_leaf (16 B, in the LD buffer)
+	uint32_t gl;            // leaf slot (32 bits in the sparse layout, like RKLEAF)
+	uint32_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL (a batch has < 2^32 strings)
+	uint32_t i0;            // piece position of the leaf's first symbol, low half (positions inside a leaf need no more)
+	uint16_t ni, nvalid;    // new symbols / symbols in the leaf after the round
+};
+
 struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; LeafMeta *own; uint64_t *sbpos; };   // sbpos[sb] = symbols in front of superblock sb (pool-wide)
 
-struct TileRec {            // per string tile, written by k_sym
+struct TileRec {            // per string tile, written by k_sym (80 bytes of it: the buffer is sized in these; layout: TileRecs below)
 	uint32_t hist[6];
 	uint32_t lhpre[6];      // symbol counts in the tile before its last group head
 	uint32_t fhpre[6];      // ... before its first group head
 	int32_t  lh, fh;        // in-tile index of last / first head, -1 when the tile has none
+};
+
+// ... as the kernels see it: a structure of arrays (20 arrays of `cap` words, cap % 4 == 0) -- a scan reads one column of consecutive
+// tiles with coalesced (16-byte) loads; records of 80 bytes made every lane of the single-block scan touch lines of its own
+struct TileRecs {
+	uint32_t *p; uint32_t cap;
+	__device__ __forceinline__ uint32_t &hist(int s, uint32_t t) const { return p[(uint64_t)s * cap + t]; }
+	__device__ __forceinline__ uint32_t &lhpre(int s, uint32_t t) const { return p[(uint64_t)(6 + s) * cap + t]; }
+	__device__ __forceinline__ uint32_t &fhpre(int s, uint32_t t) const { return p[(uint64_t)(12 + s) * cap + t]; }
+	__device__ __forceinline__ int32_t &lh(uint32_t t) const { return ((int32_t*)p)[(uint64_t)18 * cap + t]; }
+	__device__ __forceinline__ int32_t &fh(uint32_t t) const { return ((int32_t*)p)[(uint64_t)19 * cap + t]; }
 };
 
 struct TileScan {           // per string tile (+1), written by the tile scan

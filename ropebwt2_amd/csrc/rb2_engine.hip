@@ -173,7 +173,9 @@ struct rb2_hip_s {
 	int sp_maxpen = 6;                  // at most 64 dense rounds between two attempts (a failed attempt costs about four dense rounds)
 	int leaf_pipe = 8192;               // in-place rounds use the software-pipelined k_merge_leaf_pipe with at most this many workgroups (RB2_LEAF_PIPE; 0: one wave per
 	                                    // four work orders, k_merge_leaf).  1 M inserts per round: 232 us with k_merge_leaf, 259 / 228 / 212 / 207 / 212 us with 1024 / 1536 / 4096 / 8192 / 16384
-	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round; [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
+	uint32_t *h_flag = nullptr;         // pinned: verdict of a sparse round (written by k_split through d_flag); [16..16+2*NE_RING): ring of ctl->ne snapshots, one per round
+	uint32_t *d_flag = nullptr;         // ... its device address
+	uint64_t layout_epoch = 0;          // counts the re-layouts: what k_setup derived from the piece descriptors before one is stale after it
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
 	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
@@ -302,6 +304,8 @@ struct BatchState {
 	int cur = 0;                            // string array side
 	bool known_ae = false;                  // the host can tell that every interval of the batch is empty: input order, or an empty index
 	uint64_t counted = (uint64_t)-1;        // round whose counting phase (round_counts) is already queued
+	uint64_t setup_round = (uint64_t)-1;    // round whose k_setup ran inside its counting phase (k_tscan_setup) ...
+	bool setup_sparse = false; uint64_t setup_epoch = 0;   // ... for this layout, at this layout epoch (a re-layout in between: k_setup runs again)
 };
 
 // per-string arrays + tile tables for batches of up to m strings
@@ -311,7 +315,7 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
 	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
-	h->trec.ensure(nst + 1); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
+	h->trec.ensure(nst + 8); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
 
 // split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284)
@@ -382,23 +386,28 @@ bool ne_all_empty_from(rb2_hip_t *h, uint64_t r)               // may round r (a
 }
 
 // phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
-void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r)
+// spec: queued while the verdict of the in-place round in front of it is still on its way (round_merge_sparse)
+void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur;
 	const int64_t units = (int64_t)B.m;
 	h->cur_round = (int)r;
+	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
 	{ Scope sc(h, RB2_K_SYM, units);
-	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, h->trec.p); }
-	if (B.nst_ub <= 4 * SCHUNK) {                              // few tiles (long reads): one single-block launch instead of five
+	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, trs); }
+	if (B.nst_ub < (unsigned)TS_MAX) {                         // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
-	  hipLaunchKernelGGL(k_tscan_fused, dim3(1), dim3(SCHUNK), 0, st, (const Ctl*)h->ctl, sd, (const TileRec*)h->trec.p, h->tsc.p, h->tfix.p, h->gcnt);
+	  const int do_setup = h->nranks == 1;
+	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec);
+	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec);
+	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; }
 	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);
-	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p);
+	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
-	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, h->trec.p, h->cpart.p, h->tsc.p);
-	  hipLaunchKernelGGL(k_tfix, dim3(cdiv(B.nst_ub, 256)), dim3(256), 0, st, h->ctl, sd, h->trec.p, h->tsc.p, h->tfix.p);
+	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
+	  hipLaunchKernelGGL(k_tfix, dim3(cdiv(B.nst_ub, 256)), dim3(256), 0, st, h->ctl, sd, trs, h->tsc.p, h->tfix.p);
 	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(256), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
 }
 
@@ -416,6 +425,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);      // string tiles / output windows this handle launches blocks for (rank_share)
 	const unsigned wg = cdiv(B.n_tot + rank_share(h, std::min<uint64_t>(B.len, (r + 1) * B.m)), WIN) + NR;
 	if ((uint64_t)nlf * 64 >= (1ull << 32)) { rb2_fatal("[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); }
+	if (!(B.setup_round == r && !B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -470,7 +480,7 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1, to_sparse);
 		HIPCHK(hipGetLastError());                              // a refused launch here would leave descriptors without data
 	}
-	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout;
+	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout; ++h->layout_epoch;
 	if (to_sparse) h->sp_nsb = slots / SB + 1;
 	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
 		HIPCHK(hipStreamSynchronize(st));
@@ -497,18 +507,20 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	PoolView pv = h->pool[h->pside].view();
 	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);
 	if (++h->split_epoch == 0) ++h->split_epoch;
+	if (!(B.setup_round == r && B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
+	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true>), (k_prep<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true>), (k_prep<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
+	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  hipLaunchKernelGGL(k_merge_leaf, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
@@ -518,18 +530,17 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
-	  hipLaunchKernelGGL(k_split, dim3(1024), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch); }
+	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag); }
 	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
 	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
 	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
 	// the next merge.
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(h->h_flag, &h->ctl->overflow, 8, hipMemcpyDeviceToHost, st));   // {overflow, sbfull}
-	HIPCHK(hipEventRecord(h->ev_flag, st));
+	HIPCHK(hipEventRecord(h->ev_flag, st));                    // (k_split left the verdict in pinned memory)
 	h->side ^= 1; B.cur ^= 1;
 	const bool sp = spec && r + 1 <= B.max_len;
-	if (sp) round_counts(h, B, r + 1);
+	if (sp) round_counts(h, B, r + 1, true);
 	HIPCHK(hipEventSynchronize(h->ev_flag));
 	if (h->h_flag[0]) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
 	if (h->h_flag[1]) h->want_respread = true;
@@ -682,6 +693,8 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
 	HIPCHK(hipMalloc((void**)&h->gcnt, NR * 6 * 8));
 	HIPCHK(hipHostMalloc((void**)&h->h_flag, 64 + 8 * rb2_hip_s::NE_RING, hipHostMallocDefault));
+	memset(h->h_flag, 0, 64 + 8 * rb2_hip_s::NE_RING);
+	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));

@@ -242,7 +242,7 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
 // with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
 template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
-		uint8_t *A, TileRec *trec)
+		uint8_t *A, TileRecs trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
@@ -280,9 +280,8 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *c
 			}
 			run += __popcll(bm);
 		}
-		TileRec &r = trec[tile];
-		r.hist[s] = run; r.fhpre[s] = fhpre; r.lhpre[s] = lhpre;
-		if (s == 0) { r.fh = fh; r.lh = lh; }
+		trec.hist(s, tile) = run; trec.fhpre(s, tile) = fhpre; trec.lhpre(s, tile) = lhpre;
+		if (s == 0) { trec.fh(tile) = fh; trec.lh(tile) = lh; }
 	}
 	if (!STRIDE) return;
 	}
@@ -292,7 +291,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *c
 // tile scan (3 kernels): exclusive add-scan of hist, nearest head-bearing tile to the left/right
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, const TileRec *trec, ChunkPart *part)
+__global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, const TileRecs trec, ChunkPart *part)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
 	const uint32_t nt = ctl->seg[side].tile0[NR];
@@ -301,8 +300,8 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan1(const Ctl *ctl, int side, con
 	const bool ok = t < nt;
 	uint32_t tot;
 	ChunkPart p;
-	for (int s = 0; s < 6; ++s) { block_excl_add<uint32_t>(ok ? trec[t].hist[s] : 0u, s_w, &tot); p.sum[s] = tot; }
-	const bool hh = ok && trec[t].fh >= 0;
+	for (int s = 0; s < 6; ++s) { block_excl_add<uint32_t>(ok ? trec.hist(s, t) : 0u, s_w, &tot); p.sum[s] = tot; }
+	const bool hh = ok && trec.fh(t) >= 0;
 	int v = hh ? (int)t : -1;
 	v = wave_incl_max(v);
 	if (lane_id() == 63) s_wi[wave_id()] = v;
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, Chu
 	}
 }
 
-__global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRec *trec, const ChunkPart *part, TileScan *tsc)
+__global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRecs trec, const ChunkPart *part, TileScan *tsc)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
 	const uint32_t nt = ctl->seg[side].tile0[NR];
@@ -373,10 +372,10 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 	TileScan o;
 	uint32_t h[6];
 	for (int s = 0; s < 6; ++s) {
-		h[s] = ok ? trec[t].hist[s] : 0u;
+		h[s] = ok ? trec.hist(s, t) : 0u;
 		o.pre[s] = cp.sum[s] + block_excl_add<uint32_t>(h[s], s_w, (uint32_t*)0);
 	}
-	const bool hh = ok && trec[t].fh >= 0;
+	const bool hh = ok && trec.fh(t) >= 0;
 	o.lht = max(cp.mx, block_excl_max(hh ? (int)t : -1, s_wi, -1));
 	o.nht = min(cp.mn, block_excl_min_down(hh ? (int)t : INT_MAX, s_wi, INT_MAX));
 	if (ok) tsc[t] = o;
@@ -404,7 +403,7 @@ __global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, ui
 
 // one thread per string tile: fold the tile scans into the numbers group_setup needs, so that k_prep and
 // k_advance read one 76-byte record per block instead of chasing tsc[lt] / trec[lt] / tsc[nt] / trec[nt]
-__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const TileRec *trec, const TileScan *tsc, TileFix *tf)
+__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const TileRecs trec, const TileScan *tsc, TileFix *tf)
 {
 	__shared__ uint32_t s_t0[NR + 1];
 	const SegDesc &sg = ctl->seg[side];
@@ -418,121 +417,28 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 	const TileScan me = tsc[tile], first = tsc[t0];
 	const int lt = me.lht, nt = me.nht;
 	TileFix f;
-	TileScan sl, sn; TileRec rl, rn;
+	TileScan sl, sn;
 	const bool hl = lt >= (int)t0, hn = nt < (int)t1;
-	if (hl) { sl = tsc[lt]; rl = trec[lt]; }
-	if (hn) { sn = tsc[nt]; rn = trec[nt]; } else sn = tsc[t1];
+	if (hl) sl = tsc[lt];
+	if (hn) sn = tsc[nt]; else sn = tsc[t1];
 	for (int s = 0; s < 6; ++s) {
 		f.tpre[s] = me.pre[s] - first.pre[s];
-		f.popen[s] = hl ? sl.pre[s] - first.pre[s] + rl.lhpre[s] : 0u;
-		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? rn.fhpre[s] : 0u);
+		f.popen[s] = hl ? sl.pre[s] - first.pre[s] + trec.lhpre(s, (uint32_t)lt) : 0u;
+		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? trec.fhpre(s, (uint32_t)nt) : 0u);
 	}
-	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + rl.lh) : 0u;
+	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + trec.lh((uint32_t)lt)) : 0u;
 	f.b = (uint32_t)b; f.lt = tile - t0; f.pad = 0;
 	f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
 	tf[tile] = f;
-}
-
-// k_tscan1-3 + k_tfix + k_counts_local in ONE single-block launch, for rounds with few string tiles (long reads: 10^4 rounds of
-// 10^3 tiles, where five 10-microsecond launches per round are a large share of the round).  Same results, same formulas.
-__global__ __launch_bounds__(SCHUNK) void k_tscan_fused(const Ctl *ctl, int side, const TileRec *trec, TileScan *tsc, TileFix *tf, uint64_t *gcnt)
-{
-	__shared__ uint32_t s_p[7][16];                             // per-wave totals of the six histogram columns + the head marker
-	__shared__ uint32_t s_t0[NR + 1];
-	const SegDesc &sg = ctl->seg[side];
-	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
-	__syncthreads();
-	const uint32_t nt = s_t0[NR];
-	// block scans: DPP inside the wave (VALU only), one LDS exchange of the 16 wave totals, a 16-lane DPP scan of those -- two
-	// barriers per 1024 tiles for all seven columns (the first version used seven LDS-shuffle scans: 43 us for 2000 tiles)
-	uint32_t run[6] = {0, 0, 0, 0, 0, 0}, run_mx = 0;           // carries between chunks; heads are tracked as tile + 1 (0: none)
-	for (uint32_t i0 = 0; i0 < nt; i0 += SCHUNK) {              // forwards: exclusive sums, last head-bearing tile before
-		const uint32_t i = i0 + threadIdx.x;
-		const bool ok = i < nt;
-		uint32_t v[7], inc[7];
-#pragma unroll
-		for (int s = 0; s < 6; ++s) { v[s] = ok ? trec[i].hist[s] : 0u; inc[s] = dpp_incl_add(v[s]); }
-		v[6] = (ok && trec[i].fh >= 0) ? i + 1 : 0u; inc[6] = dpp_incl_max(v[6]);
-		if (ln == 63) {
-#pragma unroll
-			for (int s = 0; s < 7; ++s) s_p[s][wv] = inc[s];
-		}
-		__syncthreads();
-		TileScan o;
-#pragma unroll
-		for (int s = 0; s < 7; ++s) {
-			const uint32_t p = ln < 16 ? s_p[s][ln] : 0u;
-			const uint32_t pin = s < 6 ? dpp_incl_add(p) : dpp_incl_max(p);
-			const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
-			const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)pin, 15);
-			if (s < 6) { o.pre[s] = run[s] + off + inc[s] - v[s]; run[s] += tot; }
-			else {
-				const uint32_t prevl = dpp_prev_lane(inc[6]);       // inclusive max of the lanes below (0 for lane 0)
-				const uint32_t ex = max(max(run_mx, off), prevl);
-				o.lht = (int)ex - 1;
-				run_mx = max(run_mx, tot);
-			}
-		}
-		o.nht = INT_MAX;
-		if (ok) tsc[i] = o;
-		__syncthreads();
-	}
-	if (threadIdx.x == 0) { TileScan e; for (int s = 0; s < 6; ++s) e.pre[s] = run[s]; e.lht = -1; e.nht = INT_MAX; tsc[nt] = e; }
-	uint32_t run_nx = 0;                                        // backwards: first head-bearing tile after, as a prefix max of (BIG - tile) over reversed threads
-	for (uint32_t k = (nt + SCHUNK - 1) / SCHUNK; k-- > 0; ) {
-		const uint32_t i = k * SCHUNK + (SCHUNK - 1 - threadIdx.x);
-		const bool ok = i < nt;
-		const uint32_t v = (ok && trec[i].fh >= 0) ? 0x7fffffffu - i : 0u;
-		const uint32_t inc = dpp_incl_max(v);
-		if (ln == 63) s_p[6][wv] = inc;
-		__syncthreads();
-		const uint32_t p = ln < 16 ? s_p[6][ln] : 0u;
-		const uint32_t pin = dpp_incl_max(p);
-		const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
-		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)pin, 15);
-		const uint32_t ex = max(max(run_nx, off), dpp_prev_lane(inc));
-		if (ok) tsc[i].nht = ex ? (int)(0x7fffffffu - ex) : INT_MAX;
-		run_nx = max(run_nx, tot);
-		__syncthreads();
-	}
-	__threadfence_block();
-	__syncthreads();
-	for (uint32_t tile = threadIdx.x; tile < nt; tile += SCHUNK) {   // k_tfix
-		int b = 0;
-		while (tile >= s_t0[b+1]) ++b;
-		const uint32_t t0 = s_t0[b], t1 = s_t0[b+1];
-		const TileScan me = tsc[tile], first = tsc[t0];
-		const int lt = me.lht, nx = me.nht;
-		TileFix f;
-		TileScan sl, sn; TileRec rl, rn;
-		const bool hl = lt >= (int)t0, hn = nx < (int)t1;
-		if (hl) { sl = tsc[lt]; rl = trec[lt]; }
-		if (hn) { sn = tsc[nx]; rn = trec[nx]; } else sn = tsc[t1];
-		for (int s = 0; s < 6; ++s) {
-			f.tpre[s] = me.pre[s] - first.pre[s];
-			f.popen[s] = hl ? sl.pre[s] - first.pre[s] + rl.lhpre[s] : 0u;
-			f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? rn.fhpre[s] : 0u);
-		}
-		f.fopen = hl ? (uint32_t)((lt - t0) * STILE + rl.lh) : 0u;
-		f.b = (uint32_t)b; f.lt = tile - t0; f.pad = 0;
-		f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
-		tf[tile] = f;
-	}
-	if (threadIdx.x < NR * 6) {                                 // k_counts_local
-		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
-		gcnt[threadIdx.x] = nt ? (uint64_t)(tsc[s_t0[b+1]].pre[a] - tsc[s_t0[b]].pre[a]) : 0ull;
-	}
 }
 
 // gcnt = the GLOBAL NR x 6 count matrix of the round (== the local one on a single GPU; the sum
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.
 // SPARSE: the round inserts in place -- every piece keeps its slots (leaf0, nleaves, sb0), only n and the counts move.
-template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
+template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par)
 {
-	if (blockIdx.x) return;
-	const int r = threadIdx.x;
+	const int r = lane_id();
 	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_unpack of this round count into it
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
@@ -586,6 +492,142 @@ template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, i
 		if (ok) ctl->dest[r][a] = st2 + before;
 	}
 	if (ok) ctl->dest[r][0] = 0;
+}
+template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
+{
+	if (blockIdx.x) return;
+	setup_body<SPARSE>(ctl, side, gcnt, par);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_tscan_setup: the whole counting tail of a round with few string tiles (long reads: 10^4 rounds of 10^3 tiles) in ONE single-block
+// launch -- k_tscan1-3 + k_tfix + k_counts_local + k_setup.  Same results, same formulas; what differs is where the numbers live: the
+// exclusive prefixes of the six histogram columns stay in LDS (96 KB for 4096 tiles), the "nearest head-bearing tile" on either
+// side comes from a bitmap of the tiles that have a head (highest set bit below / lowest above), and the count matrix reaches
+// k_setup's wave through LDS.  Global memory is read twice in a row (the tile records; the records of the neighbouring head tiles)
+// instead of eight times (round 3: 25.6 us for 2000 tiles + 7.9 us for k_setup behind it).
+// do_setup = 0: a rank of a sharded index -- the count matrix is summed over the ranks before k_setup may run.
+// spec: the launch was queued before the host saw the verdict of the in-place round in front of it; if that round was void
+// (ctl->overflow) nothing may be overwritten -- the host redoes the round from its own counting phase.
+// ---------------------------------------------------------------------------------------------
+constexpr int TS_MAX = 4 * SCHUNK;          // string tiles the single-block path takes
+constexpr int TFW = 26;                     // dwords of a TileFix
+static_assert(sizeof(TileFix) == TFW * 4, "TileFix is written out as 26 dwords");
+template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(Ctl *ctl, int side, int par, const TileRecs trec, TileFix *tf, uint64_t *gcnt, int do_setup, int spec)
+{
+	__shared__ uint32_t s_pre[6][TS_MAX + 4];                    // exclusive prefix of hist over all tiles; [.][nt] = total
+	__shared__ uint32_t s_out[SCHUNK / 64][32 * TFW];            // per wave: 32 TileFix records on their way out (coalesced stores)
+	__shared__ unsigned long long s_head[TS_MAX / 64];           // bit t: tile t holds a group head
+	__shared__ uint32_t s_p[6][16];
+	__shared__ uint32_t s_t0[NR + 1];
+	__shared__ uint64_t s_g[NR * 6];
+	if (spec && ctl->overflow) return;
+	const SegDesc &sg = ctl->seg[side];
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
+	if (threadIdx.x < TS_MAX / 64) s_head[threadIdx.x] = 0;
+	// thread i owns tiles 4i .. 4i + 3: one 16-byte load per column
+	const uint32_t nt_g = sg.tile0[NR];                         // (uniform scalar load; s_t0 is not visible yet)
+	const uint32_t t_first = threadIdx.x * 4;
+	uint32_t hs[4][6], tot[6] = {0, 0, 0, 0, 0, 0}, hb = 0;
+	{
+		const bool any = t_first < nt_g;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) {
+			uint4 v = make_uint4(0, 0, 0, 0);
+			if (any) v = *(const uint4*)&trec.hist(s, t_first);
+			hs[0][s] = v.x; hs[1][s] = v.y; hs[2][s] = v.z; hs[3][s] = v.w;
+		}
+		int4 f = make_int4(-1, -1, -1, -1);
+		if (any) f = *(const int4*)&trec.fh(t_first);
+		const int fv[4] = { f.x, f.y, f.z, f.w };
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const bool ok = t_first + k < nt_g;
+			if (!ok) { for (int s = 0; s < 6; ++s) hs[k][s] = 0; }
+			if (ok && fv[k] >= 0) hb |= 1u << k;
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { const uint32_t v = hs[k][s]; hs[k][s] = tot[s]; tot[s] += v; }   // exclusive inside the thread
+	uint32_t inc[6];
+#pragma unroll
+	for (int s = 0; s < 6; ++s) { inc[s] = dpp_incl_add(tot[s]); if (ln == 63) s_p[s][wv] = inc[s]; }
+	__syncthreads();
+	if (hb) atomicOr(&s_head[t_first >> 6], (unsigned long long)hb << (t_first & 63));
+#pragma unroll
+	for (int s = 0; s < 6; ++s) {
+		const uint32_t p = ln < 16 ? s_p[s][ln] : 0u;
+		const uint32_t pin = dpp_incl_add(p);
+		const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
+		const uint32_t base = off + inc[s] - tot[s];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) if (t_first + k <= nt_g) s_pre[s][t_first + k] = base + hs[k][s];
+	}
+	__syncthreads();
+	const uint32_t nt = s_t0[NR];
+	uint32_t *so = s_out[wv];
+	for (uint32_t tb = (uint32_t)wv * 64; tb < nt; tb += SCHUNK) {   // k_tfix: a wave takes 64 consecutive tiles
+		const uint32_t tile = tb + (uint32_t)ln;
+		const bool live = tile < nt;
+		uint32_t f[TFW];
+#pragma unroll
+		for (int i = 0; i < TFW; ++i) f[i] = 0;
+		if (live) {
+			int b = 0;
+			while (tile >= s_t0[b + 1]) ++b;
+			const uint32_t t0 = s_t0[b], t1 = s_t0[b + 1];
+			int lt = -1, nx = INT_MAX;
+			{
+				int w = (int)(tile >> 6);
+				unsigned long long m = s_head[w] & lt_mask((int)(tile & 63));
+				while (m == 0 && w > 0) m = s_head[--w];
+				if (m) lt = w * 64 + 63 - __builtin_clzll(m);
+				w = (int)(tile >> 6);
+				const int wl = (int)((nt - 1) >> 6);
+				m = (tile & 63) == 63 ? 0ull : s_head[w] & (~0ull << ((tile & 63) + 1));
+				while (m == 0 && w < wl) m = s_head[++w];
+				if (m) nx = w * 64 + __builtin_ctzll(m);
+			}
+			const bool hl = lt >= (int)t0, hn = nx < (int)t1;
+			const uint32_t pn = hn ? (uint32_t)nx : t1;
+#pragma unroll
+			for (int s = 0; s < 6; ++s) {
+				const uint32_t first = s_pre[s][t0];
+				f[s] = s_pre[s][tile] - first;                                                        // tpre
+				f[6 + s] = hl ? s_pre[s][lt] - first + trec.lhpre(s, (uint32_t)lt) : 0u;              // popen
+				f[12 + s] = s_pre[s][pn] - first + (hn ? trec.fhpre(s, (uint32_t)nx) : 0u);           // pnext
+			}
+			f[18] = hl ? (uint32_t)((lt - (int)t0) * STILE + trec.lh((uint32_t)lt)) : 0u;          // fopen
+			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = 0;
+			const uint64_t ss = sg.start[b], se = ss + sg.cnt[b];
+			f[22] = (uint32_t)ss; f[23] = (uint32_t)(ss >> 32); f[24] = (uint32_t)se; f[25] = (uint32_t)(se >> 32);
+		}
+		// out through LDS, 32 records at a time: 13 store instructions of 64 consecutive dwords each instead of 26 that hit 64 lines each
+#pragma unroll
+		for (int half = 0; half < 2; ++half) {
+			if ((ln >> 5) == half) {
+#pragma unroll
+				for (int i = 0; i < TFW; ++i) so[(ln & 31) * TFW + i] = f[i];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+			const uint32_t r0 = tb + 32u * half;                        // first record of this half
+			const uint32_t nrec = r0 < nt ? min(32u, nt - r0) : 0u;
+			uint32_t *dst = (uint32_t*)(tf + r0);
+#pragma unroll
+			for (int i = 0; i < 32 * TFW / 64; ++i) { const uint32_t d = (uint32_t)(i * 64 + ln); if (d < nrec * TFW) dst[d] = so[d]; }
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+		}
+	}
+	if (threadIdx.x < NR * 6) {                                 // k_counts_local
+		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
+		const uint64_t v = nt ? (uint64_t)(s_pre[a][s_t0[b + 1]] - s_pre[a][s_t0[b]]) : 0ull;
+		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
+	}
+	__syncthreads();
+	if (do_setup && wv == 0) setup_body<SPARSE>(ctl, side, s_g, par);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -855,9 +897,9 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_part(const Ctl *
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap);
+__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap);
 
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // (first tile as ever, then a grid stride: see k_prep)
 		if (!part_sparse_tile(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap)) return;
@@ -868,7 +910,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl 
 	}
 }
 
-__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, LeafDesc *LD, uint32_t *SPL, uint32_t spl_cap)
+__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	__shared__ uint64_t s_gl[STILE + 1];
 	const TileFix &tfx = tf[tile];
@@ -917,8 +959,8 @@ __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, 
 			q1 = lo;
 		}
 		const uint64_t ni = q1 - g;
-		LeafDesc d;
-		d.i0 = lc[h].s; d.ins0 = g; d.gl = lc[h].gl; d.oleaf0 = 0;
+		SpOrd d;
+		d.i0 = (uint32_t)lc[h].s; d.ins0 = (uint32_t)g; d.gl = (uint32_t)lc[h].gl;
 		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)min(lc[h].n + ni, (uint64_t)LEAF);
 		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = 1;  // the leaf cannot take them: void round
 		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)
@@ -1046,14 +1088,16 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 // rows (fills + own counts) are rewritten to match.  The superblock's total does not change: sbcum / sbpos stay valid.
 // A marked leaf in a superblock without a free slot sets ctl->sbfull: the host re-spreads the index before the next round.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */)
+// The verdict of the round -- hv[0]: void round, hv[1]: a superblock ran out of slots -- goes straight into pinned host memory (the host
+// zeroes both words before it queues the round): no copy command behind the last kernel.
+__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */, volatile uint32_t *hv)
 {
 	__shared__ uint16_t s_row[MW][7][SB];
-	if (ctl->overflow) return;                                   // void round: nothing was inserted
+	if (ctl->overflow) { if (blockIdx.x == 0 && threadIdx.x == 0) hv[0] = 1; return; }   // void round: nothing was inserted
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
 	const uint32_t nsp_all = min(ctl->nsplit, spl_cap);
-	if (ctl->nsplit > spl_cap && blockIdx.x == 0 && threadIdx.x == 0) ctl->sbfull = 1;   // list overflow (never in practice): re-spread
+	if (ctl->nsplit > spl_cap && blockIdx.x == 0 && threadIdx.x == 0) { ctl->sbfull = 1; hv[1] = 1; }   // list overflow (never in practice): re-spread
 	for (uint32_t e = blockIdx.x * MW + wv; e < nsp_all; e += gridDim.x * MW) {
 		const uint64_t gl = SPL[e], sb = gl / SB;
 		uint32_t mine = 0;
@@ -1067,7 +1111,7 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 		if (marked == 0) continue;
 		const uint32_t room = SB - used;
 		if ((uint32_t)__popc(marked) > room) {
-			if (ln == 0) ctl->sbfull = 1;
+			if (ln == 0) { ctl->sbfull = 1; hv[1] = 1; }
 			while ((uint32_t)__popc(marked) > room) marked &= ~(1u << (31 - __builtin_clz(marked)));   // split the lowest ones that fit
 			if (marked == 0) continue;
 		}

@@ -282,45 +282,42 @@ __device__ __forceinline__ void dir_add_packed(const PoolView &pool, SbTot *sbto
 // k_merge_leaf: sparse rounds.  ONE LEAF PER DPP ROW -- a wave inserts into four touched leaves at once (work orders appended by
 // k_part_sparse, any order), each rewritten in place: rope_insert_run's descent ends here (rope.c:136-141) and this is
 // rle_insert_cached (rle.c:10-89) for all the inserts a leaf receives this round at once.  Untouched leaves keep their bytes.
-// A leaf that receives a few symbols (the normal case of a sparse round: one or two) needs no LDS: lane g of the row keeps the three
-// plane words of group g in registers; per new symbol (ascending position, so earlier ones are already in place) one plane compare
-// + row sum gives its rank, one shift with a DPP carry from the lane below opens the gap; only the groups from the first changed
-// one on are stored.  The row's j-th insert reaches its lanes through a DPP row broadcast.  A leaf that receives more than
-// LIGHT_NI symbols is merged by the whole wave with the window machinery of k_merge (merge_window<.., 1, true>).
-// The kernel is persistent and software-pipelined: while a wave shifts the words of one quad of leaves, the words and insert
-// records of its next quad are in flight and the work orders of the quad after that are being fetched.
+// No LDS: lane g of the row keeps the three plane words of group g in registers; per new symbol (ascending position, so earlier
+// ones are already in place) one plane compare + row sum gives its rank, one shift with a DPP carry from the lane below opens the
+// gap; only the groups from the first changed one on are stored.  The row's j-th insert reaches its lanes through a DPP row
+// broadcast; a leaf that receives more than LTURN symbols (hot spots: the normal case of a sparse round is one or two) takes them
+// in turns of LTURN.  The kernel is persistent and software-pipelined: while a wave shifts the words of one quad of leaves, the
+// words and insert records of its next quad are in flight and the work orders of the quad after that are being fetched.
 // (Rounds 2-3: 512-byte leaves of 3-bit fields, one WAVE per leaf: 372 VALU per four leaves and 0.95 KB per insert.)
 // A round that set ctl->overflow is void.
 // ---------------------------------------------------------------------------------------------
-constexpr int LIGHT_NI = 8;
 constexpr int LROWS = 4;                    // leaves per wave step
-struct RowOrd { uint64_t gl, ins0; uint32_t i0, ni; };                     // the row's work order (i0: low half, positions inside a leaf need no more)
+constexpr int LTURN = 8;                    // inserts a row takes per turn (lanes 0 .. LTURN - 1 of the row hold them)
+struct RowOrd { uint32_t gl, ins0, i0, ni; };                               // the row's work order (SpOrd, rb2_device.h), ni = 0: none
 struct RowJob { uint64_t w[3]; uint32_t pj, aj; };
 
-__device__ __forceinline__ void row_ord_load(const LeafDesc *LD, uint64_t g, uint32_t nwork, int ln, RowOrd &o)
+__device__ __forceinline__ void row_ord_load(const SpOrd *LD, uint64_t g, uint32_t nwork, int ln, RowOrd &o)
 {
 	const uint64_t q = g + (uint32_t)(ln >> 4);
 	const bool ok = q < nwork;
-	const uint4 *p = (const uint4*)(LD + (ok ? q : g));          // behind the end: a duplicate of the quad's first order, loaded but never run
-	const uint4 a = p[0], b = p[1];                             // {i0, ins0}, {gl, oleaf0, ni | nvalid << 16}
-	o.i0 = a.x; o.ins0 = (uint64_t)a.w << 32 | a.z; o.gl = (uint64_t)b.y << 32 | b.x;
-	o.ni = ok ? (b.w & 0xffffu) : 0u;
+	const uint4 a = *(const uint4*)(LD + (ok ? q : g));         // behind the end: a duplicate of the quad's first order, loaded but never run
+	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z;
+	o.ni = ok ? (a.w & 0xffffu) : 0u;
 }
 __device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const PoolView &pool, const uint64_t *INS_E, const uint8_t *INS_A, RowJob &J)
 {
-	const uint64_t *lw = (const uint64_t*)pool.data + o.gl * LEAFW + g;
+	const uint64_t *lw = (const uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
 #pragma unroll
 	for (int pl = 0; pl < 3; ++pl) J.w[pl] = lw[pl * LEAFG];
 	// no branch and no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
 	// row's last insert again; they never use it)
-	const uint64_t q = o.ins0 + (uint32_t)min(g, max((int)o.ni, 1) - 1);
+	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)o.ni, 1) - 1);
 	J.aj = INS_A[q]; J.pj = ((const uint32_t*)INS_E)[2 * q];
 }
 
-__global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView pool,
+__global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
 		const uint64_t *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
-	__shared__ __align__(16) uint64_t lds[MW][MergeLds<1>::WORDS];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id(), g = ln & 15;
 	const uint64_t stride = (uint64_t)gridDim.x * MW * LROWS;
@@ -341,31 +338,37 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 			row_ord_load(LD, g2 < nwork ? g2 : g1, nwork, ln, onn);
 		}
 		asm volatile("" ::: "memory");
-		// ---- the rows that receive a few symbols: all of them together, in registers
-		const uint32_t ni_l = o.ni <= (uint32_t)LIGHT_NI ? o.ni : 0u;   // (row-uniform)
-		const uint32_t pj = J.pj - o.i0 + (uint32_t)g;            // final position E[q] + q inside the leaf (lanes >= ni: unused)
-		const uint32_t nimax = max(max((uint32_t)__builtin_amdgcn_readlane((int)ni_l, 0), (uint32_t)__builtin_amdgcn_readlane((int)ni_l, 16)),
-				max((uint32_t)__builtin_amdgcn_readlane((int)ni_l, 32), (uint32_t)__builtin_amdgcn_readlane((int)ni_l, 48)));
-		if (nimax) {
+		uint64_t w0 = J.w[0], w1 = J.w[1], w2 = J.w[2];
+		uint32_t pjr = J.pj, aj = J.aj;
+		const uint32_t nimax = max(max((uint32_t)__builtin_amdgcn_readlane((int)o.ni, 0), (uint32_t)__builtin_amdgcn_readlane((int)o.ni, 16)),
+				max((uint32_t)__builtin_amdgcn_readlane((int)o.ni, 32), (uint32_t)__builtin_amdgcn_readlane((int)o.ni, 48)));
+		uint32_t pg0 = 0;                                         // first group of the row that changes
+		for (uint32_t c0 = 0; c0 < nimax; c0 += LTURN) {            // turns of LTURN inserts per row (one turn, normally)
+			if (c0) {                                               // (rare) the row's next inserts
+				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(o.ni, 1u) - 1u);
+				aj = INS_A[q]; pjr = ((const uint32_t*)INS_E)[2 * q];
+			}
+			const uint32_t nic = o.ni > c0 ? min(o.ni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
+			const uint32_t pj = pjr - o.i0 + c0 + (uint32_t)g;      // final position E[q] + q inside the leaf (lanes >= nic: unused)
+			const uint32_t ncmax = min(nimax - c0, (uint32_t)LTURN);
+			const bool mine = (uint32_t)g < nic;
 			// what a leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
 			// while the wave shifts words
 			{
-				const bool mine = (uint32_t)g < ni_l;
 				const uint32_t rsh = (uint32_t)(ln & 48);
 				uint32_t cs[6];
 #pragma unroll
-				for (int s = 0; s < 6; ++s) cs[s] = (uint32_t)__popc((uint32_t)(__ballot(mine && J.aj == (uint32_t)s) >> rsh) & 0xffffu);
-				dir_add_packed(pool, sbtot, o.gl, ni_l ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16);
-				if (mine) RKLEAF[o.ins0 + g] = (uint32_t)o.gl;
+				for (int s = 0; s < 6; ++s) cs[s] = (uint32_t)__popc((uint32_t)(__ballot(mine && aj == (uint32_t)s) >> rsh) & 0xffffu);
+				dir_add_packed(pool, sbtot, o.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16);
+				if (mine) RKLEAF[(uint64_t)o.ins0 + c0 + g] = o.gl;
 			}
-			uint64_t w0 = J.w[0], w1 = J.w[1], w2 = J.w[2];
+			if (c0 == 0) pg0 = row_share<0>(pj) >> 6;
 			uint32_t myrank = 0;
-			const uint32_t pg0 = row_share<0>(pj) >> 6;             // first group of the row that changes
-			static_for<LIGHT_NI>([&](auto jc) {
+			static_for<LTURN>([&](auto jc) {
 				constexpr int j = decltype(jc)::value;
-				if ((uint32_t)j >= nimax) return;                     // wave-uniform
-				const uint32_t p = row_share<j>(pj), a = row_share<j>(J.aj);
-				const bool act = (uint32_t)j < ni_l;
+				if ((uint32_t)j >= ncmax) return;                     // wave-uniform
+				const uint32_t p = row_share<j>(pj), a = row_share<j>(aj);
+				const bool act = (uint32_t)j < nic;
 				const uint32_t pg = p >> 6, pb = p & 63;
 				const uint64_t below = (1ull << pb) - 1ull;
 				const uint64_t msk = (uint32_t)g < pg ? ~0ull : ((uint32_t)g == pg ? below : 0ull);
@@ -384,31 +387,11 @@ __global__ __launch_bounds__(256) void k_merge_leaf(const Ctl *ctl, const LeafDe
 					}
 				}
 			});
-			if (ni_l && (uint32_t)g >= pg0) {                         // (the lines are in L2: the leaf was just read)
-				uint64_t *lw = (uint64_t*)pool.data + o.gl * LEAFW + g;
-				lw[0] = w0; lw[LEAFG] = w1; lw[2 * LEAFG] = w2;
-			}
-			if ((uint32_t)g < ni_l) RKREL[o.ins0 + g] = (uint16_t)myrank;
+			if (mine) RKREL[(uint64_t)o.ins0 + c0 + g] = (uint16_t)myrank;
 		}
-		// ---- the rows that receive many: one after the other, the whole wave on one leaf
-#pragma nounroll
-		for (int row = 0; row < LROWS; ++row) {
-			const uint32_t nr = (uint32_t)__builtin_amdgcn_readlane((int)o.ni, 16 * row);
-			if (nr <= (uint32_t)LIGHT_NI) continue;
-			LeafDesc d;
-			d.gl = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o.gl, 16 * row) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o.gl >> 32), 16 * row) << 32;
-			d.ins0 = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)o.ins0, 16 * row) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(o.ins0 >> 32), 16 * row) << 32;
-			const LeafDesc &dm = LD[g0 + row];                       // i0 (64 bits) and nvalid: from the order itself (uniform load)
-			d.i0 = dm.i0; d.oleaf0 = 0; d.ni = (uint16_t)nr; d.nvalid = dm.nvalid;
-			uint32_t dd[3] = {0, 0, 0};                              // what the leaf receives, per symbol
-			for (int j0 = 0; j0 < (int)nr; j0 += 64) {
-				const uint32_t a = j0 + ln < (int)nr ? (uint32_t)INS_A[d.ins0 + j0 + ln] : 7u;
-#pragma unroll
-				for (int sy = 0; sy < 6; ++sy) dd[sy >> 1] += (uint32_t)__popcll(__ballot(a == (uint32_t)sy)) << (16 * (sy & 1));
-			}
-			dir_add_packed(pool, sbtot, d.gl, ln, dd[0], dd[1], dd[2]);
-			merge_window<false, 1, true>(d, lds[wv], ln, pool, pool, INS_E, INS_A, RKREL, RKLEAF);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // the LDS arrays are reused by the next order
+		if (o.ni && (uint32_t)g >= pg0) {                             // (the lines are in L2: the leaf was just read)
+			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
+			lw[0] = w0; lw[LEAFG] = w1; lw[2 * LEAFG] = w2;
 		}
 		if (!more) return;
 		g0 = g1;
