@@ -239,6 +239,10 @@ void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int
  * reads as from sequencing at coverage n_reads*read_len/genome_len -- large groups, non-empty intervals in every round */
 void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads,
                              int read_len, uint64_t seed, int strand, int64_t genome_len);
+/* ... with a composition knob: skew != 0 draws 85 % A and 5 % each of C, G, T from the same random words (tools/synth_reads.c,
+ * seventh argument): sub-rope (A,A) then holds 72 % of the index and passes 2^32 symbols at 59 M x 101 bp */
+void rb2_hip_synth_reads_skew(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads,
+                              int read_len, uint64_t seed, int strand, int64_t genome_len, int skew);
 
 void rb2_hip_sync(rb2_hip_t *h);
 

@@ -140,7 +140,16 @@ struct SpOrd {              // work order of one touched leaf in a sparse round,
 	uint16_t ni, nvalid;    // new symbols / symbols in the leaf after the round
 };
 
-struct PoolView { uint8_t *data; LeafMeta *meta; Cnt6 *sbcum; LeafMeta *own; uint64_t *sbpos; };   // sbpos[sb] = symbols in front of superblock sb (pool-wide)
+// The pool-wide prefix over the superblocks, two levels: what lies in front of superblock sb = base of its chunk of SCHUNK superblocks
+// (64-bit, a few thousand records: cache-resident) + the prefix inside the chunk (32-bit: a chunk holds < 2^25 symbols).  One 32-byte
+// record per superblock instead of the 48 + 8 bytes of 64-bit values of rounds 1-3: the scan that rebuilds them every round -- the one part
+// of an in-place round that reads every superblock -- moves 48 bytes per superblock instead of 72, in whole lines.
+constexpr int SCHUNK_SH = 10;          // log2(SCHUNK)
+struct SbRec { uint32_t cum[6]; uint32_t pos; uint32_t pad; };     // inside the chunk: symbol counts / symbols in front of the superblock
+struct SbBase { uint64_t cum[6]; uint64_t pos; uint64_t pad; };    // in front of the chunk
+struct PoolView { uint8_t *data; LeafMeta *meta; SbRec *sbrec; LeafMeta *own; SbBase *sbbase; };
+__device__ __forceinline__ uint64_t sb_pos(const PoolView &pv, uint64_t sb) { return pv.sbbase[sb >> SCHUNK_SH].pos + pv.sbrec[sb].pos; }   // symbols in front of superblock sb (pool-wide)
+__device__ __forceinline__ uint64_t sb_cum(const PoolView &pv, uint64_t sb, int a) { return pv.sbbase[sb >> SCHUNK_SH].cum[a] + pv.sbrec[sb].cum[a]; }
 
 struct TileRec {            // per string tile, written by k_sym (80 bytes of it: the buffer is sized in these; layout: TileRecs below)
 	uint32_t hist[6];
@@ -340,28 +349,28 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 {
 	Loc r; r.gl = rp.leaf0; r.s = 0; r.n = 0;
 	if (rp.nleaves == 0) return r;
-	const uint64_t nsb = (rp.nleaves + SB - 1) / SB, base = pv.sbpos[rp.sb0];
+	const uint64_t nsb = (rp.nleaves + SB - 1) / SB, base = sb_pos(pv, rp.sb0);
 	// superblocks hold about the same number of symbols each (a re-layout fills them evenly, inserts land at random), so start
 	// from the interpolated guess and gallop: a handful of probes instead of log2(nsb); still O(log distance) on skewed pieces
 	uint64_t lo, hi;
 	{
 		uint64_t g = rp.n ? (uint64_t)((double)p / (double)rp.n * (double)nsb) : 0;
 		if (g >= nsb) g = nsb - 1;
-		if (pv.sbpos[rp.sb0 + g] - base <= p) {                  // answer in [g, nsb): gallop up
+		if (sb_pos(pv, rp.sb0 + g) - base <= p) {                  // answer in [g, nsb): gallop up
 			uint64_t step = 1; lo = g;
-			while (lo + step < nsb && pv.sbpos[rp.sb0 + lo + step] - base <= p) { lo += step; step <<= 1; }
+			while (lo + step < nsb && sb_pos(pv, rp.sb0 + lo + step) - base <= p) { lo += step; step <<= 1; }
 			hi = min(lo + step, nsb) - 1;                          // sbpos[lo] <= p; everything above hi is > p
 		} else {                                                   // answer in [0, g): gallop down
 			uint64_t step = 1; hi = g - 1;                         // g > 0 here: sbpos[sb0] - base == 0 <= p
-			while (hi >= step && pv.sbpos[rp.sb0 + hi - step + 1] - base > p) { hi -= step; step <<= 1; }
+			while (hi >= step && sb_pos(pv, rp.sb0 + hi - step + 1) - base > p) { hi -= step; step <<= 1; }
 			lo = hi >= step ? hi - step + 1 : 0;                   // sbpos[lo] <= p (lo == 0 at worst); everything above hi is > p
 		}
 	}
 	while (lo < hi) {
 		const uint64_t mid = (lo + hi + 1) >> 1;
-		if (pv.sbpos[rp.sb0 + mid] - base <= p) lo = mid; else hi = mid - 1;
+		if (sb_pos(pv, rp.sb0 + mid) - base <= p) lo = mid; else hi = mid - 1;
 	}
-	const uint64_t sbs = pv.sbpos[rp.sb0 + lo] - base, l0 = (rp.sb0 + lo) * SB;
+	const uint64_t sbs = sb_pos(pv, rp.sb0 + lo) - base, l0 = (rp.sb0 + lo) * SB;
 	const uint32_t rel = (uint32_t)(p - sbs);                  // < 2^16: a superblock holds at most SB * LEAF symbols
 	// inside the superblock: the fills of its slots are one 48-byte read (dir_row 0); unused slots (n == 0) trail the used ones
 	const uint4 *q = (const uint4*)dir_row(pv, rp.sb0 + lo, 0);
@@ -405,7 +414,6 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 	uint64_t gl; uint32_t off;
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
 	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
-	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	uint32_t pc[6];                                            // symbols of the superblock in front of the leaf
 	if (SPARSE) {
 #pragma unroll
@@ -420,7 +428,7 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 	uint32_t c[6];
 	pl_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s];
 }
 
 // occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],
@@ -508,7 +516,6 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 	uint64_t gl; uint32_t off;
 	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
 	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
-	const Cnt6 &c0 = pv.sbcum[rp.sb0], &c1 = pv.sbcum[gl / SB];
 	uint32_t pc[6];
 	if (SPARSE) {                                              // lane j < k holds the counts of slot j: three packed wave sums
 		const uint32_t k = (uint32_t)(gl % SB), ln = (uint32_t)lane_id();
@@ -525,7 +532,7 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 	uint32_t c[6];
 	wave_leaf_counts(leaf_words(pv.data, gl), 0, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = c1.v[s] - c0.v[s] + pc[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s];
 }
 
 // occurrences of the six symbols inside [l, u), l < u, by one wave (what range_counts does with one thread)

@@ -140,20 +140,20 @@ template <typename T> struct DevBuf {
 };
 
 struct Pool {
-	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta, own; DevBuf<Cnt6> sbcum; DevBuf<uint64_t> sbpos;
+	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta, own; DevBuf<SbRec> sbrec; DevBuf<SbBase> sbbase;
 	uint64_t cap_leaves = 0;
 	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
 		if (leaves <= cap_leaves) return;
-		data.vm = meta.vm = own.vm = sbcum.vm = sbpos.vm = true;   // grow in place (DevBuf::vm_grow)
-		meta.vm_div = own.vm_div = 32; sbcum.vm_div = 256; sbpos.vm_div = 1024;   // (16 of 512, 48 and 8 of 16384 bytes per leaf)
+		data.vm = meta.vm = own.vm = sbrec.vm = true;   // grow in place (DevBuf::vm_grow); the chunk bases are a few thousand records
+		meta.vm_div = own.vm_div = 16; sbrec.vm_div = 256;   // (16 of 384 bytes per leaf, 32 of 12288 per superblock)
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
 		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); own.ensure(nl, keep, st);
-		sbcum.ensure(nl / SB + 1, keep, st); sbpos.ensure(nl / SB + 1, keep, st);
+		sbrec.ensure(nl / SB + 1, keep, st); sbbase.ensure(nl / SB / SCHUNK + 2, keep, st);
 		cap_leaves = nl;
 	}
-	PoolView view() const { return PoolView{data.p, meta.p, sbcum.p, own.p, sbpos.p}; }
-	void release() { data.release(); meta.release(); own.release(); sbcum.release(); sbpos.release(); cap_leaves = 0; }
+	PoolView view() const { return PoolView{data.p, meta.p, sbrec.p, own.p, sbbase.p}; }
+	void release() { data.release(); meta.release(); own.release(); sbrec.release(); sbbase.release(); cap_leaves = 0; }
 };
 
 struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
@@ -201,7 +201,7 @@ struct rb2_hip_s {
 	DevBuf<uint8_t> sbuf2; hipStream_t st_copy = nullptr; const uint8_t *pf_host = nullptr; size_t pf_done = 0; std::mutex pf_mu;
 	bool pf_busy = false; std::condition_variable pf_cv;        // a prefetch copy is running (outside the lock: an insert of ANOTHER buffer must not wait for it)
 	DevBuf<TileRec> trec; DevBuf<TileScan> tsc; DevBuf<TileFix> tfix; DevBuf<ChunkPart> cpart;
-	DevBuf<SbTot> sbtot; DevBuf<Cnt6> sbpart;
+	DevBuf<SbTot> sbtot;
 	uint64_t *d_tmp = nullptr;          // small scratch (8 x u64)
 	// profiling
 	int prof = 0;
@@ -279,14 +279,14 @@ void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays 
 	if (nsb_ub == 0) return;
 	if (nsb_grid == 0 || nsb_grid > nsb_ub) nsb_grid = nsb_ub;    // k_meta_sb walks the superblocks with a grid stride (rank_share); the scans need the true bound
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
-	h->sbtot.ensure(nsb_ub); h->sbpart.ensure(nchunk);
+	h->sbtot.ensure(nsb_ub);
 	PoolView pv = h->pool[pool].view();
 	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
 	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
 	if (!leaves_done) RB2_LAUNCH_STRIDE(h, k_meta_sb<true>, k_meta_sb<false>, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
-	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p);
-	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SCHUNK), 0, h->st, h->ctl, h->sbpart.p);
-	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK), 0, h->st, h->ctl, h->sbtot.p, h->sbpart.p, pv);
+	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK / SBT), 0, h->st, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv.sbbase);
+	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SB2T), 0, h->st, (const Ctl*)h->ctl, pv.sbbase);
+	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK / SBT), 0, h->st, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv);
 }
 
 void fetch_ropes(rb2_hip_t *h)
@@ -714,7 +714,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
 	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
-	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release(); h->sbpart.release();
+	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
 	if (h->pair_d) { HIPCHK(hipFree(h->pair_d)); HIPCHK(hipHostFree(h->pair_h)); }
@@ -1287,15 +1287,20 @@ void *rb2_hip_dev_alloc(rb2_hip_t *h, int64_t bytes)
 
 void rb2_hip_dev_free(rb2_hip_t *h, void *p) { finish_pending(h); HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipFree(p)); }
 
-void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand, int64_t genome_len)
+void rb2_hip_synth_reads_skew(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand, int64_t genome_len, int skew)
 { finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	const uint64_t total = (uint64_t)n_reads * (read_len + 1) * (strand ? 2 : 1);
 	if (total == 0) return;
 	if ((uintptr_t)dst_dev & 15) { rb2_fatal("[rb2_hip] synth_reads: destination must be 16-byte aligned\n"); }
 	if (genome_len != 0 && genome_len < read_len) { rb2_fatal("[rb2_hip] synth_reads: genome shorter than a read\n"); }
-	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256 * 16)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand, (uint64_t)genome_len);
+	hipLaunchKernelGGL(k_synth, dim3(cdiv(total, 256 * 16)), dim3(256), 0, h->st, dst_dev, (uint64_t)first_read, (uint64_t)n_reads, (uint32_t)read_len, seed, strand, (uint64_t)genome_len, skew);
 	HIPCHK(hipGetLastError());
+}
+
+void rb2_hip_synth_reads_cov(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand, int64_t genome_len)
+{
+	rb2_hip_synth_reads_skew(h, dst_dev, first_read, n_reads, read_len, seed, strand, genome_len, 0);
 }
 
 void rb2_hip_synth_reads(rb2_hip_t *h, uint8_t *dst_dev, int64_t first_read, int64_t n_reads, int read_len, uint64_t seed, int strand)

@@ -1235,66 +1235,110 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_meta_sb(const Ct
 	}
 }
 
-// the three-kernel prefix over the superblock totals.  A total is six 16-bit counts (<= SB * LEAF = 43008 each) in 16 bytes; inside
-// a chunk of 1024 superblocks sums stay below 2^26, so the chunk-level work is 32-bit DPP scans with one LDS exchange (the first
-// version scanned 64-bit values through LDS shuffles, six times two barriers per chunk -- at 100 G symbols of sparse layout,
-// 4 M superblocks, that was a third of a round); only the chunk bases are 64 bit.
-__global__ __launch_bounds__(SCHUNK) void k_sbscan1(const Ctl *ctl, const SbTot *sbtot, Cnt6 *part)
+// the three-kernel prefix over the superblock totals.  A total is six 16-bit counts (<= SB * LEAF = 32768 each) in 16 bytes; inside
+// a chunk of 1024 superblocks sums stay below 2^25, so the chunk-level work is 32-bit DPP scans with one LDS exchange and what is
+// stored per superblock is a 32-byte record of 32-bit prefixes (SbRec); only the chunk bases (SbBase) are 64 bit.
+// (blocks of 256 threads, four consecutive superblocks per thread -- 64 bytes in flight per lane: with 1024-thread blocks of one
+// superblock per thread the two streaming kernels ran at half the rate, each block waiting out its one round trip to memory)
+constexpr int SBT = 4;                      // superblocks per thread in k_sbscan1 / k_sbscan3
+__global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan1(const Ctl *ctl, const SbTot *sbtot, SbBase *base)
 {
-	__shared__ uint32_t s_p[6][16];
-	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
+	__shared__ uint32_t s_p[6][4];
+	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SBT;
 	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
-	if (i < n) t = sbtot[i];
-	const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+	uint32_t v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+	for (int k = 0; k < SBT; ++k) {
+		SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
+		if (i0 + k < n) t = sbtot[i0 + k];
+		v[0] += t.p01 & 0xffffu; v[1] += t.p01 >> 16; v[2] += t.p23 & 0xffffu; v[3] += t.p23 >> 16; v[4] += t.p45 & 0xffffu; v[5] += t.p45 >> 16;
+	}
 #pragma unroll
 	for (int s = 0; s < 6; ++s) { const uint32_t w = lane63(dpp_incl_add(v[s])); if (ln == 0) s_p[s][wv] = w; }
 	__syncthreads();
-	if (threadIdx.x < 6) {
-		uint64_t tot = 0;
-		for (int k = 0; k < SCHUNK / 64; ++k) tot += s_p[threadIdx.x][k];
-		part[blockIdx.x].v[threadIdx.x] = tot;
+	if (threadIdx.x < 6) base[blockIdx.x].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
+}
+// exclusive prefix over the chunk totals, in place (one block): a thread takes eight consecutive chunks, the wave and block levels are
+// shuffles and one LDS exchange -- one pass for up to 8192 chunks (270 G symbols); more: with a running total
+constexpr int SB2T = 512;                   // threads of k_sbscan2 (its one block)
+__global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
+{
+	__shared__ uint64_t s_w[6][SB2T / 64];
+	constexpr int CT = 8;                                       // chunks per thread: 4096 per pass, all six columns in flight at once
+	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint64_t run[6] = {0, 0, 0, 0, 0, 0};
+	for (uint64_t i0 = 0; i0 < nc; i0 += CT * SB2T) {
+		const uint64_t j0 = i0 + (uint64_t)threadIdx.x * CT;
+		uint64_t v[CT][6], tot[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (int k = 0; k < CT; ++k)
+#pragma unroll
+			for (int s = 0; s < 6; ++s) v[k][s] = j0 + k < nc ? base[j0 + k].cum[s] : 0ull;
+#pragma unroll
+		for (int k = 0; k < CT; ++k)
+#pragma unroll
+			for (int s = 0; s < 6; ++s) { const uint64_t x = v[k][s]; v[k][s] = tot[s]; tot[s] += x; }
+		uint64_t inc[6];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { inc[s] = wave_incl_add<uint64_t>(tot[s]); if (ln == 63) s_w[s][wv] = inc[s]; }
+		__syncthreads();
+		uint64_t b0[6];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) {
+			uint64_t off = 0, all = 0;
+			for (int w = 0; w < SB2T / 64; ++w) { const uint64_t x = s_w[s][w]; if (w < wv) off += x; all += x; }
+			b0[s] = run[s] + off + inc[s] - tot[s];
+			run[s] += all;
+		}
+#pragma unroll
+		for (int k = 0; k < CT; ++k) if (j0 + k < nc) {
+			SbBase o;
+#pragma unroll
+			for (int s = 0; s < 6; ++s) o.cum[s] = b0[s] + v[k][s];
+			o.pos = o.cum[0] + o.cum[1] + o.cum[2] + o.cum[3] + o.cum[4] + o.cum[5]; o.pad = 0;
+			base[j0 + k] = o;
+		}
+		__syncthreads();
 	}
 }
-__global__ __launch_bounds__(SCHUNK) void k_sbscan2(const Ctl *ctl, Cnt6 *part)
+__global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, PoolView newp)
 {
-	__shared__ uint64_t s_w[16];
-	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;   // any number of chunks: SCHUNK at a time with a running total
-	Cnt6 run;
-	for (int s = 0; s < 6; ++s) run.v[s] = 0;
-	for (uint64_t i0 = 0; i0 < nc; i0 += SCHUNK) {
-		const uint64_t i = i0 + threadIdx.x;
-		const bool ok = i < nc;
-		Cnt6 p, o;
-		for (int s = 0; s < 6; ++s) p.v[s] = ok ? part[i].v[s] : 0ull;
-		for (int s = 0; s < 6; ++s) { uint64_t tot; o.v[s] = run.v[s] + block_excl_add<uint64_t>(p.v[s], s_w, &tot); run.v[s] += tot; }
-		if (ok) part[i] = o;
-	}
-}
-__global__ __launch_bounds__(SCHUNK) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, const Cnt6 *part, PoolView newp)
-{
-	__shared__ uint32_t s_p[6][16];
-	const uint64_t n = ctl->nsb_total, i = (uint64_t)blockIdx.x * SCHUNK + threadIdx.x;
+	__shared__ uint32_t s_p[6][4];
+	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SBT;
 	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
-	if (i < n) t = sbtot[i];
-	const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+	uint32_t e[SBT][6], tot[6] = {0, 0, 0, 0, 0, 0};           // exclusive inside the thread, the thread's totals
+#pragma unroll
+	for (int k = 0; k < SBT; ++k) {
+		SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
+		if (i0 + k < n) t = sbtot[i0 + k];
+		const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+#pragma unroll
+		for (int s = 0; s < 6; ++s) { e[k][s] = tot[s]; tot[s] += v[s]; }
+	}
 	uint32_t inc[6];
 #pragma unroll
-	for (int s = 0; s < 6; ++s) { inc[s] = dpp_incl_add(v[s]); if (ln == 63) s_p[s][wv] = inc[s]; }
+	for (int s = 0; s < 6; ++s) { inc[s] = dpp_incl_add(tot[s]); if (ln == 63) s_p[s][wv] = inc[s]; }
 	__syncthreads();
-	const Cnt6 base = part[blockIdx.x];
-	Cnt6 o;
+	uint32_t b0[6];
 #pragma unroll
 	for (int s = 0; s < 6; ++s) {
-		const uint32_t p = ln < 16 ? s_p[s][ln] : 0u;
-		const uint32_t pin = dpp_incl_add(p);
-		const uint32_t off = wv ? (uint32_t)__builtin_amdgcn_readlane((int)pin, wv - 1) : 0u;
-		o.v[s] = base.v[s] + off + inc[s] - v[s];
+		uint32_t off = 0;
+#pragma unroll
+		for (int w = 0; w < 3; ++w) if (w < wv) off += s_p[s][w];
+		b0[s] = off + inc[s] - tot[s];
 	}
-	if (i < n) { newp.sbcum[i] = o; newp.sbpos[i] = o.v[0] + o.v[1] + o.v[2] + o.v[3] + o.v[4] + o.v[5]; }
+#pragma unroll
+	for (int k = 0; k < SBT; ++k) if (i0 + k < n) {             // one 32-byte record per superblock: 128 contiguous bytes per lane
+		uint32_t o[6];
+#pragma unroll
+		for (int s = 0; s < 6; ++s) o[s] = b0[s] + e[k][s];
+		uint4 *q = (uint4*)&newp.sbrec[i0 + k];
+		q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+		q[1] = make_uint4(o[4], o[5], o[0] + o[1] + o[2] + o[3] + o[4] + o[5], 0u);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1364,7 +1408,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
 			gl = nrp.leaf0 + (f >> LEAF_SH);
 		}
-		const uint64_t rk = newp.sbcum[gl / SB].v[a] - newp.sbcum[nrp.sb0].v[a] + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
+		const uint64_t rk = sb_cum(newp, gl / SB, a) - sb_cum(newp, nrp.sb0, a) + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
@@ -1425,16 +1469,23 @@ __device__ __forceinline__ uint64_t synth_base_index(uint64_t i, uint32_t j, uin
 {
 	return genome_len ? splitmix(seed ^ COV_SALT, i) % (genome_len - L + 1) + j : i * L + j;
 }
-__device__ __forceinline__ uint8_t synth_byte(uint64_t g, uint64_t first, uint64_t per, uint32_t L, uint64_t seed, uint64_t genome_len)
+// skew != 0: skewed composition (85 % A, 5 % each C, G, T) from the top byte of the same random word (tools/synth_reads.c)
+__device__ __forceinline__ uint32_t synth_base(uint64_t z, int skew)
+{
+	if (!skew) return (uint32_t)(z >> 62);
+	const uint32_t u = (uint32_t)(z >> 56);
+	return u < 218u ? 0u : 1u + (u - 218u) % 3u;
+}
+__device__ __forceinline__ uint8_t synth_byte(uint64_t g, uint64_t first, uint64_t per, uint32_t L, uint64_t seed, uint64_t genome_len, int skew)
 {
 	const uint64_t r = g / per; uint32_t off = (uint32_t)(g % per);
 	const uint64_t i = first + r;
-	if (off < L) return (uint8_t)(1 + (splitmix(seed, synth_base_index(i, L - 1 - off, L, seed, genome_len)) >> 62));   // reversed forward strand
+	if (off < L) return (uint8_t)(1 + synth_base(splitmix(seed, synth_base_index(i, L - 1 - off, L, seed, genome_len)), skew));   // reversed forward strand
 	if (off == L) return 0;
 	off -= L + 1;
-	return off < L ? (uint8_t)(4 - (splitmix(seed, synth_base_index(i, off, L, seed, genome_len)) >> 62)) : 0;       // complement, original order
+	return off < L ? (uint8_t)(4 - synth_base(splitmix(seed, synth_base_index(i, off, L, seed, genome_len)), skew)) : 0;       // complement, original order
 }
-__global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand, uint64_t genome_len)
+__global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uint64_t n_reads, uint32_t L, uint64_t seed, int strand, uint64_t genome_len, int skew)
 {
 	const uint64_t per = (uint64_t)(L + 1) * (strand ? 2 : 1), total = n_reads * per;
 	const uint64_t g0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16;
@@ -1442,9 +1493,9 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t *dst, uint64_t first, uin
 	if (g0 + 16 <= total) {
 		uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed, genome_len) << ((k & 3) * 8);
+		for (int k = 0; k < 16; ++k) w[k >> 2] |= (uint32_t)synth_byte(g0 + k, first, per, L, seed, genome_len, skew) << ((k & 3) * 8);
 		*(uint4*)(dst + g0) = make_uint4(w[0], w[1], w[2], w[3]);
-	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed, genome_len);
+	} else for (uint64_t g = g0; g < total; ++g) dst[g] = synth_byte(g, first, per, L, seed, genome_len, skew);
 }
 
 // one wave per query: counts of the six symbols in [0, x[i]) of ROPE b (its pieces (b,$), (b,A), ... in order)

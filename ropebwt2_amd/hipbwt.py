@@ -62,6 +62,7 @@ def load_hip_lib():
         "rb2_hip_dev_free": (None, [vp, vp]),
         "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
         "rb2_hip_synth_reads_cov": (None, [vp, vp, i64, i64, i32, u64, i32, i64]),
+        "rb2_hip_synth_reads_skew": (None, [vp, vp, i64, i64, i32, u64, i32, i64, i32]),
         "rb2_hip_sync": (None, [vp]),
         "rb2_hip_sparse_stats": (None, [vp, vp]),
         "rb2_hip_layout_stats": (None, [vp, vp]),
@@ -112,7 +113,7 @@ ABI_SYMBOLS = [
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
     "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
-    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_profile",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_synth_reads_skew", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
@@ -254,8 +255,8 @@ class HipBwt:
     def dev_free(self, p):
         self.L.rb2_hip_dev_free(self.h, p)
 
-    def synth_reads(self, dev_ptr, first, n_reads, read_len, seed=42, strand=0, genome_len=0):
-        self.L.rb2_hip_synth_reads_cov(self.h, dev_ptr, first, n_reads, read_len, seed, strand, genome_len)
+    def synth_reads(self, dev_ptr, first, n_reads, read_len, seed=42, strand=0, genome_len=0, skew=0):
+        self.L.rb2_hip_synth_reads_skew(self.h, dev_ptr, first, n_reads, read_len, seed, strand, genome_len, skew)
 
     def sync(self):
         self.L.rb2_hip_sync(self.h)

@@ -12,7 +12,7 @@ out = {"generator": "tests/golden/make_golden_large.py", "reference": "lh3/ropeb
 if os.path.exists(os.path.join(HERE, "golden_large.json")):           # keep entries produced by other invocations
     if len(sys.argv) > 1:                                             # a sub-mode leaves the 10 M digests alone
         out["fmd_md5"] = json.load(open(os.path.join(HERE, "golden_large.json"))).get("fmd_md5", {})
-    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs") or k.startswith("coverage") or k.startswith("longreads")})
+    out.update({k: v for k, v in json.load(open(os.path.join(HERE, "golden_large.json"))).items() if k.startswith("configs") or k.startswith("coverage") or k.startswith("longreads") or k.startswith("skewed")})
 if "--longreads" in sys.argv:
     # long-read path: 200 k x 5 kbp, input order, one batch of 5001 rounds
     g = subprocess.Popen([GEN, "200000", "5000", "44"], stdout=subprocess.PIPE)
@@ -36,6 +36,25 @@ if "--coverage" in sys.argv:
         assert p.wait() == 0 and g.wait() == 0
         cov["runs"][flags] = {"fmd_bytes": n, "fmd_md5": h.hexdigest()}
     out["coverage30x"] = cov
+    json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
+    sys.exit(0)
+if "--skewed" in sys.argv:
+    # The > 2^32 regime pinned to the real reference: 60 M x 101 bp of SKEWED composition (85 % A: synth_reads ... 1), so that sub-rope
+    # (A,A) of the device index -- the A's of rope A -- holds 4.4 G symbols, more than 32 bits of piece-relative position, at a size the
+    # reference builds in minutes (run-length leaves keep its memory small).  RLO and RCLO, forward strand.
+    N = 60_000_000
+    sk = {"n_reads": N, "read_len": 101, "seed": 42, "skew": 1, "runs": {},
+          "provenance": "oracle/_ref/ropebwt2 (the real reference) in the build container: synth_reads 60000000 101 42 0 0 0 1 | ropebwt2 <flags> - ; make_golden_large.py --skewed"}
+    for flags in ("-LRds", "-LRdr"):
+        g = subprocess.Popen([GEN, str(N), "101", "42", "0", "0", "0", "1"], stdout=subprocess.PIPE)
+        p = subprocess.Popen([REF] + flags.split() + ["-"], stdin=g.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        h, n = hashlib.md5(), 0
+        for chunk in iter(lambda: p.stdout.read(1 << 24), b""):
+            h.update(chunk); n += len(chunk)
+        assert p.wait() == 0 and g.wait() == 0
+        sk["runs"][flags] = {"fmd_bytes": n, "fmd_md5": h.hexdigest()}
+        print(flags, n, h.hexdigest(), file=sys.stderr)
+    out["skewed_60M"] = sk
     json.dump(out, open(os.path.join(HERE, "golden_large.json"), "w"), indent=1)
     sys.exit(0)
 if "--configs2-order" in sys.argv:

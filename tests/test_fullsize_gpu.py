@@ -153,6 +153,41 @@ def test_configs2_order_golden_100M_through_cli_on_8_ranks(hip):
     assert n == g["fmd_bytes"] and h.hexdigest() == g["fmd_md5"]
 
 
+@pytest.mark.parametrize("flags", ["-LRds", "-LRdr"])
+def test_skewed_composition_crosses_2_to_32_symbols_per_subrope(hip, flags):
+    """The > 2^32 regime pinned to the REAL reference: 60 M x 101 bp of skewed composition (85 % A), so that sub-rope (A,A) -- the
+    A's of rope A, one piece of the device index -- holds 4.35 G symbols: piece-relative positions, window offsets (k_part /
+    merge_window: e - i0), the 48-bit fields of the exchange records and the directory prefixes all pass 32 bits.  The .fmd md5 was
+    produced by oracle/_ref/ropebwt2 (make_golden_large.py --skewed).  Through the CLI on one engine AND sharded over 8 ranks; the
+    size of the piece is asserted on an index built from the same stream generated on the device."""
+    g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json"))).get("skewed_60M")
+    if g is None or flags not in g["runs"]:
+        pytest.skip("golden_large.json has no skewed_60M entry for %s (make_golden_large.py --skewed)" % flags)
+    from test_host_layer import CLI
+    N, L = g["n_reads"], g["read_len"]
+    for devs in (None, "0,0,0,0,0,0,0,0"):
+        env = dict(os.environ)
+        if devs:
+            env["RB2_HIP_DEVICES"] = devs
+        pg = subprocess.Popen([H.GEN, str(N), str(L), str(g["seed"]), "0", "0", "0", str(g["skew"])], stdout=subprocess.PIPE)
+        pc = subprocess.Popen([CLI] + flags.split() + ["-"], stdin=pg.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        h, n = hashlib.md5(), 0
+        for chunk in iter(lambda: pc.stdout.read(1 << 24), b""):
+            h.update(chunk); n += len(chunk)
+        assert pc.wait() == 0 and pg.wait() == 0
+        assert n == g["runs"][flags]["fmd_bytes"] and h.hexdigest() == g["runs"][flags]["fmd_md5"], "devices: %s" % devs
+    if flags == "-LRds":                                                    # the piece really is that large (same stream, generated on the device)
+        dev = hip.HipBwt(1)
+        buf = dev.dev_alloc(N * (L + 1) + 64)
+        dev.synth_reads(buf, 0, N, L, seed=g["seed"], skew=g["skew"])
+        dev.sync()
+        dev.insert_multi_dev(buf, N * (L + 1))
+        c = dev.counts()
+        dev.dev_free(buf); dev.close()
+        assert int(c[1, 1]) > (1 << 32), "piece (A,A) = the A's of rope A: %d symbols" % int(c[1, 1])
+        assert int(c.sum()) == N * (L + 1) and _lf_ok(c, N)
+
+
 def test_configs3_full_size_10M_x_10k(hip):
     n, L, per = 10_000_000, 10_000, batch_reads(10, 10_000)
     dev = hip.HipBwt(0)
