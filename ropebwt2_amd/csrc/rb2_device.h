@@ -66,11 +66,20 @@ __host__ __device__ inline int rope_prev(int r) { return r == 0 ? 0 : (r - 1) % 
 __host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (a - 1) * 6 + b; }
 
 struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: prefixes inside the superblock + own fill; own[]: own counts + own fill
-constexpr int SP_FILL = 768;           // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 256 inserts)
-constexpr int SP_USED = 24;            // ... leaf slots in use per superblock; the other 8 are the superblock's own reserve: a leaf that comes within
+#ifndef RB2_SP_FILL
+#define RB2_SP_FILL 768
+#endif
+#ifndef RB2_SP_USED
+#define RB2_SP_USED 24
+#endif
+#ifndef RB2_SP_MARGIN
+#define RB2_SP_MARGIN 64
+#endif
+constexpr int SP_FILL = RB2_SP_FILL;           // sparse layout: symbols per leaf after a re-layout (75 % of LEAF: room for 256 inserts)
+constexpr int SP_USED = RB2_SP_USED;            // ... leaf slots in use per superblock; the other 8 are the superblock's own reserve: a leaf that comes within
                                        // SP_MARGIN symbols of LEAF is split into one of them at the end of the round (k_split: the counterpart of the
                                        // reference's leaf split, rope.c:143-146 / split_node rope.c:78-112, one level of its B+ tree)
-constexpr int SP_MARGIN = 64;          // a leaf is split when its fill exceeds LEAF - SP_MARGIN: whatever a round brings, a leaf takes 64 more symbols
+constexpr int SP_MARGIN = RB2_SP_MARGIN;          // a leaf is split when its fill exceeds LEAF - SP_MARGIN: whatever a round brings, a leaf takes 64 more symbols
 struct Cnt6 { uint64_t v[6]; };
 struct SbTot { uint32_t p01, p23, p45, pad; };             // symbol counts of one superblock, six 16-bit fields (<= SB * LEAF each)
 
