@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
 CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
 # the real reference on the FULL configs[1] job, same kind of box (profiles/r01_configs1_cli_vs_reference.json)
-CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5, "measured_in_round": 1,
+CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5, "measured_in_round": 1, "constant": True,
                    "source": "profiles/r01_configs1_cli_vs_reference.json (oracle/_ref/ropebwt2 -LRds -m4g on all 100 M reads, MI355X box host)"}
 
 
@@ -265,7 +265,7 @@ def measure_traffic(budget_s=240):
     if exe is None:
         return None
     tmp = tempfile.mkdtemp(prefix="rb2_pmc_", dir="/tmp")
-    res = {}
+    res, per_kernel = {}, {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, ctr)
@@ -278,8 +278,10 @@ def measure_traffic(budget_s=240):
                 return None
             tot, n = 0.0, 0
             for r in csv.DictReader(open(files[0])):
-                if r["Kernel_Name"].split("(")[0].split("<")[0].endswith("k_merge"):
+                kn = r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1].strip()
+                if kn == "k_merge":
                     tot += float(r["Counter_Value"]); n += 1
+                per_kernel.setdefault(kn, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[ctr] += float(r["Counter_Value"])
             res[ctr] = (tot, n)
     except Exception as e:  # noqa: BLE001
         sys.stderr.write("[bench] PMC passes failed: %r\n" % (e,))
@@ -289,7 +291,11 @@ def measure_traffic(budget_s=240):
     (fe, n), (wr, n2) = res["FETCH_SIZE"], res["WRITE_SIZE"]
     if n == 0 or n != n2:
         return None
+    # every kernel of the job, per ROUND (= per k_merge launch): where the bytes of a round go
+    table = {k: round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / n / 1e9, 4) for k, v in per_kernel.items() if k.startswith("k_")}
+    table = dict(sorted(table.items(), key=lambda kv: -kv[1]))
     return {"bytes_per_launch": (2 * fe + wr) * 1024 / n, "fetch_bytes_per_launch_corrected": 2 * fe * 1024 / n, "write_bytes_per_launch": wr * 1024 / n,
+            "traffic_GB_per_round": table, "all_kernels_GB_per_round": round(sum(table.values()), 4),
             "launches": n, "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 3 --warmup 0 "
                                      "--no-cpu-baseline --no-extras` (one configs[1] job, %d k_merge launches); counters in KiB, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)" % n}
 
@@ -356,6 +362,49 @@ def secondary_configs3(reads=1_000_000, L=10_000, batch_gib=10.0):
                     % (reads, L, total / 1e9)}
 
 
+def secondary_coverage(L=101):
+    """The compressible regime ropebwt2 exists for: 30 M OVERLAPPING reads (windows of one random 100 Mb genome, 30x; the job of
+    golden_large.json coverage30x, whose .fmd md5 from the real reference the test-suite checks through the CLI) on one GPU, RLO,
+    -m1g batches.  Reports the rate, the HBM bytes the index holds per symbol (packed bit planes: 0.375 + directory, whatever the
+    data) and, beside it, what the real reference needed for the same job (tools/ref_footprint.py: its run-length B+ trees)."""
+    from ropebwt2_amd import HipBwt
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json"))).get("coverage30x")
+    if g is None:
+        return None
+    reads, glen = g["n_reads"], g["genome_len"]
+    per_batch = batch_reads(1.0 * 1024 ** 3, L)
+    b = HipBwt(1, 0)
+    try:
+        total = reads * (L + 1)
+        b.reserve(per_batch * (L + 1), per_batch, total)
+        buf = b.dev_alloc(per_batch * (L + 1) + 64)
+        done, dt = 0, 0.0
+        while done < reads:
+            n = min(per_batch, reads - done)
+            b.synth_reads(buf, done, n, L, seed=g["seed"], genome_len=glen)
+            b.sync()
+            t0 = time.perf_counter()
+            b.insert_multi_dev(buf, n * (L + 1))
+            b.sync()
+            dt += time.perf_counter() - t0
+            done += n
+        c = b.counts()
+        ok = int(c.sum()) == total and int(c[:, 0].sum()) == reads
+        runs = sum(int(b.L.rb2_hip_rope_bytes(b.h, k)) for k in range(6))            # one byte per run of <= 15 symbols: what the exported stream costs
+        b.dev_free(buf)
+    finally:
+        b.close()
+    lay = HipBwt.layout()
+    leaf_b = lay["leaf_syms"] * 3 // 8
+    held = (leaf_b + 32.0 + 32.0 / 32) / lay["leaf_syms"]          # leaf + LeafMeta x 2 + superblock record share, per symbol, one pool side
+    ref = g.get("reference_run")
+    return {"value": total / dt / 1e9, "unit": "Gsymbols/s", "insert_s": dt, "counts_ok": bool(ok), "symbols": total,
+            "hbm_bytes_per_symbol": {"one_pool_side": round(held, 4), "both_sides_of_a_dense_round": round(2 * held, 4)},
+            "run_bytes_per_symbol_exported": round(runs / total, 4),
+            "reference": ref, "footprint_ratio_vs_reference_rss": round(2 * held / ref["rss_bytes_per_symbol"], 2) if ref else None,
+            "what": "coverage30x: %d x %d bp windows of one random %d bp genome (30x), RLO, -m1g batches on 1 GPU; inputs generated on the device, inserts timed" % (reads, L, glen)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -370,7 +419,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the value_host_api / whole_process / secondary / PMC legs (profiling runs)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]-shape leg")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in-run (use the committed summary if it matches the sources)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=3_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000, help="reads of the reference's bounded sample (10 M: ~25 s of inserts)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -565,6 +614,9 @@ def main():
                    "counts_ok": bool(ok_counts)},
         "roofline": {"bound": "hbm", "kernel": "k_merge", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                     # the pipeline figure: the same algorithmic bytes over the WHOLE round (all kernels, wall clock) instead of over k_merge alone
+                     "whole_round_achieved": ALG_BYTES_PER_SYMBOL * total_symbols / dt / 1e9 / max(1, n_gpus),
+                     "whole_round_frac": ALG_BYTES_PER_SYMBOL * total_symbols / dt / 1e9 / max(1, n_gpus) / HBM_PEAK_GBS,
                      "avg_launch_ms": mk["ms"] / max(1, mk["launches"]), "launches": mk["launches"],
                      "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL,
                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_SYMBOL * units / max(1, mk["launches"]),
@@ -579,6 +631,8 @@ def main():
         tr = measure_traffic()
         if tr is not None:
             out["roofline"]["traffic"] = tr["bytes_per_launch"]
+            out["roofline"]["traffic_GB_per_round"] = tr.pop("traffic_GB_per_round")
+            out["roofline"]["all_kernels_GB_per_round"] = tr.pop("all_kernels_GB_per_round")
             out["roofline"]["traffic_detail"] = tr
     traffic_file = os.path.join(ROOT, "profiles", "k_merge_traffic.json")
     if out["roofline"]["traffic"] is None and os.path.exists(traffic_file) and is_cfg1:
@@ -607,6 +661,12 @@ def main():
                 out.setdefault("secondary", {})["configs3_shape_tenth_1gpu"] = secondary_configs3()
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("[bench] secondary long-read leg failed: %r\n" % (e,))
+            try:
+                cv = secondary_coverage()
+                if cv is not None:
+                    out.setdefault("secondary", {})["coverage30x_1gpu"] = cv
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("[bench] secondary coverage leg failed: %r\n" % (e,))
     if not args.no_cpu_baseline and n_ranks == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
     print(json.dumps(out))

@@ -56,7 +56,11 @@ typedef struct rb2_hip_s rb2_hip_t;
 /* Fatal errors (a HIP call that fails, a missing GPU, a malformed batch, out of device memory): a message on stderr, then abort() --
  * the reference's own convention on this path (asserts and unchecked mallocs).  A host program that wants a say
  * installs a handler: it is called with the message before abort() and may log, release what it holds, or leave through longjmp /
- * exit (the handle that failed must not be used again; others may). */
+ * exit (the handle that failed must not be used again; others may).
+ * With N GPUs behind one handle (rb2_hip_multi_*) a failure is detected on the host thread of the rank it happens on, while the
+ * threads of the other ranks may be waiting at the round barrier or for device events that will never be recorded: there the
+ * handler must NOT return control to the program -- it may log and then end the process (_exit / abort); longjmp out of a rank's
+ * thread is undefined, and exit() would run atexit handlers beside threads that still spin. */
 typedef void (*rb2_hip_fatal_cb)(void *user, const char *message);
 void rb2_hip_set_fatal_handler(rb2_hip_fatal_cb cb, void *user);
 
@@ -190,7 +194,15 @@ typedef struct rb2_hip_multi_s rb2_hip_multi_t;
 #define RB2_TRANSPORT_RCCL 1
 #define RB2_MULTI_MAX_RANKS 64
 /* one process drives n ranks; devices[i] = HIP device of rank i; owner == NULL: the default owner map (rb2_hip_default_owners) */
+/* Start-up checks (round 4), so that the first run on real multi-GPU hardware fails loudly or not at all:
+ *   - PEER transport asked for, but some pair of the listed devices has no peer access: the handle is created on the RCCL
+ *     transport instead (message on stderr; never a CPU path).  Impossible (a device listed twice AND a pair without peer access): fatal.
+ *   - self-test: whenever the ranks sit on more than one physical device (or RB2_MULTI_SELFTEST=1; =0 turns it off) a job of
+ *     2000 short reads is built across the ranks and, sub-rope by sub-rope, compared -- device-side checksums and the count matrix
+ *     -- with the same job on one engine; a mismatch is fatal.  The handle is reset afterwards. */
 rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_order, int transport, const int *owner /* [NR] or NULL */);
+/* the transport the handle really uses (RB2_TRANSPORT_*) */
+int rb2_hip_multi_transport(const rb2_hip_multi_t *m);
 /* one rank of a group of `nranks` processes (RCCL): `nccl_id` = the 128 bytes rb2_hip_multi_unique_id() produced on rank 0 */
 void rb2_hip_multi_unique_id(void *id128);
 rb2_hip_multi_t *rb2_hip_multi_create_rank(int device, int rank, int nranks, const void *nccl_id, int sorting_order, const int *owner);

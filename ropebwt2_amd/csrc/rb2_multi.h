@@ -28,7 +28,23 @@
 #include <atomic>
 #include <thread>
 #include <dlfcn.h>
+// librccl is dlopen'ed on first use of the RCCL transport; its header only supplies the handful of types and enums the calls need.
+// A ROCm install without the RCCL development files still builds the library: the same declarations, spelled out (they are ABI).
+#if !defined(RB2_NO_RCCL_HEADER) && defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#define RB2_HAVE_RCCL_HEADER 1
+#endif
+#endif
+#ifndef RB2_HAVE_RCCL_HEADER
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+#endif
 
 namespace rb2 {
 
@@ -386,8 +402,71 @@ void rb2_hip_default_owners(int nranks, int owner[])
 	}
 }
 
+/* Build a small job across the ranks of m and compare what every LOCAL rank holds with the same job on one engine: sub-rope by
+ * sub-rope, device-side checksums of the symbols + the count matrix.  Collective over the ranks of the group (every process of an
+ * RCCL group runs it at the same point).  Fatal on a mismatch -- a first run on hardware this build has not seen either works or
+ * says where it does not.  Leaves the handle empty. */
+static void multi_selftest(rb2_hip_multi_t *m)
+{
+	const int n_reads = 2000, L = 48;
+	std::vector<uint8_t> s;
+	s.reserve((size_t)n_reads * (L + 1));
+	uint64_t x = 0x9E3779B97F4A7C15ull;
+	for (int i = 0; i < n_reads; ++i) {                          // reversed nt6 strings, 0-terminated (mrope.h:46-54); every 7th a copy of its neighbour
+		const size_t at = s.size();
+		for (int j = 0; j < L; ++j) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; s.push_back((uint8_t)(1 + (x >> 60) % 4)); }
+		if (i % 7 == 6) memcpy(&s[at], &s[at - (L + 1)], L);
+		s.push_back(0);
+	}
+	const int64_t len = (int64_t)s.size();
+	rb2_hip_multi_insert_multi(m, len, s.data());
+	rb2_hip_t *one = rb2_hip_create(m->rk[0].dev, m->so);
+	rb2_hip_insert_multi(one, len, s.data());
+	rb2_hip_wait(one);
+	int64_t cm[36], c1[36];
+	rb2_hip_multi_get_counts(m, cm); rb2_hip_get_counts(one, c1);
+	if (memcmp(cm, c1, sizeof(cm)) != 0) rb2_fatal("[rb2_hip] multi self-test: the count matrix of %d ranks (%s transport) differs from one engine's\n", m->world, m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL");
+	for (int r = 0; r < NR; ++r) {
+		const int o = m->owner[r] - m->rank0;
+		if (o < 0 || o >= m->n) continue;                        /* another process holds (and checks) it */
+		const uint64_t a = piece_hash(m->rk[o].h, r), b = piece_hash(one, r);
+		if (a != b || m->rk[o].h->h_rope[r].n != one->h_rope[r].n)
+			rb2_fatal("[rb2_hip] multi self-test: sub-rope %d held by rank %d on device %d (%s transport) differs from the one-engine build (%llu vs %llu symbols)\n", r, m->owner[r], m->rk[o].dev,
+					m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL", (unsigned long long)m->rk[o].h->h_rope[r].n, (unsigned long long)one->h_rope[r].n);
+	}
+	rb2_hip_destroy(one);
+	rb2_hip_multi_reset(m);
+	m->n_sync = m->n_rounds = m->n_batches = 0;
+	for (auto &R : m->rk) { R.h->n_sparse_rounds = R.h->n_void = R.h->n_relayout = R.h->n_respread = 0; }
+	if (m->trace) fprintf(stderr, "[rb2_hip] multi self-test passed: %d ranks, %s transport\n", m->world, m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL");
+}
+static bool multi_want_selftest(int distinct_devices, int world)
+{
+	const char *e = getenv("RB2_MULTI_SELFTEST");
+	if (e) return atoi(e) != 0;
+	(void)world;
+	return distinct_devices > 1;                                /* ranks on more than one physical device: hardware this build may never have seen */
+}
+
+int rb2_hip_multi_transport(const rb2_hip_multi_t *m) { return m->transport; }
+
 rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_order, int transport, const int *owner)
 {
+	int distinct = 0;
+	for (int k = 0; k < n; ++k) { bool seen = false; for (int p = 0; p < k; ++p) seen |= devices[p] == devices[k]; distinct += !seen; }
+	if (transport == RB2_TRANSPORT_PEER && distinct > 1) {      // every pair of distinct devices must see each other's memory
+		bool ok = true; int a = -1, b = -1;
+		for (int k = 0; k < n && ok; ++k) for (int p = 0; p < n && ok; ++p) {
+			if (devices[k] == devices[p]) continue;
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, devices[k], devices[p]) != hipSuccess || !can) { ok = false; a = devices[k]; b = devices[p]; (void)hipGetLastError(); }
+		}
+		if (!ok) {
+			if (distinct < n) rb2_fatal("[rb2_hip] multi: device %d cannot access device %d (no peer access) and a device is listed more than once: neither transport can serve this list\n", a, b);
+			fprintf(stderr, "[rb2_hip] multi: device %d cannot access device %d (no peer access): using the RCCL transport instead of PEER\n", a, b);
+			transport = RB2_TRANSPORT_RCCL;
+		}
+	}
 	rb2_hip_multi_t *m = multi_new(n, devices, n, 0, sorting_order, transport, owner);
 	if (transport == RB2_TRANSPORT_RCCL && n > 1) {
 		for (int k = 0; k < n; ++k) for (int p = 0; p < k; ++p)
@@ -401,6 +480,7 @@ rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_ord
 		NCCLCHK(rccl().GetUniqueId(&id));
 		NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, 1, id, 0));
 	}
+	if (multi_want_selftest(distinct, n)) multi_selftest(m);
 	return m;
 }
 
@@ -422,6 +502,7 @@ rb2_hip_multi_t *rb2_hip_multi_create_rank(int device, int rank, int nranks, con
 	else { rb2_fatal("[rb2_hip] multi: a group of %d ranks needs the id of rb2_hip_multi_unique_id() from rank 0\n", nranks); }
 	HIPCHK(hipSetDevice(device));
 	NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, nranks, id, rank));
+	if (multi_want_selftest(nranks, nranks)) multi_selftest(m);  /* collective: every process of the group is here */
 	return m;
 }
 

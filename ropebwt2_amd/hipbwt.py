@@ -76,6 +76,7 @@ def load_hip_lib():
         "rb2_hip_multi_destroy": (None, [vp]),
         "rb2_hip_default_owners": (None, [i32, vp]),
         "rb2_hip_multi_nranks": (i32, [vp]),
+        "rb2_hip_multi_transport": (i32, [vp]),
         "rb2_hip_multi_nlocal": (i32, [vp]),
         "rb2_hip_multi_engine": (vp, [vp, i32]),
         "rb2_hip_multi_insert_multi": (None, [vp, i64, vp]),
@@ -116,7 +117,7 @@ ABI_SYMBOLS = [
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_synth_reads_skew", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
-    "rb2_hip_multi_nranks", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
+    "rb2_hip_multi_nranks", "rb2_hip_multi_transport", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
     "rb2_hip_multi_get_counts", "rb2_hip_multi_rope_bytes", "rb2_hip_multi_download_rope", "rb2_hip_multi_stream_rope",
     "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_plan_host", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
 ]

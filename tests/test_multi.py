@@ -301,6 +301,31 @@ def test_rccl_group_of_one(hip, so):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport,n", [("peer", 4), ("peer", 8), ("rccl", 1)])
+def test_start_up_self_test(hip, transport, n):
+    """rb2_hip_multi_create's self-test (on by itself whenever the ranks sit on more than one physical device; forced here): a
+    2000-read job across the ranks against the same job on one engine, sub-rope checksums + count matrix; the handle comes back
+    empty, with clean statistics, and builds the right index afterwards"""
+    from ropebwt2_amd import MultiBwt
+    os.environ["RB2_MULTI_SELFTEST"] = "1"
+    os.environ["RB2_HIP_TRACE"] = "0"
+    try:
+        m = MultiBwt(1, [0] * n, transport)
+    finally:
+        del os.environ["RB2_MULTI_SELFTEST"]; del os.environ["RB2_HIP_TRACE"]
+    assert m.L.rb2_hip_multi_transport(m.h) == {"peer": 0, "rccl": 1}[transport]
+    st = m.stats()
+    assert st["rounds"] == 0 and st["batches"] == 0 and int(m.counts().sum()) == 0
+    o = H.Oracle(1)
+    for buf in _batches(1)[:2]:
+        o.insert_multi(buf); m.insert_multi(buf)
+    assert np.array_equal(m.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+    m.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs >= 2 GPUs on the box")
 @pytest.mark.parametrize("transport", ["peer", "rccl"])
 def test_real_devices_one_process(hip, transport):
