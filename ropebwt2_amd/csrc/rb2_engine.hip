@@ -196,7 +196,7 @@ struct rb2_hip_s {
 	DevBuf<uint64_t> qbuf;              // rank queries and their answers
 	uint64_t sp_nsb = 0;                // superblocks of the sparse pool (upper bound)
 	DevBuf<LeafDesc> LD;
-	DevBuf<uint8_t> A, INS_A, sbuf;
+	DevBuf<uint8_t> A[2], INS_A, sbuf;   // A: symbol (+ flags) of every string this round; the other side receives next round's from k_advance
 	// rb2_hip_prefetch: the NEXT batch travels to the device (second text buffer, copy stream) while the current one is inserted
 	DevBuf<uint8_t> sbuf2; hipStream_t st_copy = nullptr; const uint8_t *pf_host = nullptr; size_t pf_done = 0; std::mutex pf_mu;
 	bool pf_busy = false; std::condition_variable pf_cv;        // a prefetch copy is running (outside the lock: an insert of ANOTHER buffer must not wait for it)
@@ -313,7 +313,7 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); }
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
-	h->A.ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
+	h->A[0].ensure(m); h->A[1].ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
 	h->trec.ensure(nst + 8); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
@@ -358,7 +358,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		Scope sc(h, RB2_K_INIT, 0);
 		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len, is_srt);
 		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
-				h->L[0].p, h->U[0].p, h->W[0].p);
+				h->L[0].p, h->U[0].p, h->W[0].p, h->A[0].p);
 	}
 	HIPCHK(hipMemcpyAsync(&B.max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -395,7 +395,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 	h->cur_round = (int)r;
 	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
 	{ Scope sc(h, RB2_K_SYM, units);
-	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->W[cur].p, h->A.p, trs); }
+	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->A[cur].p, trs); }
 	if (B.nst_ub < (unsigned)TS_MAX) {                         // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
@@ -429,9 +429,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true>), (k_prep<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true>), (k_prep<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A[cur].p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true>), (k_prep<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A.p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true>), (k_prep<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A[cur].p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, k_part<true>, k_part<false>, dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
@@ -440,9 +440,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true>), (k_advance<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true>), (k_advance<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
-	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true>), (k_advance<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->START.p, h->A.p, h->tfix.p,
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true>), (k_advance<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
@@ -512,9 +512,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
 	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true>), (k_prep<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true>), (k_prep<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A[cur].p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true>), (k_prep<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A.p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true>), (k_prep<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A[cur].p,
 			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
@@ -524,9 +524,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true>), (k_advance<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true>), (k_advance<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
-	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true>), (k_advance<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->START.p, h->A.p, h->tfix.p,
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true>), (k_advance<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
@@ -712,7 +712,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); }
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
-	h->LD.release(); h->A.release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
+	h->LD.release(); h->A[0].release(); h->A[1].release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
 	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
@@ -1189,7 +1189,7 @@ void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt
 		} else h->pieces.ensure(pcs.size() + 1);
 		HIPCHK(hipMemcpyAsync(h->pieces.p, src, pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
 		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
-		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->START.p, (uint32_t)round,
+		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->A[cur].p, (uint32_t)round,
 				h->L[cur].p, h->U[cur].p, h->W[cur].p);
 	}
 	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));

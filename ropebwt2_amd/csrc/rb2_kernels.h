@@ -148,24 +148,29 @@ __global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t
 	}
 }
 
-// The per-string cursor word W that rides through the partition of every round: string id (high 32 bits) + the next CUR_SYMS
-// symbols, 3 bits each (low 30 bits).  (Rounds 1-2: a 16-symbol cursor of 4-bit codes + a separate 32-bit id array -- 12 bytes
-// read and 12 written per string and round in k_advance; one word now, refilled every 10 rounds instead of every 16.)
-constexpr int CUR_SYMS = 10;
+// The per-string cursor word W that rides through the partition of every round: the next CUR_SYMS symbols of the string, 3 bits each
+// (low 27 bits), and -- above them -- the position in the batch text where the symbols behind those start (36 bits: a batch has
+// < 64 GiB).  Every CUR_SYMS rounds the cursor is refilled by ONE gather from the text at that position.  (Rounds 1-3 carried the
+// string id instead and looked the position up in START[id]: a second random 8-byte read per refill, 64 bytes of traffic for it.)
+// The symbol a string inserts NEXT round also travels as a byte of its own (array A, written by k_advance at the string's new place):
+// k_sym reads one byte per string instead of the 8-byte word.
+constexpr int CUR_SYMS = 9;
+constexpr int CUR_BITS = 3 * CUR_SYMS;
+constexpr uint64_t CUR_MASK = (1ull << CUR_BITS) - 1ull;
 __device__ __forceinline__ uint32_t tri4(uint32_t x)      // low 3 bits of 4 bytes -> 12 bits
 {
 	x &= 0x07070707u;
 	x = (x | x >> 5) & 0x003f003fu;
 	return (x | x >> 10) & 0xfffu;
 }
-__device__ __forceinline__ uint32_t pack10(const uint8_t *s, uint64_t len, uint64_t p)   // s[p .. p+10) as 30 bits (bytes past the end read as 0)
+__device__ __forceinline__ uint32_t pack9(const uint8_t *s, uint64_t len, uint64_t p)   // s[p .. p+9) as 27 bits (bytes past the end read as 0)
 {
 	if (p + 16 <= len) {
 		const uint32_t *q = (const uint32_t*)(s + (p & ~3ull));
 		const uint32_t sh = (uint32_t)(p & 3) * 8;
 		const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
 		const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
-		return tri4(w0) | tri4(w1) << 12 | (tri4(w2) & 0x3fu) << 24;
+		return tri4(w0) | tri4(w1) << 12 | (tri4(w2) & 0x7u) << 24;
 	}
 	uint32_t w = 0;
 	for (int i = 0; i < CUR_SYMS; ++i) {
@@ -174,13 +179,13 @@ __device__ __forceinline__ uint32_t pack10(const uint8_t *s, uint64_t len, uint6
 	}
 	return w;
 }
-__device__ __forceinline__ uint64_t cur_make(uint32_t id, uint32_t syms) { return (uint64_t)id << 32 | syms; }
-__device__ __forceinline__ uint32_t cur_id(uint64_t w) { return (uint32_t)(w >> 32); }
+__device__ __forceinline__ uint64_t cur_make(uint64_t next_pos, uint32_t syms) { return next_pos << CUR_BITS | syms; }
+__device__ __forceinline__ uint64_t cur_pos(uint64_t w) { return w >> CUR_BITS; }
 __device__ __forceinline__ int cur_sym(uint64_t w) { return (int)(w & 7); }
-__device__ __forceinline__ uint64_t cur_next(uint64_t w) { return (w & 0xffffffff00000000ull) | ((uint32_t)w >> 3); }   // one symbol consumed
+__device__ __forceinline__ uint64_t cur_next(uint64_t w) { return (w & ~CUR_MASK) | ((w & CUR_MASK) >> 3); }   // one symbol consumed
 
 __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
-		uint64_t *L, uint64_t *U, uint64_t *W)
+		uint64_t *L, uint64_t *U, uint64_t *W, uint8_t *A)
 {
 	__shared__ int s_wm[4];
 	const uint64_t m = ctl->n_strings, k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -190,7 +195,9 @@ __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, cons
 		ln = START[k+1] - 1 - st;
 		L[k] = is_srt ? 0 : n0 + k;                 // mrope.c:280-283
 		U[k] = is_srt ? n0 : n0 + k;
-		W[k] = cur_make((uint32_t)k, pack10(s, ctl->len, st));
+		const uint32_t c9 = pack9(s, ctl->len, st);
+		W[k] = cur_make(st + CUR_SYMS, c9);
+		A[k] = (uint8_t)(c9 & 7u);
 	}
 	// block max of the lengths -> ctl->max_len
 	unsigned long long v = ln;
@@ -241,8 +248,8 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // tiles when the rank holds more -- an upper-bound grid of N times the work would cost more in empty workgroups than the work itself.
 // STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
 // with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU, const uint64_t *W,
-		uint8_t *A, TileRecs trec)
+template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU,
+		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
@@ -257,7 +264,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *c
 		const uint64_t k = t.base + pos;
 		int sym = 7; bool head = false;
 		if (k < t.segend) {
-			sym = cur_sym(W[k]);
+			sym = A[k] & 7;
 			head = (k == t.segstart) || (U[k] != U[k-1]);
 			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
 		}
@@ -1347,17 +1354,17 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 // ---------------------------------------------------------------------------------------------
 
 template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
-		const uint64_t *START, const uint8_t *A, const TileFix *tf,
+		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
-		const uint64_t *START, const uint8_t *A, const TileFix *tf,
+		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
-		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, START, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
+		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1366,7 +1373,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch
 }
 
 template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
-		const uint64_t *START, const uint8_t *A, const TileFix *tf,
+		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
 		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
@@ -1412,13 +1419,12 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = ctl->dest[t.b][a] + m.pa;
-		const uint32_t id = cur_id(w2[h]);
 		uint64_t wv = cur_next(w2[h]);
-		if ((round + 1) % CUR_SYMS == 0) wv = cur_make(id, pack10(s, ctl->len, START[id] + round + 1));
+		if ((round + 1) % CUR_SYMS == 0) { const uint64_t p = cur_pos(wv); wv = cur_make(p + CUR_SYMS, pack9(s, ctl->len, p)); }   // every string of the batch refills in the same rounds
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
-			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, id, wv);
+			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv);
 		} else {
-			L2[d] = l; W2[d] = wv;
+			L2[d] = l; W2[d] = wv; A2[d] = (uint8_t)cur_sym(wv);
 			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}
@@ -1430,7 +1436,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 
 // sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
 __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
-		const uint8_t *s, const uint64_t *START, uint32_t round, uint64_t *L2, uint64_t *U2, uint64_t *W2)
+		const uint8_t *s, uint8_t *A2, uint32_t round, uint64_t *L2, uint64_t *U2, uint64_t *W2)
 {
 	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	bool nonempty = false;
@@ -1441,7 +1447,7 @@ __global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *
 	const uint64_t d = pc[lo].dst + (i - pc[lo].src);
 	const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
 	L2[d] = l; U2[d] = l + size;
-	W2[d] = r.w;
+	W2[d] = r.w; A2[d] = (uint8_t)cur_sym(r.w);
 	nonempty = size != 0;
 	}
 	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne

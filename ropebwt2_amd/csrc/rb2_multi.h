@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 // records -> next round's SoA arrays in bucket order (k_unpack's job), fetched from wherever k_mlayout says they are: the
 // senders' buffers (PEER: loads over xGMI, 24 bytes per lane, consecutive per piece) or the local receive buffer (RCCL).
 // The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
-__global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, const uint64_t *START, uint32_t round,
+__global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, uint8_t *A2, uint32_t round,
 		uint64_t *L2, uint64_t *U2, uint64_t *W2)
 {
 	const uint64_t total = tab->total;
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab
 		const uint64_t d = pc.dst + (i - pc.vsrc);
 		const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
 		L2[d] = l; U2[d] = l + size;
-		W2[d] = r.w;
+		W2[d] = r.w; A2[d] = (uint8_t)cur_sym(r.w);
 		nonempty |= size != 0;
 	}
 	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
@@ -314,7 +314,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			NCCLCHK(N.GroupEnd());
 		}
 		const int cur = B.cur;
-		hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, (const uint64_t*)h->START.p, (uint32_t)r,
+		hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, h->A[cur].p, (uint32_t)r,
 				h->L[cur].p, h->U[cur].p, h->W[cur].p);
 		HIPCHK(hipGetLastError());
 	}
