@@ -32,6 +32,7 @@ typedef struct {
 	rb2_hip_t *dev;         /* one GPU ... */
 	rb2_hip_multi_t *mdev;  /* ... or the index sharded over several (RB2_HIP_DEVICES=0,1,2,...): exactly one of the two is set */
 	int host_ok, dev_ok;
+	int counts_lazy;                                           /* r[a]->c[] moved on by text-derived deltas since the device's matrix was last read (reconcile_counts) */
 	uint8_t *raw[6]; int64_t raw_n[6]; int raw_ok;          /* mr_restore_runs: the run bytes of the six ropes, no trees yet */
 	int max_nodes, block_len;
 } mrx_t;
@@ -84,6 +85,23 @@ static void dev_destroy(mrx_t *x)
 	x->dev = 0; x->mdev = 0;
 }
 static void dev_get_counts(mrx_t *x, int64_t c[36]) { if (x->mdev) rb2_hip_multi_get_counts(x->mdev, c); else rb2_hip_get_counts(x->dev, c); }
+/* After a lazy insert mr->r[a]->c[] moved on by what the batch's text says it adds (k_pair_hist), not by the device's own counts.
+ * Wherever the shim waits for the device anyway the two are reconciled: the device's matrix is the truth and overwrites the host's;
+ * a difference (a defect in one of the two derivations) is reported -- fatally when RB2_HIP_DEBUG is set. */
+static void reconcile_counts(mrx_t *x)
+{
+	int64_t c[36];
+	int a, b, bad = 0;
+	if (!x->counts_lazy || !has_dev(x) || !x->dev_ok) return;
+	x->counts_lazy = 0;
+	dev_get_counts(x, c);
+	for (a = 0; a < 6; ++a)
+		for (b = 0; b < 6; ++b) { if (x->pub.r[a]->c[b] != c[a*6+b]) bad = 1; x->pub.r[a]->c[b] = c[a*6+b]; }
+	if (bad) {
+		fprintf(stderr, "[W::%s] the count matrix derived from the batch text differs from the device's; the device's is kept\n", __func__);
+		if (getenv("RB2_HIP_DEBUG")) abort();
+	}
+}
 static int64_t dev_stream_rope(mrx_t *x, int a, rb2_hip_run_cb cb, void *user)
 {
 	return x->mdev ? rb2_hip_multi_stream_rope(x->mdev, a, cb, user) : rb2_hip_stream_rope(x->dev, a, cb, user);
@@ -124,7 +142,7 @@ int mr_thr_min(mrope_t *mr, int thr_min)
 }
 
 void *mr_hip_handle(mrope_t *mr) { return X(mr)->dev; }
-void mr_wait(mrope_t *mr) { if (X(mr)->dev) rb2_hip_wait((rb2_hip_t*)X(mr)->dev); }
+void mr_wait(mrope_t *mr) { if (X(mr)->dev) { rb2_hip_wait((rb2_hip_t*)X(mr)->dev); reconcile_counts(X(mr)); } }
 void *mr_hip_multi_handle(mrope_t *mr) { return X(mr)->mdev; }
 
 /* rb2 extension: what the caller knows about the job ahead (the size of one batch buffer, the symbols the finished index will
@@ -151,11 +169,26 @@ void mr_prefetch(mrope_t *mr, const uint8_t *s, int64_t n_final, int64_t capacit
  * itself 0.76 B per symbol), between 1 and 40 GiB.  The BWT does not depend on the batch size. */
 int64_t mr_auto_batch_bytes(mrope_t *mr)
 {
-	int64_t fr = 0, tot = 0, m;
+	/* A heuristic.  Per listed device: free memory, minus what an index that is restored but not yet uploaded (-i old.fmr) will take
+	 * there (0.8 bytes per symbol: two pool sides of 0.375 + directory; its share of it on a sharded index), an eighth of the rest;
+	 * the smallest over the devices (every rank holds a full copy of the batch text). */
+	int64_t fr = 0, tot = 0, m = -1, syms = 0;
 	const char *e = getenv("RB2_HIP_DEVICES");
-	(void)mr;
-	rb2_hip_mem_info(e && *e ? atoi(e) : device_id(), &fr, &tot);
-	m = fr / 8;
+	int devs[RB2_MULTI_MAX_RANKS], n = 0, a, b, k;
+	if (e && *e) {
+		const char *p = e;
+		while (*p && n < RB2_MULTI_MAX_RANKS) { char *q; const long v = strtol(p, &q, 10); if (q == p) break; devs[n++] = (int)v; p = *q == ',' ? q + 1 : q; }
+	}
+	if (n == 0) devs[n++] = device_id();
+	if (mr && !(has_dev(X(mr)) && X(mr)->dev_ok))
+		for (a = 0; a < 6; ++a) for (b = 0; b < 6; ++b) syms += mr->r[a]->c[b];
+	for (k = 0; k < n; ++k) {
+		int64_t avail;
+		rb2_hip_mem_info(devs[k], &fr, &tot);
+		avail = fr - (int64_t)((double)syms * 0.8 / n);
+		if (avail < 0) avail = 0;
+		if (m < 0 || avail / 8 < m) m = avail / 8;
+	}
 	if (m > ((int64_t)40 << 30)) m = (int64_t)40 << 30;
 	if (m < ((int64_t)1 << 30)) m = (int64_t)1 << 30;
 	return m;
@@ -208,6 +241,7 @@ void mr_sync_host(mrope_t *mr)
 		return;
 	}
 	assert(has_dev(x) && x->dev_ok);
+	reconcile_counts(x);
 	/* the six ropes are independent trees: each is bulk-loaded by its own thread as soon as its run bytes have arrived, while
 	 * the next rope is still streaming off the device (the reference has nothing to do here: its ropes were built on the host) */
 	{
@@ -293,6 +327,7 @@ void mr_insert_multi(mrope_t *mr, int64_t len, const uint8_t *s, int is_thr)
 	if (!x->mdev && rb2_hip_last_batch_counts(x->dev, c)) {
 		for (a = 0; a < 6; ++a)
 			for (b = 0; b < 6; ++b) mr->r[a]->c[b] += c[a*6+b];
+		x->counts_lazy = 1;                                     /* reconciled with the device's own matrix at the next wait (reconcile_counts) */
 	} else {
 	dev_get_counts(x, c);
 	for (a = 0; a < 6; ++a)

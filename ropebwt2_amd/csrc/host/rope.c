@@ -607,11 +607,12 @@ static void *canon_worker(void *arg)
 {
 	canon_job_t *j = (canon_job_t*)arg;
 	/* merging adjacent runs of one symbol can GROW the stream: a 2-byte run of 255 + a 1-byte run of 1 is a 4-byte run of 256, a
-	 * 4-byte run + a 1-byte run that crosses 2^19 an 8-byte one -- at worst 8 bytes out for 5 in.  Twice the input bounds it
-	 * (pages that are never written are never backed). */
-	j->out = (uint8_t*)malloc(2 * (size_t)j->n + 16);
-	rb2_hint_huge(j->out, 2 * (size_t)j->n + 16);
-	if (j->out == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes)\n", __func__, (long long)(2 * j->n + 16)); exit(1); }
+	 * 4-byte run + a 1-byte run that crosses 2^19 an 8-byte one -- at worst 8 bytes out for 5 in: 13/8 of the input bounds it
+	 * (pages that are never written are never backed; hosts with strict overcommit count them all the same, hence not 2x). */
+	const size_t cap = (size_t)j->n + (size_t)j->n / 8 * 5 + 64;
+	j->out = (uint8_t*)malloc(cap);
+	rb2_hint_huge(j->out, cap);
+	if (j->out == 0) { fprintf(stderr, "[E::%s] out of memory (%lld bytes for the canonical run bytes of one rope segment; RB2_DUMP_VIA_TREES=1 dumps through the host trees instead)\n", __func__, (long long)cap); exit(1); }
 	j->out_n = canon_segment(j->in, j->in + j->n, j->out);
 	return 0;
 }

@@ -318,8 +318,21 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 	h->trec.ensure(nst + 8); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
 
-// split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284)
-void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
+// A batch may hold at most this many strings (32-bit slots, tile numbers and work orders).  The reference takes any count
+// (mrope.c:269-277); the single-engine entry points cut a batch that holds more into two and insert them one after the other
+// (insert_dev) -- the BWT does not depend on how a read set is cut into batches, which is what `-m` does to every input anyway.
+// RB2_MAX_BATCH_STRINGS lowers the limit (tests).
+static uint64_t max_batch_strings()
+{
+	const char *e = getenv("RB2_MAX_BATCH_STRINGS");
+	uint64_t v = (1ull << 32) - 2 * STILE;
+	if (e && atoll(e) > 0) v = std::min<uint64_t>(v, (uint64_t)atoll(e));
+	return v;
+}
+
+// split into strings (mrope.c:269-277), size the buffers, initial state (mrope.c:279-284).  false: more strings than a batch may
+// hold (B.m says how many) -- nothing was changed, the caller cuts the batch (may_split) or gives up.
+bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, bool may_split = false)
 {
 	const uint64_t len = (uint64_t)len64;
 	hipStream_t st = h->st;
@@ -337,7 +350,8 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 		HIPCHK(hipStreamSynchronize(st));
 		m = res[0];
 		if (res[1]) { rb2_fatal("[rb2_hip] the batch contains bytes that are not nt6 codes 0..5 ($ACGTN)\n"); }
-		if (m == 0 || m >= (1ull << 32) - 2 * STILE) { rb2_fatal("[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); }
+		if (m >= max_batch_strings() && may_split) { B.m = m; return false; }
+		if (m == 0 || m >= max_batch_strings()) { rb2_fatal("[rb2_hip] unsupported number of strings in one batch: %llu\n", (unsigned long long)m); }
 		h->START.ensure(m + 1);
 		hipLaunchKernelGGL(k_write_starts, dim3(nzb), dim3(256), 0, st, s, len, h->zblk.p, h->START.p);
 	}
@@ -362,6 +376,7 @@ void batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s)
 	}
 	HIPCHK(hipMemcpyAsync(&B.max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
+	return true;
 }
 
 // Once no string of the batch has a non-empty interval, none ever will again (u' = l' + 0): ctl->ne is monotone inside a batch.
@@ -624,11 +639,42 @@ void finish_pending(rb2_hip_t *h)
 	batch_trace(h);
 }
 
+// the byte behind a sentinel near the middle of a device text of more than one string: where a batch of too many strings is cut
+static int64_t split_point(rb2_hip_t *h, const uint8_t *s, int64_t len)
+{
+	const int64_t W = 1 << 20;
+	std::vector<uint8_t> win((size_t)W);
+	for (int64_t a = len / 2; a < len - 1; a += W) {            // forwards from the middle ...
+		const int64_t n = std::min(W, len - 1 - a);
+		HIPCHK(hipMemcpyAsync(win.data(), s + a, (size_t)n, hipMemcpyDeviceToHost, h->st)); HIPCHK(hipStreamSynchronize(h->st));
+		const void *z = memchr(win.data(), 0, (size_t)n);
+		if (z) return a + ((const uint8_t*)z - win.data()) + 1;
+	}
+	for (int64_t b = len / 2; b > 0; b -= W) {                   // ... else backwards
+		const int64_t a = std::max<int64_t>(0, b - W), n = b - a;
+		HIPCHK(hipMemcpyAsync(win.data(), s + a, (size_t)n, hipMemcpyDeviceToHost, h->st)); HIPCHK(hipStreamSynchronize(h->st));
+		for (int64_t i = n - 1; i >= 0; --i) if (win[(size_t)i] == 0) return a + i + 1;
+	}
+	rb2_fatal("[rb2_hip] insert_multi: cannot cut a batch of one string\n");
+}
+
 void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false)
 {
 	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); }
 	BatchState B;
-	batch_begin(h, B, len64, s);
+	if (!batch_begin(h, B, len64, s, true)) {
+		// more strings than one batch may hold: two batches, one after the other (the second half moves to a 16-byte aligned place)
+		const int64_t p = split_point(h, s, len64);
+		if (h->trace) fprintf(stderr, "[rb2_hip] batch of %llu strings cut at byte %lld of %lld\n", (unsigned long long)B.m, (long long)p, (long long)len64);
+		insert_dev(h, p, s, false);
+		DevBuf<uint8_t> half;
+		half.ensure((size_t)(len64 - p) + 64);
+		HIPCHK(hipMemcpyAsync(half.p, s + p, (size_t)(len64 - p), hipMemcpyDeviceToDevice, h->st));
+		insert_dev(h, len64 - p, half.p, false);
+		HIPCHK(hipStreamSynchronize(h->st));
+		half.release();
+		return;
+	}
 	// The first rounds of a batch are hot spots by construction: round 0 puts every string into rope $ (at its end in input order,
 	// at a handful of positions in the sorted orders), round k touches ~4^k places.  A sparse index would void each of them (a
 	// re-layout there and back per round); one dense phase of eight rounds costs two re-layouts for all of them.

@@ -619,3 +619,26 @@ def test_lazy_host_insert_overlaps_and_stays_exact(hip):
         dev.insert_multi_dev(p, 3)
         assert dev.last_batch_counts() is None
         dev.dev_free(p); dev.close(); sync.close()
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_batch_with_too_many_strings_is_cut_not_refused(hip, so):
+    """a batch may hold 2^32 - 1024 strings; the reference takes any count (mrope.c:269-277).  More: the engine cuts the batch at a
+    sentinel near its middle and inserts the halves one after the other (recursively) -- the same BWT.  Limit lowered for the test."""
+    codes = H.splitmix_bases(5000, 37, seed=77)
+    reads = H.repetitive_reads(1500, seed=9, genome_len=400, max_len=60)
+    bufs = [H.encode_batch_fixed(codes), H.encode_batch(reads, True, True)]
+    o = H.Oracle(so)
+    for b in bufs:
+        o.insert_multi(b)
+    os.environ["RB2_MAX_BATCH_STRINGS"] = "700"
+    try:
+        g = hip.HipBwt(so, 0)
+        for b in bufs:
+            g.insert_multi(b)
+    finally:
+        del os.environ["RB2_MAX_BATCH_STRINGS"]
+    assert np.array_equal(o.counts(), g.counts())
+    for b in range(6):
+        assert np.array_equal(o.rope(b), g.rope(b)), "rope %d" % b
+    g.close()
