@@ -694,44 +694,6 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 	batch_trace(h);
 }
 
-// A copy from pageable memory is staged by the runtime through its own pinned buffers on ONE thread: 20-25 GB/s here, i.e. 0.16 s for
-// a -m4g batch -- and for the first batch of a job nothing runs beside it.  Here UP_T host threads each copy their chunks into
-// pinned staging buffers of their own and queue the DMA on a stream of their own (double-buffered): the link's rate instead of one
-// core's memcpy rate.  Returns when the bytes are on the device.
-void par_upload(rb2_hip_t *h, uint8_t *dst, const uint8_t *src, size_t n)
-{
-	if (n < (64u << 20) || getenv("RB2_NO_PAR_UPLOAD")) {
-		HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, h->st_copy));
-		HIPCHK(hipStreamSynchronize(h->st_copy));
-		return;
-	}
-	constexpr int T = rb2_hip_s::UP_T, NB = rb2_hip_s::UP_NB; constexpr size_t CH = rb2_hip_s::UP_CH;
-	if (!h->up_init) {
-		for (int t = 0; t < T; ++t) {
-			HIPCHK(hipStreamCreateWithFlags(&h->up_st[t], hipStreamNonBlocking));
-			for (int b = 0; b < NB; ++b) { HIPCHK(hipHostMalloc((void**)&h->up_pin[t][b], CH, hipHostMallocDefault)); HIPCHK(hipEventCreateWithFlags(&h->up_ev[t][b], hipEventDisableTiming)); }
-		}
-		h->up_init = true;
-	}
-	const size_t nch = (n + CH - 1) / CH;
-	std::vector<std::thread> th;
-	for (int t = 0; t < T; ++t) th.emplace_back([=]() {
-		HIPCHK(hipSetDevice(h->dev));
-		int used[NB] = {0, 0};
-		for (size_t c = (size_t)t, k = 0; c < nch; c += T, ++k) {
-			const int b = (int)(k % NB);
-			const size_t off = c * CH, len = std::min(CH, n - off);
-			if (used[b]) HIPCHK(hipEventSynchronize(h->up_ev[t][b]));   // the DMA that last read this staging buffer is done
-			memcpy(h->up_pin[t][b], src + off, len);
-			HIPCHK(hipMemcpyAsync(dst + off, h->up_pin[t][b], len, hipMemcpyHostToDevice, h->up_st[t]));
-			HIPCHK(hipEventRecord(h->up_ev[t][b], h->up_st[t]));
-			used[b] = 1;
-		}
-		HIPCHK(hipStreamSynchronize(h->up_st[t]));
-	});
-	for (auto &x : th) x.join();
-}
-
 // the batch must end with a sentinel (mrope.c:268): bytes after the last 0 would be sized for but never inserted
 void check_last_byte(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
 {
@@ -802,7 +764,6 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A[0].release(); h->A[1].release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
 	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
-	if (h->up_init) for (int t = 0; t < rb2_hip_s::UP_T; ++t) { HIPCHK(hipStreamDestroy(h->up_st[t])); for (int b = 0; b < rb2_hip_s::UP_NB; ++b) { HIPCHK(hipHostFree(h->up_pin[t][b])); HIPCHK(hipEventDestroy(h->up_ev[t][b])); } }
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
@@ -897,7 +858,8 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 		h->pf_busy = true;                                       // (keeps a concurrent rb2_hip_prefetch of the NEXT batch out of sbuf2 until the buffers are swapped)
 		lk.unlock();
 		if (h->sbuf2.cap < (size_t)len + 64) { HIPCHK(hipStreamSynchronize(h->st_copy)); h->sbuf2.ensure((size_t)len + 64); have = 0; }
-		if ((size_t)len > have) par_upload(h, h->sbuf2.p + have, s + have, (size_t)len - have);
+		if ((size_t)len > have) HIPCHK(hipMemcpyAsync(h->sbuf2.p + have, s + have, (size_t)len - have, hipMemcpyHostToDevice, h->st_copy));   // (six host threads staging through pinned
+		                                                           // buffers of their own were SLOWER than the runtime's pageable path here: 0.90-1.06 s against 0.77 s per configs[1] job, r04)
 		if (!h->pair_d) { HIPCHK(hipMalloc((void**)&h->pair_d, 36 * 8)); HIPCHK(hipHostMalloc((void**)&h->pair_h, 36 * 8, hipHostMallocDefault)); }
 		HIPCHK(hipMemsetAsync(h->pair_d, 0, 36 * 8, h->st_copy));  // the count matrix of the batch, from its text alone (rb2_hip_last_batch_counts)
 		hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)std::min<uint64_t>(((uint64_t)len + 4095) / 4096, 8192)), dim3(256), 0, h->st_copy, (const uint8_t*)h->sbuf2.p, (uint64_t)len, h->pair_d);
