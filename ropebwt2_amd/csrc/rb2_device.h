@@ -65,6 +65,11 @@ __host__ __device__ inline int rope_sym(int r)  { return r == 0 ? 0 : 1 + (r - 1
 __host__ __device__ inline int rope_prev(int r) { return r == 0 ? 0 : (r - 1) % 6; }       // x
 __host__ __device__ inline int rope_of(int a, int b) { return a == 0 ? 0 : 1 + (a - 1) * 6 + b; }
 
+// The per-string positions (L, U, INS_E, SIZE) are piece-relative: while no sub-rope holds 2^32 symbols they are STORED as 32-bit values
+// (template parameter P of the string kernels: uint32_t or uint64_t) -- 24 bytes less per string and round through HBM than with
+// 64-bit storage (configs[1]: +5.6 % on one box).  The engine starts a batch in the narrow mode when it can and widens the arrays the
+// round before a piece could reach 2^32 symbols (k_setup reports the largest piece to pinned memory; rb2_engine.hip maybe_widen).
+
 struct LeafMeta { uint16_t c[6]; uint16_t npre; uint16_t n; };   // meta[]: prefixes inside the superblock + own fill; own[]: own counts + own fill
 #ifndef RB2_SP_FILL
 #define RB2_SP_FILL 768

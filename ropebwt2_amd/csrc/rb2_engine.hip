@@ -158,6 +158,7 @@ struct Pool {
 };
 
 struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
+constexpr uint64_t POS32_LIMIT = (1ull << 32) - (1ull << 24);   // narrow position storage only while every position stays below this
 
 } // namespace
 
@@ -187,7 +188,10 @@ struct rb2_hip_s {
 	Ctl *ctl = nullptr;                 // device
 	RopeDesc h_rope[NR];                // host mirror of ctl->rope[side] (sub-ropes)
 	// per-string state
-	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;
+	DevBuf<uint64_t> L[2], U[2], W[2], START, SIZE, INS_E, zblk;   // L, U, SIZE, INS_E: sized for 64-bit values, read and written as 32-bit ones while pos32
+	bool pos32 = false, want_pos32 = false;   // positions in 32-bit storage this batch (single-engine inserts only; maybe_widen)
+	int pos_mode = getenv("RB2_POS") ? atoi(getenv("RB2_POS")) : 0;   // 0 auto, 64: never narrow; RB2_POS_WIDEN_AT=r: leave the narrow mode before round r (tests)
+	uint64_t pos_m0 = 0;                // largest piece when the batch began
 	DevBuf<uint16_t> RKREL;
 	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
 	DevBuf<uint32_t> SPL;               // sparse rounds: leaves to split at the end of the round (k_part_sparse -> k_split)
@@ -372,10 +376,20 @@ bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, b
 	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
+	{	// storage width of the positions: narrow while no piece can hold 2^32 symbols (checked again every round: maybe_widen)
+		uint64_t mx = 0;
+		for (int b = 0; b < NR; ++b) mx = std::max<uint64_t>(mx, h->h_rope[b].n);
+		h->pos_m0 = mx;
+		h->pos32 = h->want_pos32 && h->pos_mode != 64 && mx + 2 * m < POS32_LIMIT;
+		h->want_pos32 = false;
+		((volatile unsigned long long*)(h->h_flag + 4))[0] = 0;  // (round, largest piece) as k_setup last reported it: nothing yet
+	}
 	{
 		Scope sc(h, RB2_K_INIT, 0);
 		hipLaunchKernelGGL(k_batch_setup, dim3(1), dim3(1), 0, st, h->ctl, h->side, m, len, is_srt);
-		hipLaunchKernelGGL(k_init_strings, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
+		if (h->pos32) hipLaunchKernelGGL(k_init_strings<uint32_t>, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
+				(uint32_t*)h->L[0].p, (uint32_t*)h->U[0].p, h->W[0].p, h->A[0].p);
+		else hipLaunchKernelGGL(k_init_strings<uint64_t>, dim3(cdiv(m, 256)), dim3(256), 0, st, h->ctl, is_srt, s, h->START.p,
 				h->L[0].p, h->U[0].p, h->W[0].p, h->A[0].p);
 	}
 	HIPCHK(hipMemcpyAsync(&B.max_len, &h->ctl->max_len, 8, hipMemcpyDeviceToHost, st));
@@ -404,6 +418,32 @@ bool ne_all_empty_from(rb2_hip_t *h, uint64_t r)               // may round r (a
 	return false;
 }
 
+// launch F with P = the storage type of this batch's positions; PP(x) = x's array seen as P*
+template <class F> inline void with_pos(rb2_hip_t *h, F f) { if (h->pos32) f((uint32_t*)nullptr); else f((uint64_t*)nullptr); }
+#define RB2_P(x) ((P*)(x))
+
+// Leave the narrow storage mode when a piece could reach POS32_LIMIT symbols in round r.  What the host knows: the largest piece as
+// k_setup last reported it to pinned memory, for some round q < r (lock-free, possibly many rounds stale -- the host queues rounds
+// ahead of the device), and that a piece grows by at most the m strings of the batch per round.
+void maybe_widen(rb2_hip_t *h, BatchState &B, uint64_t r)
+{
+	if (!h->pos32) return;
+	const unsigned long long v = ((volatile unsigned long long*)(h->h_flag + 4))[0];
+	uint64_t known = h->pos_m0, since = r + 1;                   // rounds the bound must cover
+	if (v != 0) { known = v & ((1ull << 40) - 1); const uint64_t q = v >> 40; since = r >= q ? r - q : r + 1; }   // (the report of round q is the size AFTER round q)
+	const char *e = getenv("RB2_POS_WIDEN_AT");
+	if (known + (since + 1) * B.m < POS32_LIMIT && !(e && (uint64_t)atoll(e) == r)) return;
+	// widen L and U of the current side (what the next kernels read); scratch arrays are per round
+	hipStream_t st = h->st;
+	const int cur = B.cur;
+	for (DevBuf<uint64_t> *a : { &h->L[cur], &h->U[cur] }) {
+		HIPCHK(hipMemcpyAsync(h->INS_E.p, a->p, B.m * 4, hipMemcpyDeviceToDevice, st));
+		hipLaunchKernelGGL(k_widen, dim3(cdiv(B.m, 256)), dim3(256), 0, st, (const uint32_t*)h->INS_E.p, a->p, B.m);
+	}
+	h->pos32 = false;
+	if (h->trace) fprintf(stderr, "[rb2_hip] round %llu: positions widened to 64 bits (largest piece known: %llu symbols, %llu rounds ago)\n", (unsigned long long)r, (unsigned long long)known, (unsigned long long)since);
+}
+
 // phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
 // spec: queued while the verdict of the in-place round in front of it is still on its way (round_merge_sparse)
 void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
@@ -414,12 +454,13 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 	h->cur_round = (int)r;
 	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
 	{ Scope sc(h, RB2_K_SYM, units);
-	  RB2_LAUNCH_STRIDE(h, k_sym<true>, k_sym<false>, dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), h->L[cur].p, h->U[cur].p, h->A[cur].p, trs); }
+	  with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
+	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs); }); }
 	if (B.nst_ub < (unsigned)TS_MAX) {                         // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
-	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec);
-	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec);
+	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; }
 	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);
@@ -446,23 +487,27 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	if ((uint64_t)nlf * 64 >= (1ull << 32)) { rb2_fatal("[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); }
 	if (!(B.setup_round == r && !B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
+	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr); }
+	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true>), (k_prep<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A[cur].p,
-			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true>), (k_prep<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, h->L[cur].p, h->U[cur].p, h->A[cur].p,
-			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true, P>), (k_prep<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, k_part<true>, k_part<false>, dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, h->INS_E.p, h->LD.p); }
+	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  RB2_LAUNCH_STRIDE(h, k_merge<true>, k_merge<false>, dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, h->INS_E.p, h->INS_A.p, h->RKREL.p); }
+	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p); }
+	});
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
+	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true>), (k_advance<false, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
-	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true>), (k_advance<true, false, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true, P>), (k_advance<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true, P>), (k_advance<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+	});
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
@@ -528,25 +573,29 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	if (++h->split_epoch == 0) ++h->split_epoch;
 	if (!(B.setup_round == r && B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1)); }
+	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr); }
 	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
+	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true>), (k_prep<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A[cur].p,
-			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p);
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true>), (k_prep<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, h->L[cur].p, h->U[cur].p, h->A[cur].p,
-			h->tfix.p, h->INS_E.p, h->INS_A.p, h->SIZE.p); }
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true, P>), (k_prep<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, k_part_sparse<true>, k_part_sparse<false>, dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
+	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
-	  hipLaunchKernelGGL(k_merge_leaf, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, h->INS_E.p, h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	});
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
+	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
-	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true>), (k_advance<false, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
-	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true>), (k_advance<true, true, false>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			h->SIZE.p, h->INS_E.p, h->RKREL.p, h->L[cur].p, h->W[cur].p, h->L[cur ^ 1].p, h->U[cur ^ 1].p, h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
+	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true, P>), (k_advance<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
+	});
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
 	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag); }
@@ -666,6 +715,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 {
 	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); }
 	BatchState B;
+	h->want_pos32 = true;                                       // (one engine, whole index: the narrow position storage may be used)
 	if (!batch_begin(h, B, len64, s, true)) {
 		// more strings than one batch may hold: two batches, one after the other (the second half moves to a 16-byte aligned place)
 		const int64_t p = split_point(h, s, len64);
@@ -685,6 +735,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
+		maybe_widen(h, B, r);
 		choose_layout(h, B, r, B.m);
 		if (B.counted != r) round_counts(h, B, r);
 		round_merge_any(h, B, r, nullptr, true);

@@ -184,8 +184,8 @@ __device__ __forceinline__ uint64_t cur_pos(uint64_t w) { return w >> CUR_BITS; 
 __device__ __forceinline__ int cur_sym(uint64_t w) { return (int)(w & 7); }
 __device__ __forceinline__ uint64_t cur_next(uint64_t w) { return (w & ~CUR_MASK) | ((w & CUR_MASK) >> 3); }   // one symbol consumed
 
-__global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
-		uint64_t *L, uint64_t *U, uint64_t *W, uint8_t *A)
+template <typename P = uint64_t> __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
+		P *L, P *U, uint64_t *W, uint8_t *A)
 {
 	__shared__ int s_wm[4];
 	const uint64_t m = ctl->n_strings, k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -206,6 +206,13 @@ __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, cons
 	(void)s_wm;
 	// one atomic per wave only while the maximum still grows (40 M strings of equal length: a handful in total)
 	if (lane_id() == 0 && v > *(volatile uint64_t*)&ctl->max_len) atomicMax((unsigned long long*)&ctl->max_len, v);
+}
+
+// 32-bit positions -> 64-bit (the engine leaves the narrow storage mode: some piece may reach 2^32 symbols next round)
+__global__ __launch_bounds__(256) void k_widen(const uint32_t *src, uint64_t *dst, uint64_t n)
+{
+	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) dst[i] = src[i];
 }
 
 // round 0: every string sits in "bucket 0" and inserts its last symbol into rope $ (mrope.c:285)
@@ -248,11 +255,11 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // tiles when the rank holds more -- an upper-bound grid of N times the work would cost more in empty workgroups than the work itself.
 // STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
 // with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const uint64_t *L, const uint64_t *UU,
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const P *L, const P *UU,
 		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
-	const uint64_t *U = ctl->ne[par] == 0 ? L : UU;
+	const P *U = ctl->ne[par] == 0 ? L : UU;
 	for (uint32_t tile = blockIdx.x; ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
 	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with
 	TileCtx t;
@@ -443,7 +450,9 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 // over ranks when sub-ropes are sharded).  One wave, lane r = sub-rope r; the running sums of the
 // sequential formulation (mrope.c:332-340) are wave scans.
 // SPARSE: the round inserts in place -- every piece keeps its slots (leaf0, nleaves, sb0), only n and the counts move.
-template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par)
+// hmax (pinned host memory, may be null): the round and the size of the largest piece after it -- what the host needs to know
+// to keep the per-string positions in 32-bit storage for as long as they fit (rb2_device.h "P"; one 8-byte store, no copy command)
+template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax)
 {
 	const int r = lane_id();
 	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_unpack of this round count into it
@@ -456,6 +465,12 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 	// keep n = 0 here but their symbol counts are tracked (needed for AC and for n0).
 	RopeDesc n;
 	n.n = ok ? o.n + sg.cnt[rr] : 0;
+	if (hmax) {
+		unsigned long long mx = n.n;
+#pragma unroll
+		for (int dd = 32; dd >= 1; dd >>= 1) { const unsigned long long t = __shfl_xor(mx, dd); mx = t > mx ? t : mx; }
+		if (r == 0) *hmax = (unsigned long long)round << 40 | (mx < (1ull << 40) ? mx : (1ull << 40) - 1ull);
+	}
 	const int first = rope_of(rope_sym(rr), 0);               // first piece of my rope
 	for (int a = 0; a < 6; ++a) {
 		const uint64_t c = ok ? gcnt[rr * 6 + a] : 0ull;
@@ -500,10 +515,10 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 	}
 	if (ok) ctl->dest[r][0] = 0;
 }
-template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par)
+template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax)
 {
 	if (blockIdx.x) return;
-	setup_body<SPARSE>(ctl, side, gcnt, par);
+	setup_body<SPARSE>(ctl, side, gcnt, par, round, hmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -520,7 +535,8 @@ template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, i
 constexpr int TS_MAX = 4 * SCHUNK;          // string tiles the single-block path takes
 constexpr int TFW = 26;                     // dwords of a TileFix
 static_assert(sizeof(TileFix) == TFW * 4, "TileFix is written out as 26 dwords");
-template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(Ctl *ctl, int side, int par, const TileRecs trec, TileFix *tf, uint64_t *gcnt, int do_setup, int spec)
+template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(Ctl *ctl, int side, int par, const TileRecs trec, TileFix *tf, uint64_t *gcnt, int do_setup, int spec,
+		uint32_t round, volatile unsigned long long *hmax)
 {
 	__shared__ uint32_t s_pre[6][TS_MAX + 4];                    // exclusive prefix of hist over all tiles; [.][nt] = total
 	__shared__ uint32_t s_out[SCHUNK / 64][32 * TFW];            // per wave: 32 TileFix records on their way out (coalesced stores)
@@ -634,7 +650,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
 	}
 	__syncthreads();
-	if (do_setup && wv == 0) setup_body<SPARSE>(ctl, side, s_g, par);
+	if (do_setup && wv == 0) setup_body<SPARSE>(ctl, side, s_g, par, round, hmax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -723,18 +739,18 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	return m;
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
-		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
-		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE);                      // false: nothing (more) to do for this block
+template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
+		const P *L, const P *U, uint8_t *A, const TileFix *tf,
+		P *INS_E, uint8_t *INS_A, P *SIZE);                              // false: nothing (more) to do for this block
 
-template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
-		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
-		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
+template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
+		const P *L, const P *U, uint8_t *A, const TileFix *tf,
+		P *INS_E, uint8_t *INS_A, P *SIZE)
 {
 	// the first tile exactly as a one-tile-per-block kernel would run it (its loads are issued before anything is waited for);
 	// further tiles only when the grid is smaller than the number of tiles (grid stride: see k_sym)
 	for (uint32_t tile = blockIdx.x; ; ) {
-		if (!prep_tile<AE, SPARSE>(tile, ctl, side, par, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE)) return;
+		if (!prep_tile<AE, SPARSE, P>(tile, ctl, side, par, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -742,9 +758,9 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch
 	}
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
-		const uint64_t *L, const uint64_t *U, uint8_t *A, const TileFix *tf,
-		uint64_t *INS_E, uint8_t *INS_A, uint64_t *SIZE)
+template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
+		const P *L, const P *U, uint8_t *A, const TileFix *tf,
+		P *INS_E, uint8_t *INS_A, P *SIZE)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
@@ -772,7 +788,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const 
 			if (k >= t.segend) continue;
 			const int a = sym2[h];
 			const Member m = group_member(G, t, x, a, orda);
-			INS_E[t.segstart + m.slot] = l2[h] - m.F;          // empty interval: the new symbol goes to l (pre-round coordinates)
+			INS_E[t.segstart + m.slot] = (P)(l2[h] - m.F);     // empty interval: the new symbol goes to l (pre-round coordinates)
 			INS_A[t.segstart + m.slot] = (uint8_t)a;
 		}
 		return true;
@@ -836,10 +852,10 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const 
 				if (orda[s] < oa) e += d;
 				if (s == a) size = d;
 			}
-			SIZE[k] = size;                                    // only non-empty intervals have one (flag 0x40 in A)
+			SIZE[k] = (P)size;                                 // only non-empty intervals have one (flag 0x40 in A)
 			A[k] = (uint8_t)(a | 0x40 | (G.head[x >> 6] >> (x & 63) & 1 ? 0x80 : 0));
 		}
-		INS_E[t.segstart + mm[h].slot] = e;
+		INS_E[t.segstart + mm[h].slot] = (P)e;
 		INS_A[t.segstart + mm[h].slot] = (uint8_t)a;
 	}
 	return true;
@@ -853,7 +869,7 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool prep_tile(const 
 // A block covers 256 boundaries = 255 windows (boundaries overlap by one between blocks).
 // ---------------------------------------------------------------------------------------------
 
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const uint64_t *INS_E, LeafDesc *LD)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const P *INS_E, LeafDesc *LD)
 {
 	__shared__ uint64_t s_wf0[NR + 1];
 	__shared__ uint32_t s_q[256];
@@ -868,7 +884,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_part(const Ctl *
 		while (gid >= s_wf0[b+1] + b + 1) ++b;
 		j = gid - s_wf0[b] - b;
 		const SegDesc &sg = ctl->seg[side];
-		const uint64_t *E = INS_E + sg.start[b];
+		const P *E = INS_E + sg.start[b];
 		const uint64_t o = j * WIN;
 		uint64_t lo = 0, hi = sg.cnt[b];
 		while (lo < hi) {
@@ -904,12 +920,12 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_part(const Ctl *
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap);
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap);
 
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // (first tile as ever, then a grid stride: see k_prep)
-		if (!part_sparse_tile(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap)) return;
+		if (!part_sparse_tile<P>(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -917,7 +933,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_part_sparse(Ctl 
 	}
 }
 
-__device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const uint64_t *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
 {
 	__shared__ uint64_t s_gl[STILE + 1];
 	const TileFix &tfx = tf[tile];
@@ -925,7 +941,7 @@ __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, 
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	const RopeDesc &rp = ctl->rope[side][t.b];
-	const uint64_t *E = INS_E;
+	const P *E = INS_E;
 	Loc lc[2];
 	__shared__ uint32_t s_w[4], s_base;
 #pragma unroll
@@ -1353,18 +1369,18 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 // the stable 6-way partition into next round's buckets (mrope.c:303-309)
 // ---------------------------------------------------------------------------------------------
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
+		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
 
-template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
+template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
-		if (!advance_tile<AE, SPARSE>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
+		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1372,10 +1388,10 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false> __global__ __launch
 	}
 }
 
-template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
+template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
-		const uint64_t *SIZE, const uint64_t *INS_E, const uint16_t *RKREL, const uint64_t *L, const uint64_t *W,
-		uint64_t *L2, uint64_t *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
@@ -1424,8 +1440,8 @@ template <bool AE, bool SPARSE> __device__ __forceinline__ bool advance_tile(con
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv);
 		} else {
-			L2[d] = l; W2[d] = wv; A2[d] = (uint8_t)cur_sym(wv);
-			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
+			L2[d] = (P)l; W2[d] = wv; A2[d] = (uint8_t)cur_sym(wv);
+			if (!AE) { U2[d] = (P)u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}
 	if (!AE && !send) {                                        // does the next round see a non-empty interval?  (a flag: plain store, no atomic)

@@ -71,8 +71,8 @@ template <int GPL_> struct MergeLds { static constexpr int WG = 64 * GPL_, WORDS
 // GPL_ = groups per lane: the window is 64 * GPL_ groups (dense merge: GPL; in-place leaf merge: 1, the leaf in the first row).
 // INPLACE: the window IS one leaf with slack, rewritten where it lies (sparse rounds, leaves that receive many symbols): its old
 // symbols are its own first groups, d.i0 is the piece position of its first symbol, every new symbol also gets its leaf slot (RKLEAF).
-template <bool FULL, int GPL_, bool INPLACE> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *lds, const int ln,
-		const PoolView &oldp, const PoolView &newp, const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+template <bool FULL, int GPL_, bool INPLACE, typename P> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *lds, const int ln,
+		const PoolView &oldp, const PoolView &newp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
 {
 	constexpr int WG = 64 * GPL_, LPL = LEAFG / GPL_, WINS = WG * GSYM;      // groups per window, lanes per leaf, symbols per window
 	// LDS layout.  A lane owns GPL_ consecutive groups of the window; arrays indexed by group are kept LANE-major -- group G lives at
@@ -231,8 +231,8 @@ template <bool FULL, int GPL_, bool INPLACE> __device__ __forceinline__ void mer
 	}
 }
 
-template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
-		const uint64_t *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
+		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
 {
 	__shared__ __align__(16) uint64_t lds[MW][MergeLds<GPL>::WORDS];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -244,8 +244,8 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_merge(const Ctl 
 	LeafDesc d = LD[gw];
 	const uint64_t nwin = ctl->wf0[NR];
 	for (; gw < nwin; gw += (uint64_t)gridDim.x * MW, d = LD[gw < nwin ? gw : 0]) {
-		if (d.nvalid == WIN) merge_window<true, GPL, false>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
-		else merge_window<false, GPL, false>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		if (d.nvalid == WIN) merge_window<true, GPL, false, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		else merge_window<false, GPL, false, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
 		if (!STRIDE) return;                                    // (one GPU: the grid covers every window; no loop, no extra registers)
 		if (gw + (uint64_t)gridDim.x * MW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
 	}
@@ -304,7 +304,7 @@ __device__ __forceinline__ void row_ord_load(const SpOrd *LD, uint64_t g, uint32
 	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z;
 	o.ni = ok ? (a.w & 0xffffu) : 0u;
 }
-__device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const PoolView &pool, const uint64_t *INS_E, const uint8_t *INS_A, RowJob &J)
+template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const PoolView &pool, const P *INS_E, const uint8_t *INS_A, RowJob &J)
 {
 	const uint64_t *lw = (const uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
 #pragma unroll
@@ -312,11 +312,11 @@ __device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const
 	// no branch and no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
 	// row's last insert again; they never use it)
 	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)o.ni, 1) - 1);
-	J.aj = INS_A[q]; J.pj = ((const uint32_t*)INS_E)[2 * q];
+	J.aj = INS_A[q]; J.pj = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];   // low half: positions inside a leaf need no more
 }
 
-__global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
-		const uint64_t *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
+template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
+		const P *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
 {
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id(), g = ln & 15;
@@ -328,13 +328,13 @@ __global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpO
 	RowJob J, Jn;
 	row_ord_load(LD, g0, nwork, ln, on);
 	row_ord_load(LD, g0 + stride < nwork ? g0 + stride : g0, nwork, ln, onn);
-	row_job_load(on, g, pool, INS_E, INS_A, Jn);
+	row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);
 	for (;;) {
 		o = on; J = Jn; on = onn;
 		const uint64_t g1 = g0 + stride, g2 = g1 + stride;
 		const bool more = g1 < nwork;
 		if (more) {
-			row_job_load(on, g, pool, INS_E, INS_A, Jn);          // next quad: in flight while this one is worked on
+			row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);       // next quad: in flight while this one is worked on
 			row_ord_load(LD, g2 < nwork ? g2 : g1, nwork, ln, onn);
 		}
 		asm volatile("" ::: "memory");
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpO
 		for (uint32_t c0 = 0; c0 < nimax; c0 += LTURN) {            // turns of LTURN inserts per row (one turn, normally)
 			if (c0) {                                               // (rare) the row's next inserts
 				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(o.ni, 1u) - 1u);
-				aj = INS_A[q]; pjr = ((const uint32_t*)INS_E)[2 * q];
+				aj = INS_A[q]; pjr = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];
 			}
 			const uint32_t nic = o.ni > c0 ? min(o.ni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
 			const uint32_t pj = pjr - o.i0 + c0 + (uint32_t)g;      // final position E[q] + q inside the leaf (lanes >= nic: unused)

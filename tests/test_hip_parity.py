@@ -642,3 +642,29 @@ def test_batch_with_too_many_strings_is_cut_not_refused(hip, so):
     for b in range(6):
         assert np.array_equal(o.rope(b), g.rope(b)), "rope %d" % b
     g.close()
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
+@pytest.mark.parametrize("mode", ["widen0", "widen3", "widen17", "wide", "widen5_sparse"])
+def test_position_storage_width(hip, so, mode):
+    """The per-string positions are stored as 32-bit values while no sub-rope can hold 2^32 symbols and widened the round before
+    one could (maybe_widen).  Forced here: leave the narrow mode before round 0 / 3 / 17 of every batch, never enter it
+    (RB2_POS=64), and widen in the middle of in-place rounds -- ropes and count matrix against the oracle."""
+    env = {"widen0": {"RB2_POS_WIDEN_AT": "0"}, "widen3": {"RB2_POS_WIDEN_AT": "3"}, "widen17": {"RB2_POS_WIDEN_AT": "17"}, "wide": {"RB2_POS": "64"},
+           "widen5_sparse": {"RB2_POS_WIDEN_AT": "5", "RB2_SPARSE_LAMBDA": "1e18", "RB2_SPARSE_MAXPEN": "0", "RB2_SPARSE_HEAD": "2"}}[mode]
+    reads = H.repetitive_reads(2500, seed=31 + so, genome_len=700, max_len=90)
+    codes = H.splitmix_bases(3000, 60, seed=5)
+    bufs = [H.encode_batch(reads[:1500]), H.encode_batch_fixed(codes), H.encode_batch(reads[1500:], True, True)]
+    o = H.Oracle(so)
+    os.environ.update(env)
+    try:
+        g = hip.HipBwt(so, 0)
+        for b in bufs:
+            o.insert_multi(b); g.insert_multi(b)
+            assert np.array_equal(o.counts(), g.counts())
+    finally:
+        for k in env:
+            del os.environ[k]
+    for b in range(6):
+        assert np.array_equal(o.rope(b), g.rope(b)), "rope %d" % b
+    g.close()
