@@ -64,6 +64,20 @@ __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 	}
 }
 
+// the rewritten index is read once and written once per round: nontemporal loads and stores of the leaf words (RB2_NT=0: plain).
+// A/B on one box, r04: k_merge 0.900 -> 0.863 ms per launch, configs[1] 17.56 -> 17.9 Gsym/s.  The same hint on the per-string
+// arrays (L, W, A, INS_E) made the job SLOWER (17.85 -> 17.5): they are written by one kernel and read by the next.
+#ifndef RB2_NT
+#define RB2_NT 1
+#endif
+#if RB2_NT
+#define RB2_LDNT(p) __builtin_nontemporal_load(p)
+#define RB2_STNT(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define RB2_LDNT(p) (*(p))
+#define RB2_STNT(v, p) (*(p) = (v))
+#endif
+
 // LDS words one wave of merge_window<.., GPL_, ..> needs: flags + three planes of new symbols + three planes of staged old groups
 template <int GPL_> struct MergeLds { static constexpr int WG = 64 * GPL_, WORDS = WG + 3 * WG + 3 * (WG + 2) + 2; };
 
@@ -102,7 +116,7 @@ template <bool FULL, int GPL_, bool INPLACE, typename P> __device__ __forceinlin
 		const uint64_t og = G0 + k;
 		const uint64_t *q = ob + (og >> 4) * LEAFW + (og & 15);
 #pragma unroll
-		for (int pl = 0; pl < 3; ++pl) { wa[w][pl] = 0; if (k < nwg) wa[w][pl] = q[pl * LEAFG]; }
+		for (int pl = 0; pl < 3; ++pl) { wa[w][pl] = 0; if (k < nwg) wa[w][pl] = RB2_LDNT(&q[pl * LEAFG]); }
 	}
 	if (ln == 0 && (uint32_t)WG < nwg) {
 		const uint64_t og = G0 + WG;
@@ -227,7 +241,7 @@ template <bool FULL, int GPL_, bool INPLACE, typename P> __device__ __forceinlin
 		if (INPLACE && G >= (uint32_t)LEAFG) continue;          // in place the window is ONE leaf
 		uint64_t *dst = (uint64_t*)newp.data + (d.gl + (G >> 4)) * LEAFW + (G & 15);
 #pragma unroll
-		for (int pl = 0; pl < 3; ++pl) dst[pl * LEAFG] = out[w][pl];   // leaves past the end of the piece are padding slots of the same piece
+		for (int pl = 0; pl < 3; ++pl) RB2_STNT(out[w][pl], &dst[pl * LEAFG]);   // leaves past the end of the piece are padding slots of the same piece
 	}
 }
 
