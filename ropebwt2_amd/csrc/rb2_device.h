@@ -488,6 +488,15 @@ __device__ __forceinline__ uint32_t dpp_incl_add(uint32_t v)
 	v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
 	return v;
 }
+// the same for 64-bit values: both halves travel by the same DPP move, one 64-bit add per step (the shuffle-based wave_incl_add<uint64_t>
+// is twelve dependent LDS-crossbar round trips; k_setup runs ten such scans back to back on its one wave)
+__device__ __forceinline__ uint64_t dpp_incl_add64(uint64_t v)
+{
+#define RB2_DPP64(CTRL, MASK) v += (uint64_t)dpp0<CTRL, MASK>((uint32_t)(v >> 32)) << 32 | dpp0<CTRL, MASK>((uint32_t)v)
+	RB2_DPP64(0x111, 0xf); RB2_DPP64(0x112, 0xf); RB2_DPP64(0x114, 0xf); RB2_DPP64(0x118, 0xf); RB2_DPP64(0x142, 0xa); RB2_DPP64(0x143, 0xc);
+#undef RB2_DPP64
+	return v;
+}
 __device__ __forceinline__ uint32_t dpp_incl_max(uint32_t v)     // unsigned max, identity 0
 {
 	v = max(v, dpp0<0x111, 0xf>(v)); v = max(v, dpp0<0x112, 0xf>(v)); v = max(v, dpp0<0x114, 0xf>(v)); v = max(v, dpp0<0x118, 0xf>(v));

@@ -475,7 +475,7 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 	for (int a = 0; a < 6; ++a) {
 		const uint64_t c = ok ? gcnt[rr * 6 + a] : 0ull;
 		n.cnt[a] = ok ? o.cnt[a] + c : 0ull;
-		const uint64_t inc = wave_incl_add<uint64_t>(n.cnt[a]);
+		const uint64_t inc = dpp_incl_add64(n.cnt[a]);
 		const uint64_t ex = inc - n.cnt[a];
 		const uint64_t exf = __shfl(ex, first);
 		if (ok) { ctl->count[r][a] = c; ctl->ac[r][a] = ex - exf; }   // #a in this rope in front of piece r, after the round (mrope.c:332-336)
@@ -486,7 +486,7 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 	} else {
 		n.nleaves = (n.n + LEAF - 1) / LEAF;
 		const uint64_t padded = (n.nleaves + SB - 1) / SB * SB, nwin = (n.nleaves + WPL - 1) / WPL;
-		const uint64_t pinc = wave_incl_add<uint64_t>(padded), winc = wave_incl_add<uint64_t>(nwin);
+		const uint64_t pinc = dpp_incl_add64(padded), winc = dpp_incl_add64(nwin);
 		n.leaf0 = pinc - padded; n.sb0 = n.leaf0 / SB;
 		if (ok) { ctl->rope[side ^ 1][r] = n; ctl->wf0[r] = winc - nwin; }
 		if (r == 63) { ctl->wf0[NR] = winc; ctl->wf0[NR + 1] = winc; ctl->nsb_total = pinc / SB; }
@@ -500,9 +500,9 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 		if (b == 0) c2 = gcnt[a];
 		else for (int x = 0; x < 6; ++x) c2 += gcnt[rope_of(b, x) * 6 + a];
 	}
-	const uint64_t cinc = wave_incl_add<uint64_t>(c2), st = cinc - c2;
+	const uint64_t cinc = dpp_incl_add64(c2), st = cinc - c2;
 	const uint32_t nt = (uint32_t)((c2 + STILE - 1) / STILE);
-	const uint32_t tinc = wave_incl_add<uint32_t>(nt);
+	const uint32_t tinc = dpp_incl_add(nt);
 	if (ok) { ng.start[r] = st; ng.cnt[r] = c2; ng.tile0[r] = tinc - nt; }
 	if (r == 63) { ng.tile0[NR] = tinc; ng.tile0[NR + 1] = tinc; }
 	// dest[r][a]: where the members of bucket r = (b,x) that insert a start inside bucket (a,b)
