@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? trec.fhpre(s, (uint32_t)nt) : 0u);
 	}
 	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + trec.lh((uint32_t)lt)) : 0u;
-	f.b = (uint32_t)b; f.lt = tile - t0; f.pad = 0;
+	f.b = (uint32_t)b; f.lt = tile - t0; f.nexthead = (tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u;
 	f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
 	tf[tile] = f;
 }
@@ -624,7 +624,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 				f[12 + s] = s_pre[s][pn] - first + (hn ? trec.fhpre(s, (uint32_t)nx) : 0u);           // pnext
 			}
 			f[18] = hl ? (uint32_t)((lt - (int)t0) * STILE + trec.lh((uint32_t)lt)) : 0u;          // fopen
-			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = 0;
+			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = (tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u;   // nexthead
 			const uint64_t ss = sg.start[b], se = ss + sg.cnt[b];
 			f[22] = (uint32_t)ss; f[23] = (uint32_t)(ss >> 32); f[24] = (uint32_t)se; f[25] = (uint32_t)(se >> 32);
 		}
@@ -663,6 +663,7 @@ struct GroupLds {
 	uint64_t bal[8][6], head[8];                // per wave-chunk of the tile: lanes with symbol s / group heads
 	uint32_t cpre[9][6];
 	TileFix fix;                                // tpre, popen, pnext, fopen of this tile (k_tfix)
+	uint32_t allsingle;                         // every string of the tile is a group of its own (the rule once intervals are narrow): group_member takes the short way
 };
 
 // fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none)
@@ -688,6 +689,15 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 		uint32_t run = 0;
 		for (int c = 0; c < 8; ++c) { G.cpre[c][s] = run; run += __popcll(G.bal[c][s]); }
 		G.cpre[8][s] = run;
+	}
+	if (threadIdx.x == 6) {                                     // all heads, and the string behind the tile starts a group too?
+		const uint64_t nval = min((uint64_t)STILE, t.segend - t.base);
+		bool all = G.fix.nexthead != 0;
+		for (int c = 0; c < 8; ++c) {
+			const uint64_t vm = nval >= (uint64_t)(64 * (c + 1)) ? ~0ull : (nval > (uint64_t)(64 * c) ? lt_mask((int)(nval - 64 * c)) : 0ull);
+			all = all && G.head[c] == vm;
+		}
+		G.allsingle = all ? 1u : 0u;
 	}
 	__syncthreads();
 }
@@ -719,6 +729,11 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	}
 	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
 	Member m;
+	if (G.allsingle) {                                         // (block-uniform) a tile of one-member groups
+		m.pa = G.fix.tpre[a] + before(x, a);
+		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F; m.lead = x;
+		return m;
+	}
 	m.pa = G.fix.tpre[a] + before(x, a);
 	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
 		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F; m.lead = x;
@@ -1409,9 +1424,17 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		w2[h] = 0; l2[h] = 0;
 		if (k < t.segend) { w2[h] = W[k]; l2[h] = L[k]; }
 	}
-	group_setup(G, t, A, tf, tile, sym2, flag2);
-	uint32_t nz = 0;
+	// per tile and symbol: AC offset minus the directory prefix in front of the piece, and where the bucket's members that insert the
+	// symbol go -- six values each, looked up in LDS by every string instead of rebuilt from two directory loads and two table loads
+	__shared__ uint64_t s_acb[6], s_dst[6];
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
+	if (threadIdx.x < 6) {
+		const int a6 = threadIdx.x;
+		s_acb[a6] = ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6);
+		s_dst[a6] = ctl->dest[t.b][a6];
+	}
+	group_setup(G, t, A, tf, tile, sym2, flag2);                // (its barriers also cover the two tables)
+	uint32_t nz = 0;
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
@@ -1431,10 +1454,10 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
 			gl = nrp.leaf0 + (f >> LEAF_SH);
 		}
-		const uint64_t rk = sb_cum(newp, gl / SB, a) - sb_cum(newp, nrp.sb0, a) + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
-		const uint64_t l = ctl->ac[t.b][a] + rk - m.pa + m.pga;
+		const uint64_t rk = sb_cum(newp, gl / SB, a) + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
+		const uint64_t l = s_acb[a] + rk - m.pa + m.pga;
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
-		const uint64_t d = ctl->dest[t.b][a] + m.pa;
+		const uint64_t d = s_dst[a] + m.pa;
 		uint64_t wv = cur_next(w2[h]);
 		if ((round + 1) % CUR_SYMS == 0) { const uint64_t p = cur_pos(wv); wv = cur_make(p + CUR_SYMS, pack9(s, ctl->len, p)); }   // every string of the batch refills in the same rounds
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
