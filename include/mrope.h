@@ -52,6 +52,9 @@ mrope_t *mr_restore_runs(FILE *fp);                                             
 /* ---- additions ------------------------------------------------------------------------------ */
 /* make the host ropes reflect the device BWT now (otherwise done on demand) */
 void     mr_sync_host(mrope_t *mr);
+/* 1 when the six host B+ trees hold the current BWT.  mr_itr_first / mr_itr_next_block, mr_dump and mr_stream_runs do not
+ * build them for an index that lives on the device (or in restored run bytes): the leaves are cut from the run stream */
+int      mr_host_resident(const mrope_t *mr);
 /* the rb2_hip_t behind this mrope (NULL until the first mr_insert_multi) */
 void    *mr_hip_handle(mrope_t *mr);
 /* ... or the rb2_hip_multi_t, when RB2_HIP_DEVICES lists several devices: the index is then sharded over them and

@@ -78,6 +78,11 @@ typedef struct rope_rdump_s rope_rdump_t;
 rope_rdump_t *rope_rdump_prepare(const uint8_t *rle, int64_t n_bytes, int max_nodes, int block_len, int n_threads);
 int64_t rope_rdump_size(const rope_rdump_t *d);
 int     rope_rdump_write(rope_rdump_t *d, int fd, int64_t off);
+/* ... or walk its leaves (mrope.c:117-130 without the tree): leaf k as a leaf block -- u16 byte count + run bytes -- in blk
+ * (block_len bytes or more; returns the byte count); rope_rdump_free() instead of rope_rdump_write() when done */
+int64_t rope_rdump_nleaves(const rope_rdump_t *d);
+int     rope_rdump_block(const rope_rdump_t *d, int64_t k, uint8_t *blk);
+void    rope_rdump_free(rope_rdump_t *d);
 /* append all run bytes of the rope to a malloc'ed buffer; returns the byte count */
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out);
 

@@ -35,9 +35,11 @@ typedef struct {
 	int counts_lazy;                                           /* r[a]->c[] moved on by text-derived deltas since the device's matrix was last read (reconcile_counts) */
 	uint8_t *raw[6]; int64_t raw_n[6]; int raw_ok;          /* mr_restore_runs: the run bytes of the six ropes, no trees yet */
 	int max_nodes, block_len;
+	struct itr_stream_s *its;                                  /* mr_itr_first without host trees: the walk in progress (one at a time) */
 } mrx_t;
 
 static mrx_t *X(const mrope_t *mr) { return (mrx_t*)mr; }
+static void itr_stream_drop(mrx_t *x);
 
 static int device_id(void)
 {
@@ -129,6 +131,7 @@ void mr_destroy(mrope_t *mr)
 {
 	int a;
 	if (!mr) return;
+	itr_stream_drop(X(mr));
 	for (a = 0; a < 6; ++a) if (mr->r[a]) rope_destroy(mr->r[a]);   /* r[a] may be NULL after a freeing iteration */
 	dev_destroy(X(mr));
 	for (a = 0; a < 6; ++a) free(X(mr)->raw[a]);
@@ -396,16 +399,117 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
 	}
 }
 
+/* The walk over the leaves of an index whose host trees do not exist (it lives on the device, or it was restored as run bytes):
+ * the leaves follow from the run bytes alone -- canonical stream + leaf starts, rope_rdump_prepare: the very leaves the bulk
+ * loader would put under a tree -- so rope a's run stream comes off the device once, is cut, and its leaves are handed out one
+ * after the other from one block buffer, while a thread fetches and cuts rope a + 1.  No B+ trees (mr_host_resident() stays 0),
+ * and never more than two ropes' run bytes on the host.  This is the path main.c:288-305 of the reference takes for `-d`. */
+typedef struct itr_stream_s {
+	mrx_t *x;
+	rope_rdump_t *d; int64_t k, nl;                             /* the rope being served: next leaf, leaves (an empty rope has one empty leaf, as rope_init) */
+	rope_rdump_t *next_d; int next_a, th_on; pthread_t th;     /* the look-ahead */
+	int on_dev, nthr, to_free;
+	uint8_t blk[2 + 65536 + 8];
+} itr_stream_t;
+
+static rope_rdump_t *itr_stream_cut(itr_stream_t *t, int a)
+{
+	mrx_t *x = t->x;
+	rope_rdump_t *d;
+	if (t->on_dev) {
+		runbuf_t rb;
+		int64_t c[36], ub = 1 << 20; int b;                    /* (as mr_sync_host: the symbols of the rope bound its run bytes) */
+		memset(&rb, 0, sizeof(rb));
+		dev_get_counts(x, c);
+		for (b = 0; b < 6; ++b) ub += c[a * 6 + b];
+		rb.p = (uint8_t*)malloc((size_t)ub); rb.m = rb.p ? ub : 0;
+		rb2_hint_huge(rb.p, (size_t)ub);
+		dev_stream_rope(x, a, runbuf_add, &rb);
+		d = rope_rdump_prepare(rb.p, rb.n, x->max_nodes, x->block_len, t->nthr);
+		free(rb.p);
+	} else d = rope_rdump_prepare(x->raw[a], x->raw_n[a], x->max_nodes, x->block_len, t->nthr);
+	return d;
+}
+
+static void *itr_stream_ahead(void *arg)
+{
+	itr_stream_t *t = (itr_stream_t*)arg;
+	t->next_d = itr_stream_cut(t, t->next_a);
+	return 0;
+}
+
+/* make rope a the one being served (it is the look-ahead's, or cut now) and start the look-ahead of rope a + 1 */
+static void itr_stream_open(itr_stream_t *t, int a)
+{
+	if (t->th_on) { pthread_join(t->th, 0); t->th_on = 0; }
+	if (t->next_d && t->next_a == a) { t->d = t->next_d; t->next_d = 0; }
+	else t->d = itr_stream_cut(t, a);
+	t->k = 0; t->nl = rope_rdump_nleaves(t->d) > 0 ? rope_rdump_nleaves(t->d) : 1;
+	if (a + 1 < 6 && !getenv("RB2_ITR_NO_LOOKAHEAD")) {
+		t->next_a = a + 1;
+		if (pthread_create(&t->th, 0, itr_stream_ahead, t) == 0) t->th_on = 1;
+	}
+}
+
+static void itr_stream_drop(mrx_t *x)
+{
+	itr_stream_t *t = x->its;
+	if (t == 0) return;
+	if (t->th_on) pthread_join(t->th, 0);
+	rope_rdump_free(t->d); rope_rdump_free(t->next_d);
+	free(t); x->its = 0;
+}
+
+int mr_host_resident(const mrope_t *mr) { return X(mr)->host_ok; }
+
 void mr_itr_first(mrope_t *mr, mritr_t *i, int to_free)
 {
-	mr_sync_host(mr);
+	mrx_t *x = X(mr);
+	itr_stream_drop(x);                                         /* a walk that was left half-way */
 	i->r = mr; i->a = 0; i->to_free = to_free;
+	if (!x->host_ok && ((has_dev(x) && x->dev_ok) || x->raw_ok) && !getenv("RB2_ITR_VIA_TREES")) {
+		itr_stream_t *t = (itr_stream_t*)calloc(1, sizeof(itr_stream_t));
+		if (t == 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(1); }
+		t->x = x; t->on_dev = has_dev(x) && x->dev_ok; t->to_free = to_free;
+		if (getenv("RB2_LOAD_THREADS")) t->nthr = atoi(getenv("RB2_LOAD_THREADS"));
+		else { const long nc = sysconf(_SC_NPROCESSORS_ONLN); t->nthr = nc >= 80 ? 16 : (nc >= 40 ? 8 : 4); }
+		if (t->on_dev) reconcile_counts(x);
+		x->its = t;
+		memset(&i->i, 0, sizeof(i->i));                          /* rope == 0: this iterator is served by x->its */
+		i->i.d = -1;
+		itr_stream_open(t, 0);
+		return;
+	}
+	mr_sync_host(mr);
 	rope_itr_first(mr->r[0], &i->i);
+}
+
+static const uint8_t *itr_stream_next(mritr_t *i)
+{
+	mrx_t *x = X(i->r);
+	itr_stream_t *t = x->its;
+	if (t == 0) return 0;                                       /* (the walk is over, or another mr_itr_first took its place) */
+	while (i->a < 6) {
+		if (t->k < t->nl) {
+			if (rope_rdump_nleaves(t->d) == 0) { t->blk[0] = t->blk[1] = 0; ++t->k; }   /* the one empty leaf of an empty rope */
+			else rope_rdump_block(t->d, t->k++, t->blk);
+			return t->blk;
+		}
+		rope_rdump_free(t->d); t->d = 0;
+		if (i->to_free) {                                        /* mrope.c:122-125; the run bytes a restored file left go the same way */
+			rope_destroy(i->r->r[i->a]); i->r->r[i->a] = 0;
+			if (!t->on_dev) { free(x->raw[i->a]); x->raw[i->a] = 0; x->raw_n[i->a] = 0; }
+		}
+		if (++i->a < 6) itr_stream_open(t, i->a);
+	}
+	itr_stream_drop(x);
+	return 0;
 }
 
 const uint8_t *mr_itr_next_block(mritr_t *i)
 {
 	const uint8_t *blk;
+	if (i->i.rope == 0) return itr_stream_next(i);
 	while (i->a < 6) {
 		if ((blk = rope_itr_next_block(&i->i)) != 0) return blk;
 		if (i->to_free) { rope_destroy(i->r->r[i->a]); i->r->r[i->a] = 0; }   /* mrope.c:122-125 */

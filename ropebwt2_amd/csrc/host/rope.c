@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <time.h>
 #include <emmintrin.h>
 #include <pthread.h>
 #include <assert.h>
@@ -777,10 +778,16 @@ rope_rdump_t *rope_rdump_prepare(const uint8_t *rle, int64_t n_bytes, int max_no
 	{	/* threads that have at least 1 MiB of the stream each (RB2_LOAD_MIN_SEG: bytes, tests) */
 		const int64_t min_seg = getenv("RB2_LOAD_MIN_SEG") ? atol(getenv("RB2_LOAD_MIN_SEG")) : 1 << 20;
 		const int64_t fit = n_bytes / (min_seg > 0 ? min_seg : 1);
+		struct timespec t0, t1, t2;
+		clock_gettime(CLOCK_MONOTONIC, &t0);
 		d->nseg = canon_stream(rle, n_bytes, fit < 1 ? 1 : fit < d->nthr ? (int)fit : d->nthr, d->seg, d->pre);
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		d->total = d->pre[d->nseg];
+		d->nl = leaf_starts(d->seg, d->pre, d->nseg, d->block_len - RLE_MIN_SPACE - 2, &d->start);
+		clock_gettime(CLOCK_MONOTONIC, &t2);
+		if (getenv("RB2_SYNC_TRACE")) fprintf(stderr, "[rope_rdump] %.2f GB of runs: canonical form in %.3f s (%d segments), %lld leaf starts in %.3f s\n", n_bytes / 1e9,
+				(t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9, d->nseg, (long long)d->nl, (t2.tv_sec - t1.tv_sec) + (t2.tv_nsec - t1.tv_nsec) * 1e-9);
 	}
-	d->total = d->pre[d->nseg];
-	d->nl = leaf_starts(d->seg, d->pre, d->nseg, d->block_len - RLE_MIN_SPACE - 2, &d->start);
 	/* levels, as build_upper_levels packs them (an empty stream is the reset rope: one empty leaf in a bottom root) */
 	for (c = d->nl > 0 ? d->nl : 1, v = 0; ; ++v) {
 		const int64_t nbk = (c + d->fan - 1) / d->fan;
@@ -846,6 +853,8 @@ static void *rdump_worker(void *arg)
 int rope_rdump_write(rope_rdump_t *d, int fd, int64_t off)
 {
 	int t, err = 0;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
 	{
 		uint8_t head[8 + 3 + 50];
 		int n = 8;
@@ -868,9 +877,34 @@ int rope_rdump_write(rope_rdump_t *d, int fd, int64_t off)
 		}
 		for (t = 0; t < nthr; ++t) { if (nthr > 1) pthread_join(th[t], 0); err |= job[t].err; }
 	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	if (getenv("RB2_SYNC_TRACE")) fprintf(stderr, "[rope_rdump] %.2f GB of leaf records written in %.3f s\n", d->size / 1e9, (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9);
 	for (t = 0; t < d->nseg; ++t) free(d->seg[t].out);
 	free(d->start); free(d);
 	return err ? -1 : 0;
+}
+
+/* the leaves of that tree, one at a time, still without the tree (mr_itr_next_block of an index that lives on the device) */
+int64_t rope_rdump_nleaves(const rope_rdump_t *d) { return d->nl; }
+
+/* leaf k as a leaf block (u16 byte count + run bytes, rle.h); blk holds block_len bytes or more; returns the run bytes */
+int rope_rdump_block(const rope_rdump_t *d, int64_t k, uint8_t *blk)
+{
+	fill_job_t f;
+	const int64_t s = d->start[k], e = k + 1 < d->nl ? d->start[k + 1] : d->total;
+	memset(&f, 0, sizeof(f));
+	f.seg = d->seg; f.pre = d->pre; f.nseg = d->nseg;
+	vcopy(&f, blk + 2, s, e - s);
+	*rle_nptr(blk) = (uint16_t)(e - s);
+	return (int)(e - s);
+}
+
+void rope_rdump_free(rope_rdump_t *d)
+{
+	int t;
+	if (d == 0) return;
+	for (t = 0; t < d->nseg; ++t) free(d->seg[t].out);
+	free(d->start); free(d);
 }
 
 int64_t rope_export_runs(const rope_t *rope, uint8_t **out)

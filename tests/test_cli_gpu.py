@@ -228,6 +228,57 @@ def test_mrope_c_api(golden):
         L.mr_destroy(mr)
 
 
+def test_block_iterator_of_a_device_index_builds_no_host_trees():
+    """mr_itr_first / mr_itr_next_block (mrope.c:111-130; what the reference's main.c:288-305 walks for -d) on an index that
+    lives in HBM: the run bytes come off the device rope by rope and are cut into the leaves of the bulk-loaded tree without
+    building it -- mr_host_resident() stays 0, the blocks equal those of the tree walk (RB2_ITR_VIA_TREES=1) and decode to
+    the oracle's BWT; the index keeps taking batches afterwards"""
+    from ropebwt2_amd.build import lib_path
+    L = C.CDLL(lib_path("libropebwt2.so"))
+    L.mr_init.restype = C.c_void_p; L.mr_init.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.mr_insert_multi.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
+    L.mr_itr_first.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.mr_itr_next_block.restype = C.c_void_p; L.mr_itr_next_block.argtypes = [C.c_void_p]
+    L.mr_host_resident.argtypes = [C.c_void_p]
+    L.mr_destroy.argtypes = [C.c_void_p]
+
+    class MrItr(C.Structure):
+        _fields_ = [("r", C.c_void_p), ("a", C.c_int), ("to_free", C.c_int),
+                    ("rope", C.c_void_p), ("pa", C.c_void_p * 80), ("ia", C.c_int * 80), ("d", C.c_int)]
+
+    def walk(mr, to_free=0):
+        it = MrItr()
+        L.mr_itr_first(mr, C.byref(it), to_free)
+        out = []
+        while True:
+            q = L.mr_itr_next_block(C.byref(it))
+            if not q:
+                return out
+            out.append(C.string_at(q + 2, C.cast(q, C.POINTER(C.c_uint16))[0]))
+
+    reads = H.repetitive_reads(6000, seed=91, genome_len=900, max_len=80)
+    for so, block_len in ((0, 512), (1, 64), (2, 512)):
+        o = H.Oracle(so)
+        mr = L.mr_init(64 if block_len == 512 else 6, block_len, so)
+        buf = H.encode_batch(reads[:4000])
+        o.insert_multi(buf); L.mr_insert_multi(mr, len(buf), buf.ctypes.data, 1)
+        blocks = walk(mr)
+        assert L.mr_host_resident(mr) == 0
+        assert max(len(b) for b in blocks) <= block_len - 2
+        assert np.array_equal(H.decode_runs(np.frombuffer(b"".join(blocks), np.uint8)), o.bwt())
+        os.environ["RB2_ITR_VIA_TREES"] = "1"
+        try:
+            assert walk(mr) == blocks and L.mr_host_resident(mr) == 1
+        finally:
+            os.environ.pop("RB2_ITR_VIA_TREES", None)
+        buf = H.encode_batch(reads[4000:])                   # host trees exist now; the next batch makes the device the owner again
+        o.insert_multi(buf); L.mr_insert_multi(mr, len(buf), buf.ctypes.data, 1)
+        assert L.mr_host_resident(mr) == 0
+        blocks = walk(mr, to_free=1)                         # main.c:288: the freeing walk
+        assert np.array_equal(H.decode_runs(np.frombuffer(b"".join(blocks), np.uint8)), o.bwt())
+        L.mr_destroy(mr)
+
+
 DROPIN = os.path.join(H.ORACLE_DIR, "_ref", "ropebwt2_dropin")
 
 

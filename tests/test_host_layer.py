@@ -893,3 +893,64 @@ def test_mr_dump_of_restored_run_bytes_needs_no_trees(hostlib, tmp_path):
                 os.environ.pop("RB2_DUMP_VIA_TREES", None)
         assert outs["direct"] == outs["trees"]
         assert cli(["-m0", "-i", str(tmp_path / ("direct%s.fmr" % so))], b"") == cli(["-m0", "-i", str(f)], b"")
+
+
+class _MrItr(C.Structure):
+    """mritr_t (include/mrope.h): the caller owns it, the library only sees a pointer"""
+    _fields_ = [("r", C.c_void_p), ("a", C.c_int), ("to_free", C.c_int),
+                ("rope", C.c_void_p), ("pa", C.c_void_p * 80), ("ia", C.c_int * 80), ("d", C.c_int)]
+
+
+def _walk_blocks(L, mr, to_free):
+    L.mr_itr_first.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.mr_itr_next_block.restype = C.c_void_p; L.mr_itr_next_block.argtypes = [C.c_void_p]
+    it = _MrItr()
+    L.mr_itr_first(mr, C.byref(it), to_free)
+    blocks = []
+    while True:
+        p = L.mr_itr_next_block(C.byref(it))
+        if not p:
+            break
+        n = C.cast(p, C.POINTER(C.c_uint16))[0]
+        blocks.append(C.string_at(p + 2, n))
+    return blocks
+
+
+@pytest.mark.parametrize("so,extra,to_free", [("", [], 0), ("s", ["-l", "64", "-n", "6"], 0), ("r", ["-l", "40", "-n", "4"], 1), ("", [], 1)])
+def test_block_iterator_of_restored_run_bytes_builds_no_trees(hostlib, tmp_path, so, extra, to_free):
+    """mr_itr_first / mr_itr_next_block (mrope.c:111-130) on an index that only exists as run bytes: the leaf blocks are cut from
+    the run stream -- the same blocks, in the same order, as the walk over the bulk-loaded trees (RB2_ITR_VIA_TREES=1) -- and
+    the host trees are never built (mr_host_resident); an empty rope still yields its one empty leaf"""
+    L = hostlib
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p; libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    L.mr_restore_runs.restype = C.c_void_p; L.mr_restore_runs.argtypes = [C.c_void_p]
+    L.mr_host_resident.argtypes = [C.c_void_p]
+    L.mr_destroy.argtypes = [C.c_void_p]
+    text = H.reads_to_text(H.splitmix_bases(3000, 101, 23)) + b"A" * 90 + b"\n" + (b"G" * 70 + b"\n") * 200   # no N: rope 5 stays empty
+    f = tmp_path / "in.fmr"
+    f.write_bytes(cli(["-LRb" + so, "-m0"] + extra, text))
+    got = {}
+    for mode in ("direct", "trees", "direct_no_lookahead"):
+        env = {"trees": "RB2_ITR_VIA_TREES", "direct_no_lookahead": "RB2_ITR_NO_LOOKAHEAD"}.get(mode)
+        if env:
+            os.environ[env] = "1"
+        try:
+            fp = libc.fopen(str(f).encode(), b"rb")
+            mr = L.mr_restore_runs(fp)
+            libc.fclose(fp)
+            assert L.mr_host_resident(mr) == 0
+            got[mode] = _walk_blocks(L, mr, to_free)
+            assert L.mr_host_resident(mr) == (1 if mode == "trees" else 0)
+            if not to_free and mode == "direct":                # a second walk, and one that is left half-way
+                assert _walk_blocks(L, mr, 0) == got[mode]
+                it = _MrItr()
+                L.mr_itr_first(mr, C.byref(it), 0)
+                assert L.mr_itr_next_block(C.byref(it))
+            L.mr_destroy(mr)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+    assert got["direct"] == got["trees"] == got["direct_no_lookahead"]
+    assert len(got["direct"]) > 12 and b"" in got["direct"]
