@@ -25,8 +25,7 @@ N > 1: ONE index, its 31 sub-ropes sharded over the ranks (rb2_hip_default_owner
 (rb2_hip_multi_*, csrc/rb2_multi.h) -- Python only hands over one batch at a time:
   under torch.distributed.run  one process per GPU; every process is one rank of an RCCL group
                                (rb2_hip_multi_create_rank; the ncclUniqueId travels through torch.distributed):
-                               ncclAllReduce + grouped ncclSend/ncclRecv.  RB2_BENCH_DRIVER=python selects the
-                               round-2 driver (ropebwt2_amd/sharded.py, collectives issued from Python) as a cross-check
+                               ncclAllReduce + grouped ncclSend/ncclRecv
   plain `python bench.py --gpus N`  ONE process drives N devices over the PEER transport (peer access + device
                                events, no host synchronisation between rounds); RB2_BENCH_DEVICES=0,0,0,0 lists the
                                devices explicitly (virtual ranks on one GPU)
@@ -447,15 +446,8 @@ def main():
     if world > 1 or force_multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # test hook for single-GPU boxes: RB2_BENCH_BACKEND=gloo puts every rank on cuda:0 and stages
-        # the exchange through host memory (tests/test_sharded.py uses the same path; Python driver only)
-        if os.environ.get("RB2_BENCH_BACKEND") == "gloo":
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ropebwt2_amd import HipBwt, MultiBwt, build_all
     if rank == 0:
@@ -471,7 +463,6 @@ def main():
     L = args.read_len
     per_batch = batch_reads(args.batch * 1024 ** 3, L)
     dev = local_rank if world > 1 else 0
-    py_driver = (world > 1 or force_multi) and (os.environ.get("RB2_BENCH_DRIVER") == "python" or os.environ.get("RB2_BENCH_BACKEND") == "gloo")
     driver = "single engine"
 
     def fresh_nccl_id():
@@ -486,25 +477,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    class PyDriver(Single):
-        """round 2's driver: collectives issued from Python (ropebwt2_amd/sharded.py) -- kept as a cross-check"""
-
-        def __init__(self, so_, dev_):
-            from ropebwt2_amd.sharded import ShardedBwt, TorchComm
-            self.b = ShardedBwt(so_, rank, world, dev_)
-            self.eng = self.b
-            self.comm = TorchComm(self.b)
-
-        def insert(self, ptrs, nbytes):
-            self.comm.insert_multi_dev(ptrs[0], nbytes)
-
     def make(so_, dev_):
         nonlocal driver
         if not sharded:
             return Single(so_, dev_)
-        if py_driver:
-            driver = "python round loop (sharded.py) over %s" % dist.get_backend()
-            return PyDriver(so_, dev_)
         if world > 1 or force_multi:
             driver = "librb2hip round loop, one process per GPU, RCCL C API (ncclAllReduce + grouped ncclSend/ncclRecv)"
             return Multi(so_, [dev_], "rccl", rank=rank, nranks=world, nccl_id=fresh_nccl_id())
@@ -544,10 +520,7 @@ def main():
     # capacity hint (rb2_hip_reserve): the job's size is known up front, as it is to `ropebwt2 -m`; without it
     # the engine grows its buffers batch by batch (hipMalloc + copy + hipFree inside the timed region)
     tot_syms = sum(sizes)
-    if sharded and (world > 1 and py_driver):
-        bwt.reserve(max(sizes), max(n for _, n in job), int(tot_syms * 1.25 / world))
-    else:
-        bwt.reserve(max(sizes), max(n for _, n in job), tot_syms)          # (a Multi handle divides by its active ranks itself)
+    bwt.reserve(max(sizes), max(n for _, n in job), tot_syms)              # (a Multi handle divides by its active ranks itself)
     bwt.sync()
     bwt.eng.profile_get(reset=True)
     barrier()

@@ -136,46 +136,26 @@ void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_
 uint64_t rb2_hip_rope_hash(rb2_hip_t *h, int b);
 
 /* ---- rope sharding across GPUs ---------------------------------------------------------------
- * One handle per GPU (one process per GPU).  The unit of ownership is a SUB-ROPE: rope b is kept as
- * six independent pieces (b,x), x = the symbol that follows b in the row's suffix (piece (b,x) holds
- * exactly the b-symbols of rope x; rope $ is one piece; NR = 31 pieces, see rb2_device.h).
- * owner[r] = rank that holds piece r and processes its bucket; every rank sees the whole batch
- * buffer.  Inside a round the pieces are independent (the reference runs the ropes on separate
- * threads, mrope.c:312-329); between rounds every rank needs the NR x 6 count matrix (the master
- * reads r[b]->c[] of all ropes, mrope.c:332-340) and strings move from piece (b,x) to the owner of
- * piece (a,b) for the symbol a they just inserted (mrope.c:303-309).  The library does the
- * GPU work of each phase; the caller moves the two buffers with its collective of choice
- * (ropebwt2_amd/sharded.py: torch.distributed all_reduce + all_to_all_single over RCCL):
- *
- *   rounds = rb2_hip_shard_begin(h, len, s_dev)
- *   for r in 0..rounds-1:
- *       rb2_hip_shard_counts(h, r, local)              ->  global = all_reduce_sum(local)
- *       rb2_hip_shard_merge(h, r, global, send, nsend) ->  recv = all_to_all(send, nsend)   (24-byte records)
- *       rb2_hip_shard_finish(h, r, global, recv, nrecv)
- *   rb2_hip_shard_end(h)
- */
+ * The unit of ownership is a SUB-ROPE: rope b is kept as six independent pieces (b,x), x = the symbol that follows b in the
+ * row's suffix (piece (b,x) holds exactly the b-symbols of rope x; rope $ is one piece; NR = 31 pieces, see rb2_device.h).
+ * owner[r] = rank that holds piece r and processes its bucket.  Inside a round the pieces are independent (the reference runs
+ * the ropes on separate threads, mrope.c:312-329); between rounds every rank needs the NR x 6 count matrix (the master reads
+ * r[b]->c[] of all ropes, mrope.c:332-340) and strings move from piece (b,x) to the owner of piece (a,b) for the symbol a they
+ * just inserted (mrope.c:303-309).  Both exchanges happen inside the library: rb2_hip_multi_* below.  (Rounds 2-3 also exported
+ * the phases of a round one by one, rb2_hip_shard_*, for a Python driver that issued the collectives itself; that second
+ * protocol was retired in round 4.) */
 int     rb2_hip_num_subropes(void);                    /* NR = 31: rope $ + pieces (b,x), index 1+(b-1)*6+x */
-void    rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner /* [NR] */);
-int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev);
-int64_t rb2_hip_shard_capacity(rb2_hip_t *h);          /* records the send / receive buffers must hold */
-void    rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt /* [NR*6] */);
-void    rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, void *send_dev, int64_t send_counts[]);
-void    rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[]);
-void    rb2_hip_shard_end(rb2_hip_t *h);
-void    rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind);
-/* stream-ordered variant (no host synchronisation between kernels and collectives; one per round for the caller to read the
- * reduced matrix): run on the caller's stream and keep the count matrix in a caller-owned device buffer that is all-reduced
- * in place.  With it: shard_counts(h, r, NULL); all_reduce(gcnt_dev); copy gcnt_dev to the host; shard_merge(h, r, host copy,
- * send, nsend); all_to_all; shard_finish(...) -- merge and finish return while the device is still working. */
-void    rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream);       /* e.g. torch.cuda.current_stream().cuda_stream */
-void    rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev);     /* NR*6 int64 on this device; NULL switches back */
+void    rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind);   /* on the handle's stream; kind 0 host->device, 1 device->host, 2 device->device */
+/* run on the caller's stream (e.g. torch.cuda.current_stream().cuda_stream): the caller's own work on that stream and the
+ * engine's kernels then need no host synchronisation between them */
+void    rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream);
 
 
 /* ---- N GPUs behind one handle (round 3) ------------------------------------------------------------------
  * The reference fans a round out to its workers and joins them INSIDE mr_insert_multi (mrope.c:287-296, 312-329) and reads
  * every rope's counts after the barrier (mrope.c:332-340); callers just call mr_insert_multi (main.c:240, 248).  This is the
  * same contract for N engines: one call inserts a batch into ONE index whose 31 sub-ropes are dealt out over the ranks
- * (owner map as in rb2_hip_shard_setup), the round loop -- count matrix, merge, exchange of the string records, unpack --
+ * (owner map: owner[r] = rank of sub-rope r), the round loop -- count matrix, merge, exchange of the string records, unpack --
  * runs inside the library, one host thread per local rank, no host <-> device synchronisation between the rounds of a
  * batch on the PEER transport.  Two transports behind the same loop:
  *   RB2_TRANSPORT_PEER  one process, every rank an engine of its own on devices[i] (the same device may be listed several

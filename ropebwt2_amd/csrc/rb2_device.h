@@ -137,7 +137,6 @@ __host__ __device__ inline ShardRec shard_pack(uint64_t l, uint64_t size, uint32
 {
 	ShardRec r; r.a = (l & 0xffffffffffffull) | (size & 0xffffull) << 48; r.b = (uint64_t)id | (size >> 16) << 32; r.w = w; return r;
 }
-struct ShardPiece { uint64_t src, dst, cnt; };             // unpack: cnt records at recv[src..] go to the next arrays at dst
 
 struct LeafDesc {           // work order of one output window (WPL leaves), written by k_part, read by k_merge (32 B)
 	uint64_t i0;            // position (in the old sub-rope) of the first old symbol the window consumes = j*WIN - q0

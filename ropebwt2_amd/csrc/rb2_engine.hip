@@ -219,13 +219,9 @@ struct rb2_hip_s {
 	int debug = 0;
 	int cur_round = -1;
 	uint64_t *gcnt = nullptr;           // device: NR x 6 count matrix of the current round
-	uint64_t *gcnt_own = nullptr;       // ... the engine's own buffer while a caller-owned one is bound (rb2_hip_shard_async)
-	int async_proto = 0; bool own_stream = true;
-	uint64_t *pin_sd = nullptr; ShardPiece *pin_pcs = nullptr;   // pinned staging of the per-round exchange layout (async protocol)
+	bool own_stream = true;
 	int rank = 0, nranks = 1; int owner[NR] = {0};
 	int nactive = 1;                    // ranks that own a sub-rope other than rope $ (sizes the grids of a sharded rank: tile_grid)
-	void *batch = nullptr;              // BatchState of a sharded batch in flight
-	DevBuf<ShardPiece> pieces;
 	DevBuf<uint8_t> xstage, xpack; DevBuf<uint16_t> xnb; DevBuf<uint64_t> xoff;   // k_export staging, packed bytes, chunk offsets
 	uint8_t *xhost[2] = {nullptr, nullptr}; uint64_t *xtot[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr};   // pinned double buffer
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
@@ -304,7 +300,7 @@ void fetch_ropes(rb2_hip_t *h)
 }
 
 // ---- one batch, in phases (the single-GPU path runs them back to back; the rope-sharded path
-// ---- interleaves them with the exchanges driven by the caller, see rb2_hip_shard_*) ---------------
+// ---- interleaves them with the exchanges of the round, rb2_multi.h) --------------------------------
 
 struct BatchState {
 	const uint8_t *s = nullptr; uint64_t len = 0, m = 0, max_len = 0, n_tot = 0, nsb_ub = 0;
@@ -713,7 +709,7 @@ static int64_t split_point(rb2_hip_t *h, const uint8_t *s, int64_t len)
 
 void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false)
 {
-	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is rope-sharded: use the rb2_hip_shard_* protocol\n"); }
+	if (h->nranks > 1) { rb2_fatal("[rb2_hip] this handle is one rank of a rope-sharded index: insert through its rb2_hip_multi_t\n"); }
 	BatchState B;
 	h->want_pos32 = true;                                       // (one engine, whole index: the narrow position storage may be used)
 	if (!batch_begin(h, B, len64, s, true)) {
@@ -819,9 +815,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
 	if (h->pair_d) { HIPCHK(hipFree(h->pair_d)); HIPCHK(hipHostFree(h->pair_h)); }
-	if (h->gcnt_own) h->gcnt = h->gcnt_own;
-	if (h->pin_sd) { HIPCHK(hipHostFree(h->pin_sd)); HIPCHK(hipHostFree(h->pin_pcs)); }
-	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->pieces.release(); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
+	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
 	for (int i = 0; i < 2; ++i) if (h->xhost[i]) { HIPCHK(hipHostFree(h->xhost[i])); HIPCHK(hipHostFree(h->xtot[i])); HIPCHK(hipEventDestroy(h->xev[i])); }
 	if (h->own_stream) HIPCHK(hipStreamDestroy(h->st));
 	delete h;
@@ -833,7 +827,6 @@ int rb2_hip_sorting_order(const rb2_hip_t *h) { return h->so; }
 void rb2_hip_reset(rb2_hip_t *h)
 { finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
-	if (h->batch) { rb2_fatal("[rb2_hip] reset inside a sharded batch\n"); }
 	memset(h->h_rope, 0, sizeof(h->h_rope));
 	h->sparse = false; h->sp_backoff = h->sp_penalty = 0;
 	HIPCHK(hipMemsetAsync(&h->ctl->rope[0][0], 0, sizeof(RopeDesc) * 2 * NR, h->st));
@@ -1132,7 +1125,8 @@ void rb2_hip_load_ropes(rb2_hip_t *h, const uint8_t *const rle[6], const int64_t
 
 /* ---- rope sharding across GPUs ------------------------------------------- */
 
-void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
+// this engine becomes rank `rank` of `nranks`: it holds (and launches blocks for) the sub-ropes owner[] gives it (rb2_multi.h)
+void engine_set_shard(rb2_hip_t *h, int rank, int nranks, const int *owner)
 { finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
 	if (nranks < 1 || rank < 0 || rank >= nranks) { rb2_fatal("[rb2_hip] bad shard rank %d/%d\n", rank, nranks); }
@@ -1151,37 +1145,8 @@ void rb2_hip_shard_setup(rb2_hip_t *h, int rank, int nranks, const int *owner)
 
 int rb2_hip_num_subropes(void) { return NR; }
 
-int64_t rb2_hip_shard_begin(rb2_hip_t *h, int64_t len, const uint8_t *s_dev)
-{ finish_pending(h);
-	HIPCHK(hipSetDevice(h->dev));
-	if (len <= 0 || ((uintptr_t)s_dev & 15)) { rb2_fatal("[rb2_hip] shard_begin: need a non-empty, 16-byte aligned device buffer\n"); }
-	check_last_byte(h, len, s_dev);
-	ensure_dense(h);                                           /* the protocol below runs dense rounds (k_part / k_merge): a handle that went sparse through rb2_hip_insert_multi is converted first */
-	BatchState *B = new BatchState();
-	batch_begin(h, *B, len, s_dev);
-	h->batch = B;
-	return (int64_t)B->max_len + 1;                            /* rounds */
-}
-
-int64_t rb2_hip_shard_capacity(rb2_hip_t *h) { return h->batch ? (int64_t)((BatchState*)h->batch)->m : 0; }
-
-void rb2_hip_shard_counts(rb2_hip_t *h, int64_t round, int64_t *local_cnt)
-{
-	HIPCHK(hipSetDevice(h->dev));
-	BatchState &B = *(BatchState*)h->batch;
-	round_counts(h, B, (uint64_t)round);
-	if (h->async_proto && !local_cnt) return;                  /* stream-ordered protocol: the caller reduces the bound device buffer in place */
-	HIPCHK(hipMemcpyAsync(local_cnt, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, h->st));
-	HIPCHK(hipStreamSynchronize(h->st));
-}
-
-/* ---- stream-ordered variant of the protocol ------------------------------------------------------------
- * rb2_hip_use_stream: run everything on the caller's stream (e.g. torch's current stream, on which RCCL collectives are
- * ordered), so that kernels and collectives need no host synchronisation between them.
- * rb2_hip_shard_async: bind a caller-owned device buffer (NR*6 int64) as the count matrix: shard_counts(h, r, NULL) leaves
- * this rank's rows there, the caller all-reduces it IN PLACE on the same stream, shard_merge then reads it from the device
- * (its host copy is only used to lay out the exchange); shard_merge / shard_finish return without waiting for the device.
- * One host synchronisation per round remains: the caller reading the reduced matrix to size the uneven all-to-all. */
+/* run everything on the caller's stream (e.g. torch's current stream), so that the caller's own work on that stream and the
+ * engine's kernels need no host synchronisation between them */
 void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
 { finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));
@@ -1189,23 +1154,6 @@ void rb2_hip_use_stream(rb2_hip_t *h, void *hip_stream)
 	if (h->own_stream) { HIPCHK(hipStreamSynchronize(h->st)); HIPCHK(hipStreamDestroy(h->st)); h->own_stream = false; }
 	else HIPCHK(hipDeviceSynchronize());                                       /* the previous foreign stream may be gone */
 	h->st = (hipStream_t)hip_stream;
-}
-
-void rb2_hip_shard_async(rb2_hip_t *h, int64_t *gcnt_dev)
-{ finish_pending(h);
-	HIPCHK(hipSetDevice(h->dev));
-	HIPCHK(hipStreamSynchronize(h->st));
-	if (gcnt_dev) {
-		if (!h->gcnt_own) h->gcnt_own = h->gcnt;
-		h->gcnt = (uint64_t*)gcnt_dev; h->async_proto = 1;
-		if (!h->pin_sd) {
-			HIPCHK(hipHostMalloc((void**)&h->pin_sd, 2 * NR * 6 * 8, hipHostMallocDefault));
-			HIPCHK(hipHostMalloc((void**)&h->pin_pcs, 2 * sizeof(ShardPiece) * 64 * NR * 6, hipHostMallocDefault));
-		}
-	} else {
-		if (h->gcnt_own) h->gcnt = h->gcnt_own;
-		h->async_proto = 0;
-	}
 }
 
 /* where the members of (piece r -> symbol a) sit in the send buffer of rank `src`: per destination rank d,
@@ -1228,84 +1176,7 @@ static void shard_layout(const int owner[NR], int nranks, int src, const int64_t
 	}
 }
 
-void rb2_hip_shard_merge(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, void *send_dev, int64_t send_counts[])
-{
-	HIPCHK(hipSetDevice(h->dev));
-	BatchState &B = *(BatchState*)h->batch;
-	int64_t off[NR][6], start[64];
-	memset(off, 0, sizeof(off));
-	if (h->nranks > 64) { rb2_fatal("[rb2_hip] too many ranks\n"); }
-	shard_layout(h->owner, h->nranks, h->rank, global_cnt, off, send_counts, start);
-	uint64_t sd_stack[NR][6];
-	uint64_t (*sd)[6] = h->async_proto ? (uint64_t (*)[6])(h->pin_sd + (round & 1) * NR * 6) : sd_stack;   /* async: the copy outlives this call */
-	for (int r = 0; r < NR; ++r) for (int a = 0; a < 6; ++a) sd[r][a] = (uint64_t)off[r][a];
-	if (!h->async_proto) HIPCHK(hipMemcpyAsync(h->gcnt, global_cnt, NR * 6 * 8, hipMemcpyHostToDevice, h->st));   /* async: already reduced in place on the device */
-	HIPCHK(hipMemcpyAsync(&h->ctl->sdest[0][0], sd, sizeof(sd_stack), hipMemcpyHostToDevice, h->st));
-	round_merge(h, B, (uint64_t)round, (ShardRec*)send_dev);
-	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));  /* the send buffer is complete (and sd / global_cnt consumed) when we return */
-}
-
-void rb2_hip_shard_finish(rb2_hip_t *h, int64_t round, const int64_t *global_cnt, const void *recv_dev, const int64_t recv_counts[])
-{
-	HIPCHK(hipSetDevice(h->dev));
-	BatchState &B = *(BatchState*)h->batch;
-	/* local layout of next round's buckets (same rule as k_setup): owned pieces ascending; inside bucket (a,b)
-	 * the sources (b,x) in the order of x */
-	int64_t nstart[NR], run = 0;
-	for (int r2 = 0; r2 < NR; ++r2) {
-		nstart[r2] = run;
-		if (r2 >= 1 && h->owner[r2] == h->rank) {
-			const int a = rope_sym(r2), b = rope_prev(r2);
-			for (int r = 0; r < NR; ++r) if (rope_sym(r) == b) run += global_cnt[r * 6 + a];
-		}
-	}
-	std::vector<ShardPiece> pcs;
-	int64_t base = 0;
-	for (int s = 0; s < h->nranks; ++s) {
-		int64_t off[NR][6], per[64], start[64];
-		memset(off, 0, sizeof(off));
-		shard_layout(h->owner, h->nranks, s, global_cnt, off, per, start);
-		if (per[h->rank] != recv_counts[s]) { rb2_fatal("[rb2_hip] shard_finish: rank %d expected %lld records from rank %d, caller says %lld\n", h->rank, (long long)per[h->rank], s, (long long)recv_counts[s]); }
-		for (int r2 = 1; r2 < NR; ++r2) {
-			if (h->owner[r2] != h->rank) continue;
-			const int a = rope_sym(r2), b = rope_prev(r2);
-			for (int r = 0; r < NR; ++r) {
-				if (rope_sym(r) != b || h->owner[r] != s || global_cnt[r * 6 + a] == 0) continue;
-				int64_t before = 0;
-				for (int rr = 0; rr < r; ++rr) if (rope_sym(rr) == b) before += global_cnt[rr * 6 + a];
-				ShardPiece p; p.src = (uint64_t)(base + off[r][a] - start[h->rank]); p.dst = (uint64_t)(nstart[r2] + before); p.cnt = (uint64_t)global_cnt[r * 6 + a];
-				pcs.push_back(p);
-			}
-		}
-		base += recv_counts[s];
-	}
-	if (base > 0) {
-		std::sort(pcs.begin(), pcs.end(), [](const ShardPiece &x, const ShardPiece &y) { return x.src < y.src; });
-		const ShardPiece *src = pcs.data();
-		if (h->async_proto) {                                   /* the copy outlives this call: stage in pinned memory, and never reallocate the device list mid-batch */
-			if (pcs.size() > (size_t)64 * NR * 6) { rb2_fatal("[rb2_hip] shard_finish: too many exchange pieces\n"); }
-			ShardPiece *pin = h->pin_pcs + (round & 1) * 64 * NR * 6;
-			memcpy(pin, pcs.data(), pcs.size() * sizeof(ShardPiece));
-			src = pin;
-			if (h->pieces.cap < (size_t)64 * NR * 6 + 1) { HIPCHK(hipStreamSynchronize(h->st)); h->pieces.ensure((size_t)64 * NR * 6 + 1); }
-		} else h->pieces.ensure(pcs.size() + 1);
-		HIPCHK(hipMemcpyAsync(h->pieces.p, src, pcs.size() * sizeof(ShardPiece), hipMemcpyHostToDevice, h->st));
-		const int cur = B.cur;                                 /* round_merge already flipped: these are next round's arrays */
-		hipLaunchKernelGGL(k_unpack, dim3(cdiv((uint64_t)base, 256)), dim3(256), 0, h->st, h->ctl, (const ShardRec*)recv_dev, h->pieces.p, (int)pcs.size(), (uint64_t)base, B.s, h->A[cur].p, (uint32_t)round,
-				h->L[cur].p, h->U[cur].p, h->W[cur].p);
-	}
-	if (!h->async_proto) HIPCHK(hipStreamSynchronize(h->st));
-}
-
-void rb2_hip_shard_end(rb2_hip_t *h)
-{
-	HIPCHK(hipSetDevice(h->dev));
-	batch_end(h);
-	delete (BatchState*)h->batch;
-	h->batch = nullptr;
-}
-
-/* plain copies for callers that stage exchange buffers themselves: kind 0 host->device, 1 device->host, 2 device->device */
+/* plain copies on the handle's stream: kind 0 host->device, 1 device->host, 2 device->device */
 void rb2_hip_memcpy(rb2_hip_t *h, void *dst, const void *src, int64_t bytes, int kind)
 { finish_pending(h);
 	HIPCHK(hipSetDevice(h->dev));

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax)
 {
 	const int r = lane_id();
-	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_unpack of this round count into it
+	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
@@ -1471,25 +1471,6 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		if (__any(nz != 0) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;
 	}
 	return true;
-}
-
-// sharded mode: records received from the other ranks -> next round's SoA arrays, bucket order
-__global__ __launch_bounds__(256) void k_unpack(const Ctl *ctl, const ShardRec *recv, const ShardPiece *pc, int npieces, uint64_t total,
-		const uint8_t *s, uint8_t *A2, uint32_t round, uint64_t *L2, uint64_t *U2, uint64_t *W2)
-{
-	const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-	bool nonempty = false;
-	if (i < total) {
-	int lo = 0, hi = npieces - 1;                              // last piece with src <= i (pieces tile recv[] in order)
-	while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pc[mid].src <= i) lo = mid; else hi = mid - 1; }
-	const ShardRec r = recv[i];
-	const uint64_t d = pc[lo].dst + (i - pc[lo].src);
-	const uint64_t l = r.a & 0xffffffffffffull, size = r.a >> 48 | (r.b >> 32) << 16;
-	L2[d] = l; U2[d] = l + size;
-	W2[d] = r.w; A2[d] = (uint8_t)cur_sym(r.w);
-	nonempty = size != 0;
-	}
-	if (__any(nonempty) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;   // see Ctl::ne
 }
 
 // ---------------------------------------------------------------------------------------------

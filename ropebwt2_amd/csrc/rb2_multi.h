@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 	if (t == 0) { tab->total = s_tot; tab->npieces = s_np; tab->pad = 0; }
 }
 
-// records -> next round's SoA arrays in bucket order (k_unpack's job), fetched from wherever k_mlayout says they are: the
+// records -> next round's SoA arrays in bucket order, fetched from wherever k_mlayout says they are: the
 // senders' buffers (PEER: loads over xGMI, 24 bytes per lane, consecutive per piece) or the local receive buffer (RCCL).
 // The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
 __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, uint8_t *A2, uint32_t round,
@@ -349,7 +349,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 		MRank &R = m->rk[k];
 		R.dev = devices[k]; R.grank = rank0 + k;
 		R.h = rb2_hip_create(R.dev, so);
-		rb2_hip_shard_setup(R.h, R.grank, world, m->owner);
+		engine_set_shard(R.h, R.grank, world, m->owner);
 		HIPCHK(hipSetDevice(R.dev));
 		R.gloc = R.h->gcnt;
 		HIPCHK(hipMalloc((void**)&R.gred, NR * 6 * 8));
@@ -391,7 +391,7 @@ extern "C" {
 
 /* piece -> rank.  On DNA the 16 pieces (b,x), b,x in ACGT, carry ~1/16 of the rows each; they are dealt out in contiguous
  * blocks, so up to 16 ranks get load.  The light pieces ((b,$): one row per read; everything with N) ride with a neighbour,
- * rope $ with rank 0.  (The same map as ropebwt2_amd/sharded.py default_owners.) */
+ * rope $ with rank 0.  (tests/helpers.py restates it in Python.) */
 void rb2_hip_default_owners(int nranks, int owner[])
 {
 	for (int r = 0; r < NR; ++r) owner[r] = 0;

@@ -48,16 +48,8 @@ def load_hip_lib():
         "rb2_hip_rank_batch": (None, [vp, i32, i64, vp, vp]),
         "rb2_hip_reserve": (None, [vp, i64, i64, i64]),
         "rb2_hip_num_subropes": (i32, []),
-        "rb2_hip_shard_setup": (None, [vp, i32, i32, vp]),
-        "rb2_hip_shard_begin": (i64, [vp, i64, vp]),
-        "rb2_hip_shard_capacity": (i64, [vp]),
-        "rb2_hip_shard_counts": (None, [vp, i64, vp]),
-        "rb2_hip_shard_merge": (None, [vp, i64, vp, vp, vp]),
-        "rb2_hip_shard_finish": (None, [vp, i64, vp, vp, vp]),
-        "rb2_hip_shard_end": (None, [vp]),
         "rb2_hip_memcpy": (None, [vp, vp, vp, i64, i32]),
         "rb2_hip_use_stream": (None, [vp, vp]),
-        "rb2_hip_shard_async": (None, [vp, vp]),
         "rb2_hip_dev_alloc": (vp, [vp, i64]),
         "rb2_hip_dev_free": (None, [vp, vp]),
         "rb2_hip_synth_reads": (None, [vp, vp, i64, i64, i32, u64, i32]),
@@ -112,8 +104,7 @@ ABI_SYMBOLS = [
     "rb2_hip_device_count", "rb2_hip_set_fatal_handler", "rb2_hip_create", "rb2_hip_destroy", "rb2_hip_sorting_order", "rb2_hip_reset",
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_set_lazy", "rb2_hip_wait", "rb2_hip_last_batch_counts", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
-    "rb2_hip_num_subropes", "rb2_hip_shard_setup", "rb2_hip_shard_begin", "rb2_hip_shard_capacity", "rb2_hip_shard_counts",
-    "rb2_hip_shard_merge", "rb2_hip_shard_finish", "rb2_hip_shard_end", "rb2_hip_memcpy", "rb2_hip_use_stream", "rb2_hip_shard_async",
+    "rb2_hip_num_subropes", "rb2_hip_memcpy", "rb2_hip_use_stream",
     "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_synth_reads_skew", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",

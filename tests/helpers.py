@@ -250,3 +250,65 @@ def run_ref(flags, text, extra=()):
 
 def md5(b):
     return hashlib.md5(b).hexdigest()
+
+
+# ---- sub-ropes: Python restatement of the owner map and the exchange layout of the sharded build (rb2_device.h rope_of /
+# ---- rope_sym / rope_prev, rb2_hip_default_owners, shard_layout in rb2_engine.hip) for the tests that check the library's own
+
+NR = 31                 # sub-ropes: rope $ + pieces (b,x)
+REC_WORDS = 3           # a string record on the wire: 24 bytes (rb2_device.h ShardRec)
+
+
+def rope_sym(r):
+    """rope the piece belongs to (0 = $ ... 5 = N)"""
+    return 0 if r == 0 else (r - 1) // 6 + 1
+
+
+def rope_prev(r):
+    """x of piece (b,x): the symbol following b in the suffix"""
+    return 0 if r == 0 else (r - 1) % 6
+
+
+def rope_of(b, x):
+    return 0 if b == 0 else 1 + (b - 1) * 6 + x
+
+
+def default_owners(nranks):
+    """piece -> rank.  On DNA the 16 pieces (b,x), b,x in ACGT, carry ~1/16 of the rows each; they are dealt out in contiguous
+    blocks, so up to 16 ranks get load.  The light pieces ((b,$): one row per read; everything with N) ride with a neighbour,
+    rope $ with rank 0."""
+    own = [0] * NR
+    if nranks <= 1:
+        return own
+    for b in range(1, 6):
+        for x in range(6):
+            k = (min(b, 4) - 1) * 4 + (min(max(x, 1), 4) - 1)
+            own[rope_of(b, x)] = min(k * nranks // 16, nranks - 1)
+    return own
+
+
+def exchange_layout(owner, nranks, src, g):
+    """records rank ``src`` sends to every rank for the count matrix g (NR x 6): the members of bucket r that insert a
+    (a = 1..5) travel from owner[r] to owner[(a, rope_sym(r))]"""
+    g = np.asarray(g, dtype=np.int64).reshape(NR, 6)
+    per = [0] * nranks
+    for r in range(NR):
+        if owner[r] != src:
+            continue
+        for a in range(1, 6):
+            per[owner[rope_of(a, rope_sym(r))]] += int(g[r, a])
+    return per
+
+
+def exchange_block(owner, src, dst, g):
+    """the records src sends to dst in the order they sit in src's send buffer, tagged (r, a, index): for the pieces r2 = (a,b)
+    owned by dst (ascending), for the pieces r of rope b owned by src (ascending), the g[r][a] members in their old order"""
+    out = []
+    for r2 in range(1, NR):
+        if owner[r2] != dst:
+            continue
+        a, b = rope_sym(r2), rope_prev(r2)
+        for r in range(NR):
+            if rope_sym(r) == b and owner[r] == src:
+                out += [(r, a, i) for i in range(int(g[r, a]))]
+    return out

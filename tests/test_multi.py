@@ -2,7 +2,7 @@
 library -- what mr_insert_multi does with its worker threads (/root/reference/mrope.c:287-296, 312-340) -- through the C ABI,
 the mrope C API and the CLI (RB2_HIP_DEVICES).
 
-CPU  : the owner map and the symbols.
+CPU  : the owner map, the exchange plan against a simulation, and the exchange itself with world_size 2 and 3 over gloo.
 GPU  : N virtual ranks on one device over the PEER transport (the complete round loop, device-side exchange plan, records
        fetched from the senders' buffers, no host synchronisation between rounds) bit-exact against the oracle and the
        reference's goldens; the RCCL transport on a group of one (librccl really loaded and called); a real multi-GPU run
@@ -17,12 +17,82 @@ import pytest
 import helpers as H
 
 
-def test_default_owners_match_python_driver():
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def launch(n, args, port):
+    """tests/multi_worker.py as n processes under torch.distributed.run"""
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "multi_worker.py")] + [str(a) for a in args]
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+
+
+def test_subrope_indexing():
+    from helpers import NR, rope_sym, rope_prev, rope_of
+    from ropebwt2_amd import load_hip_lib, build_all
+    build_all()
+    assert NR == load_hip_lib().rb2_hip_num_subropes() == 31 and rope_sym(0) == 0 and rope_prev(0) == 0
+    seen = set()
+    for b in range(1, 6):
+        for x in range(6):
+            r = rope_of(b, x)
+            assert 1 <= r < NR and rope_sym(r) == b and rope_prev(r) == x
+            seen.add(r)
+    assert len(seen) == 30
+    # pieces of one rope are contiguous and ordered by x: concatenating pieces in index order gives rope order
+    assert [rope_sym(r) for r in range(NR)] == sorted(rope_sym(r) for r in range(NR))
+
+
+def test_default_owners():
+    """the library's owner map: equal to its Python restatement; every rank up to 16 carries load; on uniform DNA the heaviest
+    rank holds at most ceil(16/n) of the 16 heavy pieces"""
     from ropebwt2_amd import MultiBwt, build_all
-    from ropebwt2_amd.sharded import default_owners
+    from helpers import NR, default_owners, rope_of
     build_all()
     for n in (1, 2, 3, 4, 5, 7, 8, 16, 20, 64):
-        assert MultiBwt.default_owners(n) == default_owners(n)
+        owner = MultiBwt.default_owners(n)
+        assert owner == default_owners(n) and len(owner) == NR and max(owner) < n
+        if n <= 16:
+            assert len(set(owner)) == n
+    for n in (2, 4, 8, 16):
+        owner = MultiBwt.default_owners(n)
+        load = [0] * n
+        for b in range(1, 5):
+            for x in range(1, 5):
+                load[owner[rope_of(b, x)]] += 1
+        assert max(load) == -(-16 // n) and min(load) == 16 // n
+
+
+def test_exchange_layout_is_consistent():
+    from helpers import NR, default_owners, exchange_layout, rope_sym
+    rng = np.random.RandomState(0)
+    for n in (1, 2, 3, 4, 8, 16, 20):
+        owner = default_owners(n)
+        g = rng.randint(0, 1000, size=(NR, 6))
+        sent = np.array([exchange_layout(owner, n, s, g) for s in range(n)])
+        # everything that inserts a symbol 1..5 is sent exactly once, to the owner of piece (a, b)
+        assert sent.sum() == g[:, 1:].sum()
+        for d in range(n):
+            want = 0
+            for r in range(NR):
+                for a in range(1, 6):
+                    if owner[1 + (a - 1) * 6 + rope_sym(r)] == d:
+                        want += g[r, a]
+            assert sent[:, d].sum() == want
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_exchange_over_gloo_cpu(n):
+    """world_size 2 and 3 on the CPU: all_reduce of the count matrix, the library's exchange plan, the records through
+    all_to_all_single -- every record where the plan of its receiver expects it (tests/multi_worker.py, mode "plan")"""
+    from ropebwt2_amd import build_all
+    build_all()
+    p = launch(n, ["plan"], 29600 + n)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out
+    assert out.count("plan exchange ok") == n, out
 
 
 def _plan(owner, n, g, me):
@@ -44,7 +114,7 @@ def test_device_exchange_plan_against_a_simulated_exchange(n):
     a literal simulation: the strings of bucket (a,b) of the next round are the members of the pieces (b,x), x = $ACGTN in order,
     that inserted a, in their old order (the stable scatter of mrope.c:303-309) -- for the default and for random owner maps"""
     from ropebwt2_amd import MultiBwt, build_all
-    from ropebwt2_amd.sharded import NR, rope_sym, rope_prev, rope_of, exchange_layout
+    from helpers import NR, rope_sym, rope_prev, rope_of, exchange_layout
     build_all()
     rng = np.random.RandomState(n)
     for trial in range(6):
@@ -350,7 +420,6 @@ def test_real_devices_one_process(hip, transport):
 def test_processes_over_rccl_c_driver(hip, so):
     """one process per GPU, each ONE rank of an RCCL group driven inside librb2hip.so (rb2_hip_multi_create_rank): what
     bench.py runs under torch.distributed.run"""
-    from test_sharded import launch
     n = min(_gpu_count(), 8)
     p = launch(n, ["crank", so], 29750 + so)
     out = p.stdout.decode()
@@ -362,7 +431,6 @@ def test_processes_over_rccl_c_driver(hip, so):
 def test_one_process_group_over_rccl_c_driver(hip):
     """the same worker as a group of ONE process on the one-GPU box: unique id through torch.distributed, ncclCommInitRank,
     the round loop with ncclAllReduce on the real communicator"""
-    from test_sharded import launch
     p = launch(1, ["crank", 2], 29760)
     out = p.stdout.decode()
     assert p.returncode == 0, out

@@ -1,6 +1,6 @@
 """GPU tests at the sizes BASELINE.json's configs name (or the largest slice of them one GPU and a few minutes allow):
 
-  configs[2]  1.2 B x 101 bp, -brR, 8 GPUs     -> the sharded protocol with 8 virtual ranks on one FULL -m4g batch + a second
+  configs[2]  1.2 B x 101 bp, -brR, 8 GPUs     -> the sharded build (8 virtual ranks behind one handle) on one FULL -m4g batch + a second
                                                   batch (60.8 M reads, RCLO, forward strand) against the single-GPU engine,
                                                   and the 100 M-read golden .fmd md5 (real reference) through the sharded path
   configs[3]  10 M x 10 kbp, input order       -> 1 M x 10 kbp (one -m10g batch of 10,001 rounds): size-independent properties
@@ -32,11 +32,10 @@ def test_configs2_shape_sharded_full_batch_vs_single_gpu(hip):
     """8 virtual ranks (the owner map an 8-GPU run uses), RCLO, forward strand: one full -m4g batch (40.8 M reads) and a
     second batch of 20 M on top.  Count matrix after every batch and all six ropes, run byte for run byte, equal to the
     single-GPU engine's (which the other tests pin to the oracle and the reference)."""
-    from ropebwt2_amd.sharded import VirtualCluster
     L = 101
     plan = [(0, batch_reads(4, L)), (batch_reads(4, L), 20_000_000)]
     one = hip.HipBwt(2)
-    vc = VirtualCluster(2, 8)
+    vc = hip.MultiBwt(2, [0] * 8, "peer")
     p = one.dev_alloc(plan[0][1] * (L + 1))
     for first, n in plan:
         one.synth_reads(p, first, n, L, seed=42)
@@ -87,11 +86,10 @@ def _fmd_md5_of(run_streams):
 def test_configs1_golden_through_sharded_path(hip):
     """the full configs[1] job (100 M x 101 bp, RLO, three -m4g batches) built by 8 virtual ranks; the ropes are gathered
     from their owners and encoded by the host writer: the 6.0 GB .fmd has the md5 of the real reference's output"""
-    from ropebwt2_amd.sharded import VirtualCluster
     g = json.load(open(os.path.join(H.GOLDEN_DIR, "golden_large.json")))["configs1"]
     L, per = g["read_len"], batch_reads(4, g["read_len"])
-    vc = VirtualCluster(1, 8)
-    r0 = vc.ranks[0]
+    vc = hip.MultiBwt(1, [0] * 8, "peer")
+    r0 = vc.engine(0)
     p = r0.dev_alloc(per * (L + 1))
     done = 0
     while done < g["n_reads"]:
