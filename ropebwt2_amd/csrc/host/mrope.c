@@ -406,6 +406,7 @@ void mr_rank2a(const mrope_t *mr, int64_t x, int64_t y, int64_t *cx, int64_t *cy
  * and never more than two ropes' run bytes on the host.  This is the path main.c:288-305 of the reference takes for `-d`. */
 typedef struct itr_stream_s {
 	mrx_t *x;
+	const mritr_t *owner;                                      /* the iterator this walk belongs to: a second mr_itr_first ends it */
 	rope_rdump_t *d; int64_t k, nl;                             /* the rope being served: next leaf, leaves (an empty rope has one empty leaf, as rope_init) */
 	rope_rdump_t *next_d; int next_a, th_on; pthread_t th;     /* the look-ahead */
 	int on_dev, nthr, to_free;
@@ -470,7 +471,7 @@ void mr_itr_first(mrope_t *mr, mritr_t *i, int to_free)
 	if (!x->host_ok && ((has_dev(x) && x->dev_ok) || x->raw_ok) && !getenv("RB2_ITR_VIA_TREES")) {
 		itr_stream_t *t = (itr_stream_t*)calloc(1, sizeof(itr_stream_t));
 		if (t == 0) { fprintf(stderr, "[E::%s] out of memory\n", __func__); exit(1); }
-		t->x = x; t->on_dev = has_dev(x) && x->dev_ok; t->to_free = to_free;
+		t->x = x; t->owner = i; t->on_dev = has_dev(x) && x->dev_ok; t->to_free = to_free;
 		if (getenv("RB2_LOAD_THREADS")) t->nthr = atoi(getenv("RB2_LOAD_THREADS"));
 		else { const long nc = sysconf(_SC_NPROCESSORS_ONLN); t->nthr = nc >= 80 ? 16 : (nc >= 40 ? 8 : 4); }
 		if (t->on_dev) reconcile_counts(x);
@@ -488,7 +489,7 @@ static const uint8_t *itr_stream_next(mritr_t *i)
 {
 	mrx_t *x = X(i->r);
 	itr_stream_t *t = x->its;
-	if (t == 0) return 0;                                       /* (the walk is over, or another mr_itr_first took its place) */
+	if (t == 0 || t->owner != i) return 0;                      /* (the walk is over, or another mr_itr_first took its place) */
 	while (i->a < 6) {
 		if (t->k < t->nl) {
 			if (rope_rdump_nleaves(t->d) == 0) { t->blk[0] = t->blk[1] = 0; ++t->k; }   /* the one empty leaf of an empty rope */
