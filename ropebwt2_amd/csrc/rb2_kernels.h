@@ -148,22 +148,25 @@ __global__ __launch_bounds__(256) void k_write_starts(const uint8_t *s, uint64_t
 	}
 }
 
-// The per-string cursor word W that rides through the partition of every round: the next CUR_SYMS symbols of the string, 3 bits each
-// (low 27 bits), and -- above them -- the position in the batch text where the symbols behind those start (36 bits: a batch has
-// < 64 GiB).  Every CUR_SYMS rounds the cursor is refilled by ONE gather from the text at that position.  (Rounds 1-3 carried the
-// string id instead and looked the position up in START[id]: a second random 8-byte read per refill, 64 bytes of traffic for it.)
+// The per-string cursor word W that rides through the partition of every round: the next symbols of the string -- up to CUR_SYMS of
+// them, 3 bits each, stored as code + 1 so that an empty slot is 0 (low 27 bits) -- and, above them, the position in the batch text
+// where the symbols behind those start (36 bits: a batch has < 64 GiB).  A string whose cursor runs empty refills it by ONE gather
+// from the text at that position.  The strings of a batch start with 1 .. CUR_SYMS symbols in turn, so in every round one string in
+// CUR_SYMS refills: the random reads are spread over all rounds and run beside the streaming traffic of the same launch (while all
+// strings refilled in the same rounds, every ninth k_advance took 3.8 times as long as the others).  (Rounds 1-3 carried the string
+// id instead and looked the position up in START[id]: a second random 8-byte read per refill, 64 bytes of traffic for it.)
 // The symbol a string inserts NEXT round also travels as a byte of its own (array A, written by k_advance at the string's new place):
 // k_sym reads one byte per string instead of the 8-byte word.
 constexpr int CUR_SYMS = 9;
 constexpr int CUR_BITS = 3 * CUR_SYMS;
 constexpr uint64_t CUR_MASK = (1ull << CUR_BITS) - 1ull;
-__device__ __forceinline__ uint32_t tri4(uint32_t x)      // low 3 bits of 4 bytes -> 12 bits
+__device__ __forceinline__ uint32_t tri4(uint32_t x)      // (low 3 bits of 4 bytes) + 1 each -> 12 bits
 {
-	x &= 0x07070707u;
+	x = (x & 0x07070707u) + 0x01010101u;
 	x = (x | x >> 5) & 0x003f003fu;
 	return (x | x >> 10) & 0xfffu;
 }
-__device__ __forceinline__ uint32_t pack9(const uint8_t *s, uint64_t len, uint64_t p)   // s[p .. p+9) as 27 bits (bytes past the end read as 0)
+__device__ __forceinline__ uint32_t pack9(const uint8_t *s, uint64_t len, uint64_t p)   // s[p .. p+9) as 27 bits, code + 1 each (bytes past the end read as 0)
 {
 	if (p + 16 <= len) {
 		const uint32_t *q = (const uint32_t*)(s + (p & ~3ull));
@@ -175,14 +178,16 @@ __device__ __forceinline__ uint32_t pack9(const uint8_t *s, uint64_t len, uint64
 	uint32_t w = 0;
 	for (int i = 0; i < CUR_SYMS; ++i) {
 		const uint64_t q = p + i;
-		w |= (uint32_t)(q < len ? (s[q] & 7) : 0) << (3 * i);
+		w |= (uint32_t)((q < len ? (s[q] & 7) : 0) + 1) << (3 * i);
 	}
 	return w;
 }
 __device__ __forceinline__ uint64_t cur_make(uint64_t next_pos, uint32_t syms) { return next_pos << CUR_BITS | syms; }
 __device__ __forceinline__ uint64_t cur_pos(uint64_t w) { return w >> CUR_BITS; }
-__device__ __forceinline__ int cur_sym(uint64_t w) { return (int)(w & 7); }
+__device__ __forceinline__ bool cur_empty(uint64_t w) { return (w & 7) == 0; }
+__device__ __forceinline__ int cur_sym(uint64_t w) { return (int)(w & 7) - 1; }
 __device__ __forceinline__ uint64_t cur_next(uint64_t w) { return (w & ~CUR_MASK) | ((w & CUR_MASK) >> 3); }   // one symbol consumed
+__device__ __forceinline__ uint64_t cur_refill(const uint8_t *s, uint64_t len, uint64_t w) { const uint64_t p = cur_pos(w); return cur_make(p + CUR_SYMS, pack9(s, len, p)); }
 
 template <typename P = uint64_t> __global__ __launch_bounds__(256) void k_init_strings(Ctl *ctl, int is_srt, const uint8_t *s, const uint64_t *START,
 		P *L, P *U, uint64_t *W, uint8_t *A)
@@ -195,9 +200,10 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256) void k_init_s
 		ln = START[k+1] - 1 - st;
 		L[k] = is_srt ? 0 : n0 + k;                 // mrope.c:280-283
 		U[k] = is_srt ? n0 : n0 + k;
-		const uint32_t c9 = pack9(s, ctl->len, st);
-		W[k] = cur_make(st + CUR_SYMS, c9);
-		A[k] = (uint8_t)(c9 & 7u);
+		const uint32_t n1 = 1 + (uint32_t)(k % CUR_SYMS);       // the refills of the batch take turns (see above)
+		const uint32_t c9 = pack9(s, ctl->len, st) & ((1u << 3 * n1) - 1u);
+		W[k] = cur_make(st + n1, c9);
+		A[k] = (uint8_t)cur_sym(c9);
 	}
 	// block max of the lengths -> ctl->max_len
 	unsigned long long v = ln;
@@ -1459,7 +1465,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
 		const uint64_t d = s_dst[a] + m.pa;
 		uint64_t wv = cur_next(w2[h]);
-		if ((round + 1) % CUR_SYMS == 0) { const uint64_t p = cur_pos(wv); wv = cur_make(p + CUR_SYMS, pack9(s, ctl->len, p)); }   // every string of the batch refills in the same rounds
+		if (cur_empty(wv)) wv = cur_refill(s, ctl->len, wv);     // (one string in CUR_SYMS per round)
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv);
 		} else {
