@@ -117,7 +117,7 @@ struct Ctl {
 	// order; on random reads from round ~14 of a batch on) selects the kernel variants that never touch U / SIZE.
 	uint32_t ne[2];
 	// ---- sparse (in-place) rounds
-	uint32_t nwork;         // work orders (touched leaves) appended by k_part_sparse this round
+	uint32_t wstride;       // work orders of a sparse round: WLC lists of at most wstride entries each, list c at LD[c * wstride ..) (see wcnt)
 	uint32_t overflow;      // some touched leaf cannot take its inserts: the round is void (every later kernel returns) and the host redoes it densely
 	uint32_t sbfull;        // (same 8-byte verdict word) k_split found a leaf to split in a superblock without a free slot: the host re-spreads the index before the next round
 	uint32_t nsplit;        // leaves that came within SP_MARGIN of LEAF this round (k_part_sparse appends them, k_split splits them)
@@ -127,7 +127,15 @@ struct Ctl {
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
 	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
 	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
+	// The work list of a sparse round (touched leaves, appended by k_part_sparse, read by k_merge_leaf) is WLC lists, the c-th 64th of the
+	// string tiles appends to list c: ONE counter took a returning atomic from every string tile, and atomics on one address are served
+	// one after the other (~12 ns each on MI355X: 25 us for 2048 tiles, tools/ubench/hot_atomic.hip; counters inside one 128-byte line
+	// are no better than one counter); 16 counters on lines of their own cost < 1 us.  Consecutive tiles share a list; a wave of
+	// k_merge_leaf works on one list.  wcnt[c * WLS] = entries of list c.
+	uint32_t wcnt[16 * 32];
 };
+constexpr int WLC = 16;                 // work lists of a sparse round
+constexpr int WLS = 32;                 // their counters sit 128 bytes apart
 
 // one string's state on the wire (24 B): a = l (48 bits) | size[15:0] << 48;  b = id | size[47:16] << 32;  w = the symbol cursor.
 // (Rounds 1-2 sent 16 bytes and rebuilt the cursor on arrival from the batch text every rank holds: a 20-byte random gather per

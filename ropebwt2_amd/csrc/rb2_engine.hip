@@ -369,7 +369,7 @@ bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, b
 		h->pool[h->pside].ensure(leaves_ub, true, st);
 		h->pool[h->pside ^ 1].ensure(leaves_ub, false, st);
 	}
-	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
+	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64 + (uint64_t)(NR + WLC + 1) * STILE / 2));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
 	{	// storage width of the positions: narrow while no piece can hold 2^32 symbols (checked again every round: maybe_widen)
@@ -581,7 +581,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
-	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(std::max<unsigned>(WLC / MW, (h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads) / (WLC / MW) * (WLC / MW))), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
 	});
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }

@@ -461,7 +461,9 @@ __global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const Ti
 template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax)
 {
 	const int r = lane_id();
-	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->nwork = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
+	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
+	if (r < WLC) ctl->wcnt[r * WLS] = 0;                       // the work lists of a sparse round
+	if (r == 0) ctl->wstride = max(1u, (ctl->seg[side].tile0[NR] + WLC - 1) / WLC) * STILE;   // wstride / STILE consecutive tiles share a list, a tile appends at most STILE orders
 	const bool ok = r < NR;
 	const int rr = ok ? r : 0;
 	const SegDesc &sg = ctl->seg[side];
@@ -956,36 +958,88 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 
 template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
 {
-	__shared__ uint64_t s_gl[STILE + 1];
 	const TileFix &tfx = tf[tile];
 	if (tile >= ctl->seg[side].tile0[NR]) return false;
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const P *E = INS_E;
-	Loc lc[2];
 	__shared__ uint32_t s_w[4], s_base;
+	// The descent (locate(), rb2_device.h) of the thread's TWO inserts, level by level, the loads of a level issued together: a thread
+	// that ran one locate() after the other (and thread 0 a third one for the tile's left neighbour) had eight to twelve dependent
+	// round trips to memory in a row.  Superblocks fill evenly, so the one that holds p is the interpolated guess or a neighbour of
+	// it: three probes side by side (two of them share a line) instead of a gallop; anything else falls back to the search.
+	const uint64_t nsb = (rp.nleaves + SB - 1) / SB;
+	const uint64_t base = nsb ? sb_pos(oldp, rp.sb0) : 0;
+	bool ok[2];
+	uint64_t p[2], pprev[2], sbi[2], sbs[2];
+	uint64_t pr[2][3];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const int x = h * 256 + threadIdx.x;
-		const uint64_t g = t.base + x;
-		lc[h].gl = ~0ull; lc[h].s = 0; lc[h].n = 0;
-		if (g < t.segend) lc[h] = locate(oldp, rp, E[g]);
-		s_gl[x + 1] = lc[h].gl;
+		const uint64_t g = t.base + h * 256 + threadIdx.x;
+		ok[h] = g < t.segend;
+		p[h] = ok[h] ? (uint64_t)E[g] : 0;
+		pprev[h] = (ok[h] && g > t.segstart) ? (uint64_t)E[g - 1] : ~0ull;   // ~0: no insert in front of mine in this piece
 	}
-	if (threadIdx.x == 0) s_gl[0] = t.base > t.segstart ? locate(oldp, rp, E[t.base - 1]).gl : ~0ull;
-	__syncthreads();
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		uint64_t g = (rp.n && nsb) ? (uint64_t)((double)p[h] / (double)rp.n * (double)nsb) : 0;
+		if (nsb && g >= nsb) g = nsb - 1;
+		sbi[h] = g;
+		const bool on = ok[h] && nsb;
+		pr[h][0] = (on && g > 0) ? sb_pos(oldp, rp.sb0 + g - 1) - base : 0;
+		pr[h][1] = on ? sb_pos(oldp, rp.sb0 + g) - base : 0;
+		pr[h][2] = (on && g + 1 < nsb) ? sb_pos(oldp, rp.sb0 + g + 1) - base : ~0ull;
+	}
+	bool slow[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		slow[h] = false;
+		if (pr[h][1] <= p[h]) {
+			if (pr[h][2] > p[h]) sbs[h] = pr[h][1];
+			else slow[h] = true;
+		} else if (sbi[h] > 0 && pr[h][0] <= p[h]) { sbs[h] = pr[h][0]; --sbi[h]; }
+		else slow[h] = true;
+		slow[h] = slow[h] && ok[h] && nsb;
+	}
+	Loc lc[2];
+	uint4 fr[2][4];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {                              // the fills of the superblock's 32 slots: one 64-byte line
+		const uint4 *q = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 0);
+		const bool ld = ok[h] && nsb && !slow[h];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) fr[h][i] = ld ? q[i] : make_uint4(0, 0, 0, 0);
+	}
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		lc[h].gl = rp.leaf0; lc[h].s = 0; lc[h].n = 0;
+		if (!ok[h] || !nsb) continue;
+		if (slow[h]) { lc[h] = locate(oldp, rp, p[h]); continue; }   // (rare: a piece that fills unevenly)
+		const uint32_t rel = (uint32_t)(p[h] - sbs[h]);
+		uint32_t run = 0, klo = 0, pre = 0, nk = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const uint32_t w[4] = { fr[h][i].x, fr[h][i].y, fr[h][i].z, fr[h][i].w };
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				const uint32_t n = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
+				if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = n; }
+				run += n;
+			}
+		}
+		lc[h].gl = (rp.sb0 + sbi[h]) * SB + klo; lc[h].s = sbs[h] + pre; lc[h].n = nk;
+	}
+	// first insert of its leaf: the insert in front of mine (ascending positions) lies in front of my leaf's first symbol -- a leaf is
+	// the LAST one in use that starts at or before the position, so two inserts share it exactly when the earlier one is not in front of it
 	bool head[2];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		const int x = h * 256 + threadIdx.x;
-		head[h] = t.base + x < t.segend && s_gl[x + 1] != s_gl[x];   // first insert of its leaf
-	}
+	for (int h = 0; h < 2; ++h) head[h] = ok[h] && (pprev[h] == ~0ull || pprev[h] < lc[h].s);
 	// one slot in the work list per head: block-aggregated, one atomic per tile
 	uint32_t tot;
 	const uint32_t mine = (uint32_t)head[0] + (uint32_t)head[1];
 	uint32_t off = block_excl_add<uint32_t>(mine, s_w, &tot);
-	if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctl->nwork, tot) : 0u;
+	if (threadIdx.x == 0) { const uint32_t ws = ctl->wstride, c = tile / (ws / STILE); s_base = c * ws + (tot ? atomicAdd(&ctl->wcnt[c * WLS], tot) : 0u); }   // my list (Ctl::wcnt)
 	__syncthreads();
 	off += s_base;
 #pragma unroll
@@ -1442,34 +1496,54 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	group_setup(G, t, A, tf, tile, sym2, flag2);                // (its barriers also cover the two tables)
 	uint32_t nz = 0;
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
+	// The two strings of a thread go through the kernel level by level -- group bookkeeping (LDS), then every gather of both, then the
+	// stores: written string after string, the second one's loads sat behind the first one's stores (the arrays may alias as far as the
+	// compiler knows) and a thread walked two chains of dependent round trips one after the other.
+	bool act[2];
+	Member mem[2];
+	uint64_t gl[2], rk[2], sz[2], wv[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
-		const uint64_t k = t.base + x;
-		if (k >= t.segend) continue;
-		const int a = sym2[h];
-		if (a == 0) continue;                                  // sentinel inserted: string is done (mrope.c:310)
-		const Member m = group_member(G, t, x, a, orda);
-		// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
-		// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
-		// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
-		// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
-		uint64_t gl;
-		if (SPARSE) gl = RKLEAF[t.segstart + m.slot];          // where k_merge_leaf put my symbol
+		act[h] = t.base + x < t.segend && sym2[h] != 0;         // sentinel inserted: string is done (mrope.c:310)
+		if (act[h]) mem[h] = group_member(G, t, x, sym2[h], orda);
+	}
+	// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
+	// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
+	// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
+	// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		gl[h] = 0;
+		if (!act[h]) continue;
+		if (SPARSE) gl[h] = RKLEAF[t.segstart + mem[h].slot];   // where k_merge_leaf put my symbol
 		else {
-			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + m.slot] : l2[h] - m.F) + m.slot;
-			gl = nrp.leaf0 + (f >> LEAF_SH);
+			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + mem[h].slot] : l2[h] - mem[h].F) + mem[h].slot;
+			gl[h] = nrp.leaf0 + (f >> LEAF_SH);
 		}
-		const uint64_t rk = sb_cum(newp, gl / SB, a) + (SPARSE ? dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)) : (uint32_t)newp.meta[gl].c[a]) + RKREL[t.segstart + m.slot];
-		const uint64_t l = s_acb[a] + rk - m.pa + m.pga;
-		const uint64_t u = l + ((!AE && flag2[h]) ? SIZE[k] : 0ull);
+	}
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		rk[h] = 0; sz[h] = 0; wv[h] = 0;
+		if (!act[h]) continue;
+		const int a = sym2[h];
+		rk[h] = sb_cum(newp, gl[h] / SB, a) + (SPARSE ? dir_prefix(newp, gl[h] / SB, 1 + a, (uint32_t)(gl[h] % SB)) : (uint32_t)newp.meta[gl[h]].c[a]) + RKREL[t.segstart + mem[h].slot];
+		if (!AE && flag2[h]) sz[h] = SIZE[t.base + h * 256 + threadIdx.x];
+		wv[h] = cur_next(w2[h]);
+		if (cur_empty(wv[h])) wv[h] = cur_refill(s, ctl->len, wv[h]);   // (one string in CUR_SYMS per round)
+	}
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		if (!act[h]) continue;
+		const int a = sym2[h];
+		const Member &m = mem[h];
+		const uint64_t l = s_acb[a] + rk[h] - m.pa + m.pga;
+		const uint64_t u = l + sz[h];
 		const uint64_t d = s_dst[a] + m.pa;
-		uint64_t wv = cur_next(w2[h]);
-		if (cur_empty(wv)) wv = cur_refill(s, ctl->len, wv);     // (one string in CUR_SYMS per round)
 		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
-			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv);
+			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv[h]);
 		} else {
-			L2[d] = (P)l; W2[d] = wv; A2[d] = (uint8_t)cur_sym(wv);
+			L2[d] = (P)l; W2[d] = wv[h]; A2[d] = (uint8_t)cur_sym(wv[h]);
 			if (!AE) { U2[d] = (P)u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}

@@ -334,10 +334,15 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 {
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id(), g = ln & 15;
-	const uint64_t stride = (uint64_t)gridDim.x * MW * LROWS;
-	uint64_t g0 = ((uint64_t)blockIdx.x * MW + wv) * LROWS;
-	const uint32_t nwork = ctl->nwork;
-	if (ctl->overflow || g0 >= nwork) return;
+	// the round's work orders are WLC lists (Ctl::wcnt): wave gw takes list gw % WLC and walks it with the stride of the waves that
+	// share it -- one counter to read per wave, and no search for "the q-th order of the round"
+	const uint32_t gw = blockIdx.x * MW + (uint32_t)wv, per = gridDim.x * MW / WLC;   // (the host launches at least WLC waves)
+	const uint32_t lc = gw % WLC, wi = gw / WLC;
+	const uint64_t stride = (uint64_t)per * LROWS;
+	uint64_t g0 = (uint64_t)wi * LROWS;
+	const uint32_t nwork = ctl->wcnt[lc * WLS];
+	LD += (uint64_t)lc * ctl->wstride;
+	if (ctl->overflow || wi >= per || g0 >= nwork) return;
 	RowOrd o, on, onn;
 	RowJob J, Jn;
 	row_ord_load(LD, g0, nwork, ln, on);
