@@ -57,10 +57,9 @@ typedef struct rb2_hip_s rb2_hip_t;
  * the reference's own convention on this path (asserts and unchecked mallocs).  A host program that wants a say
  * installs a handler: it is called with the message before abort() and may log, release what it holds, or leave through longjmp /
  * exit (the handle that failed must not be used again; others may).
- * With N GPUs behind one handle (rb2_hip_multi_*) a failure is detected on the host thread of the rank it happens on, while the
- * threads of the other ranks may be waiting at the round barrier or for device events that will never be recorded: there the
- * handler must NOT return control to the program -- it may log and then end the process (_exit / abort); longjmp out of a rank's
- * thread is undefined, and exit() would run atexit handlers beside threads that still spin. */
+ * With N GPUs behind one handle (rb2_hip_multi_*) a failure may be detected on the host thread of the rank it happens on: that
+ * thread records the message and ends, the threads of the other ranks leave at their next round barrier, and the handler is called
+ * -- once, with the first message -- on the thread that called the API, after all rank threads are joined: the same rules as above. */
 typedef void (*rb2_hip_fatal_cb)(void *user, const char *message);
 void rb2_hip_set_fatal_handler(rb2_hip_fatal_cb cb, void *user);
 
@@ -212,7 +211,7 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
  * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
 uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);
-/* the device-side exchange plan (k_mlayout) evaluated on the host, for tests: see csrc/rb2_multi.h */
+/* the device-side exchange plan (k_mround) evaluated on the host, for tests: see csrc/rb2_multi.h */
 int rb2_hip_multi_plan_host(const int *owner /* [NR] */, int nranks, const int64_t *g /* [NR*6] */, int me, int64_t *sdest /* [NR*6] */, int64_t (*pieces)[5] /* [NR*6] */, int64_t *total);   /* == rb2_hip_rope_hash of the same rope on one engine */
 
 /* ---- measurement helpers (bench.py; not part of the reference API) ------------------------ */

@@ -22,9 +22,20 @@ using namespace rb2;
 // Fatal errors.  The reference has no error convention on this path (asserts, unchecked mallocs: SURVEY.md 8b); the engine keeps that
 // -- a message on stderr, then abort() -- but a host program can ask to be told first (rb2_hip_set_fatal_handler): it may log, clean up,
 // or leave by longjmp / exit; if the handler returns, abort() follows.
+// With N ranks behind one handle the failure may happen on a rank's own host thread (rb2_multi.h).  A handler that leaves by longjmp
+// must not run there, and exit() there would run the atexit handlers while the other ranks still spin at their barrier: the first
+// failure is recorded, the thread unwinds (RankAbort), the other rank threads leave at their next barrier, and the thread that called
+// the API reports it -- message, handler, abort() -- once all of them are joined.
 static rb2_hip_fatal_cb g_fatal_cb = nullptr;
 static void *g_fatal_user = nullptr;
 #include <cstdarg>
+#include <atomic>
+#include <mutex>
+static thread_local bool t_rank_thread = false;
+static std::atomic<int> g_rank_failed{0};
+static std::mutex g_rank_mu;
+static char g_rank_msg[1024];
+struct RankAbort {};
 [[noreturn]] static void rb2_fatal(const char *fmt, ...)
 {
 	char msg[1024];
@@ -32,6 +43,10 @@ static void *g_fatal_user = nullptr;
 	va_start(ap, fmt);
 	vsnprintf(msg, sizeof(msg), fmt, ap);
 	va_end(ap);
+	if (t_rank_thread) {
+		{ std::lock_guard<std::mutex> lk(g_rank_mu); if (!g_rank_failed.load()) { memcpy(g_rank_msg, msg, sizeof(msg)); g_rank_failed.store(1); } }
+		throw RankAbort();
+	}
 	fputs(msg, stderr);
 	if (g_fatal_cb) g_fatal_cb(g_fatal_user, msg);
 	abort();

@@ -8,8 +8,8 @@
 // the reference's master touches all ropes become the two exchange steps of a round:
 //
 //   counts     every rank's rows of the 31 x 6 matrix "members of bucket r that insert a"  ->  their sum on every rank
-//              PEER: k_mreduce reads the peers' rows (peer access), RCCL: ncclAllReduce in place
-//   layout     k_mlayout (one block, on every rank, from the summed matrix and the owner map): where this rank's k_advance
+//              PEER: k_mround reads the peers' rows (peer access), RCCL: ncclAllReduce in place
+//   layout     k_mround (one block, on every rank, from the summed matrix and the owner map): where this rank's k_advance
 //              writes the records it sends (Ctl::sdest) and the list of pieces k_munpack fetches (MTab) -- the host never
 //              needs the matrix for that
 //   records    24-byte ShardRec {l, size, id, symbol cursor} per surviving string, from the owner of piece (b,x) to the owner of (a,b)
@@ -18,9 +18,9 @@
 // Ordering between ranks on the PEER transport is by device events (hipStreamWaitEvent), two per round and rank; the host
 // threads only meet at a spin barrier so that nobody waits on an event that has not been recorded yet.  No host <-> device
 // synchronisation inside a batch.  Buffers a peer reads are never rewritten before that peer is done with them:
-//   gcnt (local rows)  written by round_counts(r), read by the peers' k_mreduce(r); rewritten by round_counts(r + 1), which
+//   gcnt (local rows)  written by round_counts(r), read by the peers' k_mround(r); rewritten by round_counts(r + 1), which
 //                      is queued behind this rank's k_munpack(r), which waited for every peer's evB(r), recorded behind
-//                      that peer's k_mreduce(r);
+//                      that peer's k_mround(r);
 //   send[r & 1]        written by k_advance(r), read by the peers' k_munpack(r); rewritten by k_advance(r + 2), queued
 //                      behind this rank's k_munpack(r + 1), which waited for every peer's evB(r + 1), recorded behind that
 //                      peer's k_munpack(r).
@@ -54,15 +54,6 @@ struct MTab { uint64_t total; uint32_t npieces, pad; MPiece pc[MPIECES]; };
 struct MPtrs { const void *p[RB2_MULTI_MAX_RANKS]; };
 struct MOwner { uint8_t o[32]; };
 
-__global__ __launch_bounds__(256) void k_mreduce(MPtrs rows, int n, uint64_t *out)
-{
-	const int i = threadIdx.x;
-	if (i >= NR * 6) return;
-	uint64_t s = 0;
-	for (int p = 0; p < n; ++p) s += ((const uint64_t*)rows.p[p])[i];
-	out[i] = s;
-}
-
 // The exchange plan of a round, on the device, from the global count matrix g and the owner map.  An ENTRY is (r, a):
 // the members of bucket r that insert a (a = 1..5; strings that insert $ retire, mrope.c:310); it travels from
 // s = owner[r] to d = owner[(a, rope_sym(r))].  One thread per entry; every quantity is an exclusive sum over the entries
@@ -94,12 +85,23 @@ __host__ __device__ inline MPlan mplan_entry(const uint64_t *g, const uint8_t *o
 	return P;
 }
 
-__global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in, MOwner ow, int me, int peer, MPtrs srcs, const ShardRec *recv, MTab *tab)
+// One single-block launch per round and rank for everything that sits between the counting phase and the merge phase of a sharded
+// round: the sum of the count rows over the peers (PEER), the exchange plan (mplan_entry) and k_setup of the round -- three
+// launches in a row on every rank's stream otherwise, and launches are what N rank threads of one process queue up behind each other
+// for (profiles/r04d_vranks8_one_gpu.txt: 8 ranks on one device keep it busy 40 % of the time).
+// npeer == 0: g_inout already holds the sum (RCCL: ncclAllReduce in place).
+template <bool SPARSE> __global__ __launch_bounds__(256) void k_mround(Ctl *ctl, MPtrs rows, int npeer, uint64_t *g_inout, MOwner ow, int me, int peer, MPtrs srcs, const ShardRec *recv, MTab *tab,
+		int side, int par, uint32_t round, volatile unsigned long long *hmax)
 {
 	__shared__ uint64_t g[NR * 6];
 	__shared__ unsigned long long s_tot;
 	__shared__ uint32_t s_np;
-	for (int i = threadIdx.x; i < NR * 6; i += 256) g[i] = g_in[i];
+	for (int i = threadIdx.x; i < NR * 6; i += 256) {
+		uint64_t v = 0;
+		if (npeer) { for (int p = 0; p < npeer; ++p) v += ((const uint64_t*)rows.p[p])[i]; g_inout[i] = v; }   // (a void in-place round is redone from the summed matrix: k_setup<false>)
+		else v = g_inout[i];
+		g[i] = v;
+	}
 	if (threadIdx.x == 0) { s_tot = 0; s_np = 0; }
 	__syncthreads();
 	const int t = threadIdx.x;
@@ -116,9 +118,10 @@ __global__ __launch_bounds__(256) void k_mlayout(Ctl *ctl, const uint64_t *g_in,
 	}
 	__syncthreads();
 	if (t == 0) { tab->total = s_tot; tab->npieces = s_np; tab->pad = 0; }
+	if (t < 64) setup_body<SPARSE>(ctl, side, g, par, round, hmax);
 }
 
-// records -> next round's SoA arrays in bucket order, fetched from wherever k_mlayout says they are: the
+// records -> next round's SoA arrays in bucket order, fetched from wherever k_mround says they are: the
 // senders' buffers (PEER: loads over xGMI, 24 bytes per lane, consecutive per piece) or the local receive buffer (RCCL).
 // The host does not know how many strings arrive: the grid covers about twice the rank's fair share, with a grid stride behind it.
 __global__ __launch_bounds__(256) void k_munpack(const Ctl *ctl, const MTab *tab, const uint8_t *s, uint8_t *A2, uint32_t round,
@@ -192,9 +195,26 @@ struct SpinBarrier {
 		if (n <= 1) return;
 		const int g = gen.load(std::memory_order_acquire);
 		if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); return; }
-		for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) if (spins > 4000) std::this_thread::yield();
+		for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
+			if (g_rank_failed.load(std::memory_order_relaxed)) throw RankAbort();   // a rank gave up (rb2_fatal on its thread): nobody waits for it
+			if (spins > 4000) std::this_thread::yield();
+		}
 	}
 };
+
+// f(local rank) on a thread per local rank; a fatal error on one of them is reported here, on the calling thread (rb2_fatal)
+template <class F> void rank_threads(int n, F f)
+{
+	std::vector<std::thread> th;
+	for (int k = 0; k < n; ++k) th.emplace_back([&f, k]() { t_rank_thread = true; try { f(k); } catch (const RankAbort &) {} });
+	for (auto &t : th) t.join();
+	if (g_rank_failed.load()) {                                 // (cleared first: the handler may leave by longjmp, and other handles may live on)
+		char msg[1024];
+		memcpy(msg, g_rank_msg, sizeof(msg)); msg[sizeof(msg) - 1] = 0;
+		g_rank_failed.store(0);
+		rb2_fatal("%s", msg);
+	}
+}
 
 struct MRank {
 	rb2_hip_t *h = nullptr;
@@ -266,21 +286,27 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                 // one round per string position (mrope.c:299-342)
 		h->gcnt = R.gloc;
 		round_counts(h, B, r);
+		// the layout of the round (a host decision; a change re-lays the slice out on this stream before anything of the round reads it)
+		choose_layout(h, B, r, m_eff);
 		if (peer) {
 			HIPCHK(hipEventRecord(R.evA, st));
 			m->bar.wait();                                        // every evA of this round is recorded
 			for (int p = 0; p < m->n; ++p) if (p != k) HIPCHK(hipStreamWaitEvent(st, m->rk[p].evA, 0));
-			hipLaunchKernelGGL(k_mreduce, dim3(1), dim3(256), 0, st, rows, m->n, R.gred);
 			h->gcnt = R.gred;
 		} else {
 			if (R.comm) NCCLCHK(rccl().AllReduce(h->gcnt, h->gcnt, NR * 6, ncclUint64, ncclSum, R.comm, st));
 			HIPCHK(hipMemcpyAsync(R.pin_g + (r & 1) * NR * 6, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, st));
 			HIPCHK(hipEventRecord(R.evG, st));
 		}
-		hipLaunchKernelGGL(k_mlayout, dim3(1), dim3(256), 0, st, h->ctl, (const uint64_t*)h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab);
+		// sum of the count rows (PEER) + exchange plan + k_setup of the round: one launch (k_mround)
+		{
+			volatile unsigned long long *hmax = h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr;
+			if (h->sparse) hipLaunchKernelGGL(k_mround<true>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax);
+			else hipLaunchKernelGGL(k_mround<false>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax);
+			B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch;
+		}
 		// dense round: the slice is rewritten pool -> pool; in-place round: only the touched leaves, and the host reads a one-word
 		// verdict before the exchange may go ahead (a void round is redone densely: its records do not exist yet)
-		choose_layout(h, B, r, m_eff);
 		round_merge_any(h, B, r, R.send[r & 1], false);           // flips side / cur: B.cur now names next round's arrays
 		if (peer) {
 			HIPCHK(hipEventRecord(R.evB, st));
@@ -327,9 +353,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 void multi_run(rb2_hip_multi_t *m, int64_t len)
 {
 	if (m->n == 1) { multi_rank_batch(m, 0, len); return; }
-	std::vector<std::thread> th;
-	for (int k = 0; k < m->n; ++k) th.emplace_back(multi_rank_batch, m, k, len);
-	for (auto &t : th) t.join();
+	rank_threads(m->n, [&](int k) { multi_rank_batch(m, k, len); });
 }
 
 rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int so, int transport, const int *owner)
@@ -380,9 +404,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 template <class F> void multi_each(rb2_hip_multi_t *m, F f)
 {
 	if (m->n == 1) { f(0); return; }
-	std::vector<std::thread> th;
-	for (int k = 0; k < m->n; ++k) th.emplace_back([&f, k]() { f(k); });
-	for (auto &t : th) t.join();
+	rank_threads(m->n, f);
 }
 
 } // namespace
@@ -629,7 +651,7 @@ uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b)
 	return acc;
 }
 
-/* the exchange plan of one round as rank `me` sees it, computed on the HOST by the very function k_mlayout runs per entry
+/* the exchange plan of one round as rank `me` sees it, computed on the HOST by the very function k_mround runs per entry
  * (mplan_entry): sdest[r*6+a] = where `me` writes the records of (r,a) in its send buffer (-1: not its entry); pieces[i] =
  * {source rank, offset in that rank's send buffer, offset in me's receive order, offset in me's next string arrays, records}
  * for the i-th piece `me` receives; returns their number, *total = records received.  No device needed (CPU tests). */

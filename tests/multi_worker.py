@@ -3,7 +3,7 @@
 mode "crank": one process per GPU, the round loop INSIDE librb2hip.so (MultiBwt(rank=...) = rb2_hip_multi_create_rank): RCCL's C API,
              the ncclUniqueId handed round through torch.distributed; every rank compares the pieces it holds with the oracle.
 mode "plan":  no GPU, gloo: the count matrix is summed by all_reduce, the exchange plan comes from the library
-             (rb2_hip_multi_plan_host = the device's k_mlayout on the host), tagged records travel through all_to_all_single and
+             (rb2_hip_multi_plan_host = the device's k_mround on the host), tagged records travel through all_to_all_single and
              must land where the plan says -- the RCCL transport's layout on real processes.
 """
 import os
@@ -60,7 +60,7 @@ def main():
     else:
         # "plan": no GPU.  Five rounds of the exchange as the RCCL transport lays it out (rb2_multi.h): every rank knows only the
         # rows of the count matrix of the pieces it owns -> all_reduce; rb2_hip_multi_plan_host (the per-entry function of the
-        # device's k_mlayout) says where this rank writes the records it sends and which pieces it receives from whom; the records
+        # device's k_mround) says where this rank writes the records it sends and which pieces it receives from whom; the records
         # travel through all_to_all_single over gloo and must arrive exactly where the plan expects them.
         import ctypes as C
         import helpers as H

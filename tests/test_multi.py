@@ -96,7 +96,7 @@ def test_exchange_over_gloo_cpu(n):
 
 
 def _plan(owner, n, g, me):
-    """rb2_hip_multi_plan_host: the per-entry function of k_mlayout, run on the host"""
+    """rb2_hip_multi_plan_host: the per-entry function of k_mround, run on the host"""
     from ropebwt2_amd import load_hip_lib
     L = load_hip_lib()
     own = (C.c_int * 31)(*owner)
@@ -110,7 +110,7 @@ def _plan(owner, n, g, me):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 16, 20])
 def test_device_exchange_plan_against_a_simulated_exchange(n):
-    """k_mlayout's plan (where every rank writes its records, which pieces every rank fetches from whom, where they land) against
+    """k_mround's plan (where every rank writes its records, which pieces every rank fetches from whom, where they land) against
     a literal simulation: the strings of bucket (a,b) of the next round are the members of the pieces (b,x), x = $ACGTN in order,
     that inserted a, in their old order (the stable scatter of mrope.c:303-309) -- for the default and for random owner maps"""
     from ropebwt2_amd import MultiBwt, build_all
@@ -223,7 +223,7 @@ def test_peer_many_ranks_and_odd_counts(hip, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_peer_random_owner_maps(hip, seed):
-    """any assignment of the 31 sub-ropes to ranks gives the same BWT: the device-side exchange plan (k_mlayout) against
+    """any assignment of the 31 sub-ropes to ranks gives the same BWT: the device-side exchange plan (k_mround) against
     pieces of one rope scattered over ranks, ranks with only light pieces, a rank that owns nothing"""
     from ropebwt2_amd import MultiBwt
     rng = np.random.RandomState(seed)
@@ -546,3 +546,29 @@ print("c api ok")
     import sys
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, RB2_HIP_DEVICES="0,0,0,0"))
     assert p.returncode == 0 and b"c api ok" in p.stdout, p.stderr.decode()[-2000:]
+
+
+@pytest.mark.gpu
+def test_fatal_error_on_a_rank_thread_reaches_the_handler_on_the_calling_thread(hip):
+    """N ranks behind one handle: a failure on a rank's own host thread (here: a batch with a byte that is no nt6 code, found by the
+    rank that holds rope $) is reported through rb2_hip_set_fatal_handler on the thread that called the API, after the rank threads are joined"""
+    import sys
+    root = os.path.dirname(HERE)
+    code = ("import sys, os, threading, ctypes as C; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from ropebwt2_amd.hipbwt import load_hip_lib\n"
+            "L = load_hip_lib()\n"
+            "CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p)\n"
+            "main = threading.get_ident()\n"
+            "def h(user, msg):\n"
+            "    sys.stdout.write('handler on %%s thread: ' %% ('the calling' if threading.get_ident() == main else 'another') + msg.decode()); sys.stdout.flush(); os._exit(7)\n"
+            "cb = CB(h)\n"
+            "L.rb2_hip_set_fatal_handler(cb, None)\n"
+            "dev = (C.c_int * 4)(0, 0, 0, 0)\n"
+            "L.rb2_hip_multi_create.restype = C.c_void_p\n"
+            "m = L.rb2_hip_multi_create(4, dev, 0, 0, None)\n"
+            "s = np.array([1, 2, 9, 4, 0, 3, 3, 0], np.uint8)\n"
+            "L.rb2_hip_multi_insert_multi(C.c_void_p(m), C.c_int64(len(s)), s.ctypes.data_as(C.c_void_p))\n") % root
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 7, (p.returncode, p.stderr.decode()[-400:])
+    assert b"handler on the calling thread: [rb2_hip] the batch contains bytes that are not nt6 codes" in p.stdout, p.stdout

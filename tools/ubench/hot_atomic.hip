@@ -57,11 +57,10 @@ int main()
 			printf(" | %u counter(s) %.1f us", c, timeit([&] { hipLaunchKernelGGL(k_app<1>, dim3(nb), dim3(256), 0, 0, cnt, c, out, 1u); }));
 		printf("\n");
 	}
-	return 0;
 	// dependent gathers: tables of 4 M .. 512 M words (16 MB .. 2 GB), from hipMalloc and from hipMemCreate + hipMemMap (how the engine's
-	// pools are mapped); entries point at random 32-byte-aligned words, groups of 8 lanes share one
+	// pools are mapped); entries point at random lines: 64 line requests per wave and level (20 us per level and million = 50 G lines/s)
 	const uint32_t n = 1u << 20;
-	printf("1 M threads, dependent random 4-byte reads (8 neighbouring lanes share a 32-byte chunk): us per level = (depth 3 - depth 1) / 2\n");
+	printf("1 M threads, dependent random 4-byte reads (every lane a random line of its own): us per level = (depth 3 - depth 1) / 2\n");
 	for (int vmm = 0; vmm < 2; ++vmm) for (uint32_t lg : {22u, 26u, 29u}) {
 		const uint32_t nw = 1u << lg, mask = nw - 1;
 		std::vector<uint32_t> h(nw);
