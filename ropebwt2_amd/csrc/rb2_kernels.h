@@ -271,14 +271,23 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], tile, t)) return;
 	const int ln = lane_id(), w = wave_id();
+	// all loads of the thread's two strings first: A is a byte array (it may alias anything as far as the compiler knows), so a load
+	// written behind the store of the first string's flag would wait for it
+	uint32_t av[2]; P uv[2], up[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		av[h] = 7; uv[h] = 0; up[h] = 0;
+		if (k < t.segend) { av[h] = A[k]; uv[h] = U[k]; up[h] = k > t.segstart ? U[k - 1] : (P)0; }
+	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int pos = h * 256 + threadIdx.x;
 		const uint64_t k = t.base + pos;
 		int sym = 7; bool head = false;
 		if (k < t.segend) {
-			sym = A[k] & 7;
-			head = (k == t.segstart) || (U[k] != U[k-1]);
+			sym = (int)(av[h] & 7);
+			head = (k == t.segstart) || (uv[h] != up[h]);
 			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
 		}
 		const int c = h * 4 + w;
