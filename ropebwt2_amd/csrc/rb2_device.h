@@ -134,6 +134,9 @@ struct Ctl {
 	// k_merge_leaf works on one list.  wcnt[c * WLS] = entries of list c.
 	uint32_t wcnt[16 * 32];
 };
+constexpr int GCN = NR * 6 + 2;         // words of the per-round count matrix buffers: NR x 6 counts + [NR * 6] = "some string of this rank has a non-empty
+                                        // interval this round" (summed over the ranks of a sharded index like the counts: zero = every rank may launch the
+                                        // all-empty kernel variants only, from this round on) + one word of padding
 constexpr int WLC = 16;                 // work lists of a sparse round
 constexpr int WLS = 32;                 // their counters sit 128 bytes apart
 

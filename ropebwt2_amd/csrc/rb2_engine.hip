@@ -478,8 +478,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
-	  hipLaunchKernelGGL(k_tfix, dim3(cdiv(B.nst_ub, 256)), dim3(256), 0, st, h->ctl, sd, trs, h->tsc.p, h->tfix.p);
-	  hipLaunchKernelGGL(k_counts_local, dim3(1), dim3(256), 0, st, h->ctl, sd, h->tsc.p, h->gcnt); }
+	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt); }
 }
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
@@ -803,7 +802,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void**)&h->ctl, sizeof(Ctl)));
 	HIPCHK(hipMalloc((void**)&h->d_tmp, 256));
-	HIPCHK(hipMalloc((void**)&h->gcnt, NR * 6 * 8));
+	HIPCHK(hipMalloc((void**)&h->gcnt, GCN * 8));
 	HIPCHK(hipHostMalloc((void**)&h->h_flag, 64 + 8 * rb2_hip_s::NE_RING, hipHostMallocDefault));
 	memset(h->h_flag, 0, 64 + 8 * rb2_hip_s::NE_RING);
 	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));

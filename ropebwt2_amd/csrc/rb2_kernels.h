@@ -6,7 +6,7 @@
 //
 //   k_sym      next symbol of every active string + group heads (mrope.c:189-192)
 //   k_tscan*   prefix of the per-tile symbol histograms, nearest group head left/right of a tile
-//   k_tfix     the same, folded into one record per tile for k_prep / k_advance
+//   k_tfix     the same, folded into one record per tile for k_prep / k_advance; + the rows of the count matrix seen here
 //   k_setup    NR x 6 count matrix -> new sub-rope sizes, AC offsets (mrope.c:332-336), next buckets
 //   k_prep     per string: pre-round position of its new symbol, slot in the sorted insert list,
 //              interval sizes via rank on non-empty intervals (mrope.c:199-224)
@@ -420,24 +420,21 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // k_setup: everything the rest of the round needs that depends on the NR x 6 count matrix
 // ---------------------------------------------------------------------------------------------
 
-// rows of the count matrix this rank can see: count[r][a] = members of (local) bucket r inserting a
-__global__ void k_counts_local(const Ctl *ctl, int side, const TileScan *tsc, uint64_t *gcnt)
-{
-	const int i = threadIdx.x;
-	if (blockIdx.x || i >= NR * 6) return;
-	const SegDesc &sg = ctl->seg[side];
-	const int b = i / 6, a = i % 6;
-	gcnt[i] = sg.tile0[NR] ? (uint64_t)(tsc[sg.tile0[b+1]].pre[a] - tsc[sg.tile0[b]].pre[a]) : 0ull;
-}
-
 // one thread per string tile: fold the tile scans into the numbers group_setup needs, so that k_prep and
 // k_advance read one 76-byte record per block instead of chasing tsc[lt] / trec[lt] / tsc[nt] / trec[nt]
-__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, const TileRecs trec, const TileScan *tsc, TileFix *tf)
+// Block 0 also writes the rows of the count matrix this rank can see -- gcnt[r * 6 + a] = members of (local) bucket r inserting a --
+// and word NR * 6 of the buffer (GCN, rb2_device.h): a launch of its own before.
+__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, int par, const TileRecs trec, const TileScan *tsc, TileFix *tf, uint64_t *gcnt)
 {
 	__shared__ uint32_t s_t0[NR + 1];
 	const SegDesc &sg = ctl->seg[side];
 	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
 	__syncthreads();
+	if (blockIdx.x == 0) {
+		const int i = threadIdx.x;
+		if (i < NR * 6) { const int b = i / 6, a = i % 6; gcnt[i] = s_t0[NR] ? (uint64_t)(tsc[s_t0[b + 1]].pre[a] - tsc[s_t0[b]].pre[a]) : 0ull; }
+		if (i == NR * 6) gcnt[NR * 6] = ctl->ne[par];
+	}
 	const uint32_t tile = blockIdx.x * 256 + threadIdx.x;
 	if (tile >= s_t0[NR]) return;
 	int b = 0;
@@ -666,6 +663,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 		const uint64_t v = nt ? (uint64_t)(s_pre[a][s_t0[b + 1]] - s_pre[a][s_t0[b]]) : 0ull;
 		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
 	}
+	if (threadIdx.x == NR * 6) gcnt[NR * 6] = ctl->ne[par];     // (GCN, rb2_device.h)
 	__syncthreads();
 	if (do_setup && wv == 0) setup_body<SPARSE>(ctl, side, s_g, par, round, hmax);
 }

@@ -91,7 +91,7 @@ __host__ __device__ inline MPlan mplan_entry(const uint64_t *g, const uint8_t *o
 // for (profiles/r04d_vranks8_one_gpu.txt: 8 ranks on one device keep it busy 40 % of the time).
 // npeer == 0: g_inout already holds the sum (RCCL: ncclAllReduce in place).
 template <bool SPARSE> __global__ __launch_bounds__(256) void k_mround(Ctl *ctl, MPtrs rows, int npeer, uint64_t *g_inout, MOwner ow, int me, int peer, MPtrs srcs, const ShardRec *recv, MTab *tab,
-		int side, int par, uint32_t round, volatile unsigned long long *hmax)
+		int side, int par, uint32_t round, volatile unsigned long long *hmax, volatile unsigned long long *hne)
 {
 	__shared__ uint64_t g[NR * 6];
 	__shared__ unsigned long long s_tot;
@@ -103,6 +103,12 @@ template <bool SPARSE> __global__ __launch_bounds__(256) void k_mround(Ctl *ctl,
 		g[i] = v;
 	}
 	if (threadIdx.x == 0) { s_tot = 0; s_np = 0; }
+	if (threadIdx.x == 255) {                                   // does ANY rank hold a string with a non-empty interval this round?  (word NR * 6 of the rows, GCN)
+		uint64_t v = 0;
+		if (npeer) { for (int p = 0; p < npeer; ++p) v += ((const uint64_t*)rows.p[p])[NR * 6]; g_inout[NR * 6] = v; }
+		else v = g_inout[NR * 6];
+		*hne = (unsigned long long)round << 32 | (v != 0 ? 1ull : 0ull);   // pinned host memory: the host reads it when it gets there, no synchronisation
+	}
 	__syncthreads();
 	const int t = threadIdx.x;
 	if (t < NR * 5) {
@@ -225,7 +231,7 @@ struct MRank {
 	uint64_t *gloc = nullptr;               // = h->gcnt as created
 	MTab *tab = nullptr;
 	hipEvent_t evA = nullptr, evB = nullptr, evG = nullptr;
-	uint64_t *pin_g = nullptr;              // RCCL: 2 x (NR * 6) pinned, the reduced matrix of the round (host sizes the sends from it)
+	uint64_t *pin_g = nullptr;              // RCCL: 2 x GCN pinned, the reduced matrix of the round (host sizes the sends from it)
 	ncclComm_t comm = nullptr;
 	DevBuf<uint8_t> text;                   // the batch on this rank's device (host-buffer entry point)
 	const uint8_t *s_dev = nullptr;
@@ -283,7 +289,15 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	memset(&rows, 0, sizeof(rows)); memset(sends, 0, sizeof(sends));
 	if (peer) for (int p = 0; p < m->n; ++p) { rows.p[p] = m->rk[p].gloc; sends[0].p[p] = m->rk[p].send[0]; sends[1].p[p] = m->rk[p].send[1]; }
 	const unsigned grid_m = cdiv(rank_share(h, B.m), 256);
+	((volatile unsigned long long*)(h->h_flag + 8))[0] = ~0ull;   // nothing reported yet
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                 // one round per string position (mrope.c:299-342)
+		// Once NO rank holds a string with a non-empty interval none ever will again: k_mround reports the sum of the ranks' flags of
+		// every round to pinned memory; a report that has landed and reads zero lets this rank launch only the all-empty variants of
+		// k_prep / k_advance from here on (before: both variants every round of every batch on a loaded index, one returning at once)
+		if (!B.known_ae) {
+			const unsigned long long v = ((volatile unsigned long long*)(h->h_flag + 8))[0];
+			if (v != ~0ull && (v & 1ull) == 0 && (v >> 32) < r) B.known_ae = true;
+		}
 		h->gcnt = R.gloc;
 		round_counts(h, B, r);
 		// the layout of the round (a host decision; a change re-lays the slice out on this stream before anything of the round reads it)
@@ -294,15 +308,16 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			for (int p = 0; p < m->n; ++p) if (p != k) HIPCHK(hipStreamWaitEvent(st, m->rk[p].evA, 0));
 			h->gcnt = R.gred;
 		} else {
-			if (R.comm) NCCLCHK(rccl().AllReduce(h->gcnt, h->gcnt, NR * 6, ncclUint64, ncclSum, R.comm, st));
-			HIPCHK(hipMemcpyAsync(R.pin_g + (r & 1) * NR * 6, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, st));
+			if (R.comm) NCCLCHK(rccl().AllReduce(h->gcnt, h->gcnt, NR * 6 + 1, ncclUint64, ncclSum, R.comm, st));
+			HIPCHK(hipMemcpyAsync(R.pin_g + (r & 1) * GCN, h->gcnt, NR * 6 * 8, hipMemcpyDeviceToHost, st));
 			HIPCHK(hipEventRecord(R.evG, st));
 		}
 		// sum of the count rows (PEER) + exchange plan + k_setup of the round: one launch (k_mround)
 		{
 			volatile unsigned long long *hmax = h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr;
-			if (h->sparse) hipLaunchKernelGGL(k_mround<true>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax);
-			else hipLaunchKernelGGL(k_mround<false>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax);
+			volatile unsigned long long *hne = (volatile unsigned long long*)(h->d_flag + 8);   // (round, any non-empty interval on any rank) as k_mround last saw it
+			if (h->sparse) hipLaunchKernelGGL(k_mround<true>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax, hne);
+			else hipLaunchKernelGGL(k_mround<false>, dim3(1), dim3(256), 0, st, h->ctl, rows, peer ? m->n : 0, h->gcnt, ow, R.grank, (int)peer, sends[r & 1], (const ShardRec*)R.recv, R.tab, h->side, (int)(r & 1), (uint32_t)r, hmax, hne);
 			B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch;
 		}
 		// dense round: the slice is rewritten pool -> pool; in-place round: only the touched leaves, and the host reads a one-word
@@ -317,7 +332,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			// drain the stream -- the host sizes the sends while the GPU merges
 			HIPCHK(hipEventSynchronize(R.evG));
 			if (k == 0) ++m->n_sync;
-			const int64_t *g = (const int64_t*)(R.pin_g + (r & 1) * NR * 6);
+			const int64_t *g = (const int64_t*)(R.pin_g + (r & 1) * GCN);
 			int64_t off[NR][6], per[RB2_MULTI_MAX_RANKS], start[RB2_MULTI_MAX_RANKS];
 			memset(off, 0, sizeof(off));
 			shard_layout(m->owner, m->world, R.grank, g, off, per, start);
@@ -376,13 +391,13 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 		engine_set_shard(R.h, R.grank, world, m->owner);
 		HIPCHK(hipSetDevice(R.dev));
 		R.gloc = R.h->gcnt;
-		HIPCHK(hipMalloc((void**)&R.gred, NR * 6 * 8));
+		HIPCHK(hipMalloc((void**)&R.gred, GCN * 8));
 		HIPCHK(hipMalloc((void**)&R.tab, sizeof(MTab)));
 		HIPCHK(hipMemset(R.tab, 0, sizeof(MTab)));
 		HIPCHK(hipEventCreateWithFlags(&R.evA, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&R.evB, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&R.evG, hipEventDisableTiming));
-		HIPCHK(hipHostMalloc((void**)&R.pin_g, 2 * NR * 6 * 8, hipHostMallocDefault));
+		HIPCHK(hipHostMalloc((void**)&R.pin_g, 2 * GCN * 8, hipHostMallocDefault));
 	}
 	if (transport == RB2_TRANSPORT_PEER) {
 		// the receiver's kernels read the senders' memory: every pair of distinct devices needs peer access
