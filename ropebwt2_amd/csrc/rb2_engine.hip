@@ -303,9 +303,9 @@ void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays 
 	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
 	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
 	if (!leaves_done) RB2_LAUNCH_STRIDE(h, k_meta_sb<true>, k_meta_sb<false>, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
-	hipLaunchKernelGGL(k_sbscan1, dim3(nchunk), dim3(SCHUNK / SBT), 0, h->st, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv.sbbase);
-	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SB2T), 0, h->st, (const Ctl*)h->ctl, pv.sbbase);
+	// in-chunk prefixes (SbRec) + chunk totals in one pass over the totals, then the chunk bases (the in-chunk prefixes need no base: queries add it)
 	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK / SBT), 0, h->st, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv);
+	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SB2T), 0, h->st, (const Ctl*)h->ctl, pv.sbbase);
 }
 
 void fetch_ropes(rb2_hip_t *h)
@@ -478,7 +478,10 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
 	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
-	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt); }
+	  const int do_setup = h->nranks == 1;                     // one GPU: k_setup of the round rides on block 0 of k_tfix (the local count matrix is the global one)
+	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt, do_setup, (int)h->sparse, (uint32_t)r,
+	                     h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; } }
 }
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.

@@ -423,17 +423,25 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // one thread per string tile: fold the tile scans into the numbers group_setup needs, so that k_prep and
 // k_advance read one 76-byte record per block instead of chasing tsc[lt] / trec[lt] / tsc[nt] / trec[nt]
 // Block 0 also writes the rows of the count matrix this rank can see -- gcnt[r * 6 + a] = members of (local) bucket r inserting a --
-// and word NR * 6 of the buffer (GCN, rb2_device.h): a launch of its own before.
-__global__ __launch_bounds__(256) void k_tfix(const Ctl *ctl, int side, int par, const TileRecs trec, const TileScan *tsc, TileFix *tf, uint64_t *gcnt)
+// and word NR * 6 of the buffer (GCN, rb2_device.h), and, on one GPU (do_setup), runs k_setup of the round on its first wave: the local
+// matrix IS the global one.  (Two launches of their own before; nothing k_setup writes is read by the other blocks of this kernel.)
+template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax);
+__global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const TileRecs trec, const TileScan *tsc, TileFix *tf, uint64_t *gcnt, int do_setup, int sparse,
+		uint32_t round, volatile unsigned long long *hmax)
 {
 	__shared__ uint32_t s_t0[NR + 1];
+	__shared__ uint64_t s_g[NR * 6];
 	const SegDesc &sg = ctl->seg[side];
 	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
 	__syncthreads();
 	if (blockIdx.x == 0) {
 		const int i = threadIdx.x;
-		if (i < NR * 6) { const int b = i / 6, a = i % 6; gcnt[i] = s_t0[NR] ? (uint64_t)(tsc[s_t0[b + 1]].pre[a] - tsc[s_t0[b]].pre[a]) : 0ull; }
+		if (i < NR * 6) { const int b = i / 6, a = i % 6; const uint64_t v = s_t0[NR] ? (uint64_t)(tsc[s_t0[b + 1]].pre[a] - tsc[s_t0[b]].pre[a]) : 0ull; gcnt[i] = v; s_g[i] = v; }
 		if (i == NR * 6) gcnt[NR * 6] = ctl->ne[par];
+		if (do_setup) {                                          // (block-uniform)
+			__syncthreads();
+			if (i < 64) { if (sparse) setup_body<true>(ctl, side, s_g, par, round, hmax); else setup_body<false>(ctl, side, s_g, par, round, hmax); }
+		}
 	}
 	const uint32_t tile = blockIdx.x * 256 + threadIdx.x;
 	if (tile >= s_t0[NR]) return;
@@ -1340,30 +1348,12 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_meta_sb(const Ct
 	}
 }
 
-// the three-kernel prefix over the superblock totals.  A total is six 16-bit counts (<= SB * LEAF = 32768 each) in 16 bytes; inside
+// the two-kernel prefix over the superblock totals (k_sbscan3: prefixes inside every chunk + the chunk totals; k_sbscan2: the chunk bases).  A total is six 16-bit counts (<= SB * LEAF = 32768 each) in 16 bytes; inside
 // a chunk of 1024 superblocks sums stay below 2^25, so the chunk-level work is 32-bit DPP scans with one LDS exchange and what is
 // stored per superblock is a 32-byte record of 32-bit prefixes (SbRec); only the chunk bases (SbBase) are 64 bit.
 // (blocks of 256 threads, four consecutive superblocks per thread -- 64 bytes in flight per lane: with 1024-thread blocks of one
 // superblock per thread the two streaming kernels ran at half the rate, each block waiting out its one round trip to memory)
-constexpr int SBT = 4;                      // superblocks per thread in k_sbscan1 / k_sbscan3
-__global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan1(const Ctl *ctl, const SbTot *sbtot, SbBase *base)
-{
-	__shared__ uint32_t s_p[6][4];
-	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SBT;
-	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
-	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint32_t v[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-	for (int k = 0; k < SBT; ++k) {
-		SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
-		if (i0 + k < n) t = sbtot[i0 + k];
-		v[0] += t.p01 & 0xffffu; v[1] += t.p01 >> 16; v[2] += t.p23 & 0xffffu; v[3] += t.p23 >> 16; v[4] += t.p45 & 0xffffu; v[5] += t.p45 >> 16;
-	}
-#pragma unroll
-	for (int s = 0; s < 6; ++s) { const uint32_t w = lane63(dpp_incl_add(v[s])); if (ln == 0) s_p[s][wv] = w; }
-	__syncthreads();
-	if (threadIdx.x < 6) base[blockIdx.x].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
-}
+constexpr int SBT = 4;                      // superblocks per thread in k_sbscan3
 // exclusive prefix over the chunk totals, in place (one block): a thread takes eight consecutive chunks, the wave and block levels are
 // shuffles and one LDS exchange -- one pass for up to 8192 chunks (270 G symbols); more: with a running total
 constexpr int SB2T = 512;                   // threads of k_sbscan2 (its one block)
@@ -1435,6 +1425,8 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 		for (int w = 0; w < 3; ++w) if (w < wv) off += s_p[s][w];
 		b0[s] = off + inc[s] - tot[s];
 	}
+	// the chunk's totals, for k_sbscan2 behind this kernel (a kernel of its own read every total a second time for them)
+	if (threadIdx.x < 6) newp.sbbase[blockIdx.x].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
 #pragma unroll
 	for (int k = 0; k < SBT; ++k) if (i0 + k < n) {             // one 32-byte record per superblock: 128 contiguous bytes per lane
 		uint32_t o[6];
