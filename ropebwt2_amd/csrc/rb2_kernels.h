@@ -613,8 +613,20 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	}
 	__syncthreads();
 	const uint32_t nt = s_t0[NR];
+	if (threadIdx.x < NR * 6) {                                 // the rows of the count matrix seen here (k_tfix's block 0 in the many-tiles path)
+		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
+		const uint64_t v = nt ? (uint64_t)(s_pre[a][s_t0[b + 1]] - s_pre[a][s_t0[b]]) : 0ull;
+		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
+	}
+	if (threadIdx.x == NR * 6) gcnt[NR * 6] = ctl->ne[par];     // (GCN, rb2_device.h)
+	__syncthreads();
+	// k_setup of the round (one GPU) runs on the LAST wave while the others write the tile records: it needs the count matrix only,
+	// and its ten 64-bit wave scans in a row were 4 us at the end of the kernel with fifteen waves waiting
+	constexpr int NWV = SCHUNK / 64;
+	const int tw = do_setup ? NWV - 1 : NWV;                    // waves that write tile records
+	if (do_setup && wv == NWV - 1) { setup_body<SPARSE>(ctl, side, s_g, par, round, hmax); return; }
 	uint32_t *so = s_out[wv];
-	for (uint32_t tb = (uint32_t)wv * 64; tb < nt; tb += SCHUNK) {   // k_tfix: a wave takes 64 consecutive tiles
+	for (uint32_t tb = (uint32_t)wv * 64; tb < nt; tb += (uint32_t)tw * 64) {   // k_tfix: a wave takes 64 consecutive tiles
 		const uint32_t tile = tb + (uint32_t)ln;
 		const bool live = tile < nt;
 		uint32_t f[TFW];
@@ -666,14 +678,6 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 		}
 	}
-	if (threadIdx.x < NR * 6) {                                 // k_counts_local
-		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
-		const uint64_t v = nt ? (uint64_t)(s_pre[a][s_t0[b + 1]] - s_pre[a][s_t0[b]]) : 0ull;
-		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
-	}
-	if (threadIdx.x == NR * 6) gcnt[NR * 6] = ctl->ne[par];     // (GCN, rb2_device.h)
-	__syncthreads();
-	if (do_setup && wv == 0) setup_body<SPARSE>(ctl, side, s_g, par, round, hmax);
 }
 
 // ---------------------------------------------------------------------------------------------
