@@ -457,7 +457,8 @@ void maybe_widen(rb2_hip_t *h, BatchState &B, uint64_t r)
 
 // phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
 // spec: queued while the verdict of the in-place round in front of it is still on its way (round_merge_sparse)
-void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
+// with_split: the k_sym launch also does the leaf splits of the in-place round in front of it and the verdict event follows it (round_merge_sparse)
+void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bool with_split = false)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur;
@@ -466,7 +467,15 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false)
 	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
 	{ Scope sc(h, RB2_K_SYM, units);
 	  with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
-	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs); }); }
+	    SplitArgs sp; memset(&sp, 0, sizeof(sp));
+	    if (with_split) {
+	      constexpr unsigned NSPLITB = 64;
+	      sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
+	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
+	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp);
+	    } else
+	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp); }); }
+	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
 	if (B.nst_ub < (unsigned)TS_MAX) {                         // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
@@ -609,7 +618,10 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
 	});
-	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h)
+	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h) --
+	// or, when the counting phase of round r + 1 is queued at once (spec), blocks of their own in its first launch (k_sym<.., SPLIT>)
+	const bool sp = spec && r + 1 <= B.max_len;
+	if (!sp)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
 	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag); }
 	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
@@ -618,10 +630,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	// the next merge.
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(h->ev_flag, st));                    // (k_split left the verdict in pinned memory)
+	if (!sp) HIPCHK(hipEventRecord(h->ev_flag, st));           // (k_split left the verdict in pinned memory)
 	h->side ^= 1; B.cur ^= 1;
-	const bool sp = spec && r + 1 <= B.max_len;
-	if (sp) round_counts(h, B, r + 1, true);
+	if (sp) round_counts(h, B, r + 1, true, true);             // (records the event behind its first launch)
 	HIPCHK(hipEventSynchronize(h->ev_flag));
 	if (h->h_flag[0]) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
 	if (h->h_flag[1]) h->want_respread = true;

@@ -261,10 +261,20 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // tiles when the rank holds more -- an upper-bound grid of N times the work would cost more in empty workgroups than the work itself.
 // STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
 // with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const P *L, const P *UU,
-		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec)
+// SPLIT: the launch that follows an in-place round on one GPU also does that round's leaf splits (k_split), in nsplitb blocks of its own
+// behind the tile blocks: k_sym reads string arrays only, the splits touch the pool only -- one launch instead of two, the two running
+// side by side; the verdict of the round reaches the host behind this launch.
+struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb; };
+__device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
+		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB]);
+template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const P *L, const P *UU,
+		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec, SplitArgs sp)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
+	if (SPLIT) {
+		__shared__ uint16_t s_row[MW][7][SB];
+		if (blockIdx.x >= gridDim.x - sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x - (gridDim.x - sp.nsplitb), sp.nsplitb, s_row); return; }
+	}
 	const P *U = ctl->ne[par] == 0 ? L : UU;
 	for (uint32_t tile = blockIdx.x; ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
 	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with
@@ -1207,15 +1217,16 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 // ---------------------------------------------------------------------------------------------
 // The verdict of the round -- hv[0]: void round, hv[1]: a superblock ran out of slots -- goes straight into pinned host memory (the host
 // zeroes both words before it queues the round): no copy command behind the last kernel.
-__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */, volatile uint32_t *hv)
+// (the body: k_split proper, and the last blocks of the k_sym launch that follows an in-place round -- k_sym<.., SPLIT> -- run it: bidx of nblk)
+__device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */, volatile uint32_t *hv,
+		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB])
 {
-	__shared__ uint16_t s_row[MW][7][SB];
-	if (ctl->overflow) { if (blockIdx.x == 0 && threadIdx.x == 0) hv[0] = 1; return; }   // void round: nothing was inserted
+	if (ctl->overflow) { if (bidx == 0 && threadIdx.x == 0) hv[0] = 1; return; }   // void round: nothing was inserted
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
 	const uint32_t nsp_all = min(ctl->nsplit, spl_cap);
-	if (ctl->nsplit > spl_cap && blockIdx.x == 0 && threadIdx.x == 0) { ctl->sbfull = 1; hv[1] = 1; }   // list overflow (never in practice): re-spread
-	for (uint32_t e = blockIdx.x * MW + wv; e < nsp_all; e += gridDim.x * MW) {
+	if (ctl->nsplit > spl_cap && bidx == 0 && threadIdx.x == 0) { ctl->sbfull = 1; hv[1] = 1; }   // list overflow (never in practice): re-spread
+	for (uint32_t e = bidx * MW + wv; e < nsp_all; e += nblk * MW) {
 		const uint64_t gl = SPL[e], sb = gl / SB;
 		uint32_t mine = 0;
 		if (ln == 0) mine = atomicExch((uint32_t*)dir_row(pool, sb, 7), epoch) != epoch;
@@ -1289,6 +1300,11 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // R is reused by the wave's next entry
 	}
+}
+__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv)
+{
+	__shared__ uint16_t s_row[MW][7][SB];
+	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, gridDim.x, s_row);
 }
 
 } // namespace rb2
