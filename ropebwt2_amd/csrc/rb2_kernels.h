@@ -262,7 +262,7 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // STRIDE = false is the one-GPU kernel, one tile per block and no loop (the loop costs registers: k_advance 87 -> 112 VGPRs, k_prep
 // with interval counts 121 -> 254); the host launches STRIDE = true only on a rank of a sharded index.
 // SPLIT: the launch that follows an in-place round on one GPU also does that round's leaf splits (k_split), in nsplitb blocks of its own
-// behind the tile blocks: k_sym reads string arrays only, the splits touch the pool only -- one launch instead of two, the two running
+// in front of the tile blocks: k_sym reads string arrays only, the splits touch the pool only -- one launch instead of two, the two running
 // side by side; the verdict of the round reaches the host behind this launch.
 struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb; };
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
@@ -273,11 +273,13 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	if (SPLIT) {
 		__shared__ uint16_t s_row[MW][7][SB];
-		if (blockIdx.x >= gridDim.x - sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x - (gridDim.x - sp.nsplitb), sp.nsplitb, s_row); return; }
+		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
+		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
+		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row); return; }
 	}
 	const P *U = ctl->ne[par] == 0 ? L : UU;
-	for (uint32_t tile = blockIdx.x; ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
-	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with
+	for (uint32_t tile = blockIdx.x - (SPLIT ? sp.nsplitb : 0u); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
+	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with (STRIDE and SPLIT never come together)
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], tile, t)) return;
 	const int ln = lane_id(), w = wave_id();
