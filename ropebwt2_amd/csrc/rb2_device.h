@@ -359,8 +359,7 @@ __device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, 
 		}
 	};
 #pragma unroll
-	for (int i = 0; i < SP_USED / 8; ++i) add8(i);
-	if (k > (uint32_t)SP_USED) add8(SP_USED / 8);               // reserve slots: only for a leaf that sits in one
+	for (int i = 0; i <= SP_USED / 8; ++i) if (k > (uint32_t)(8 * i)) add8(i);   // only the 16-byte pieces in front of slot k (all in one 64-byte line)
 	return (acc & 0xffffu) + (acc >> 16);
 }
 
