@@ -557,7 +557,7 @@ template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, i
 
 // ---------------------------------------------------------------------------------------------
 // k_tscan_setup: the whole counting tail of a round with few string tiles (long reads: 10^4 rounds of 10^3 tiles) in ONE single-block
-// launch -- k_tscan1-3 + k_tfix + k_counts_local + k_setup.  Same results, same formulas; what differs is where the numbers live: the
+// launch -- k_tscan1-3 + k_tfix (with the count matrix) + k_setup.  Same results, same formulas; what differs is where the numbers live: the
 // exclusive prefixes of the six histogram columns stay in LDS (96 KB for 4096 tiles), the "nearest head-bearing tile" on either
 // side comes from a bitmap of the tiles that have a head (highest set bit below / lowest above), and the count matrix reaches
 // k_setup's wave through LDS.  Global memory is read twice in a row (the tile records; the records of the neighbouring head tiles)
