@@ -210,6 +210,11 @@ void rb2_hip_multi_rank1a(rb2_hip_multi_t *m, int b, int64_t x, int64_t cx[6]);
  * one-word verdict before its exchange; RCCL: one event wait per round, behind the reduce only), out[1] rounds, out[2] batches,
  * out[3] in-place (sparse) rounds summed over the ranks, out[4] void sparse rounds, out[5] re-layouts */
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6]);
+/* bytes of device memory local rank k holds for the text of the last batch given to rb2_hip_multi_insert_multi (host buffer): with
+ * ranks on several devices of one process (PEER) the text is ONE copy, shared piece by piece between the devices' memories and
+ * mapped for all of them -- about len / n per rank, each rank uploads its own share --, otherwise a copy of the whole batch per
+ * device, held by the first rank on it (0 for the others); -1: no such rank.  RB2_MULTI_TEXT=shard / =copy forces either. */
+int64_t rb2_hip_multi_text_bytes(const rb2_hip_multi_t *m, int k);
 uint64_t rb2_hip_multi_rope_hash(rb2_hip_multi_t *m, int b);
 /* the device-side exchange plan (k_mround) evaluated on the host, for tests: see csrc/rb2_multi.h */
 int rb2_hip_multi_plan_host(const int *owner /* [NR] */, int nranks, const int64_t *g /* [NR*6] */, int me, int64_t *sdest /* [NR*6] */, int64_t (*pieces)[5] /* [NR*6] */, int64_t *total);   /* == rb2_hip_rope_hash of the same rope on one engine */

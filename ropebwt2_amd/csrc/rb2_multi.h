@@ -240,7 +240,27 @@ struct MRank {
 
 } // namespace
 
+// The batch text of a host-buffer insert, ONE copy for all local ranks: a reserved address range with the text in it, piece by piece in
+// the memory of the ranks' devices (rank k's device holds the k-th share of the pieces) and mapped for every device of the handle -- each
+// rank uploads its own share (1 / n of the batch over its own PCIe link), every kernel of every rank sees the same linear text, and
+// what a rank reads outside its share (the cursor refills: 16 bytes per string every nine rounds; the batch set-up on the rank that holds
+// rope $) travels over xGMI.  Used when the ranks sit on more than one physical device (RB2_MULTI_TEXT=shard forces it on one device:
+// the tests; =copy switches it off); any failing call means one copy of the whole text per device, as before.
+struct ShardedText {
+	void *base = nullptr; size_t range = 0, piece = 0, mapped = 0;
+	std::vector<hipMemGenericAllocationHandle_t> h;
+	std::vector<int> owner;                                     // local rank that holds piece i
+	std::vector<int64_t> bytes;                                 // per local rank: bytes of text memory it holds
+	void release()
+	{
+		for (size_t i = 0; i < h.size(); ++i) { (void)hipMemUnmap((char*)base + i * piece, piece); (void)hipMemRelease(h[i]); }
+		if (base) (void)hipMemAddressFree(base, range);
+		h.clear(); owner.clear(); base = nullptr; range = mapped = piece = 0;
+	}
+};
+
 struct rb2_hip_multi_s {
+	ShardedText stext;
 	int n = 0, world = 0, rank0 = 0, transport = 0, so = 0;
 	int owner[NR];
 	std::vector<MRank> rk;
@@ -424,6 +444,69 @@ template <class F> void multi_each(rb2_hip_multi_t *m, F f)
 
 } // namespace
 
+namespace {
+
+// see ShardedText.  true: every rank's s_dev names the shared range and the text is in it.
+bool multi_text_sharded(rb2_hip_multi_t *m, int64_t len, const uint8_t *s)
+{
+	ShardedText &T = m->stext;
+	T.bytes.assign(m->n, 0);
+	const char *e = getenv("RB2_MULTI_TEXT");
+	if (e && !strcmp(e, "copy")) return false;
+	int distinct = 0;
+	std::vector<int> devs;
+	for (int k = 0; k < m->n; ++k) { bool seen = false; for (int d : devs) seen |= d == m->rk[k].dev; if (!seen) { devs.push_back(m->rk[k].dev); ++distinct; } }
+	if (m->n < 2 || m->transport != RB2_TRANSPORT_PEER || !vmm_enabled()) return false;
+	if (distinct < 2 && !(e && !strcmp(e, "shard"))) return false;
+	// pieces of one size, a power of two (mixed or odd sizes made hipMemSetAccess fail on this stack: DevBuf::vm_grow), about a rank's share
+	const size_t need = (size_t)len + 64;
+	size_t piece = 64ull << 20;
+	while (piece < (2ull << 30) && piece * (size_t)m->n < need) piece <<= 1;
+	const size_t npieces = (need + piece - 1) / piece;
+	if (T.base && (T.piece != piece || npieces * piece > T.range)) { for (auto &R : m->rk) { HIPCHK(hipSetDevice(R.dev)); HIPCHK(hipStreamSynchronize(R.h->st)); } T.release(); }
+	if (!T.base) {
+		const size_t range = std::max<size_t>(npieces * piece, 4 * piece);
+		void *base = nullptr;
+		if (hipMemAddressReserve(&base, range, piece, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+		T.base = base; T.range = range; T.piece = piece;
+	}
+	std::vector<hipMemAccessDesc> acc(devs.size());
+	for (size_t i = 0; i < devs.size(); ++i) { acc[i] = hipMemAccessDesc(); acc[i].location.type = hipMemLocationTypeDevice; acc[i].location.id = devs[i]; acc[i].flags = hipMemAccessFlagsProtReadWrite; }
+	while (T.h.size() < npieces) {                              // (pieces are kept from batch to batch; a batch needs at most as many as the largest before it, or more)
+		const size_t i = T.h.size();
+		const int k = (int)(i * (size_t)m->n / npieces);          // contiguous shares: rank k holds pieces [k * np / n, (k + 1) * np / n)
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = m->rk[k].dev;
+		hipMemGenericAllocationHandle_t hd;
+		bool ok = hipMemCreate(&hd, piece, &prop, 0) == hipSuccess;
+		if (ok && hipMemMap((char*)T.base + i * piece, piece, 0, hd, 0) != hipSuccess) { (void)hipMemRelease(hd); ok = false; }
+		if (ok && hipMemSetAccess((char*)T.base + i * piece, piece, acc.data(), acc.size()) != hipSuccess) { (void)hipMemUnmap((char*)T.base + i * piece, piece); (void)hipMemRelease(hd); ok = false; }
+		if (!ok) {
+			fprintf(stderr, "[rb2_hip] multi: the batch text cannot be shared between the devices (%s): every device gets a copy of its own\n", hipGetErrorString(hipGetLastError()));
+			(void)hipGetLastError();
+			T.release();
+			return false;
+		}
+		T.h.push_back(hd); T.owner.push_back(k);
+	}
+	// every rank uploads the pieces it holds, on its own stream; the kernels of the other ranks read them: all uploads are waited for
+	multi_each(m, [&](int k) {
+		MRank &R = m->rk[k];
+		HIPCHK(hipSetDevice(R.dev));
+		for (size_t i = 0; i < npieces; ++i) {
+			if (T.owner[i] != k) continue;
+			T.bytes[k] += (int64_t)piece;
+			const size_t o = i * piece, nb = std::min(piece, (size_t)len > o ? (size_t)len - o : 0);
+			if (nb) HIPCHK(hipMemcpyAsync((char*)T.base + o, s + o, nb, hipMemcpyHostToDevice, R.h->st));
+		}
+		HIPCHK(hipStreamSynchronize(R.h->st));
+	});
+	for (int k = 0; k < m->n; ++k) m->rk[k].s_dev = (const uint8_t*)T.base;
+	return true;
+}
+
+} // namespace
+
 extern "C" {
 
 /* piece -> rank.  On DNA the 16 pieces (b,x), b,x in ACGT, carry ~1/16 of the rows each; they are dealt out in contiguous
@@ -559,6 +642,7 @@ void rb2_hip_multi_destroy(rb2_hip_multi_t *m)
 		R.h->gcnt = R.gloc;
 		rb2_hip_destroy(R.h);
 	}
+	m->stext.release();
 	delete m;
 }
 
@@ -581,13 +665,16 @@ void rb2_hip_multi_insert_multi_dev(rb2_hip_multi_t *m, int64_t len, const uint8
 void rb2_hip_multi_insert_multi(rb2_hip_multi_t *m, int64_t len, const uint8_t *s)
 {
 	if (len <= 0 || s[len - 1] != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }   // mrope.c:268
+	if (multi_text_sharded(m, len, s)) { multi_run(m, len); return; }
 	// one copy of the batch text per DEVICE (every rank reads all of it: the cursor refills every 10 rounds), uploaded by the first rank on it
+	for (auto &b : m->stext.bytes) b = 0;
 	std::vector<const uint8_t*> ptr(m->n, nullptr);
 	multi_each(m, [&](int k) {
 		MRank &R = m->rk[k];
 		for (int p = 0; p < k; ++p) if (m->rk[p].dev == R.dev) return;
 		HIPCHK(hipSetDevice(R.dev));
 		R.text.ensure((size_t)len + 64);
+		if ((size_t)k < m->stext.bytes.size()) m->stext.bytes[k] = (int64_t)R.text.cap;
 		HIPCHK(hipMemcpyAsync(R.text.p, s, (size_t)len, hipMemcpyHostToDevice, R.h->st));
 		HIPCHK(hipStreamSynchronize(R.h->st));                  // ranks on other streams read it
 		ptr[k] = R.text.p;
@@ -689,6 +776,8 @@ int rb2_hip_multi_plan_host(const int *owner, int nranks, const int64_t *g, int 
 	}
 	return np;
 }
+
+int64_t rb2_hip_multi_text_bytes(const rb2_hip_multi_t *m, int k) { return (k >= 0 && (size_t)k < m->stext.bytes.size()) ? m->stext.bytes[k] : -1; }
 
 void rb2_hip_multi_stats(rb2_hip_multi_t *m, int64_t out[6])
 {

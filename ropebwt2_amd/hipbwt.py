@@ -83,6 +83,7 @@ def load_hip_lib():
         "rb2_hip_multi_sync": (None, [vp]),
         "rb2_hip_multi_rank1a": (None, [vp, i32, i64, vp]),
         "rb2_hip_multi_stats": (None, [vp, vp]),
+        "rb2_hip_multi_text_bytes": (i64, [vp, C.c_int]),
         "rb2_hip_multi_rope_hash": (u64, [vp, i32]),
         "rb2_hip_multi_plan_host": (i32, [vp, i32, vp, i32, vp, vp, vp]),
         "rb2_hip_rope_hash": (u64, [vp, i32]),
@@ -110,7 +111,7 @@ ABI_SYMBOLS = [
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_transport", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",
     "rb2_hip_multi_get_counts", "rb2_hip_multi_rope_bytes", "rb2_hip_multi_download_rope", "rb2_hip_multi_stream_rope",
-    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_plan_host", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats",
+    "rb2_hip_multi_load_ropes", "rb2_hip_multi_reserve", "rb2_hip_multi_rope_hash", "rb2_hip_rope_hash", "rb2_hip_multi_plan_host", "rb2_hip_multi_reset", "rb2_hip_multi_sync", "rb2_hip_multi_rank1a", "rb2_hip_multi_stats", "rb2_hip_multi_text_bytes",
 ]
 
 
@@ -329,6 +330,10 @@ class MultiBwt:
         a = (C.c_int * 31)()
         load_hip_lib().rb2_hip_default_owners(nranks, a)
         return list(a)
+
+    def text_bytes(self):
+        """bytes of device memory every local rank holds for the text of the last host-buffer batch (rb2_hip_multi_text_bytes)"""
+        return [int(self.L.rb2_hip_multi_text_bytes(self.h, k)) for k in range(self.n)]
 
     def close(self):
         if getattr(self, "h", None):

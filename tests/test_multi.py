@@ -572,3 +572,50 @@ def test_fatal_error_on_a_rank_thread_reaches_the_handler_on_the_calling_thread(
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 7, (p.returncode, p.stderr.decode()[-400:])
     assert b"handler on the calling thread: [rb2_hip] the batch contains bytes that are not nt6 codes" in p.stdout, p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 4])
+def test_peer_shared_batch_text(hip, n, monkeypatch):
+    """Ranks of one process (PEER): the text of a host-buffer batch is ONE copy, its pieces spread over the ranks' devices and mapped
+    for all of them (RB2_MULTI_TEXT=shard forces that on one device) -- every rank holds about 1 / n of it, results as ever."""
+    from ropebwt2_amd import MultiBwt
+    monkeypatch.setenv("RB2_MULTI_TEXT", "shard")
+    so = 1
+    o = H.Oracle(so)
+    m = MultiBwt(so, [0] * n, "peer")
+    for buf in _batches(so):                                     # small batches: one 64 MiB piece, held by rank 0
+        o.insert_multi(buf)
+        m.insert_multi(buf)
+        tb = m.text_bytes()
+        assert tb[0] == 64 << 20 and sum(tb[1:]) == 0, tb
+        assert np.array_equal(m.counts(), o.counts())
+    for b in range(6):
+        assert np.array_equal(m.rope(b), o.rope(b)), "rope %d" % b
+    m.close()
+    # a batch of several pieces against one engine (device-side checksums of the ropes + the count matrix)
+    L, reads = 100, 3_000_000
+    one = hip.HipBwt(so, 0)
+    buf = one.dev_alloc(reads * (L + 1) + 64)
+    one.synth_reads(buf, 0, reads, L, seed=77)
+    one.sync()
+    host = np.empty(reads * (L + 1), np.uint8)
+    one.L.rb2_hip_memcpy(one.h, host.ctypes.data, buf, host.size, 1)
+    one.sync()
+    one.insert_multi_dev(buf, reads * (L + 1))
+    one.sync()
+    m = MultiBwt(so, [0] * n, "peer")
+    m.insert_multi(host)
+    tb = m.text_bytes()
+    need = reads * (L + 1) + 64
+    assert sum(tb) >= need and sum(tb) < need + 2 * max(tb) and max(tb) <= -(-need // n) + (128 << 20), (tb, need)
+    assert sum(1 for x in tb if x > 0) >= min(n, 2)
+    assert np.array_equal(m.counts(), one.counts())
+    assert m.rope_hashes() == one.rope_hashes()
+    monkeypatch.setenv("RB2_MULTI_TEXT", "copy")                # ... and switched off: the whole batch on the first rank of the device
+    m2 = MultiBwt(so, [0] * n, "peer")
+    m2.insert_multi(host)
+    tb2 = m2.text_bytes()
+    assert tb2[0] >= need and sum(tb2[1:]) == 0, tb2
+    assert m2.rope_hashes() == one.rope_hashes()
+    one.dev_free(buf); one.close(); m.close(); m2.close()
