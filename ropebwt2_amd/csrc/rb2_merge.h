@@ -322,7 +322,7 @@ template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd 
 {
 	const uint64_t *lw = (const uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
 #pragma unroll
-	for (int pl = 0; pl < 3; ++pl) J.w[pl] = lw[pl * LEAFG];
+	for (int pl = 0; pl < 3; ++pl) J.w[pl] = RB2_LDNT(&lw[pl * LEAFG]);   // (nontemporal, like the stores: see the end of the loop)
 	// no branch and no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
 	// row's last insert again; they never use it)
 	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)o.ni, 1) - 1);
@@ -408,9 +408,14 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 			});
 			if (mine) RKREL[(uint64_t)o.ins0 + c0 + g] = (uint16_t)myrank;
 		}
-		if (o.ni && (uint32_t)g >= pg0) {                             // (the lines are in L2: the leaf was just read)
+		// The WHOLE leaf goes back, three full 128-byte lines, with nontemporal stores behind nontemporal loads: the leaf streams through
+		// once and nothing of it has to wait in L2 for a partial line to be merged.  (Rounds 2-4 stored only the groups from the first
+		// changed one on, counting on the lines the load had left in L2: 1 M x 10 kbp 3.09-3.19 s, this way 2.72-2.75 s on one box.  Each
+		// half alone is no gain: whole lines with plain accesses 3.09, nontemporal accesses with partial lines 3.31-3.39.)
+		(void)pg0;
+		if (o.ni) {
 			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
-			lw[0] = w0; lw[LEAFG] = w1; lw[2 * LEAFG] = w2;
+			RB2_STNT(w0, &lw[0]); RB2_STNT(w1, &lw[LEAFG]); RB2_STNT(w2, &lw[2 * LEAFG]);
 		}
 		if (!more) return;
 		g0 = g1;
