@@ -248,6 +248,12 @@ void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4]);
 /* the same four, then out[4] re-spreads among the re-layouts (sparse -> sparse: a superblock had no free slot for a split),
  * out[5] leaves split in place by k_split (the leaf split of rope.c:143-146); out[6..7] reserved */
 void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8]);
+/* window formats of the dense layout (a window = 4 leaves = 4096 symbols; csrc/rb2_merge.h): out[0..3] = windows the dense merge wrote
+ * plain (three bit planes) / compact with no, one, two lines of exception positions -- counted on the device only when the handle was
+ * created with RB2_COMPACT_STATS=1 in the environment (zeros otherwise) --, out[4] = dense rounds that were allowed to write compact
+ * windows (all intervals empty, not the last round of a batch, no re-layout ahead), out[5] = 1 when the per-format counts are on.
+ * RB2_COMPACT=0 keeps every window plain.  The reference has no counterpart: its leaves are always run-length coded (rle.h:39-75). */
+void rb2_hip_window_stats(rb2_hip_t *h, int64_t out[6]);
 
 /* per-kernel timing, measured with hipEvents on the engine's own stream when enabled */
 #define RB2_K_SYM      0

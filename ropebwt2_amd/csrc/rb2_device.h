@@ -133,6 +133,7 @@ struct Ctl {
 	// are no better than one counter); 16 counters on lines of their own cost < 1 us.  Consecutive tiles share a list; a wave of
 	// k_merge_leaf works on one list.  wcnt[c * WLS] = entries of list c.
 	uint32_t wcnt[16 * 32];
+	unsigned long long wfmt[4]; // windows k_merge wrote in each format (rb2_merge.h), counted only when asked for (RB2_COMPACT_STATS=1: one atomic per window)
 };
 constexpr int GCN = NR * 6 + 2;         // words of the per-round count matrix buffers: NR x 6 counts + [NR * 6] = "some string of this rank has a non-empty
                                         // interval this round" (summed over the ranks of a sharded index like the counts: zero = every rank may launch the
@@ -154,7 +155,7 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 	uint64_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL
 	uint64_t gl;            // first leaf slot on the new pool side
 	uint32_t oleaf0;        // first leaf slot of the sub-rope on the old pool side
-	uint16_t ni, nvalid;    // new symbols / symbols in the window
+	uint16_t ni, nvalid;    // new symbols / symbols in the window (low 14 bits); bits 14-15: the formats of the first / second old window it draws from (rb2_merge.h)
 };
 
 struct SpOrd {              // work order of one touched leaf in a sparse round, written by k_part_sparse, read by k_merge_leaf (16 B, in the LD buffer)

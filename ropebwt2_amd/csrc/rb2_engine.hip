@@ -239,6 +239,12 @@ struct rb2_hip_s {
 	int nactive = 1;                    // ranks that own a sub-rope other than rope $ (sizes the grids of a sharded rank: tile_grid)
 	DevBuf<uint8_t> xstage, xpack; DevBuf<uint16_t> xnb; DevBuf<uint64_t> xoff;   // k_export staging, packed bytes, chunk offsets
 	uint8_t *xhost[2] = {nullptr, nullptr}; uint64_t *xtot[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr};   // pinned double buffer
+	int compact_ok = 1;                 // RB2_COMPACT=0: dense rounds always write plain (three-plane) windows
+	int compact_stats = 0;              // RB2_COMPACT_STATS=1: k_merge counts the windows it writes per format (rb2_hip_window_stats)
+	int64_t n_compact_rounds = 0;       // dense rounds that were allowed to write compact windows
+	bool pool_compact = false;          // the last dense round wrote compact windows (only k_merge may read the pool now)
+	bool plain_next = false;            // choose_layout wants to leave the dense layout: this round writes plain windows
+	int ts_max = TS_MAX;                // batches with fewer string tiles run their counting tail in one single-block launch (k_tscan_setup); RB2_TS_MAX lowers it (tests)
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
 
@@ -476,7 +482,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	    } else
 	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp); }); }
 	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
-	if (B.nst_ub < (unsigned)TS_MAX) {                         // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
+	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
 	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
@@ -489,14 +495,15 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
 	  const int do_setup = h->nranks == 1;                     // one GPU: k_setup of the round rides on block 0 of k_tfix (the local count matrix is the global one)
 	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt, do_setup, (int)h->sparse, (uint32_t)r,
-	                     h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	                     h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)spec);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; } }
 }
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
 // send == nullptr: strings go straight to the next-round arrays; else they are written as ShardRec.
 // Dense round: every piece is rewritten pool[pside] -> pool[pside ^ 1] (k_merge).
-void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
+// compact_out: the new windows may be written in the compact format (rb2_merge.h): only k_merge reads them again before the next rewrite
+void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool compact_out = false)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
@@ -517,9 +524,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p); }
+	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, (const LeafMeta*)oldp.own); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p); }
+	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0)); }
 	});
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
@@ -533,6 +540,8 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send)
 	if (!B.known_ae && !send) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
+	h->pool_compact = compact_out;
+	if (compact_out) ++h->n_compact_rounds;
 }
 
 // leaf slots the pools must hold for an index of n symbols in the given layout
@@ -566,7 +575,7 @@ void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 		build_directory(h, h->side, h->pside ^ 1, slots / SB + 1, to_sparse);
 		HIPCHK(hipGetLastError());                              // a refused launch here would leave descriptors without data
 	}
-	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout; ++h->layout_epoch;
+	h->pside ^= 1; h->sparse = to_sparse; ++h->n_relayout; ++h->layout_epoch; h->pool_compact = false;   // (k_relayout writes plain windows)
 	if (to_sparse) h->sp_nsb = slots / SB + 1;
 	if (!to_sparse && h->pool[h->pside ^ 1].cap_leaves < cap) {   // the pool just left becomes the target of the next dense round
 		HIPCHK(hipStreamSynchronize(st));
@@ -660,6 +669,8 @@ void choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
 	bool want = h->sp_lambda > 0 && lambda < h->sp_lambda && h->sp_backoff == 0 && B.m < (1ull << 27);   // (k_merge_leaf: one wave per LROWS work orders, 2^32 threads per launch)
 	if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 	if (h->sp_backoff > 0) --h->sp_backoff;
+	h->plain_next = false;
+	if (want && !h->sparse && h->pool_compact) { want = false; h->plain_next = true; }   // the re-layout reads plain windows: this round writes them, the next one switches
 	if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
 		const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
 		const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
@@ -695,7 +706,10 @@ void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bo
 		h->sp_backoff = 1 << h->sp_penalty;
 		if (spec) round_counts(h, B, r);                       // the scratch of this round's counting phase was reused by the look-ahead
 	}
-	round_merge(h, B, r, send);
+	// compact windows (rb2_merge.h) while k_merge is the only reader of the pool until the next rewrite: every interval of the batch is
+	// empty from here on (k_prep<AE> reads no leaf), the batch goes on (its last round leaves plain windows to whoever comes next:
+	// export, rank queries, the next batch's first rounds), and no re-layout is pending
+	round_merge(h, B, r, send, h->compact_ok && B.known_ae && r < B.max_len && !h->plain_next);
 }
 
 void batch_trace(rb2_hip_t *h)
@@ -810,6 +824,9 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	if (getenv("RB2_SPARSE_LAMBDA")) h->sp_lambda = atof(getenv("RB2_SPARSE_LAMBDA"));   // 0: never leave the dense layout
 	if (getenv("RB2_SPARSE_HEAD")) h->sp_head = atoi(getenv("RB2_SPARSE_HEAD"));
 	if (getenv("RB2_LEAF_PIPE")) h->leaf_pipe = atoi(getenv("RB2_LEAF_PIPE"));
+	if (getenv("RB2_COMPACT")) h->compact_ok = atoi(getenv("RB2_COMPACT"));
+	if (getenv("RB2_COMPACT_STATS")) h->compact_stats = atoi(getenv("RB2_COMPACT_STATS"));
+	if (getenv("RB2_TS_MAX")) h->ts_max = std::max(0, std::min((int)TS_MAX, atoi(getenv("RB2_TS_MAX"))));
 	if (getenv("RB2_HIP_LAZY_INSERT")) h->lazy_insert = atoi(getenv("RB2_HIP_LAZY_INSERT"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
@@ -1337,6 +1354,16 @@ void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
 	HIPCHK(hipStreamSynchronize(h->st));
 	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
 	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = out[7] = 0;
+}
+
+void rb2_hip_window_stats(rb2_hip_t *h, int64_t out[6])
+{ finish_pending(h);
+	unsigned long long w[4] = {0, 0, 0, 0};
+	HIPCHK(hipSetDevice(h->dev));
+	HIPCHK(hipMemcpyAsync(w, &h->ctl->wfmt[0], sizeof(w), hipMemcpyDeviceToHost, h->st));
+	HIPCHK(hipStreamSynchronize(h->st));
+	for (int i = 0; i < 4; ++i) out[i] = (int64_t)w[i];
+	out[4] = h->n_compact_rounds; out[5] = h->compact_stats ? 1 : 0;
 }
 
 void rb2_hip_sync(rb2_hip_t *h) { finish_pending(h); HIPCHK(hipSetDevice(h->dev)); HIPCHK(hipStreamSynchronize(h->st)); }

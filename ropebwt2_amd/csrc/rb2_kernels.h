@@ -438,11 +438,14 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // and word NR * 6 of the buffer (GCN, rb2_device.h), and, on one GPU (do_setup), runs k_setup of the round on its first wave: the local
 // matrix IS the global one.  (Two launches of their own before; nothing k_setup writes is read by the other blocks of this kernel.)
 template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax);
+// spec: as in k_tscan_setup below -- queued before the host saw the verdict of the in-place round in front of it; a void round (ctl->overflow) is redone
+// from its own counting phase, and k_setup of the NEXT round must not have replaced the descriptors it starts from.
 __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const TileRecs trec, const TileScan *tsc, TileFix *tf, uint64_t *gcnt, int do_setup, int sparse,
-		uint32_t round, volatile unsigned long long *hmax)
+		uint32_t round, volatile unsigned long long *hmax, int spec)
 {
 	__shared__ uint32_t s_t0[NR + 1];
 	__shared__ uint64_t s_g[NR * 6];
+	if (spec && ctl->overflow) return;
 	const SegDesc &sg = ctl->seg[side];
 	if (threadIdx.x <= NR) s_t0[threadIdx.x] = sg.tile0[threadIdx.x];
 	__syncthreads();
@@ -923,7 +926,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 // A block covers 256 boundaries = 255 windows (boundaries overlap by one between blocks).
 // ---------------------------------------------------------------------------------------------
 
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const P *INS_E, LeafDesc *LD)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const P *INS_E, LeafDesc *LD, const LeafMeta *old_own)
 {
 	__shared__ uint64_t s_wf0[NR + 1];
 	__shared__ uint32_t s_q[256];
@@ -958,8 +961,14 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	d.ins0 = ctl->seg[side].start[b] + q;
 	d.gl = nrp.leaf0 + j * WPL;
 	d.oleaf0 = (uint32_t)orp.leaf0;
-	d.ni = (uint16_t)(q1 - q);
-	d.nvalid = (uint16_t)min((uint64_t)WIN, nrp.n - o0);
+	// the formats of the (at most two) old windows the merge will draw from (rb2_merge.h "window formats"): the npre field of their first
+	// leaves' entries in own[]; a window that does not exist reads as "compact, no exceptions" (nothing to fetch)
+	const uint64_t ow = i0 >> 12, onw = (orp.nleaves + WPL - 1) / WPL;
+	static_assert(WPL * LEAF == 4096, "a window is 4096 symbols");
+	const uint32_t h0 = ow < onw ? (uint32_t)old_own[orp.leaf0 + ow * WPL].npre & 3u : 1u;
+	const uint32_t h1 = ow + 1 < onw ? (uint32_t)old_own[orp.leaf0 + (ow + 1) * WPL].npre & 3u : 1u;
+	d.ni = (uint16_t)((uint32_t)(q1 - q) | h0 << 14);
+	d.nvalid = (uint16_t)((uint32_t)min((uint64_t)WIN, nrp.n - o0) | h1 << 14);
 	LD[s_wf0[b] + j] = d;
 	if (!STRIDE) return;
 	}

@@ -44,24 +44,19 @@ __device__ __forceinline__ uint32_t row_incl_add(uint32_t v)
 template <class F, int... Js> __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Js...>) { (f(std::integral_constant<int, Js>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// open a one-bit gap at every set bit of f (ascending), in all three planes: the low bits of x[] move up past the gaps
-// (a software bit deposit; f has few bits in steady state -- one new symbol per ~170 old ones at configs[1])
+// open a one-bit gap at every set bit of f (ascending), in all three planes: the low bits of x[] move up past the gaps (a software bit
+// deposit; f has few bits in steady state -- one new symbol per ~170 old ones at configs[1]).  Per gap: the bits below the lowest set bit
+// of f are lm = (f - 1) & ~f -- all ones when f is empty, which makes the step a no-op for a lane that is done, no branch --, and moving
+// the part of x above them up by one is an ADD: x + (x & ~lm).  14 VALU per trip for the three planes (r04: masks from a count of
+// trailing zeros, shift and two ORs per plane: 28).  The trip count is the largest number of new symbols in one group of the window.
 __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 {
-	{	// first new symbol of the group, branch-free (most groups have none or one)
-		const uint64_t lm = f ? (1ull << __builtin_ctzll(f)) - 1ull : ~0ull;   // no new symbol: everything stays
+	do {
+		const uint64_t t = f - 1ull, lm = t & ~f;
 #pragma unroll
-		for (int pl = 0; pl < 3; ++pl) x[pl] = (x[pl] & lm) | ((x[pl] & ~lm) << 1);
-		f &= f - 1;
-	}
-	while (__any(f != 0)) {
-		if (f) {
-			const uint64_t lm = (1ull << __builtin_ctzll(f)) - 1ull;   // bits below the new symbol
-			f &= f - 1;
-#pragma unroll
-			for (int pl = 0; pl < 3; ++pl) x[pl] = (x[pl] & lm) | ((x[pl] & ~lm) << 1);
-		}
-	}
+		for (int pl = 0; pl < 3; ++pl) x[pl] += x[pl] & ~lm;
+		f &= t;
+	} while (__any(f != 0));
 }
 
 // the rewritten index is read once and written once per round: nontemporal loads and stores of the leaf words (RB2_NT=0: plain).
@@ -78,175 +73,218 @@ __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 #define RB2_STNT(v, p) (*(p) = (v))
 #endif
 
-// LDS words one wave of merge_window<.., GPL_, ..> needs: flags + three planes of new symbols + three planes of staged old groups
+// ---- window formats of the dense layout ------------------------------------------------------------------------------------
+// A window = WPL = 4 consecutive leaves = 4096 symbols = twelve 128-byte lines (leaf-major, three plane lines per leaf).  DNA needs two
+// planes: with $ACGTN = 000 001 010 011 100 101, planes 0 and 1 tell A, C, G, T apart, and plane 2 is 1 for T -- a quarter of all symbols.
+// Swap the codes of $ and T (plane 2' = plane 2 ^ ~(plane 0 | plane 1)) and plane 2' is set for `$` and `N` only: about 1 % of the
+// symbols of a read set (one sentinel per read), none at all while the first batch of a job is being inserted.  A COMPACT window keeps
+// planes 0 and 1 where they always are and, instead of the four plane-2 lines, the POSITIONS of its plane-2' bits as 16-bit entries
+// ("exceptions": entry 0 = their number, entries 1 .. n = positions 0 .. 4095) in the plane-2 line of its first leaf (n <= 63) and of its
+// second leaf (n <= 127); the other plane-2 lines are not touched at all.  A window with more exceptions (runs of N, very short reads)
+// stays PLAIN: three planes, original codes.  The memory side moves whole lines, and lines that are skipped cost nothing
+// (tools/ubench/window_stream.hip: 10 of 12 lines of every window at the same 5.9-6.0 TB/s as 12 of 12, 8 of 12 at 6.6) -- so the
+// stride, the leaf addresses and the directory stay what they are, and a round reads and writes 8 to 10 lines per window instead of 12.
+// What rle_insert_cached gains by coding runs (rle.c:63-86, rle.h:53-75) -- fewer bytes per symbol than a fixed-width field -- is gained
+// here by not storing the plane that almost never differs.
+// The format of a window is the `npre` field of its first leaf's entry in own[] (written by the merge with the leaf's counts; k_relayout
+// and the loader write 0 = plain).  k_part hands the formats of the (at most two) old windows an output window draws from to the merge
+// in its work order.  Only k_merge reads and writes compact windows: the host asks for them (compact_out) only when every reader of
+// the pool until the next rewrite is k_merge again -- all intervals empty, not the last round of the batch, no change of layout ahead.
+constexpr uint32_t WF_PLAIN = 0, WF_C0 = 1, WF_C1 = 2, WF_C2 = 3;   // compact: 0 / 1 / 2 exception lines
+constexpr uint32_t XCAP1 = 63, XCAP2 = 127;                          // exceptions one / two lines hold
+static_assert(WIN < (1 << 14), "LeafDesc packs the old windows' formats above ni / nvalid");
+
+// LDS words one wave of merge_window needs: flags + three planes of new symbols + three planes of staged old groups
 template <int GPL_> struct MergeLds { static constexpr int WG = 64 * GPL_, WORDS = WG + 3 * WG + 3 * (WG + 2) + 2; };
 
-// FULL: the window holds WIN symbols (all but the last window of a piece) -- every position is valid.
-// GPL_ = groups per lane: the window is 64 * GPL_ groups (dense merge: GPL; in-place leaf merge: 1, the leaf in the first row).
-// INPLACE: the window IS one leaf with slack, rewritten where it lies (sparse rounds, leaves that receive many symbols): its old
-// symbols are its own first groups, d.i0 is the piece position of its first symbol, every new symbol also gets its leaf slot (RKLEAF).
-template <bool FULL, int GPL_, bool INPLACE, typename P> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *lds, const int ln,
-		const PoolView &oldp, const PoolView &newp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, uint32_t *RKLEAF)
+// bits [op, op + 64) of a staged plane (dwords `pl` ... in LDS), op = 32 * dk + sh: three dword reads and two funnel shifts
+__device__ __forceinline__ uint64_t stage_bits(const uint32_t *pl, uint32_t dk, uint32_t sh)
 {
-	constexpr int WG = 64 * GPL_, LPL = LEAFG / GPL_, WINS = WG * GSYM;      // groups per window, lanes per leaf, symbols per window
-	// LDS layout.  A lane owns GPL_ consecutive groups of the window; arrays indexed by group are kept LANE-major -- group G lives at
-	// (G % GPL_) * 64 + G / GPL_, so lane ln's w-th group is at w * 64 + ln and the lanes of a wave hit 64 different banks pairs.
-	uint64_t *LF = lds, *LX = lds + WG, *LO = lds + 4 * WG;                // flags; planes of the new symbols (later: of the output); staged old groups, plane pl at LO + pl * (WG + 2)
-	auto SX = [](uint32_t G) -> uint32_t { return GPL_ == 1 ? G : (G % GPL_) * 64u + G / GPL_; };
-	auto LM = [](int w, int lane) -> int { return 64 * w + lane; };         // index of lane's w-th group
-	const int nvalid = FULL ? WINS : d.nvalid, ni = d.ni;
-	const uint32_t nold = (uint32_t)(nvalid - ni);              // old symbols consumed by this window
-	const uint64_t G0 = INPLACE ? 0 : d.i0 >> 6;                // old group that holds the first of them
-	const uint32_t sh0 = INPLACE ? 0u : (uint32_t)(d.i0 & 63);  // ... and its place in that group
-	const uint32_t nwg = (sh0 + nold + 63) >> 6;                // groups of the old side they live in (<= WG + 1)
+	const uint32_t d0 = pl[dk], d1 = pl[dk + 1], d2 = pl[dk + 2];
+	return (uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32 | __builtin_amdgcn_alignbit(d1, d0, sh);
+}
+
+// One output window of 64 groups, lane = group.  FULL: the window holds WIN symbols (all but the last window of a piece) -- every
+// position is valid.  Inside, symbols are in the swapped coding (plane 2' above).
+// compact_out: bit 0 -- new windows may be written compact (else plain); bit 1 -- count the windows per format in Ctl::wfmt.
+// The kernel is bound by VALU issue as much as by HBM (r04: 272 VALU per window at 75 % of the issue rate while moving 5 GB at 6 TB/s;
+// r05 first cut of the compact format: 25 % fewer bytes, 323 VALU, 11 % SLOWER), so every step is written for instruction count: lane
+// offsets in 32 bits on uniform bases, funnel shifts of dwords for the unaligned plane windows, gaps opened by additions, scans inside
+// the DPP row (= leaf) only, exception bookkeeping from numbers the counts already provide.
+template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge_window(const LeafDesc &d, uint64_t *lds, const int ln,
+		const PoolView &oldp, const PoolView &newp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, const int compact_out, unsigned long long *wfmt)
+{
+	static_assert(GPL_ == 1, "one group per lane");
+	constexpr int WG = 64, WINS = WG * GSYM;
+	uint64_t *LF = lds, *LX = lds + WG, *LO = lds + 4 * WG;                  // flags; planes of the new symbols (later: of the output); staged old groups, plane pl at LO + pl * (WG + 2)
+	uint64_t *LO2 = LO + 2 * (WG + 2);
+	const uint32_t nvalid = FULL ? (uint32_t)WINS : (uint32_t)(d.nvalid & 0x3fffu), ni = d.ni & 0x3fffu;
+	const uint32_t h0 = d.ni >> 14, h1 = d.nvalid >> 14;        // formats of the first / second old window this one draws from
+	const uint32_t nold = nvalid - ni;                          // old symbols consumed by this window
+	const uint32_t sh0 = (uint32_t)d.i0 & 63u;                  // the first of them: bit sh0 of old group G0 = i0 >> 6 ...
+	const uint32_t g0 = (uint32_t)(d.i0 >> 6) & 63u;            // ... which is group g0 of old window ow (of the piece)
+	const uint64_t ow = d.i0 >> 12;
+	const uint32_t nwg = (sh0 + nold + 63) >> 6;                // old groups they live in (<= WG + 1)
+	const uint64_t *obw = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 + ow * WPL) * LEAFW;   // window ow; staged group k is its group g0 + k
+	const uint32_t ln32 = (uint32_t)ln;
 
 	// ---- 1. new symbols of this window, by output position (planes and "new here" flag); the old groups it draws from
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w) {
-		LF[ln + 64 * w] = 0;
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) LX[pl * WG + ln + 64 * w] = 0;
-	}
+	LF[ln] = 0; LX[ln] = 0; LX[WG + ln] = 0; LX[2 * WG + ln] = 0;
+	LO2[ln] = 0;                                                // plane 2' of the old groups of compact windows is OR-ed together from their exception lists
+	if (ln == 0) LO2[WG] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
-	const uint64_t *ob = (const uint64_t*)oldp.data + (INPLACE ? d.gl : (uint64_t)d.oleaf0) * LEAFW;
-	uint64_t wa[GPL_][3], wt[3] = {0, 0, 0};
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w) {
-		const uint32_t k = (uint32_t)(ln + 64 * w);
-		const uint64_t og = G0 + k;
-		const uint64_t *q = ob + (og >> 4) * LEAFW + (og & 15);
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) { wa[w][pl] = 0; if (k < nwg) wa[w][pl] = RB2_LDNT(&q[pl * LEAFG]); }
+	// Loads in the order their values are needed (the wave waits for its loads in issue order): my first new symbol, the exception
+	// entries, then the plane words -- the LDS atomics of the first two run while the planes are still on their way.
+	const P *E0 = INS_E + d.ins0; const uint8_t *A0 = INS_A + d.ins0;
+	const uint32_t i0lo = (uint32_t)d.i0;
+	uint32_t e_first = 0, a_first = 0;
+	if (ln32 < ni) { e_first = (uint32_t)E0[ln32]; a_first = A0[ln32]; }   // (positions inside a window: the low half decides)
+	// the exception lists of the old windows: lane ln reads entry ln of a line (entry 0 of the first line = the number of exceptions)
+	const bool two = g0 + nwg > 64u;                            // some staged group lies in window ow + 1
+	const bool xa = nwg > 0 && h0 >= WF_C1, xb = two && h1 >= WF_C1;
+	uint32_t xe[4] = {0, 0, 0, 0};
+	{
+		const uint16_t *x0 = (const uint16_t*)(obw + 2 * LEAFG);   // plane-2 line of the first leaf of window ow
+		if (xa) xe[0] = x0[ln32];
+		if (xa && h0 == WF_C2) xe[1] = x0[LEAFW * 4 + ln32];        // ... of its second leaf
+		if (xb) xe[2] = x0[WPL * LEAFW * 4 + ln32];
+		if (xb && h1 == WF_C2) xe[3] = x0[WPL * LEAFW * 4 + LEAFW * 4 + ln32];
 	}
-	if (ln == 0 && (uint32_t)WG < nwg) {
-		const uint64_t og = G0 + WG;
-		const uint64_t *q = ob + (og >> 4) * LEAFW + (og & 15);
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) wt[pl] = q[pl * LEAFG];
+	const uint32_t t = g0 + ln32;                               // my staged group as a group of window ow (or, from 64 on, of ow + 1)
+	const uint32_t woff = (t >> 4) * LEAFW + (t & 15u);         // its plane-0 word
+	const bool have = ln32 < nwg;
+	const bool plain_k = have && (t < 64u ? h0 : h1) == WF_PLAIN;
+	uint64_t wa0 = 0, wa1 = 0, wa2 = 0, wt0 = 0, wt1 = 0, wt2 = 0;
+	if (have) { wa0 = RB2_LDNT(&obw[woff]); wa1 = RB2_LDNT(&obw[woff + LEAFG]); }
+	if (plain_k) wa2 = RB2_LDNT(&obw[woff + 2 * LEAFG]);
+	const bool tail = ln == 0 && (uint32_t)WG < nwg;            // (group g0 + 64 lies in window ow + 1)
+	if (tail) {
+		const uint32_t t2 = g0 + 64u, w2 = (t2 >> 4) * LEAFW + (t2 & 15u);
+		wt0 = obw[w2]; wt1 = obw[w2 + LEAFG];
+		if (h1 == WF_PLAIN) wt2 = obw[w2 + 2 * LEAFG];
 	}
-	uint32_t p_first = 0, a_first = 0;                          // my first new symbol, kept for step 5
-	for (int jj = ln; jj < ni; jj += 64) {
-		const uint64_t e = INS_E[d.ins0 + jj];
-		const uint32_t a = INS_A[d.ins0 + jj];
-		const uint32_t p = (uint32_t)(e - d.i0) + (uint32_t)jj;   // final position E[q] + q, relative to the window
-		if (jj == ln) { p_first = p; a_first = a; }
-		const uint32_t ix = SX(p >> 6);
+	auto put_new = [&](uint32_t p, uint32_t a) {
+		const uint32_t ix = p >> 6;
 		const unsigned long long bit = 1ull << (p & 63);
 		atomicOr((unsigned long long*)&LF[ix], bit);
 		if (a & 1u) atomicOr((unsigned long long*)&LX[ix], bit);
 		if (a & 2u) atomicOr((unsigned long long*)&LX[WG + ix], bit);
-		if (a & 4u) atomicOr((unsigned long long*)&LX[2 * WG + ix], bit);
+		if ((0x21u >> a) & 1u) atomicOr((unsigned long long*)&LX[2 * WG + ix], bit);   // plane 2': $ and N
+	};
+	const uint32_t p_first = e_first - i0lo + ln32;             // final position E[q] + q, relative to the window (kept for step 5)
+	if (ln32 < ni) put_new(p_first, a_first);
+	for (uint32_t jj = ln32 + 64; jj < ni; jj += 64) put_new((uint32_t)E0[jj] - i0lo + jj, A0[jj]);   // (more than 64 new symbols: rare in steady state)
+	{	// exceptions -> plane 2' bits of the staged groups: entry e of window ow + wi is bit e & 63 of its group e >> 6 = staged group (e >> 6) + 64 wi - g0
+		auto x_in = [&](uint32_t e, uint32_t idx_m1 /* entry number - 1 */, uint32_t cnt, uint32_t delta) {
+			const uint32_t k = (e >> 6) + delta;
+			if (idx_m1 < cnt && k <= (uint32_t)WG) atomicOr((unsigned long long*)&LO2[k], 1ull << (e & 63));
+		};
+		if (xa) {
+			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)xe[0]);
+			x_in(xe[0], ln32 - 1u, cnt, 0u - g0);
+			if (h0 == WF_C2) x_in(xe[1], ln32 + 63u, cnt, 0u - g0);
+		}
+		if (xb) {
+			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)xe[2]);
+			x_in(xe[2], ln32 - 1u, cnt, 64u - g0);
+			if (h1 == WF_C2) x_in(xe[3], ln32 + 63u, cnt, 64u - g0);
+		}
 	}
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w)
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) LO[pl * (WG + 2) + ln + 64 * w] = wa[w][pl];
+	asm volatile("" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wt0), "+v"(wt1), "+v"(wt2));   // nothing of the plane words is looked at before this point (the first look waits for them)
+	LO[ln] = wa0; LO[(WG + 2) + ln] = wa1;
+	if (plain_k) LO2[ln] = wa2 ^ ~(wa0 | wa1);                  // plain window: to the swapped coding (a word no exception list writes to)
 	if (ln == 0) {
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) LO[pl * (WG + 2) + WG] = wt[pl];
+		LO[WG] = wt0; LO[(WG + 2) + WG] = wt1;
+		if (tail && h1 == WF_PLAIN) LO2[WG] = wt2 ^ ~(wt0 | wt1);
 	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 
 	// ---- 2. what does each lane consume
-	uint64_t F[GPL_], VM[GPL_], out[GPL_][3];
-	uint32_t non[GPL_], ntot = 0, ktot = 0, vtot = 0;
-	const int p0 = ln * GSYM * GPL_;
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w) {
-		F[w] = LF[LM(w, ln)];                                   // bit i: position i holds a new symbol
-		const int v = FULL ? GSYM : min(GSYM, max(0, nvalid - p0 - GSYM * w));
-		VM[w] = FULL ? ~0ull : bits_below((uint32_t)v);         // the valid positions
-		const uint32_t kin = (uint32_t)__popcll(F[w]);
-		non[w] = (uint32_t)v - kin;
-		ntot += non[w]; ktot += kin; vtot += (uint32_t)v;
-	}
-	const uint32_t sc2 = dpp_incl_add(ntot | ktot << 16);       // both prefix sums in one scan (each <= WINS < 2^16)
+	uint64_t F = LF[ln];                                        // bit i: position i holds a new symbol
+	const uint32_t v = FULL ? (uint32_t)GSYM : (uint32_t)min((int)GSYM, max(0, (int)nvalid - ln * GSYM));
+	const uint64_t VM = FULL ? ~0ull : bits_below(v);           // the valid positions
+	const uint32_t non = v - (uint32_t)__popcll(F);
+	uint64_t out[3];
 	{
-		uint32_t op = sh0 + ((sc2 & 0xffffu) - ntot);             // first old symbol of this lane, in symbols of the stage
+		const uint32_t op = sh0 + (dpp_incl_add(non) - non);      // first old symbol of this lane, in symbols of the stage
+		const uint32_t dk = op >> 5, sh = op & 31u;
+		const uint32_t *S = (const uint32_t*)LO;
 #pragma unroll
-		for (int w = 0; w < GPL_; ++w) {
-			const uint32_t k = op >> 6, sh = op & 63;
-#pragma unroll
-			for (int pl = 0; pl < 3; ++pl) {
-				const uint64_t w0 = LO[pl * (WG + 2) + k], w1 = LO[pl * (WG + 2) + k + 1];   // k + 1 <= WG + 1
-				out[w][pl] = (w0 >> sh) | ((w1 << 1) << (63 - sh));   // bits [op, op + 64) of the plane; what lies behind my non[w] bits is shifted out or masked below
-			}
-			op += non[w];
-		}
+		for (int pl = 0; pl < 3; ++pl) out[pl] = stage_bits(S + pl * 2 * (WG + 2), dk, sh);   // what lies behind my `non` bits is shifted out or masked below
 	}
 
 	// ---- 3. deal the old symbols to the not-new positions, add the new ones
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w) {
-		if (__any(F[w] != 0)) {
-			if (__all(F[w] == VM[w])) { out[w][0] = out[w][1] = out[w][2] = 0; }   // nothing old in any lane's group (the first rounds on an empty index)
-			else open_gaps(out[w], F[w]);
-		}
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) out[w][pl] = (out[w][pl] & VM[w]) | LX[pl * WG + LM(w, ln)];   // (the gaps hold zeros)
-	}
+	if (nold == 0) { out[0] = out[1] = out[2] = 0; }            // nothing old (the first rounds on an empty index)
+	else if (ni) open_gaps(out, F);
+	out[0] = (out[0] & VM) | LX[ln]; out[1] = (out[1] & VM) | LX[WG + ln]; out[2] = (out[2] & VM) | LX[2 * WG + ln];   // (the gaps hold zeros)
 
-	// ---- 4. counts per lane -> prefix over the window -> LeafMeta of its leaves
+	// ---- 4. counts per lane -> prefix inside the leaf (= DPP row) -> LeafMeta of the leaves, rank bases of the new symbols
 	uint32_t c[6];
 	{
 		PlAcc A;
-#pragma unroll
-		for (int w = 0; w < GPL_; ++w) pl_acc(A, out[w][0], out[w][1], out[w][2], VM[w]);
-		pl_finish(A, vtot, c);
+		pl_acc(A, out[0], out[1], out[2], VM);
+		pl_finish(A, v, c);
+		const uint32_t t4 = c[0]; c[0] = c[4]; c[4] = t4;         // (the planes are in the swapped coding)
 	}
 	const uint32_t e01 = c[0] | c[1] << 16, e23 = c[2] | c[3] << 16, e45 = c[4] | c[5] << 16;
-	const uint32_t s01 = dpp_incl_add(e01), s23 = dpp_incl_add(e23), s45 = dpp_incl_add(e45);
-	// publish my groups and my exclusive prefixes (the old-group stage is dead by now)
+	const uint32_t s01 = row_incl_add(e01), s23 = row_incl_add(e23), s45 = row_incl_add(e45);
+	// the format of the new window: its exceptions are its $ and N symbols, already counted and scanned
+	const uint32_t nx = c[0] + c[5], xs = (s01 & 0xffffu) + (s45 >> 16);   // mine / inclusive prefix inside my row
+	uint32_t fmt = WF_PLAIN, xr0 = 0, xr1 = 0, xr2 = 0, xt = 0;
+	if (compact_out & 1) {
+		xr0 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 15); xr1 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 31);
+		xr2 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 47); xt = xr0 + xr1 + xr2 + (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
+		fmt = xt == 0 ? WF_C0 : (xt <= XCAP1 ? WF_C1 : (xt <= XCAP2 ? WF_C2 : WF_PLAIN));
+	}
+	if ((compact_out & 2) && ln == 0) atomicAdd(wfmt + fmt, 1ull);   // statistics for the tests (RB2_COMPACT_STATS=1)
+	// publish my group and my exclusive prefixes inside the leaf (the old-group stage is dead by now)
 	uint32_t *LP = (uint32_t*)LO;
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w)
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) LX[pl * WG + LM(w, ln)] = out[w][pl];
+	LX[ln] = out[0]; LX[WG + ln] = out[1]; LX[2 * WG + ln] = out[2];
 	LP[ln] = s01 - e01; LP[64 + ln] = s23 - e23; LP[128 + ln] = s45 - e45;   // LP[q * 64 + lane]
+	uint16_t *XL = (uint16_t*)LF;                               // the exception list on its way out (the flags are dead)
+	if (fmt >= WF_C1) {                                          // (wave-uniform)
+		uint64_t x = out[2];
+		const uint32_t row = ln32 >> 4;
+		uint32_t at = 1u + xs - nx + (row > 0 ? xr0 : 0u) + (row > 1 ? xr1 : 0u) + (row > 2 ? xr2 : 0u);
+		if (ln == 0) XL[0] = (uint16_t)xt;
+		while (x) { XL[at++] = (uint16_t)((ln32 << 6) + (uint32_t)__builtin_ctzll(x)); x &= x - 1; }
+	}
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 
 	// ---- 5. leaf-relative rank of every new symbol, one per lane
-	for (int jj = ln; jj < ni; jj += 64) {
+	uint16_t *RK0 = RKREL + d.ins0;
+	for (uint32_t jj = ln32; jj < ni; jj += 64) {
 		uint32_t p = p_first, a = a_first;
-		if (jj != ln) {                                        // more than 64 new symbols in the window: read them again
-			a = INS_A[d.ins0 + jj];
-			p = (uint32_t)(INS_E[d.ins0 + jj] - d.i0) + (uint32_t)jj;
-		}
-		const uint32_t G = p >> 6, lo = G / GPL_, wi = G - lo * GPL_;
-		const uint32_t bl = (p >> LEAF_SH) * LPL;                // first lane of its leaf
-		const uint32_t sh = (a & 1) * 16;
-		uint32_t r = ((LP[64 * (a >> 1) + lo] >> sh) & 0xffffu) - ((LP[64 * (a >> 1) + bl] >> sh) & 0xffffu);
-#pragma unroll
-		for (int w = 0; w < GPL_; ++w) {
-			const uint64_t m = (uint32_t)w < wi ? ~0ull : ((uint32_t)w == wi ? (1ull << (p & 63)) - 1ull : 0ull);
-			const int ix = LM(w, (int)lo);
-			r += (uint32_t)__popcll(pl_eq(LX[ix], LX[WG + ix], LX[2 * WG + ix], a) & m);
-		}
-		RKREL[d.ins0 + jj] = (uint16_t)r;
-		if (INPLACE) RKLEAF[d.ins0 + jj] = (uint32_t)d.gl;
+		if (jj != ln32) { a = A0[jj]; p = (uint32_t)E0[jj] - i0lo + jj; }   // more than 64 new symbols in the window: read them again
+		const uint32_t lo = p >> 6;
+		uint32_t r = (LP[64 * (a >> 1) + lo] >> ((a & 1u) * 16u)) & 0xffffu;   // equal symbols in the groups of its leaf in front of its group
+		const uint32_t ai = (a & 3u) ? a : a ^ 4u;               // its code in the planes: $ <-> T
+		// the planes of its group XORed with all-ones where the bit of the code is clear (the mask is 32 bits wide: both halves use it)
+		const uint32_t m0 = (ai & 1u) - 1u, m1 = ((ai >> 1) & 1u) - 1u, m2 = (ai >> 2) - 1u;
+		const uint64_t q0 = LX[lo], q1 = LX[WG + lo], q2 = LX[2 * WG + lo];
+		const uint32_t el = ((uint32_t)q0 ^ m0) & ((uint32_t)q1 ^ m1) & ((uint32_t)q2 ^ m2), eh = ((uint32_t)(q0 >> 32) ^ m0) & ((uint32_t)(q1 >> 32) ^ m1) & ((uint32_t)(q2 >> 32) ^ m2);
+		const uint64_t below = (1ull << (p & 63)) - 1ull;
+		r += (uint32_t)__popc(el & (uint32_t)below) + (uint32_t)__popc(eh & (uint32_t)(below >> 32));
+		RK0[jj] = (uint16_t)r;
 	}
-	if (!INPLACE && (ln % LPL) == LPL - 1 && (ln / LPL) * LEAF < nvalid) {   // last lane of a leaf that exists (in place: the directory is kept by dir_add)
-		const uint32_t bl = (uint32_t)(ln / LPL) * LPL;
-		const uint32_t t01 = s01 - LP[bl], t23 = s23 - LP[64 + bl], t45 = s45 - LP[128 + bl];
+	const uint32_t lf = ln32 >> 4;                              // my leaf of the window
+	if ((ln32 & 15u) == 15u && lf * (uint32_t)LEAF < nvalid) {  // last lane of a leaf that exists: the inclusive row prefixes are the leaf's counts
 		LeafMeta m;
-		m.c[0] = (uint16_t)t01; m.c[1] = (uint16_t)(t01 >> 16); m.c[2] = (uint16_t)t23; m.c[3] = (uint16_t)(t23 >> 16);
-		m.c[4] = (uint16_t)t45; m.c[5] = (uint16_t)(t45 >> 16);
-		m.npre = 0;
-		m.n = (uint16_t)((t01 & 0xffffu) + (t01 >> 16) + (t23 & 0xffffu) + (t23 >> 16) + (t45 & 0xffffu) + (t45 >> 16));
-		newp.own[d.gl + ln / LPL] = m;                          // own counts + fill; k_meta_sb turns them into prefixes
+		m.c[0] = (uint16_t)s01; m.c[1] = (uint16_t)(s01 >> 16); m.c[2] = (uint16_t)s23; m.c[3] = (uint16_t)(s23 >> 16);
+		m.c[4] = (uint16_t)s45; m.c[5] = (uint16_t)(s45 >> 16);
+		m.npre = (uint16_t)(lf == 0 ? fmt : 0u);                // the window's format rides in its first leaf's entry
+		m.n = (uint16_t)(FULL ? (uint32_t)LEAF : min((uint32_t)LEAF, nvalid - lf * (uint32_t)LEAF));
+		newp.own[d.gl + lf] = m;                                // own counts + fill; k_meta_sb turns them into prefixes
 	}
-#pragma unroll
-	for (int w = 0; w < GPL_; ++w) {
-		const uint32_t G = (uint32_t)(ln * GPL_ + w);
-		if (INPLACE && G >= (uint32_t)LEAFG) continue;          // in place the window is ONE leaf
-		uint64_t *dst = (uint64_t*)newp.data + (d.gl + (G >> 4)) * LEAFW + (G & 15);
-#pragma unroll
-		for (int pl = 0; pl < 3; ++pl) RB2_STNT(out[w][pl], &dst[pl * LEAFG]);   // leaves past the end of the piece are padding slots of the same piece
-	}
+	uint64_t *dstw = (uint64_t*)newp.data + d.gl * LEAFW;       // the window; lane's group: leaf lf, group ln & 15
+	const uint32_t doff = lf * LEAFW + (ln32 & 15u);
+	RB2_STNT(out[0], &dstw[doff]); RB2_STNT(out[1], &dstw[doff + LEAFG]);   // leaves past the end of the piece are padding slots of the same piece
+	if (fmt == WF_PLAIN) RB2_STNT((out[2] ^ ~(out[0] | out[1])) & VM, &dstw[doff + 2 * LEAFG]);   // back to the original codes
+	else if (fmt >= WF_C1 && ln32 < (fmt == WF_C2 ? 32u : 16u)) RB2_STNT(((const uint64_t*)XL)[ln], &dstw[doff + 2 * LEAFG]);   // one or two whole lines of 64 entries
 }
 
 template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
-		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL)
+		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, int compact_out)
 {
 	__shared__ __align__(16) uint64_t lds[MW][MergeLds<GPL>::WORDS];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -258,8 +296,8 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	LeafDesc d = LD[gw];
 	const uint64_t nwin = ctl->wf0[NR];
 	for (; gw < nwin; gw += (uint64_t)gridDim.x * MW, d = LD[gw < nwin ? gw : 0]) {
-		if (d.nvalid == WIN) merge_window<true, GPL, false, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
-		else merge_window<false, GPL, false, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, nullptr);
+		if ((d.nvalid & 0x3fffu) == WIN) merge_window<true, GPL, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, compact_out, (unsigned long long*)ctl->wfmt);
+		else merge_window<false, GPL, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, compact_out, (unsigned long long*)ctl->wfmt);
 		if (!STRIDE) return;                                    // (one GPU: the grid covers every window; no loop, no extra registers)
 		if (gw + (uint64_t)gridDim.x * MW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
 	}

@@ -96,6 +96,23 @@ def test_many_strings_into_one_leaf_is_a_void_round_and_still_right(hip):
             dev.close()
 
 
+def test_void_round_behind_a_many_tiles_look_ahead(hip):
+    """the counting phase of round r + 1 is queued before the host sees the verdict of in-place round r; with many string tiles its
+    k_setup rides on k_tfix (not on the single-block k_tscan_setup) and must not replace the descriptors of a round that turns out
+    void (RB2_TS_MAX lowers the tile count at which the many-tiles kernels take over: 5000 strings are 10 tiles)"""
+    base = H.splitmix_bases(2000, 120, seed=9)
+    dup = [[1, 2, 3, 4] * 10] * 5000
+    more = H.splitmix_bases(3000, 150, seed=10)
+    with Env(RB2_TS_MAX=2, **FORCED):
+        for so in (0, 1, 2):
+            dev, o = hip.HipBwt(so), H.Oracle(so)
+            for buf in (H.encode_batch_fixed(base), H.encode_batch(dup), H.encode_batch_fixed(more)):
+                o.insert_multi(buf); dev.insert_multi(buf)
+            _same(dev, o)
+            assert dev.layout_stats()["void_rounds"] > 0
+            dev.close()
+
+
 @pytest.mark.parametrize("so", [0, 1, 2])
 @pytest.mark.parametrize("n", [2, 8])
 def test_sharded_index_inserts_in_place(hip, so, n):
