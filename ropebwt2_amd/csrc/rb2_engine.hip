@@ -284,6 +284,7 @@ void drain_profile(rb2_hip_t *h)
 }
 
 inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+inline unsigned grid8(unsigned g) { return (g + 7u) & ~7u; }   // grids of the tile / window kernels: a multiple of the XCD count (xcd_item(), rb2_device.h); the extra blocks find nothing to do
 
 // Grids of a rank of a sharded index.  The host knows the batch (m strings, len symbols), not the rank's share of it this round --
 // asking would cost a synchronisation per round.  The upper bound "all of it" makes every launch N times too large: at N = 8
@@ -340,7 +341,7 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
 	h->A[0].ensure(m); h->A[1].ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
-	h->trec.ensure(nst + 8); h->tsc.ensure(nst + 2); h->tfix.ensure(nst + 1); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
+	h->trec.ensure(nst + 16); h->tsc.ensure(nst + 16); h->tfix.ensure(nst + 16); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
 
 // A batch may hold at most this many strings (32-bit slots, tile numbers and work orders).  The reference takes any count
@@ -480,7 +481,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
 	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp);
 	    } else
-	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3((unsigned)rank_share(h, B.nst_ub)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp); }); }
+	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp); }); }
 	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
 	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
@@ -511,7 +512,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
 	const uint64_t n_new_ub = B.n_tot + std::min<uint64_t>(B.len, (r + 1) * B.m);
 	const unsigned nlf = cdiv(n_new_ub, WIN) + NR;            // output windows, upper bound
-	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);      // string tiles / output windows this handle launches blocks for (rank_share)
+	const unsigned tg = grid8((unsigned)rank_share(h, B.nst_ub));   // string tiles / output windows this handle launches blocks for (rank_share)
 	const unsigned wg = cdiv(B.n_tot + rank_share(h, std::min<uint64_t>(B.len, (r + 1) * B.m)), WIN) + NR;
 	if ((uint64_t)nlf * 64 >= (1ull << 32)) { rb2_fatal("[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); }
 	if (!(B.setup_round == r && !B.setup_sparse && B.setup_epoch == h->layout_epoch))
@@ -526,7 +527,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, (const LeafMeta*)oldp.own); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(cdiv(wg, MW)), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0)); }
+	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(grid8(cdiv(wg, MW))), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0), (int)(r & 1)); }
 	});
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
@@ -600,7 +601,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView pv = h->pool[h->pside].view();
-	const unsigned tg = (unsigned)rank_share(h, B.nst_ub);
+	const unsigned tg = grid8((unsigned)rank_share(h, B.nst_ub));
 	if (++h->split_epoch == 0) ++h->split_epoch;
 	if (!(B.setup_round == r && B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
@@ -709,7 +710,9 @@ void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bo
 	// compact windows (rb2_merge.h) while k_merge is the only reader of the pool until the next rewrite: every interval of the batch is
 	// empty from here on (k_prep<AE> reads no leaf), the batch goes on (its last round leaves plain windows to whoever comes next:
 	// export, rank queries, the next batch's first rounds), and no re-layout is pending
-	round_merge(h, B, r, send, h->compact_ok && B.known_ae && r < B.max_len && !h->plain_next);
+	// (one engine: the kernel itself checks that every interval is empty -- the host learns that ~20 rounds late, from the ne snapshots; a
+	// rank of a sharded index may receive a string with a non-empty interval from another rank: there the global flag decides)
+	round_merge(h, B, r, send, h->compact_ok && (B.known_ae || h->nranks == 1) && r < B.max_len && !h->plain_next);
 }
 
 void batch_trace(rb2_hip_t *h)

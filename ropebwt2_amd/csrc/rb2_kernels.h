@@ -278,7 +278,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row); return; }
 	}
 	const P *U = ctl->ne[par] == 0 ? L : UU;
-	for (uint32_t tile = blockIdx.x - (SPLIT ? sp.nsplitb : 0u); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
+	for (uint32_t tile = (STRIDE || SPLIT) ? blockIdx.x - (SPLIT ? sp.nsplitb : 0u) : xcd_item(); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
 	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with (STRIDE and SPLIT never come together)
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], tile, t)) return;
@@ -806,7 +806,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64
 {
 	// the first tile exactly as a one-tile-per-block kernel would run it (its loads are issued before anything is waited for);
 	// further tiles only when the grid is smaller than the number of tiles (grid stride: see k_sym)
-	for (uint32_t tile = blockIdx.x; ; ) {
+	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {
 		if (!prep_tile<AE, SPARSE, P>(tile, ctl, side, par, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
@@ -1484,7 +1484,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
 		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
 {
-	for (uint32_t tile = blockIdx.x; ; ) {                      // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
+	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {   // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
 		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;

@@ -284,15 +284,20 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 }
 
 template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
-		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, int compact_out)
+		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, int compact_out, int par)
 {
 	__shared__ __align__(16) uint64_t lds[MW][MergeLds<GPL>::WORDS];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
+	// Compact windows only when the device itself knows that no string has a non-empty interval any more (ctl->ne of this round: once zero
+	// it stays zero for the rest of the batch, so the next round's k_prep<false> -- the one reader of leaf words besides this kernel --
+	// returns at once even if the host, which learns it rounds later, still launches it).  The host's consent (bit 0) covers what the
+	// device cannot know: the last round of a batch and a pending change of layout.
+	if (ctl->ne[par] != 0) compact_out &= ~1;
 	// one window per wave; a rank of a sharded index launches fewer waves than the upper bound of its windows (the host does not
 	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows.  The first window's
 	// work order is loaded together with the window count (LD holds an entry for every window a grid can name).
-	uint64_t gw = (uint64_t)blockIdx.x * MW + wv;
+	uint64_t gw = (uint64_t)(STRIDE ? blockIdx.x : xcd_item()) * MW + wv;
 	LeafDesc d = LD[gw];
 	const uint64_t nwin = ctl->wf0[NR];
 	for (; gw < nwin; gw += (uint64_t)gridDim.x * MW, d = LD[gw < nwin ? gw : 0]) {
