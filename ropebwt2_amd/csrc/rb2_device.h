@@ -205,7 +205,7 @@ struct TileFix {            // per string tile, written by k_tfix: what group_se
 	uint32_t popen[6];      // the same count in front of the group that is open at the start of the tile
 	uint32_t pnext[6];      // ... in front of the first group head after the tile (segment total if none)
 	uint32_t fopen;         // first member (segment-relative index) of the group open at the start of the tile
-	uint32_t b, lt, nexthead;   // bucket (sub-rope) of the tile, its number inside the bucket; nexthead: the string behind the tile starts a group (or the bucket ends there)
+	uint32_t b, lt, nexthead;   // bucket (sub-rope) of the tile, its number inside the bucket; nexthead bit 0: the string behind the tile starts a group (or the bucket ends there), bit 1: k_sym did k_prep's work for this tile
 	uint64_t segstart, segend;   // the bucket's range in the string arrays: k_prep / k_advance get their tile context
 	                             // from this one record instead of chasing tile0[] -> start[] / cnt[]
 };

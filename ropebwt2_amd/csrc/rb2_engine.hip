@@ -459,6 +459,7 @@ void maybe_widen(rb2_hip_t *h, BatchState &B, uint64_t r)
 		hipLaunchKernelGGL(k_widen, dim3(cdiv(B.m, 256)), dim3(256), 0, st, (const uint32_t*)h->INS_E.p, a->p, B.m);
 	}
 	h->pos32 = false;
+	B.counted = (uint64_t)-1;                                  // a counting phase queued ahead wrote INS_E in the narrow form (k_sym's fused k_prep): count again
 	if (h->trace) fprintf(stderr, "[rb2_hip] round %llu: positions widened to 64 bits (largest piece known: %llu symbols, %llu rounds ago)\n", (unsigned long long)r, (unsigned long long)known, (unsigned long long)since);
 }
 
@@ -479,9 +480,9 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	      constexpr unsigned NSPLITB = 64;
 	      sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
 	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
-	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp);
+	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
 	    } else
-	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp); }); }
+	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p); }); }
 	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
 	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);

@@ -182,6 +182,12 @@ __device__ __forceinline__ uint32_t pack9(const uint8_t *s, uint64_t len, uint64
 	}
 	return w;
 }
+// ... from the four dwords at s + (p & ~3) (the fast path of pack9, split so that the load can be issued long before its value is needed)
+__device__ __forceinline__ uint32_t pack9_words(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t sh /* 8 * (p & 3) */)
+{
+	const uint32_t w0 = __builtin_amdgcn_alignbit(d1, d0, sh), w1 = __builtin_amdgcn_alignbit(d2, d1, sh), w2 = __builtin_amdgcn_alignbit(d3, d2, sh);
+	return tri4(w0) | tri4(w1) << 12 | (tri4(w2) & 0x7u) << 24;
+}
 __device__ __forceinline__ uint64_t cur_make(uint64_t next_pos, uint32_t syms) { return next_pos << CUR_BITS | syms; }
 __device__ __forceinline__ uint64_t cur_pos(uint64_t w) { return w >> CUR_BITS; }
 __device__ __forceinline__ bool cur_empty(uint64_t w) { return (w & 7) == 0; }
@@ -267,8 +273,15 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb; };
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
 		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB]);
+// Fused k_prep: in a round whose intervals are all empty (ctl->ne[par] == 0) a tile in which every string is a group of its own -- the
+// rule from round ~14 of a batch on -- needs nothing from the tile scans to place its new symbols: slot = the string's index in its
+// bucket, e = l - slot (prep_tile's all-single path).  k_sym has l in hand (it reads L in U's place) and writes INS_E / INS_A itself;
+// the tile is marked done (bit TILE_DONE of its `lh` record -> bit 1 of TileFix::nexthead) and k_prep<AE> returns at once for it.
+// (r04: k_prep<AE> was a second pass over the same strings at 2.3 TB/s: 0.18 ms per round of 42 M strings.)
+constexpr int32_t TILE_DONE = 0x10000;       // in TileRecs::lh (a head index is < STILE)
 template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const P *L, const P *UU,
-		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec, SplitArgs sp)
+		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec, SplitArgs sp,
+		P *INS_E, uint8_t *INS_A)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
 	if (SPLIT) {
@@ -277,7 +290,8 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
 		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row); return; }
 	}
-	const P *U = ctl->ne[par] == 0 ? L : UU;
+	const bool ae = ctl->ne[par] == 0;
+	const P *U = ae ? L : UU;
 	for (uint32_t tile = (STRIDE || SPLIT) ? blockIdx.x - (SPLIT ? sp.nsplitb : 0u) : xcd_item(); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
 	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with (STRIDE and SPLIT never come together)
 	TileCtx t;
@@ -285,13 +299,18 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 	const int ln = lane_id(), w = wave_id();
 	// all loads of the thread's two strings first: A is a byte array (it may alias anything as far as the compiler knows), so a load
 	// written behind the store of the first string's flag would wait for it
-	uint32_t av[2]; P uv[2], up[2];
+	uint32_t av[2]; P uv[2], up[2], un = 0;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		av[h] = 7; uv[h] = 0; up[h] = 0;
 		if (k < t.segend) { av[h] = A[k]; uv[h] = U[k]; up[h] = k > t.segstart ? U[k - 1] : (P)0; }
 	}
+	const bool last_thread = threadIdx.x == 255;
+	const bool has_next = last_thread && t.base + STILE < t.segend;   // the string behind the tile (same bucket): does it start a group?
+	if (has_next) un = U[t.base + STILE];
+	bool single = true;                                       // my strings are groups of their own (and, last thread: so is the tile's end)
+	int sym2[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int pos = h * 256 + threadIdx.x;
@@ -301,14 +320,27 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 			sym = (int)(av[h] & 7);
 			head = (k == t.segstart) || (uv[h] != up[h]);
 			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
+			single = single && head;
 		}
+		sym2[h] = sym;
 		const int c = h * 4 + w;
 #pragma unroll
 		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) s_bal[c][s] = bm; }
 		uint64_t hm = __ballot(head);
 		if (ln == 0) s_head[c] = hm;
 	}
-	__syncthreads();
+	if (has_next) single = single && un != uv[1];
+	const bool fused = __syncthreads_and((int)(ae && single)) != 0;   // (the barrier the tile summaries need anyway)
+	if (fused) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
+			if (t.base + x >= t.segend) continue;
+			const uint64_t slot = t.lt * STILE + x;               // = F: first (only) member of its group, its place in the bucket's insert list
+			INS_E[t.segstart + slot] = (P)((uint64_t)uv[h] - slot);   // empty interval: the new symbol goes to l (pre-round coordinates)
+			INS_A[t.segstart + slot] = (uint8_t)sym2[h];
+		}
+	}
 	if (threadIdx.x < 6) {
 		const int s = threadIdx.x;
 		uint32_t run = 0, fhpre = 0, lhpre = 0; int fh = -1, lh = -1;
@@ -322,7 +354,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 			run += __popcll(bm);
 		}
 		trec.hist(s, tile) = run; trec.fhpre(s, tile) = fhpre; trec.lhpre(s, tile) = lhpre;
-		if (s == 0) { trec.fh(tile) = fh; trec.lh(tile) = lh; }
+		if (s == 0) { trec.fh(tile) = fh; trec.lh(tile) = lh | (fused ? TILE_DONE : 0); }   // (fused: every string is a head, lh >= 0)
 	}
 	if (!STRIDE) return;
 	}
@@ -475,8 +507,9 @@ __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const
 		f.popen[s] = hl ? sl.pre[s] - first.pre[s] + trec.lhpre(s, (uint32_t)lt) : 0u;
 		f.pnext[s] = sn.pre[s] - first.pre[s] + (hn ? trec.fhpre(s, (uint32_t)nt) : 0u);
 	}
-	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + trec.lh((uint32_t)lt)) : 0u;
-	f.b = (uint32_t)b; f.lt = tile - t0; f.nexthead = (tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u;
+	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + (trec.lh((uint32_t)lt) & (TILE_DONE - 1))) : 0u;
+	const int32_t mylh = trec.lh(tile);
+	f.b = (uint32_t)b; f.lt = tile - t0; f.nexthead = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u);
 	f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
 	tf[tile] = f;
 }
@@ -672,8 +705,9 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 				f[6 + s] = hl ? s_pre[s][lt] - first + trec.lhpre(s, (uint32_t)lt) : 0u;              // popen
 				f[12 + s] = s_pre[s][pn] - first + (hn ? trec.fhpre(s, (uint32_t)nx) : 0u);           // pnext
 			}
-			f[18] = hl ? (uint32_t)((lt - (int)t0) * STILE + trec.lh((uint32_t)lt)) : 0u;          // fopen
-			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = (tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u;   // nexthead
+			f[18] = hl ? (uint32_t)((lt - (int)t0) * STILE + (trec.lh((uint32_t)lt) & (TILE_DONE - 1))) : 0u;          // fopen
+			const int32_t mylh = trec.lh(tile);
+			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u);   // nexthead | done
 			const uint64_t ss = sg.start[b], se = ss + sg.cnt[b];
 			f[22] = (uint32_t)ss; f[23] = (uint32_t)(ss >> 32); f[24] = (uint32_t)se; f[25] = (uint32_t)(se >> 32);
 		}
@@ -708,16 +742,20 @@ struct GroupLds {
 	uint32_t allsingle;                         // every string of the tile is a group of its own (the rule once intervals are narrow): group_member takes the short way
 };
 
-// fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none)
-__device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint8_t *A, const TileFix *tf, uint32_t tile, int sym2[2], int flag2[2])
+// fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none).
+// araw[h] = the string's byte of A (symbol + flags), fixw = word threadIdx.x of the tile's TileFix: both LOADED BY THE CALLER together with
+// its own loads of the tile (r04 loaded them in here, one after the other, each waited for at once: the tile kernels walked five
+// dependent round trips to memory -- tile record, strings, A of the first string, A of the second, gathers -- where three do).
+__device__ __forceinline__ uint32_t tilefix_word(const TileFix *tf, uint32_t tile) { return threadIdx.x < TILEFIX_LDS_WORDS ? ((const uint32_t*)&tf[tile])[threadIdx.x] : 0u; }
+__device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const uint32_t araw[2], const uint32_t fixw, int sym2[2], int flag2[2])
 {
 	const int ln = lane_id(), w = wave_id();
-	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = ((const uint32_t*)&tf[tile])[threadIdx.x];
+	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = fixw;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		int sym = 7, fl = 0; bool head = false;
-		if (k < t.segend) { const uint8_t a = A[k]; sym = a & 7; head = (a & 0x80) != 0; fl = a & 0x40; }
+		if (k < t.segend) { const uint32_t a = araw[h]; sym = (int)(a & 7u); head = (a & 0x80u) != 0; fl = (int)(a & 0x40u); }
 		sym2[h] = sym; flag2[h] = fl;
 		const int c = h * 4 + w;
 #pragma unroll
@@ -734,7 +772,7 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 	}
 	if (threadIdx.x == 6) {                                     // all heads, and the string behind the tile starts a group too?
 		const uint64_t nval = min((uint64_t)STILE, t.segend - t.base);
-		bool all = G.fix.nexthead != 0;
+		bool all = (G.fix.nexthead & 1u) != 0;
 		for (int c = 0; c < 8; ++c) {
 			const uint64_t vm = nval >= (uint64_t)(64 * (c + 1)) ? ~0ull : (nval > (uint64_t)(64 * c) ? lt_mask((int)(nval - 64 * c)) : 0ull);
 			all = all && G.head[c] == vm;
@@ -824,17 +862,20 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	const SegDesc &sg = ctl->seg[side];
 	if ((ctl->ne[par] == 0) != AE) return false;
 	if (tile >= sg.tile0[NR]) return false;
+	if (AE && (tfx.nexthead & 2u)) return true;                // k_sym placed this tile's new symbols itself (all-single tile)
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
 	uint64_t l2[2], u2[2];                                     // issued before the barriers of group_setup
+	uint32_t araw[2];
+	const uint32_t fixw = tilefix_word(tf, tile);
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		l2[h] = u2[h] = 0;
-		if (k < t.segend) { l2[h] = L[k]; u2[h] = AE ? l2[h] : U[k]; }
+		l2[h] = u2[h] = 0; araw[h] = 7;
+		if (k < t.segend) { l2[h] = L[k]; u2[h] = AE ? l2[h] : U[k]; araw[h] = A[k]; }
 	}
-	group_setup(G, t, A, tf, tile, sym2, flag2);
+	group_setup(G, t, araw, fixw, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
 	if (AE) {
@@ -1508,11 +1549,13 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
 	uint64_t w2[2], l2[2];                                     // issued before the barriers of group_setup
+	uint32_t araw[2];
+	const uint32_t fixw = tilefix_word(tf, tile);
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		w2[h] = 0; l2[h] = 0;
-		if (k < t.segend) { w2[h] = W[k]; l2[h] = L[k]; }
+		w2[h] = 0; l2[h] = 0; araw[h] = 7;
+		if (k < t.segend) { w2[h] = W[k]; l2[h] = L[k]; araw[h] = A[k]; }
 	}
 	// per tile and symbol: AC offset minus the directory prefix in front of the piece, and where the bucket's members that insert the
 	// symbol go -- six values each, looked up in LDS by every string instead of rebuilt from two directory loads and two table loads
@@ -1523,44 +1566,82 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		s_acb[a6] = ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6);
 		s_dst[a6] = ctl->dest[t.b][a6];
 	}
-	group_setup(G, t, A, tf, tile, sym2, flag2);                // (its barriers also cover the two tables)
-	uint32_t nz = 0;
+	// The gathers of the round -- the directory entries in front of my new symbol, its rank inside its leaf, the text of a cursor that ran
+	// empty -- are issued NOW, on the assumption that every string of the tile is a group of its own (slot = index in the bucket; the rule
+	// from round ~14 of a batch on): they are in flight while group_setup runs its ballots and barriers.  A tile with a larger group
+	// (block-uniform: G.allsingle) asks again with its real slots.  (r04: gathers behind the barriers -- one more round trip per tile.)
 	const int orda[6] = { sym_ord(0, is_comp), sym_ord(1, is_comp), sym_ord(2, is_comp), sym_ord(3, is_comp), sym_ord(4, is_comp), sym_ord(5, is_comp) };
+	// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
+	// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
+	// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
+	uint64_t rk[2], sz[2], wv[2];
+	bool act0[2];
+	// the four (dense layout) loads of one rank, issued together and only added up when their sum is needed
+	struct RankRaw { uint64_t sbb; uint32_t sbr, meta, rkrel; };
+	auto rank_issue = [&](int h, int a, uint64_t slot, uint64_t F, bool flag, RankRaw &q) {
+		if (SPARSE) {                                          // in-place rounds: the leaf comes from RKLEAF, the prefix from a directory row -- dependent loads, summed here
+			const uint64_t gl = RKLEAF[t.segstart + slot];     // where k_merge_leaf put my symbol
+			q.sbb = sb_cum(newp, gl / SB, a); q.sbr = 0; q.meta = dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)); q.rkrel = RKREL[t.segstart + slot];
+			return;
+		}
+		const uint64_t f = ((!AE && flag) ? (uint64_t)INS_E[t.segstart + slot] : l2[h] - F) + slot;   // where my symbol went: e + slot; empty interval: e = l - F (k_prep)
+		const uint64_t gl = nrp.leaf0 + (f >> LEAF_SH), sb = gl / SB;
+		q.sbb = newp.sbbase[sb >> SCHUNK_SH].cum[a]; q.sbr = newp.sbrec[sb].cum[a]; q.meta = newp.meta[gl].c[a]; q.rkrel = RKREL[t.segstart + slot];
+	};
+	auto rank_sum = [](const RankRaw &q) -> uint64_t { return q.sbb + q.sbr + q.meta + q.rkrel; };
+	RankRaw rq[2];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {                              // speculative: slot = F = my index in the bucket
+		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
+		const int a = (int)(araw[h] & 7u);
+		act0[h] = t.base + x < t.segend && a != 0 && a != 7;
+		rq[h].sbb = 0; rq[h].sbr = rq[h].meta = rq[h].rkrel = 0;
+		const uint64_t slot = t.lt * STILE + x;
+		if (act0[h]) rank_issue(h, a, slot, slot, (araw[h] & 0x40u) != 0, rq[h]);
+	}
+	// a cursor that ran empty (one string in CUR_SYMS per round) is refilled from the batch text: the 16 bytes are asked for here, with the
+	// gathers -- by EVERY lane, the ones that need nothing read the first bytes of the text (one hot line): a load inside a branch of its
+	// own was moved behind the barriers by the compiler, where every wave then waited a whole round trip for it
+	uint32_t rt[2][4]; bool need[2], fastr[2];
+	const uint64_t tlen = ctl->len;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		sz[h] = 0;
+		wv[h] = cur_next(w2[h]);
+		need[h] = act0[h] && cur_empty(wv[h]);
+		const uint64_t tp = cur_pos(wv[h]);
+		fastr[h] = need[h] && tp + 16 <= tlen;
+		const uint32_t *q = fastr[h] ? (const uint32_t*)(s + (tp & ~3ull)) : (const uint32_t*)ctl;   // (16 readable bytes whatever the batch)
+		rt[h][0] = q[0]; rt[h][1] = q[1]; rt[h][2] = q[2]; rt[h][3] = q[3];
+	}
+	group_setup(G, t, araw, fixw, sym2, flag2);                 // (its barriers also cover the two tables)
+	uint32_t nz = 0;
 	// The two strings of a thread go through the kernel level by level -- group bookkeeping (LDS), then every gather of both, then the
 	// stores: written string after string, the second one's loads sat behind the first one's stores (the arrays may alias as far as the
 	// compiler knows) and a thread walked two chains of dependent round trips one after the other.
 	bool act[2];
 	Member mem[2];
-	uint64_t gl[2], rk[2], sz[2], wv[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
 		act[h] = t.base + x < t.segend && sym2[h] != 0;         // sentinel inserted: string is done (mrope.c:310)
 		if (act[h]) mem[h] = group_member(G, t, x, sym2[h], orda);
 	}
-	// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
-	// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
-	// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
-	// where my symbol went: e + slot.  Empty interval: e = l - F (k_prep), no dependent gather needed
+	if (!G.allsingle) {                                        // (block-uniform) some group of the tile has more than one member: the real slots
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		gl[h] = 0;
-		if (!act[h]) continue;
-		if (SPARSE) gl[h] = RKLEAF[t.segstart + mem[h].slot];   // where k_merge_leaf put my symbol
-		else {
-			const uint64_t f = ((!AE && flag2[h]) ? INS_E[t.segstart + mem[h].slot] : l2[h] - mem[h].F) + mem[h].slot;
-			gl[h] = nrp.leaf0 + (f >> LEAF_SH);
-		}
+		for (int h = 0; h < 2; ++h) if (act[h]) rank_issue(h, sym2[h], mem[h].slot, mem[h].F, flag2[h] != 0, rq[h]);
 	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		rk[h] = 0; sz[h] = 0; wv[h] = 0;
-		if (!act[h]) continue;
-		const int a = sym2[h];
-		rk[h] = sb_cum(newp, gl[h] / SB, a) + (SPARSE ? dir_prefix(newp, gl[h] / SB, 1 + a, (uint32_t)(gl[h] % SB)) : (uint32_t)newp.meta[gl[h]].c[a]) + RKREL[t.segstart + mem[h].slot];
-		if (!AE && flag2[h]) sz[h] = SIZE[t.base + h * 256 + threadIdx.x];
-		wv[h] = cur_next(w2[h]);
-		if (cur_empty(wv[h])) wv[h] = cur_refill(s, ctl->len, wv[h]);   // (one string in CUR_SYMS per round)
+		rk[h] = rank_sum(rq[h]);
+		if (need[h]) {
+			const uint64_t tp = cur_pos(wv[h]);
+			wv[h] = fastr[h] ? cur_make(tp + CUR_SYMS, pack9_words(rt[h][0], rt[h][1], rt[h][2], rt[h][3], (uint32_t)(tp & 3) * 8)) : cur_refill(s, tlen, wv[h]);   // (slow way: the last bytes of the text)
+		}
+	}
+	if (!AE) {
+#pragma unroll
+		for (int h = 0; h < 2; ++h) if (act[h] && flag2[h]) sz[h] = SIZE[t.base + h * 256 + threadIdx.x];
 	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
