@@ -52,6 +52,8 @@ GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
 CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
 # the real reference on the FULL configs[1] job, same kind of box (profiles/r01_configs1_cli_vs_reference.json)
 CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5, "measured_in_round": 1, "constant": True,
+                   "age": "a constant from round 1 (four rounds old; the reference has not changed: /root/reference is read-only) -- the full job takes 6.5 min of host time, "
+                          "more than the default run may spend; `bench.py --cpu-full-config` re-measures it on this box",
                    "source": "profiles/r01_configs1_cli_vs_reference.json (oracle/_ref/ropebwt2 -LRds -m4g on all 100 M reads, MI355X box host)"}
 
 
@@ -96,7 +98,7 @@ def cpu_baseline(read_len, so_flag, sample_reads, budget_s=120):
             "full_config": CPU_FULL_CONFIG}
 
 
-def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
+def host_api_rate(HipBwt, so, dev, bufs_dev, sizes, pinned=False):
     """the same job through the host-buffer entry point (rb2_hip_insert_multi): every batch crosses PCIe inside the
     call and nothing is reserved up front -- what a caller of mr_insert_multi gets (mrope.c:258 takes a host buffer)"""
     import numpy as np
@@ -106,6 +108,16 @@ def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
         a = np.empty(n, np.uint8)
         b.L.rb2_hip_memcpy(b.h, a.ctypes.data, p, n, 1)
         host.append(a)
+    reg = []
+    if pinned:                                   # the caller registers its batch buffers once, before the clock (what a long-lived caller -- our CLI -- can do)
+        for a in host:
+            if b.L.rb2_hip_host_register(a.ctypes.data, a.nbytes) == 0:
+                reg.append(a)
+        if len(reg) != len(host):
+            for a in reg:
+                b.L.rb2_hip_host_unregister(a.ctypes.data)
+            b.close()
+            return None
     b.sync()
     t0 = time.perf_counter()
     for a in host:
@@ -113,7 +125,12 @@ def host_api_rate(HipBwt, so, dev, bufs_dev, sizes):
     b.sync()
     dt = time.perf_counter() - t0
     ok = int(b.counts().sum()) == sum(sizes)
+    for a in reg:
+        b.L.rb2_hip_host_unregister(a.ctypes.data)
     b.close()
+    if pinned:
+        return {"value": sum(sizes) / dt / 1e9, "unit": "Gsymbols/s", "seconds": dt, "counts_ok": ok,
+                "what": "the same, the caller's buffers registered with the runtime (rb2_hip_host_register = hipHostRegister) once, before the clock: PCIe-inclusive"}
     # (rb2_hip_prefetch does not help THIS pattern -- batches fired back to back from pageable memory: a copy that runs beside the
     # insert kernels takes twice as long and slows them, tools/prefetch_probe.py; it pays where a batch is assembled over seconds,
     # as in the CLI: profiles/r03_configs2_full_cli_1gpu.txt)
@@ -299,7 +316,7 @@ def measure_traffic(budget_s=240):
                                      "--no-cpu-baseline --no-extras` (one configs[1] job, %d k_merge launches); counters in KiB, FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md)" % n}
 
 
-def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.0):
+def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.0, name="configs[2] shape"):
     """BASELINE.json configs[2]'s shape on ONE GPU (1.2 B x 101 bp, RCLO, -R, ropebwt2's default -m10g: 12 batches on a growing
     index): how the rate falls as the index grows.  Batches are generated on the device just before they are inserted; only the
     inserts are timed.  Result checked through the count matrix (sums, LF consistency)."""
@@ -314,7 +331,7 @@ def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.
         done, times = 0, []
         while done < reads:
             n = min(per_batch, reads - done)
-            b.synth_reads(buf, done, n, L, seed=42)
+            b.synth_reads(buf, done, n, L, seed=42 if L == 101 else 44)
             b.sync()
             t0 = time.perf_counter()
             b.insert_multi_dev(buf, n * (L + 1))
@@ -329,8 +346,8 @@ def secondary_configs2(so_name="rclo", reads=1_200_000_000, L=101, batch_gib=10.
     finally:
         b.close()
     return {"value": total / sum(times) / 1e9, "unit": "Gsymbols/s", "insert_s": sum(times), "batch_s": [round(t, 3) for t in times], "counts_ok": bool(ok),
-            "layout": st, "what": "configs[2] shape on 1 GPU: %d x %d bp, %s, forward strand, -m%gg (%d batches, %.1f G symbols), inputs generated on the device, inserts timed"
-                                  % (reads, L, so_name.upper(), batch_gib, len(times), total / 1e9)}
+            "layout": st, "what": "%s on 1 GPU: %d x %d bp, %s, forward strand, -m%gg (%d batches, %.1f G symbols), inputs generated on the device, inserts timed"
+                                  % (name, reads, L, so_name.upper(), batch_gib, len(times), total / 1e9)}
 
 
 def secondary_configs3(reads=1_000_000, L=10_000, batch_gib=10.0):
@@ -419,6 +436,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2]-shape leg")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic in-run (use the committed summary if it matches the sources)")
     ap.add_argument("--cpu-sample-reads", type=int, default=10_000_000, help="reads of the reference's bounded sample (10 M: ~25 s of inserts)")
+    ap.add_argument("--configs3-full", action="store_true", help="also run BASELINE.json configs[3] at FULL size on one GPU (10 M x 10 kbp, ten -m10g batches, ~40 s): secondary.configs3_full_1gpu")
+    ap.add_argument("--cpu-full-config", action="store_true", help="re-measure cpu_baseline.full_config: the reference on ALL reads of configs[1] (~6.5 min of host time)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -543,10 +562,14 @@ def main():
     counts = bwt.counts()
     ok_counts = int(counts.sum()) == sum(sizes[:last]) and int(counts[:, 0].sum()) == sum(n for _, n in job[:last])
     mstats = bwt.stats() if isinstance(bwt, Multi) else None
-    host_api = None
+    host_api = host_api_pinned = None
     if rank == 0 and n_ranks == 1 and not args.no_extras:
         bwt.reset()
         host_api = host_api_rate(HipBwt, so, dev, [p[0] for p in bufs], sizes)
+        try:
+            host_api_pinned = host_api_rate(HipBwt, so, dev, [p[0] for p in bufs], sizes, pinned=True)
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("[bench] pinned host-API leg failed: %r\n" % (e,))
     for p in bufs:
         bwt.free(p)
     bwt.close()
@@ -619,8 +642,24 @@ def main():
                                                              % (tf.get("src_sha"), src_sha())}
         except Exception:  # noqa: BLE001
             pass
+    # achieved HBM rate per kernel group: the PMC bytes per round (a separate, serialised run of the same job) over the in-run hipEvent time per round
+    tgr = out["roofline"].get("traffic_GB_per_round")
+    if tgr and mk["launches"]:
+        groups = {"k_sym": ["k_sym"], "k_tscan": ["k_tscan1", "k_tscan2", "k_tscan3", "k_tfix", "k_tscan_setup", "k_setup"], "k_prep": ["k_prep"], "k_part": ["k_part"],
+                  "k_merge": ["k_merge"], "k_meta": ["k_meta_sb", "k_sbscan3", "k_sbscan2"], "k_advance": ["k_advance"]}
+        per = {}
+        for g, ks in groups.items():
+            gb = sum(tgr.get(k, 0.0) for k in ks)
+            ms = prof[g]["ms"] / mk["launches"] if g in prof else 0.0
+            if gb > 0 and ms > 0:
+                per[g] = {"GB_per_round": round(gb, 4), "ms_per_round": round(ms, 4), "TB_per_s": round(gb / ms, 3), "frac_of_peak": round(gb / ms / (HBM_PEAK_GBS / 1e3), 3)}
+        out["roofline"]["per_kernel"] = per
+        out["roofline"]["per_kernel_note"] = ("GB_per_round: FETCH x2 + WRITE of the PMC passes (the x2 is calibrated for wide streaming reads, MI355X_MICROARCH.md: it overstates kernels "
+                                              "that gather 2-16 byte items); ms_per_round: hipEvent scopes of the timed run, launch gaps inside a scope included")
     if host_api is not None:
         out["value_host_api"] = host_api
+    if host_api_pinned is not None:
+        out["value_host_api_pinned"] = host_api_pinned
     if n_ranks == 1 and not args.no_extras:
         wp = whole_process(args.reads, L, so_flag, args.batch)
         if wp is not None:
@@ -634,6 +673,11 @@ def main():
                 out.setdefault("secondary", {})["configs3_shape_tenth_1gpu"] = secondary_configs3()
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("[bench] secondary long-read leg failed: %r\n" % (e,))
+            if args.configs3_full:
+                try:
+                    out.setdefault("secondary", {})["configs3_full_1gpu"] = secondary_configs2("io", 10_000_000, 10_000, 10.0, name="configs[3] at full size")
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("[bench] full configs[3] leg failed: %r\n" % (e,))
             try:
                 cv = secondary_coverage()
                 if cv is not None:
@@ -642,6 +686,10 @@ def main():
                 sys.stderr.write("[bench] secondary coverage leg failed: %r\n" % (e,))
     if not args.no_cpu_baseline and n_ranks == 1:
         out["cpu_baseline"] = cpu_baseline(L, so_flag, args.cpu_sample_reads)
+        if args.cpu_full_config and is_cfg1:
+            full = cpu_baseline(L, so_flag, args.reads, budget_s=900)
+            if full.get("kind") == "reference":
+                out["cpu_baseline"]["full_config"] = {"value": full["value"], "unit": "Gsymbols/s", "threads": 5, "constant": False, "sample": full["sample"], "measured": "in this run"}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

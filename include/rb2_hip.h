@@ -93,6 +93,14 @@ int  rb2_hip_last_batch_counts(rb2_hip_t *h, int64_t d[36]);
  * call it before reallocating or freeing a buffer that was announced).  (The reference reads and inserts in one thread,
  * main.c:238-242; this is what lets the PCIe crossing of batch k+1 hide behind the insertion of batch k.) */
 void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t capacity);
+/* A caller that hands the same host buffers to rb2_hip_insert_multi again and again (batch after batch, as main.c:238 does with its
+ * one read buffer) can page-lock them once: the batch then crosses PCIe by DMA straight from the caller's memory instead of through the
+ * runtime's staging copies of pageable memory.  Thin wrappers of hipHostRegister / hipHostUnregister, so that a plain-C host needs no HIP
+ * header; 0 on success.  Optional: an unregistered buffer works as before.  (No counterpart in the reference: mrope.c:258 takes a
+ * pointer and reads it on the CPU.) */
+int rb2_hip_host_register(void *p, int64_t nbytes);
+int rb2_hip_host_unregister(void *p);
+
 /* free / total memory of a device in bytes (0, 0 without a usable GPU; never aborts): what `ropebwt2 -m auto` sizes its batches from */
 void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes);
 

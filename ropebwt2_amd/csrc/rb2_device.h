@@ -2,34 +2,32 @@
 //
 // Layout in HBM (all sizes are compile-time constants below):
 //
-//   sub-rope      rope b is kept as six independent pieces (b,x), x = the symbol following b in the
-//                 row's suffix; NR = 31 pieces (see below).  A piece is a flat array of 3-bit symbols.
-//   group         GSYM = 64 consecutive symbols as three 64-bit BIT PLANES: bit i of plane k = bit k of symbol i.
-//                 Counting symbols is popcounts of dense words, a symbol compare is two ANDs of XORed planes, and every
-//                 position -> (word, bit) computation is a shift (rounds 1-3 packed 21 three-bit fields into a word:
-//                 divisions by 21 and 1344 everywhere, 22 VALU per 21 symbols for the counts).
-//   leaf          LEAFG = 16 groups = LEAF = 1024 symbols = LEAFW = 48 words = LEAFB = 384 bytes = three 128-byte
-//                 lines, PLANE-MAJOR: word pl * 16 + g holds plane pl of group g.  A leaf is one DPP row of 16 lanes
-//                 (lane = group, the three planes in registers): a wave works on four leaves at once and every
-//                 wave-level load or store moves whole 128-byte lines.
-//                 Dense layout: every leaf of a piece holds exactly LEAF symbols except the last, so "which leaf
-//                 holds position p" is p >> 10 -- no B+ tree descent (the reference walks rpnode_t buckets,
-//                 rope.c:119-134).  Run-length coding (rle.h:39-75) only happens on export (k_export).
-//   LeafMeta      16 B per leaf: per-symbol counts of the preceding leaves of the same superblock
-//                 (u16 x 6), their total (npre) and the leaf's own fill (n).  A second array (`own`)
-//                 holds every leaf's own counts: the merge kernels write it, k_meta_sb turns it into
-//                 the prefixes.
-//   sparse layout the same arrays, but leaves carry SLACK (fill <= LEAF, only the first few slots of
-//                 a superblock in use): rounds that touch few leaves insert IN PLACE into the leaves
-//                 they hit (k_merge_leaf) instead of rewriting the piece, and position -> leaf becomes
-//                 a search over sbpos / the fills (locate()) instead of a shift -- the counterpart of
-//                 the reference's B+ tree descent (rope.c:119-134) with its half-full leaves.
-//   superblock    SB consecutive leaves; Cnt6 (6 x u64) exclusive prefix of symbol counts over
-//                 the whole pool.  rank(a, p) = sbcum + meta.rel + in-leaf popcounts  (rope_rank2a,
-//                 rope.c:179-194 / rle_rank2a, rle.c:134-191).
-//   pool          two sides (ping-pong); each round the merge kernel streams side -> side^1.
-//   strings       SoA per-string state (reference triple64_t, mrope.c:174-178): L, U (interval in
-//                 the reference's own coordinates), W (string id + the next 10 symbols, 3 bits each).
+//   sub-rope      rope b is kept as six independent pieces (b,x), x = the symbol following b in the row's suffix; NR = 31 pieces
+//                 (see below).  A piece is a flat array of symbols; pieces lie back to back in the pool, each on a superblock boundary.
+//   group         GSYM = 64 consecutive symbols as three 64-bit BIT PLANES: bit i of plane k = bit k of symbol i.  Counting symbols is
+//                 popcounts of dense words, a symbol compare is two ANDs of XORed planes, every position -> (word, bit) is a shift.
+//   leaf          LEAFG = 16 groups = LEAF = 1024 symbols = LEAFW = 48 words = LEAFB = 384 bytes = three 128-byte lines, PLANE-MAJOR:
+//                 word pl * 16 + g holds plane pl of group g.  A leaf is one DPP row of 16 lanes (lane = group, the planes in registers).
+//                 Dense layout: every leaf of a piece holds exactly LEAF symbols except the last, "which leaf holds position p" is
+//                 p >> 10 -- no B+ tree descent (the reference walks rpnode_t buckets, rope.c:119-134).
+//   window        WPL = 4 consecutive leaves = 4096 symbols = twelve lines: the unit of the dense merge (one wave, lane = group) and of the
+//                 COMPACT format (rb2_merge.h "window formats"): between two rewrites that only the merge reads, a window keeps planes 0, 1
+//                 and, in place of its four plane-2 lines, up to two lines of exception positions ($ / N) -- or nothing at all.
+//                 The format of a window = LeafMeta::npre of its first leaf in own[] (0 = plain, what everything but k_merge expects).
+//   own[]         16 B per leaf (LeafMeta): its six own counts + fill, written by whoever writes the leaf (k_merge, k_relayout, the loader).
+//   meta[]        dense layout: 16 B per leaf, the counts of the preceding leaves of the same superblock (k_meta_sb, from own[]);
+//                 sparse layout: the same 512 bytes per superblock are eight rows of 32 u16 -- row 0 fills, rows 1-6 own counts, row 7 the
+//                 claim word of k_split -- that an in-place insert updates by atomics on its own entries (dir_row / dir_commit).
+//   sparse layout the same arrays, but leaves carry SLACK (SP_FILL symbols after a re-layout, SP_USED of a superblock's 32 slots in use):
+//                 rounds that touch few leaves insert IN PLACE (k_merge_leaf), position -> leaf is a search (locate()), a leaf that fills
+//                 up is split into a free slot of its superblock (k_split: split_node, rope.c:78-112).
+//   superblock    SB = 32 leaf slots.  Pool-wide prefix in two levels: SbRec (32 B per superblock: 32-bit prefixes of the six counts and of
+//                 the position inside its chunk of SCHUNK = 1024 superblocks) + SbBase (64-bit, per chunk); SbTot: the superblock's own
+//                 totals, six 16-bit fields.  rank(a, p) = sbbase + sbrec + meta prefix + in-leaf popcounts (rope_rank2a, rope.c:179-194).
+//   pool          two sides (ping-pong in dense rounds, one side in place in sparse ones); arrays grow behind reserved address ranges.
+//   strings       SoA per-string state (reference triple64_t, mrope.c:174-178), ping-pong: L, U (the interval in the reference's own
+//                 coordinates, piece-relative, 32-bit storage while no piece can hold 2^32 symbols), W (the next CUR_SYMS = 9 symbols,
+//                 3 bits each, + the text position of the symbols behind them), A (this round's symbol + group-head / non-empty flags).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

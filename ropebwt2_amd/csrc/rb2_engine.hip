@@ -926,6 +926,18 @@ void rb2_hip_prefetch(rb2_hip_t *h, const uint8_t *s, int64_t n_final, int64_t c
 	h->pf_cv.notify_all();
 }
 
+int rb2_hip_host_register(void *p, int64_t nbytes)
+{
+	if (!p || nbytes <= 0) return -1;
+	if (hipHostRegister(p, (size_t)nbytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	return 0;
+}
+int rb2_hip_host_unregister(void *p)
+{
+	if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+	return 0;
+}
+
 void rb2_hip_mem_info(int device, int64_t *free_bytes, int64_t *total_bytes)
 {
 	size_t fr = 0, tot = 0;

@@ -59,6 +59,8 @@ def load_hip_lib():
         "rb2_hip_sparse_stats": (None, [vp, vp]),
         "rb2_hip_layout_stats": (None, [vp, vp]),
         "rb2_hip_window_stats": (None, [vp, vp]),
+        "rb2_hip_host_register": (C.c_int, [vp, C.c_int64]),
+        "rb2_hip_host_unregister": (C.c_int, [vp]),
         "rb2_hip_profile": (None, [vp, i32]),
         "rb2_hip_profile_get": (None, [vp, vp, vp, vp, i32]),
         "rb2_hip_kernel_name": (C.c_char_p, [i32]),
@@ -107,7 +109,7 @@ ABI_SYMBOLS = [
     "rb2_hip_insert_multi", "rb2_hip_insert_multi_dev", "rb2_hip_set_lazy", "rb2_hip_wait", "rb2_hip_last_batch_counts", "rb2_hip_prefetch", "rb2_hip_mem_info", "rb2_hip_get_counts", "rb2_hip_rope_bytes",
     "rb2_hip_download_rope", "rb2_hip_stream_rope", "rb2_hip_load_ropes", "rb2_hip_rank1a", "rb2_hip_rank_batch", "rb2_hip_reserve", "rb2_hip_dev_alloc",
     "rb2_hip_num_subropes", "rb2_hip_memcpy", "rb2_hip_use_stream",
-    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_synth_reads_skew", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_window_stats", "rb2_hip_profile",
+    "rb2_hip_dev_free", "rb2_hip_synth_reads", "rb2_hip_synth_reads_cov", "rb2_hip_synth_reads_skew", "rb2_hip_sync", "rb2_hip_sparse_stats", "rb2_hip_layout_stats", "rb2_hip_window_stats", "rb2_hip_host_register", "rb2_hip_host_unregister", "rb2_hip_profile",
     "rb2_hip_profile_get", "rb2_hip_kernel_name", "rb2_hip_layout",
     "rb2_hip_multi_create", "rb2_hip_multi_unique_id", "rb2_hip_multi_create_rank", "rb2_hip_multi_destroy", "rb2_hip_default_owners",
     "rb2_hip_multi_nranks", "rb2_hip_multi_transport", "rb2_hip_multi_nlocal", "rb2_hip_multi_engine", "rb2_hip_multi_insert_multi", "rb2_hip_multi_insert_multi_dev",

@@ -20,7 +20,7 @@ SETS = [("10k_x_101", 10000, 101, 42), ("100k_x_101", 100000, 101, 42), ("1M_x_1
 for name, n, L, seed in SETS:
     text = reads_to_text(splitmix_bases(n, L, seed))
     rec = {"n_reads": n, "read_len": L, "seed": seed, "input_md5": md5(text), "fmd_md5": {}, "text_md5": {}}
-    for fl in ("-LR", "-LRs", "-LRr", "-Lr"):
+    for fl in ("-LR", "-LRs", "-LRr", "-Lr", "-L", "-Ls"):      # forward strand in input order / RLO / RCLO; both strands in RCLO, input order, RLO (main.c:227-236)
         rec["fmd_md5"][fl + "d"] = md5(run_ref([fl + "d"], text))
         rec["text_md5"][fl] = md5(run_ref([fl], text))
     out["sets"][name] = rec

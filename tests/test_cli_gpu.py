@@ -28,14 +28,14 @@ def test_kat_fmd_bytes_gpu(golden):
 
 
 @pytest.mark.parametrize("name", ["10k_x_101", "100k_x_101", "200_x_10k", "3k_x_300_s44"])
-@pytest.mark.parametrize("flag", ["-LRd", "-LRsd", "-LRrd", "-Lrd"])
+@pytest.mark.parametrize("flag", ["-LRd", "-LRsd", "-LRrd", "-Lrd", "-Ld", "-Lsd"])
 def test_fmd_golden(golden, name, flag):
     g = golden["sets"][name]
     text = H.reads_to_text(H.splitmix_bases(g["n_reads"], g["read_len"], g["seed"]))
     assert H.md5(cli([flag], text)) == g["fmd_md5"][flag]
 
 
-@pytest.mark.parametrize("flag", ["-LRsd", "-Lrd"])
+@pytest.mark.parametrize("flag", ["-LRsd", "-Lrd", "-Ld", "-Lsd"])
 def test_fmd_golden_1M_small_batches(golden, flag):
     """1 M reads, -m20m -> 5..10 GPU batches; .fmd is independent of the batching"""
     g = golden["sets"]["1M_x_101"]
