@@ -124,7 +124,9 @@ struct Ctl {
 	RopeDesc relay_old[NR]; // k_relayout: the layout being read while rope[side] already describes the one being written
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)
 	uint32_t own[NR + 1];   // own[r] != 0: this rank holds sub-rope r and processes bucket r
-	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a
+	uint64_t sdest[NR][6];  // sharded mode: record offset in the send buffer for members of bucket r inserting a (RCCL transport) ...
+	uint64_t pdst[NR][6];   // ... or where they start in the NEXT arrays of the rank that owns piece (a, b) (PEER transport: k_advance writes them there itself)
+	uint32_t pdev[NR][6];   // ... and which rank that is
 	// The work list of a sparse round (touched leaves, appended by k_part_sparse, read by k_merge_leaf) is WLC lists, the c-th 64th of the
 	// string tiles appends to list c: ONE counter took a returning atomic from every string tile, and atomics on one address are served
 	// one after the other (~12 ns each on MI355X: 25 us for 2048 tiles, tools/ubench/hot_atomic.hip; counters inside one 128-byte line
@@ -143,6 +145,10 @@ constexpr int WLS = 32;                 // their counters sit 128 bytes apart
 // (Rounds 1-2 sent 16 bytes and rebuilt the cursor on arrival from the batch text every rank holds: a 20-byte random gather per
 // string and round on the receiver, ~100 B of HBM traffic to save 8 B on the wire -- and pure loss between ranks of one device.)
 struct ShardRec { uint64_t a, b, w; };
+// PEER transport: the next-round string arrays and the control block of every rank of the handle, as this device sees them (its own
+// memory or a peer mapping): k_advance stores a string that changes owner straight into the owner's arrays (posted writes over xGMI)
+// instead of leaving a record for the owner to fetch.  64 = RB2_MULTI_MAX_RANKS (include/rb2_hip.h).
+struct PushTab { uint64_t *L2[64], *U2[64], *W2[64]; uint8_t *A2[64]; struct Ctl *ctl[64]; };
 __host__ __device__ inline ShardRec shard_pack(uint64_t l, uint64_t size, uint32_t id, uint64_t w)
 {
 	ShardRec r; r.a = (l & 0xffffffffffffull) | (size & 0xffffull) << 48; r.b = (uint64_t)id | (size >> 16) << 32; r.w = w; return r;

@@ -236,6 +236,7 @@ struct rb2_hip_s {
 	uint64_t *gcnt = nullptr;           // device: NR x 6 count matrix of the current round
 	bool own_stream = true;
 	int rank = 0, nranks = 1; int owner[NR] = {0};
+	PushTab *push[2] = {nullptr, nullptr};   // PEER transport of a sharded index: device tables of every rank's next arrays, [side of the arrays being written] (rb2_multi.h); else null
 	int nactive = 1;                    // ranks that own a sub-rope other than rope $ (sizes the grids of a sharded rank: tile_grid)
 	DevBuf<uint8_t> xstage, xpack; DevBuf<uint16_t> xnb; DevBuf<uint64_t> xoff;   // k_export staging, packed bytes, chunk offsets
 	uint8_t *xhost[2] = {nullptr, nullptr}; uint64_t *xtot[2] = {nullptr, nullptr}; hipEvent_t xev[2] = {nullptr, nullptr};   // pinned double buffer
@@ -518,7 +519,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	if ((uint64_t)nlf * 64 >= (1ull << 32)) { rb2_fatal("[rb2_hip] the index is too large for one k_merge launch (%llu symbols: a launch is capped at 2^32 threads)\n", (unsigned long long)n_new_ub); }
 	if (!(B.setup_round == r && !B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr); }
+	  hipLaunchKernelGGL(k_setup<false>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)(h->push[0] != nullptr)); }
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true, P>), (k_prep<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
@@ -535,11 +536,11 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true, P>), (k_advance<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr);
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true, P>), (k_advance<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]); }
 	});
-	if (!B.known_ae && !send) ne_snapshot(h, r);
+	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
 	h->pool_compact = compact_out;
@@ -606,7 +607,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	if (++h->split_epoch == 0) ++h->split_epoch;
 	if (!(B.setup_round == r && B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
-	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr); }
+	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)(h->push[0] != nullptr)); }
 	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
@@ -625,9 +626,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true, P>), (k_advance<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p);
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p, (const PushTab*)h->push[cur ^ 1]);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p, (const PushTab*)h->push[cur ^ 1]); }
 	});
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h) --
 	// or, when the counting phase of round r + 1 is queued at once (spec), blocks of their own in its first launch (k_sym<.., SPLIT>)
@@ -639,7 +640,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
 	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
 	// the next merge.
-	if (!B.known_ae && !send) ne_snapshot(h, r);
+	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());
 	if (!sp) HIPCHK(hipEventRecord(h->ev_flag, st));           // (k_split left the verdict in pinned memory)
 	h->side ^= 1; B.cur ^= 1;

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, con
 // Block 0 also writes the rows of the count matrix this rank can see -- gcnt[r * 6 + a] = members of (local) bucket r inserting a --
 // and word NR * 6 of the buffer (GCN, rb2_device.h), and, on one GPU (do_setup), runs k_setup of the round on its first wave: the local
 // matrix IS the global one.  (Two launches of their own before; nothing k_setup writes is read by the other blocks of this kernel.)
-template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax);
+template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax, bool keep_ne = false);
 // spec: as in k_tscan_setup below -- queued before the host saw the verdict of the in-place round in front of it; a void round (ctl->overflow) is redone
 // from its own counting phase, and k_setup of the NEXT round must not have replaced the descriptors it starts from.
 __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const TileRecs trec, const TileScan *tsc, TileFix *tf, uint64_t *gcnt, int do_setup, int sparse,
@@ -520,10 +520,12 @@ __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const
 // SPARSE: the round inserts in place -- every piece keeps its slots (leaf0, nleaves, sb0), only n and the counts move.
 // hmax (pinned host memory, may be null): the round and the size of the largest piece after it -- what the host needs to know
 // to keep the per-string positions in 32-bit storage for as long as they fit (rb2_device.h "P"; one 8-byte store, no copy command)
-template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax)
+// keep_ne: the next round's "some interval is non-empty" flag is not cleared here (PEER transport of a sharded index: the other ranks'
+// k_advance set it, and they may run ahead of this rank's k_mround; the host clears it before the round's counting phase instead)
+template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax, bool keep_ne)
 {
 	const int r = lane_id();
-	if (r == 0) { ctl->ne[par ^ 1] = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
+	if (r == 0) { if (!keep_ne) ctl->ne[par ^ 1] = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
 	if (r < WLC) ctl->wcnt[r * WLS] = 0;                       // the work lists of a sparse round
 	if (r == 0) ctl->wstride = max(1u, (ctl->seg[side].tile0[NR] + WLC - 1) / WLC) * STILE;   // wstride / STILE consecutive tiles share a list, a tile appends at most STILE orders
 	const bool ok = r < NR;
@@ -585,10 +587,10 @@ template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int 
 	}
 	if (ok) ctl->dest[r][0] = 0;
 }
-template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax)
+template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, int side, const uint64_t *gcnt, int par, uint32_t round, volatile unsigned long long *hmax, int keep_ne)
 {
 	if (blockIdx.x) return;
-	setup_body<SPARSE>(ctl, side, gcnt, par, round, hmax);
+	setup_body<SPARSE>(ctl, side, gcnt, par, round, hmax, keep_ne != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1518,15 +1520,15 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF);
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push);
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push)
 {
 	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {   // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
-		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF)) return;
+		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF, push)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1537,7 +1539,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64
 template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF)
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
@@ -1561,10 +1563,12 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	// symbol go -- six values each, looked up in LDS by every string instead of rebuilt from two directory loads and two table loads
 	__shared__ uint64_t s_acb[6], s_dst[6];
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
+	__shared__ uint32_t s_pr[6];                               // PEER transport: the rank a member that inserts the symbol moves to
 	if (threadIdx.x < 6) {
 		const int a6 = threadIdx.x;
 		s_acb[a6] = ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6);
-		s_dst[a6] = ctl->dest[t.b][a6];
+		s_dst[a6] = push ? ctl->pdst[t.b][a6] : ctl->dest[t.b][a6];
+		s_pr[a6] = push ? ctl->pdev[t.b][a6] : 0u;
 	}
 	// The gathers of the round -- the directory entries in front of my new symbol, its rank inside its leaf, the text of a cursor that ran
 	// empty -- are issued NOW, on the assumption that every string of the tile is a group of its own (slot = index in the bucket; the rule
@@ -1651,14 +1655,19 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		const uint64_t l = s_acb[a] + rk[h] - m.pa + m.pga;
 		const uint64_t u = l + sz[h];
 		const uint64_t d = s_dst[a] + m.pa;
-		if (send) {                                            // sharded: the string travels to the owner of piece (a, b), cursor and all
+		if (push) {                                            // sharded, PEER transport: straight into the next arrays of the owner of piece (a, b) (mrope.c:303-309: the scatter is a write)
+			const uint32_t pr = s_pr[a];
+			push->L2[pr][d] = l; push->W2[pr][d] = wv[h]; push->A2[pr][d] = (uint8_t)cur_sym(wv[h]);
+			push->U2[pr][d] = u;                                 // always: the owner may hold non-empty intervals of other senders next round and then reads U of every string
+			if (!AE && u != l) push->ctl[pr]->ne[(round & 1) ^ 1] = 1;   // (the owner's flag: its next round sees a non-empty interval)
+		} else if (send) {                                     // sharded, RCCL transport: the string travels as a record, cursor and all
 			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv[h]);
 		} else {
 			L2[d] = (P)l; W2[d] = wv[h]; A2[d] = (uint8_t)cur_sym(wv[h]);
 			if (!AE) { U2[d] = (P)u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}
-	if (!AE && !send) {                                        // does the next round see a non-empty interval?  (a flag: plain store, no atomic)
+	if (!AE && !send && !push) {                               // does the next round see a non-empty interval?  (a flag: plain store, no atomic)
 		if (__any(nz != 0) && lane_id() == 0) ((Ctl*)ctl)->ne[(round & 1) ^ 1] = 1;
 	}
 	return true;

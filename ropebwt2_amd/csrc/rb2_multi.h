@@ -113,7 +113,7 @@ template <bool SPARSE> __global__ __launch_bounds__(256) void k_mround(Ctl *ctl,
 	const int t = threadIdx.x;
 	if (t < NR * 5) {
 		const MPlan P = mplan_entry(g, ow.o, t);
-		if (P.s == me) ctl->sdest[P.r][P.a] = P.off;
+		if (P.s == me) { ctl->sdest[P.r][P.a] = P.off; ctl->pdst[P.r][P.a] = P.dst; ctl->pdev[P.r][P.a] = (uint32_t)P.d; }   // RCCL: place in my send buffer; PEER: place in the owner's next arrays
 		if (P.d == me && P.cnt) {
 			MPiece p;
 			p.vsrc = P.vsrc; p.dst = P.dst; p.cnt = P.cnt;
@@ -124,7 +124,7 @@ template <bool SPARSE> __global__ __launch_bounds__(256) void k_mround(Ctl *ctl,
 	}
 	__syncthreads();
 	if (t == 0) { tab->total = s_tot; tab->npieces = s_np; tab->pad = 0; }
-	if (t < 64) setup_body<SPARSE>(ctl, side, g, par, round, hmax);
+	if (t < 64) setup_body<SPARSE>(ctl, side, g, par, round, hmax, peer != 0);
 }
 
 // records -> next round's SoA arrays in bucket order, fetched from wherever k_mround says they are: the
@@ -230,6 +230,7 @@ struct MRank {
 	uint64_t *gred = nullptr;               // PEER: the summed matrix (h->gcnt keeps this rank's rows for the peers to read)
 	uint64_t *gloc = nullptr;               // = h->gcnt as created
 	MTab *tab = nullptr;
+	PushTab *push[2] = {nullptr, nullptr};  // PEER: every rank's string arrays of either side as this rank's device sees them (k_advance stores into them)
 	hipEvent_t evA = nullptr, evB = nullptr, evG = nullptr;
 	uint64_t *pin_g = nullptr;              // RCCL: 2 x GCN pinned, the reduced matrix of the round (host sizes the sends from it)
 	ncclComm_t comm = nullptr;
@@ -275,6 +276,7 @@ namespace {
 
 void multi_ensure_exchange(rb2_hip_multi_t *m, MRank &R, uint64_t records)
 {
+	if (m->transport == RB2_TRANSPORT_PEER) return;            // strings are stored straight into their next owner's arrays: no records, no staging
 	if (records <= R.send_cap) return;
 	const size_t cap = records + records / 8 + 1024;
 	for (int i = 0; i < 2; ++i) { if (R.send[i]) HIPCHK(hipFree(R.send[i])); HIPCHK(hipMalloc((void**)&R.send[i], cap * sizeof(ShardRec))); }
@@ -302,6 +304,16 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 	// batches only, and the peers learn the new addresses behind the barrier below.
 	multi_ensure_exchange(m, R, B.m);
 	m->bar.wait();
+	if (peer) {                                                // (behind the barrier: every rank's arrays have their size for this batch)
+		for (int c = 0; c < 2; ++c) {
+			PushTab T;
+			memset(&T, 0, sizeof(T));
+			for (int p = 0; p < m->n; ++p) { rb2_hip_t *q = m->rk[p].h; T.L2[p] = q->L[c].p; T.U2[p] = q->U[c].p; T.W2[p] = q->W[c].p; T.A2[p] = q->A[c].p; T.ctl[p] = q->ctl; }
+			HIPCHK(hipMemcpyAsync(R.push[c], &T, sizeof(T), hipMemcpyHostToDevice, st));
+			h->push[c] = R.push[c];
+		}
+		HIPCHK(hipStreamSynchronize(st));                          // (T lives on this stack)
+	}
 	MOwner ow;
 	memset(&ow, 0, sizeof(ow));
 	for (int r = 0; r < NR; ++r) ow.o[r] = (uint8_t)m->owner[r];
@@ -319,6 +331,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			if (v != ~0ull && (v & 1ull) == 0 && (v >> 32) < r) B.known_ae = true;
 		}
 		h->gcnt = R.gloc;
+		if (peer) HIPCHK(hipMemsetAsync(&h->ctl->ne[(r & 1) ^ 1], 0, 4, st));   // next round's flag: the peers' k_advance of THIS round set it (ordered behind this by evA)
 		round_counts(h, B, r);
 		// the layout of the round (a host decision; a change re-lays the slice out on this stream before anything of the round reads it)
 		choose_layout(h, B, r, m_eff);
@@ -342,7 +355,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 		}
 		// dense round: the slice is rewritten pool -> pool; in-place round: only the touched leaves, and the host reads a one-word
 		// verdict before the exchange may go ahead (a void round is redone densely: its records do not exist yet)
-		round_merge_any(h, B, r, R.send[r & 1], false);           // flips side / cur: B.cur now names next round's arrays
+		round_merge_any(h, B, r, peer ? (ShardRec*)nullptr : R.send[r & 1], false);   // flips side / cur: B.cur now names next round's arrays (PEER: k_advance stores into the owners' arrays, h->push)
 		if (peer) {
 			HIPCHK(hipEventRecord(R.evB, st));
 			m->bar.wait();                                        // every evB of this round is recorded
@@ -374,9 +387,11 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 			}
 			NCCLCHK(N.GroupEnd());
 		}
-		const int cur = B.cur;
-		hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, h->A[cur].p, (uint32_t)r,
-				h->L[cur].p, h->U[cur].p, h->W[cur].p);
+		if (!peer) {                                             // RCCL: the records that arrived -> next round's arrays
+			const int cur = B.cur;
+			hipLaunchKernelGGL(k_munpack, dim3(grid_m), dim3(256), 0, st, (const Ctl*)h->ctl, (const MTab*)R.tab, B.s, h->A[cur].p, (uint32_t)r,
+					h->L[cur].p, h->U[cur].p, h->W[cur].p);
+		}
 		HIPCHK(hipGetLastError());
 	}
 	h->gcnt = R.gloc;
@@ -414,6 +429,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 		HIPCHK(hipMalloc((void**)&R.gred, GCN * 8));
 		HIPCHK(hipMalloc((void**)&R.tab, sizeof(MTab)));
 		HIPCHK(hipMemset(R.tab, 0, sizeof(MTab)));
+		for (int c = 0; c < 2; ++c) HIPCHK(hipMalloc((void**)&R.push[c], sizeof(PushTab)));
 		HIPCHK(hipEventCreateWithFlags(&R.evA, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&R.evB, hipEventDisableTiming));
 		HIPCHK(hipEventCreateWithFlags(&R.evG, hipEventDisableTiming));
@@ -635,7 +651,7 @@ void rb2_hip_multi_destroy(rb2_hip_multi_t *m)
 		if (R.comm) NCCLCHK(rccl().CommDestroy(R.comm));
 		for (int i = 0; i < 2; ++i) if (R.send[i]) HIPCHK(hipFree(R.send[i]));
 		if (R.recv) HIPCHK(hipFree(R.recv));
-		HIPCHK(hipFree(R.gred)); HIPCHK(hipFree(R.tab));
+		HIPCHK(hipFree(R.gred)); HIPCHK(hipFree(R.tab)); for (int c = 0; c < 2; ++c) if (R.push[c]) HIPCHK(hipFree(R.push[c]));
 		HIPCHK(hipEventDestroy(R.evA)); HIPCHK(hipEventDestroy(R.evB)); HIPCHK(hipEventDestroy(R.evG));
 		HIPCHK(hipHostFree(R.pin_g));
 		R.text.release();
