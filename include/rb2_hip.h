@@ -186,7 +186,9 @@ typedef struct rb2_hip_multi_s rb2_hip_multi_t;
  *     transport instead (message on stderr; never a CPU path).  Impossible (a device listed twice AND a pair without peer access): fatal.
  *   - self-test: whenever the ranks sit on more than one physical device (or RB2_MULTI_SELFTEST=1; =0 turns it off) a job of
  *     2000 short reads is built across the ranks and, sub-rope by sub-rope, compared -- device-side checksums and the count matrix
- *     -- with the same job on one engine; a mismatch is fatal.  The handle is reset afterwards. */
+ *     -- with the same job on one engine; a mismatch is fatal.  The handle is reset afterwards.  Under rb2_hip_multi_create_rank (one
+ *     process per GPU) the self-test is a COLLECTIVE: every process of the group must take the same decision, i.e. RB2_MULTI_SELFTEST
+ *     must be set to the same value (or left unset) in all of them -- a rank that skips it alone leaves the others waiting in RCCL. */
 rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_order, int transport, const int *owner /* [NR] or NULL */);
 /* the transport the handle really uses (RB2_TRANSPORT_*) */
 int rb2_hip_multi_transport(const rb2_hip_multi_t *m);

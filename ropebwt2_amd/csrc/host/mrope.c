@@ -36,7 +36,15 @@ typedef struct {
 	uint8_t *raw[6]; int64_t raw_n[6]; int raw_ok;          /* mr_restore_runs: the run bytes of the six ropes, no trees yet */
 	int max_nodes, block_len;
 	struct itr_stream_s *its;                                  /* mr_itr_first without host trees: the walk in progress (one at a time) */
+	int consumed;                                              /* a freeing walk (mr_itr_first(.., 1)) has taken the ropes away: only mr_destroy is valid now (mrope.c:122-125) */
 } mrx_t;
+
+/* The reference destroys each rope behind a freeing iterator and nothing but mr_destroy may follow; it does not check.  Here more entry
+ * points can reach the index afterwards (the lazy host / device copies): they stop with a message instead of reading freed state. */
+static void check_live(const mrope_t *mr, const char *who)
+{
+	if (((const mrx_t*)mr)->consumed) { fprintf(stderr, "[E::%s] this index was consumed by a freeing iterator (mr_itr_first(mr, itr, 1)): only mr_destroy may follow\n", who); exit(1); }
+}
 
 static mrx_t *X(const mrope_t *mr) { return (mrx_t*)mr; }
 static void itr_stream_drop(mrx_t *x);
@@ -226,6 +234,7 @@ static void *load_worker(void *arg)
 
 void mr_sync_host(mrope_t *mr)
 {
+	check_live(mr, "mr_sync_host");
 	mrx_t *x = X(mr);
 	load_job_t job[6];
 	pthread_t th[6];
@@ -295,6 +304,7 @@ void mr_stream_runs(mrope_t *mr, void (*cb)(void *user, const uint8_t *runs, int
 /* host ropes -> device */
 static void sync_dev(mrope_t *mr)
 {
+	check_live(mr, "mr_insert_multi");
 	mrx_t *x = X(mr);
 	uint8_t *rle[6]; int64_t nb[6]; int a;
 	dev_create(x);
@@ -465,6 +475,7 @@ int mr_host_resident(const mrope_t *mr) { return X(mr)->host_ok; }
 
 void mr_itr_first(mrope_t *mr, mritr_t *i, int to_free)
 {
+	check_live(mr, "mr_itr_first");
 	mrx_t *x = X(mr);
 	itr_stream_drop(x);                                         /* a walk that was left half-way */
 	i->r = mr; i->a = 0; i->to_free = to_free;
@@ -503,6 +514,7 @@ static const uint8_t *itr_stream_next(mritr_t *i)
 		}
 		if (++i->a < 6) itr_stream_open(t, i->a);
 	}
+	if (i->to_free) { if (!t->on_dev) x->raw_ok = 0; x->consumed = 1; }   /* the run bytes / the ropes are gone: no copy of the index is whole any more (check_live) */
 	itr_stream_drop(x);
 	return 0;
 }
@@ -516,6 +528,7 @@ const uint8_t *mr_itr_next_block(mritr_t *i)
 		if (i->to_free) { rope_destroy(i->r->r[i->a]); i->r->r[i->a] = 0; }   /* mrope.c:122-125 */
 		if (++i->a < 6) rope_itr_first(i->r->r[i->a], &i->i);
 	}
+	if (i->to_free) X(i->r)->consumed = 1;                      /* (check_live) */
 	return 0;
 }
 

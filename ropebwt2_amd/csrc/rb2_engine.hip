@@ -31,10 +31,10 @@ static void *g_fatal_user = nullptr;
 #include <cstdarg>
 #include <atomic>
 #include <mutex>
-static thread_local bool t_rank_thread = false;
-static std::atomic<int> g_rank_failed{0};
-static std::mutex g_rank_mu;
-static char g_rank_msg[1024];
+// (the failure record belongs to the HANDLE whose rank thread failed: the rank threads of another, healthy rb2_hip_multi_t in the same
+// process neither see the flag at their barriers nor consume the message)
+struct RankFail { std::atomic<int> failed{0}; std::mutex mu; char msg[1024]; };
+static thread_local RankFail *t_rank_fail = nullptr;       // set on the host threads of a handle's ranks (rank_threads, rb2_multi.h)
 struct RankAbort {};
 [[noreturn]] static void rb2_fatal(const char *fmt, ...)
 {
@@ -43,8 +43,8 @@ struct RankAbort {};
 	va_start(ap, fmt);
 	vsnprintf(msg, sizeof(msg), fmt, ap);
 	va_end(ap);
-	if (t_rank_thread) {
-		{ std::lock_guard<std::mutex> lk(g_rank_mu); if (!g_rank_failed.load()) { memcpy(g_rank_msg, msg, sizeof(msg)); g_rank_failed.store(1); } }
+	if (t_rank_fail) {
+		{ std::lock_guard<std::mutex> lk(t_rank_fail->mu); if (!t_rank_fail->failed.load()) { memcpy(t_rank_fail->msg, msg, sizeof(msg)); t_rank_fail->failed.store(1); } }
 		throw RankAbort();
 	}
 	fputs(msg, stderr);

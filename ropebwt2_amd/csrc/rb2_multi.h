@@ -196,28 +196,29 @@ RcclApi &rccl()
 struct SpinBarrier {
 	std::atomic<int> count{0}, gen{0};
 	int n = 1;
+	RankFail *fail = nullptr;                                   // the owning handle's failure record
 	void wait()
 	{
 		if (n <= 1) return;
 		const int g = gen.load(std::memory_order_acquire);
 		if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); gen.fetch_add(1, std::memory_order_release); return; }
 		for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
-			if (g_rank_failed.load(std::memory_order_relaxed)) throw RankAbort();   // a rank gave up (rb2_fatal on its thread): nobody waits for it
+			if (fail && fail->failed.load(std::memory_order_relaxed)) throw RankAbort();   // a rank of THIS handle gave up (rb2_fatal on its thread): nobody waits for it
 			if (spins > 4000) std::this_thread::yield();
 		}
 	}
 };
 
 // f(local rank) on a thread per local rank; a fatal error on one of them is reported here, on the calling thread (rb2_fatal)
-template <class F> void rank_threads(int n, F f)
+template <class F> void rank_threads(RankFail *rf, int n, F f)
 {
 	std::vector<std::thread> th;
-	for (int k = 0; k < n; ++k) th.emplace_back([&f, k]() { t_rank_thread = true; try { f(k); } catch (const RankAbort &) {} });
+	for (int k = 0; k < n; ++k) th.emplace_back([&f, k, rf]() { t_rank_fail = rf; try { f(k); } catch (const RankAbort &) {} });
 	for (auto &t : th) t.join();
-	if (g_rank_failed.load()) {                                 // (cleared first: the handler may leave by longjmp, and other handles may live on)
+	if (rf->failed.load()) {                                    // (cleared first: the handler may leave by longjmp)
 		char msg[1024];
-		memcpy(msg, g_rank_msg, sizeof(msg)); msg[sizeof(msg) - 1] = 0;
-		g_rank_failed.store(0);
+		memcpy(msg, rf->msg, sizeof(msg)); msg[sizeof(msg) - 1] = 0;
+		rf->failed.store(0);
 		rb2_fatal("%s", msg);
 	}
 }
@@ -261,6 +262,7 @@ struct ShardedText {
 };
 
 struct rb2_hip_multi_s {
+	RankFail fail;                          // a fatal error on one of this handle's rank threads (reported on the calling thread)
 	ShardedText stext;
 	int n = 0, world = 0, rank0 = 0, transport = 0, so = 0;
 	int owner[NR];
@@ -403,7 +405,7 @@ void multi_rank_batch(rb2_hip_multi_t *m, int k, int64_t len)
 void multi_run(rb2_hip_multi_t *m, int64_t len)
 {
 	if (m->n == 1) { multi_rank_batch(m, 0, len); return; }
-	rank_threads(m->n, [&](int k) { multi_rank_batch(m, k, len); });
+	rank_threads(&m->fail, m->n, [&](int k) { multi_rank_batch(m, k, len); });
 }
 
 rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int so, int transport, const int *owner)
@@ -417,7 +419,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 	if (owner) { for (int r = 0; r < NR; ++r) m->owner[r] = owner[r]; } else rb2_hip_default_owners(world, m->owner);
 	for (int r = 0; r < NR; ++r) if (m->owner[r] < 0 || m->owner[r] >= world) { rb2_fatal("[rb2_hip] multi: bad owner of sub-rope %d\n", r); }
 	{ bool seen[RB2_MULTI_MAX_RANKS] = {false}; m->active = 0; for (int r = 1; r < NR; ++r) if (!seen[m->owner[r]]) { seen[m->owner[r]] = true; ++m->active; } }
-	m->bar.n = n;
+	m->bar.n = n; m->bar.fail = &m->fail;
 	m->rk.resize(n);
 	for (int k = 0; k < n; ++k) {
 		MRank &R = m->rk[k];
@@ -455,7 +457,7 @@ rb2_hip_multi_t *multi_new(int n, const int *devices, int world, int rank0, int 
 template <class F> void multi_each(rb2_hip_multi_t *m, F f)
 {
 	if (m->n == 1) { f(0); return; }
-	rank_threads(m->n, f);
+	rank_threads(&m->fail, m->n, f);
 }
 
 } // namespace
