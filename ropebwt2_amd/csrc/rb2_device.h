@@ -226,16 +226,20 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Block b of a launch is observed to run on XCD b % 8 (MI355X_MICROARCH.md), and every XCD has an L2 of its own.  Neighbouring work items
 // of the tile and window kernels share 128-byte lines -- the partial lines at the ends of the chunks a string tile scatters, the old
 // lines two output windows both draw from -- and with blocks dealt round-robin the two halves of such a line meet in two different
-// L2s: the line is fetched twice, a partial write is merged at the memory side.  xcd_item() hands every XCD a contiguous eighth of the
-// items instead (a permutation of the block numbers when the grid is a multiple of eight: the host rounds its grids up; else the
-// identity).  A speed choice only: nothing depends on where a block runs.
+// L2s: the line is fetched twice, a partial write is merged at the memory side.  xcd_item() hands every XCD runs of XCD_RUN consecutive
+// items instead, the runs dealt round-robin (a permutation of the block numbers when the grid is a multiple of 8 * XCD_RUN -- the host
+// rounds its grids up -- else the identity).  Runs, not one contiguous eighth per XCD: work per item is not uniform (round 0 of a batch
+// puts every string into the first windows of the pool), and an eighth of the GRID is an eighth of the CHIP.  A speed choice only:
+// nothing depends on where a block runs.
 #ifndef RB2_XCD
 #define RB2_XCD 1
 #endif
+constexpr uint32_t XCD_RUN = 16;
 __device__ __forceinline__ uint32_t xcd_item()
 {
-	if (!RB2_XCD || (gridDim.x & 7u)) return blockIdx.x;
-	return (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+	if (!RB2_XCD || (gridDim.x & (8u * XCD_RUN - 1u))) return blockIdx.x;
+	const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;    // my XCD, my number among its blocks
+	return (i / XCD_RUN) * (8u * XCD_RUN) + x * XCD_RUN + (i % XCD_RUN);
 }
 
 // segment lookup in a monotone table tab[0..NR] for a WAVE-UNIFORM value v: the s with tab[s] <= v < tab[s+1].

@@ -285,7 +285,7 @@ void drain_profile(rb2_hip_t *h)
 }
 
 inline unsigned cdiv(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
-inline unsigned grid8(unsigned g) { return (g + 7u) & ~7u; }   // grids of the tile / window kernels: a multiple of the XCD count (xcd_item(), rb2_device.h); the extra blocks find nothing to do
+inline unsigned grid8(unsigned g) { return (g + 8u * XCD_RUN - 1u) & ~(8u * XCD_RUN - 1u); }   // grids of the tile / window kernels: a multiple of the XCD count (xcd_item(), rb2_device.h); the extra blocks find nothing to do
 
 // Grids of a rank of a sharded index.  The host knows the batch (m strings, len symbols), not the rank's share of it this round --
 // asking would cost a synchronisation per round.  The upper bound "all of it" makes every launch N times too large: at N = 8
@@ -342,7 +342,7 @@ void ensure_strings(rb2_hip_t *h, uint64_t m)
 	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
 	h->A[0].ensure(m); h->A[1].ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
-	h->trec.ensure(nst + 16); h->tsc.ensure(nst + 16); h->tfix.ensure(nst + 16); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
+	h->trec.ensure(nst + 8 * XCD_RUN + 8); h->tsc.ensure(nst + 8 * XCD_RUN + 8); h->tfix.ensure(nst + 8 * XCD_RUN + 8); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
 }
 
 // A batch may hold at most this many strings (32-bit slots, tile numbers and work orders).  The reference takes any count

@@ -868,7 +868,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
-	uint64_t l2[2], u2[2];                                     // issued before the barriers of group_setup
+	P l2[2], u2[2];                                            // issued before the barriers of group_setup (in the batch's storage width: half the registers while positions fit 32 bits)
 	uint32_t araw[2];
 	const uint32_t fixw = tilefix_word(tf, tile);
 #pragma unroll
@@ -901,13 +901,13 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	//     so one or two waves run the scan instead of all of them;
 	//   - long intervals and those that span leaves are served by whole WAVES (wave_range_counts: one coalesced 512-byte load
 	//     per leaf, bit-plane popcounts per lane, packed DPP reductions): their cost does not grow with the interval.
-	__shared__ uint64_t s_d[AE ? 1 : STILE][6];                // in: [0] = l, [1] = u; out: #s in [l, u) of the group led by string x of the tile
+	__shared__ P s_d[AE ? 1 : STILE][6];                       // in: [0] = l, [1] = u; out: #s in [l, u) of the group led by string x of the tile (a count is at most u - l: it fits the positions' width)
 	__shared__ uint16_t s_qs[AE ? 1 : STILE], s_qw[AE ? 1 : STILE];
 	__shared__ uint32_t s_ns, s_nw;
 	if (threadIdx.x == 0) { s_ns = 0; s_nw = 0; }
 	__syncthreads();
 	Member mm[2];
-	uint64_t l0[2], u0[2];
+	P l0[2], u0[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
@@ -915,7 +915,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 		l0[h] = u0[h] = 0; mm[h].lead = -1;
 		if (k >= t.segend) continue;
 		mm[h] = group_member(G, t, x, sym2[h], orda);
-		l0[h] = l2[h] - mm[h].F; u0[h] = u2[h] - mm[h].F;      // coordinates on the pre-round rope
+		l0[h] = (P)(l2[h] - (P)mm[h].F); u0[h] = (P)(u2[h] - (P)mm[h].F);   // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
 			const bool small = u0[h] - l0[h] <= 3 * GSYM && (SPARSE || ((u0[h] - 1) >> LEAF_SH) == (l0[h] >> LEAF_SH));
 			s_d[x][0] = l0[h]; s_d[x][1] = u0[h];
@@ -934,7 +934,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 		uint64_t d[6];
 		wave_range_counts<SPARSE>(oldp, rp, s_d[x][0], s_d[x][1], d);
 		__builtin_amdgcn_wave_barrier();
-		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
+		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[x][s] = (P)d[s];
 	}
 	__syncthreads();
 #pragma unroll
@@ -943,12 +943,12 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 		const uint64_t k = t.base + x;
 		if (k >= t.segend) continue;
 		const int a = sym2[h];
-		uint64_t e = l0[h];
+		P e = l0[h];
 		if (u0[h] != l0[h]) {
 			const int oa = orda[a];
-			uint64_t size = 0;
+			P size = 0;
 			for (int s = 0; s < 6; ++s) {
-				const uint64_t d = s_d[mm[h].lead][s];
+				const P d = s_d[mm[h].lead][s];
 				if (orda[s] < oa) e += d;
 				if (s == a) size = d;
 			}
