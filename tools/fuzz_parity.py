@@ -13,11 +13,15 @@ from ropebwt2_amd import HipBwt, MultiBwt, build_all
 build_all(); H.build_oracle()
 
 def gen_batch(rng, so):
-    kind = rng.choice(["fixed", "var", "repet", "homo", "tiny", "long", "big", "cover"], p=[.26, .18, .18, .1, .1, .1, .04, .04])
+    kind = rng.choice(["fixed", "var", "repet", "homo", "tiny", "long", "big", "cover", "shorts", "nruns"], p=[.22, .16, .16, .1, .08, .1, .06, .04, .04, .04])
     both = bool(rng.rand() < 0.4)
     if kind == "fixed":
         codes = H.splitmix_bases(int(rng.randint(1, 6000)), int(rng.choice([1, 2, 17, 50, 101, 150])), seed=int(rng.randint(1, 1 << 30)))
         return H.encode_batch_fixed(codes, True, both)
+    if kind == "shorts":                                          # very short reads: a sentinel every few symbols -- windows of the dense layout overflow their exception lists and stay plain
+        return H.encode_batch([rng.randint(1, 5, size=int(n)).astype(np.uint8) for n in rng.randint(1, 8, size=int(rng.randint(5000, 30000)))], True, both)
+    if kind == "nruns":                                           # runs of N between stretches of ACGT
+        return H.encode_batch([np.concatenate([np.full(int(rng.randint(100, 500)), 5, np.uint8), rng.randint(1, 5, size=60).astype(np.uint8)]) for _ in range(int(rng.randint(50, 400)))], True, both)
     if kind == "big":                                             # enough strings for the dense regime on a grown index, and for several tiles per piece
         return H.encode_batch_fixed(H.splitmix_bases(int(rng.randint(20000, 60000)), 101, seed=int(rng.randint(1, 1 << 30))), True, both)
     if kind == "cover":                                           # overlapping reads of one genome: non-empty intervals for many rounds, large groups
@@ -45,6 +49,9 @@ def one(seed):
     elif rng.rand() < 0.2: env.update(RB2_SPARSE_LAMBDA="0")
     if rng.rand() < 0.3: env.update(RB2_SPARSE_HEAD=str(int(rng.choice([0, 1, 3]))))
     if rng.rand() < 0.3: env.update(RB2_LEAF_PIPE=str(int(rng.choice([0, 64, 8192]))))
+    if rng.rand() < 0.2: env.update(RB2_COMPACT="0")               # round 5: windows of the dense layout never compact
+    if rng.rand() < 0.25: env.update(RB2_POS="64")                 # positions in 64-bit storage from the start
+    if rng.rand() < 0.2: env.update(RB2_TS_MAX="2")                # the many-tiles counting kernels for every batch of more than 1024 strings
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     nr = int(rng.choice([1, 1, 1, 2, 3, 8]))
