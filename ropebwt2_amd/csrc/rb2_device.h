@@ -176,7 +176,7 @@ struct SpOrd {              // work order of one touched leaf in a sparse round,
 constexpr int SCHUNK_SH = 10;          // log2(SCHUNK)
 struct SbRec { uint32_t cum[6]; uint32_t pos; uint32_t pad; };     // inside the chunk: symbol counts / symbols in front of the superblock
 struct SbBase { uint64_t cum[6]; uint64_t pos; uint64_t pad; };    // in front of the chunk
-struct PoolView { uint8_t *data; LeafMeta *meta; SbRec *sbrec; LeafMeta *own; SbBase *sbbase; };
+struct PoolView { uint8_t *data; LeafMeta *meta; SbRec *sbrec; LeafMeta *own; SbBase *sbbase; uint8_t *xh; };   // xh: one byte per window (4 leaf slots), the format k_merge wrote it in (rb2_merge.h)
 __device__ __forceinline__ uint64_t sb_pos(const PoolView &pv, uint64_t sb) { return pv.sbbase[sb >> SCHUNK_SH].pos + pv.sbrec[sb].pos; }   // symbols in front of superblock sb (pool-wide)
 __device__ __forceinline__ uint64_t sb_cum(const PoolView &pv, uint64_t sb, int a) { return pv.sbbase[sb >> SCHUNK_SH].cum[a] + pv.sbrec[sb].cum[a]; }
 

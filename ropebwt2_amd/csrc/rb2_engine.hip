@@ -156,7 +156,7 @@ template <typename T> struct DevBuf {
 };
 
 struct Pool {
-	DevBuf<uint8_t> data; DevBuf<LeafMeta> meta, own; DevBuf<SbRec> sbrec; DevBuf<SbBase> sbbase;
+	DevBuf<uint8_t> data, xh; DevBuf<LeafMeta> meta, own; DevBuf<SbRec> sbrec; DevBuf<SbBase> sbbase;
 	uint64_t cap_leaves = 0;
 	void ensure(uint64_t leaves, bool keep, hipStream_t st) {
 		if (leaves <= cap_leaves) return;
@@ -165,11 +165,11 @@ struct Pool {
 		uint64_t nl = std::max<uint64_t>(leaves, cap_leaves + cap_leaves / 4);
 		nl = (nl + SB - 1) / SB * SB;
 		data.ensure(nl * LEAFB, keep, st); meta.ensure(nl, keep, st); own.ensure(nl, keep, st);
-		sbrec.ensure(nl / SB + 1, keep, st); sbbase.ensure(nl / SB / SCHUNK + 2, keep, st);
+		sbrec.ensure(nl / SB + 1, keep, st); sbbase.ensure(nl / SB / SCHUNK + 2, keep, st); xh.ensure(nl / WPL + 1024, keep, st);
 		cap_leaves = nl;
 	}
-	PoolView view() const { return PoolView{data.p, meta.p, sbrec.p, own.p, sbbase.p}; }
-	void release() { data.release(); meta.release(); own.release(); sbrec.release(); sbbase.release(); cap_leaves = 0; }
+	PoolView view() const { return PoolView{data.p, meta.p, sbrec.p, own.p, sbbase.p, xh.p}; }
+	void release() { data.release(); meta.release(); own.release(); sbrec.release(); sbbase.release(); xh.release(); cap_leaves = 0; }
 };
 
 struct ProfRec { int k; hipEvent_t a, b; int64_t units; int round; };
@@ -527,7 +527,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, (const LeafMeta*)oldp.own); }
+	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, h->pool_compact ? (const uint8_t*)oldp.xh : (const uint8_t*)nullptr); }   // (the formats of the old windows: only a pool side the compact-capable merge wrote has any but plain)
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(grid8(cdiv(wg, MW))), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0), (int)(r & 1)); }
 	});

@@ -969,7 +969,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 // A block covers 256 boundaries = 255 windows (boundaries overlap by one between blocks).
 // ---------------------------------------------------------------------------------------------
 
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const P *INS_E, LeafDesc *LD, const LeafMeta *old_own)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part(const Ctl *ctl, int side, const P *INS_E, LeafDesc *LD, const uint8_t *old_xh)
 {
 	__shared__ uint64_t s_wf0[NR + 1];
 	__shared__ uint32_t s_q[256];
@@ -1004,12 +1004,14 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	d.ins0 = ctl->seg[side].start[b] + q;
 	d.gl = nrp.leaf0 + j * WPL;
 	d.oleaf0 = (uint32_t)orp.leaf0;
-	// the formats of the (at most two) old windows the merge will draw from (rb2_merge.h "window formats"): the npre field of their first
-	// leaves' entries in own[]; a window that does not exist reads as "compact, no exceptions" (nothing to fetch)
+	// the formats of the (at most two) old windows the merge will draw from (rb2_merge.h "window formats"): one byte per window, written by the
+	// merge that wrote the old side (old_xh == null: that side holds plain windows only -- a re-layout, the loader, or a round that was
+	// not allowed to write compact ones); a window that does not exist reads as "compact, no exceptions" (nothing to fetch)
 	const uint64_t ow = i0 >> 12, onw = (orp.nleaves + WPL - 1) / WPL;
 	static_assert(WPL * LEAF == 4096, "a window is 4096 symbols");
-	const uint32_t h0 = ow < onw ? (uint32_t)old_own[orp.leaf0 + ow * WPL].npre & 3u : 1u;
-	const uint32_t h1 = ow + 1 < onw ? (uint32_t)old_own[orp.leaf0 + (ow + 1) * WPL].npre & 3u : 1u;
+	const uint8_t *xw = old_xh ? old_xh + orp.leaf0 / WPL : nullptr;
+	const uint32_t h0 = ow < onw ? (xw ? (uint32_t)xw[ow] & 3u : 0u) : 1u;
+	const uint32_t h1 = ow + 1 < onw ? (xw ? (uint32_t)xw[ow + 1] & 3u : 0u) : 1u;
 	d.ni = (uint16_t)((uint32_t)(q1 - q) | h0 << 14);
 	d.nvalid = (uint16_t)((uint32_t)min((uint64_t)WIN, nrp.n - o0) | h1 << 14);
 	LD[s_wf0[b] + j] = d;

@@ -87,8 +87,8 @@ __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 // What rle_insert_cached gains by coding runs (rle.c:63-86, rle.h:53-75) -- fewer bytes per symbol than a fixed-width field -- is gained
 // here by not storing the plane that almost never differs.
 // The format of a window is the `npre` field of its first leaf's entry in own[] (written by the merge with the leaf's counts; k_relayout
-// and the loader write 0 = plain).  k_part hands the formats of the (at most two) old windows an output window draws from to the merge
-// in its work order.  Only k_merge reads and writes compact windows: the host asks for them (compact_out) only when every reader of
+// and the loader write 0 = plain), mirrored in one byte per window (PoolView::xh) that is valid on a pool side this kernel wrote.  k_part
+// hands the formats of the (at most two) old windows an output window draws from to the merge in its work order.  Only k_merge reads and writes compact windows: the host asks for them (compact_out) only when every reader of
 // the pool until the next rewrite is k_merge again -- all intervals empty, not the last round of the batch, no change of layout ahead.
 constexpr uint32_t WF_PLAIN = 0, WF_C0 = 1, WF_C1 = 2, WF_C2 = 3;   // compact: 0 / 1 / 2 exception lines
 constexpr uint32_t XCAP1 = 63, XCAP2 = 127;                          // exceptions one / two lines hold
@@ -275,6 +275,7 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 		m.npre = (uint16_t)(lf == 0 ? fmt : 0u);                // the window's format rides in its first leaf's entry
 		m.n = (uint16_t)(FULL ? (uint32_t)LEAF : min((uint32_t)LEAF, nvalid - lf * (uint32_t)LEAF));
 		newp.own[d.gl + lf] = m;                                // own counts + fill; k_meta_sb turns them into prefixes
+		if (lf == 0) newp.xh[d.gl / WPL] = (uint8_t)fmt;       // ... and in the byte per window k_part reads next round (16 bytes apart in own[], a line per 128 windows here)
 	}
 	uint64_t *dstw = (uint64_t*)newp.data + d.gl * LEAFW;       // the window; lane's group: leaf lf, group ln & 15
 	const uint32_t doff = lf * LEAFW + (ln32 & 15u);
