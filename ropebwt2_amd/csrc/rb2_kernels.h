@@ -299,27 +299,32 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 	const int ln = lane_id(), w = wave_id();
 	// all loads of the thread's two strings first: A is a byte array (it may alias anything as far as the compiler knows), so a load
 	// written behind the store of the first string's flag would wait for it
+	// every access of the tile is a wave-uniform base + a 32-bit offset (string x of the tile = string t.base + x of the arrays; its slot in the
+	// bucket's insert list, lt * STILE + x, is the same place in INS_E / INS_A): no 64-bit address arithmetic per lane
+	const uint32_t nval = (uint32_t)min((uint64_t)STILE, t.segend - t.base);   // strings in this tile
+	const uint8_t *Ab = A + t.base; const P *Ub = U + t.base;
+	const bool first_tile = t.base == t.segstart;
 	uint32_t av[2]; P uv[2], up[2], un = 0;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
 		av[h] = 7; uv[h] = 0; up[h] = 0;
-		if (k < t.segend) { av[h] = A[k]; uv[h] = U[k]; up[h] = k > t.segstart ? U[k - 1] : (P)0; }
+		if (x < nval) { av[h] = Ab[x]; uv[h] = Ub[x]; up[h] = (x > 0 || !first_tile) ? Ub[(int32_t)x - 1] : (P)0; }
 	}
 	const bool last_thread = threadIdx.x == 255;
 	const bool has_next = last_thread && t.base + STILE < t.segend;   // the string behind the tile (same bucket): does it start a group?
-	if (has_next) un = U[t.base + STILE];
+	if (has_next) un = Ub[STILE];
 	bool single = true;                                       // my strings are groups of their own (and, last thread: so is the tile's end)
 	int sym2[2];
+	uint8_t *Aw = A + t.base;
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const int pos = h * 256 + threadIdx.x;
-		const uint64_t k = t.base + pos;
+		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
 		int sym = 7; bool head = false;
-		if (k < t.segend) {
+		if (x < nval) {
 			sym = (int)(av[h] & 7);
-			head = (k == t.segstart) || (uv[h] != up[h]);
-			A[k] = (uint8_t)(sym | (head ? 0x80 : 0));
+			head = (x == 0 && first_tile) || (uv[h] != up[h]);
+			Aw[x] = (uint8_t)(sym | (head ? 0x80 : 0));
 			single = single && head;
 		}
 		sym2[h] = sym;
@@ -332,13 +337,14 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 	if (has_next) single = single && un != uv[1];
 	const bool fused = __syncthreads_and((int)(ae && single)) != 0;   // (the barrier the tile summaries need anyway)
 	if (fused) {
+		P *Eb = INS_E + t.base; uint8_t *Ib = INS_A + t.base;     // slot + segstart = t.base + x
+		const P slot0 = (P)(t.lt * STILE);
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
-			if (t.base + x >= t.segend) continue;
-			const uint64_t slot = t.lt * STILE + x;               // = F: first (only) member of its group, its place in the bucket's insert list
-			INS_E[t.segstart + slot] = (P)((uint64_t)uv[h] - slot);   // empty interval: the new symbol goes to l (pre-round coordinates)
-			INS_A[t.segstart + slot] = (uint8_t)sym2[h];
+			if (x >= nval) continue;
+			Eb[x] = (P)(uv[h] - (slot0 + (P)x));                   // empty interval: the new symbol goes to l - F (pre-round coordinates), F = slot = lt * STILE + x
+			Ib[x] = (uint8_t)sym2[h];
 		}
 	}
 	if (threadIdx.x < 6) {
