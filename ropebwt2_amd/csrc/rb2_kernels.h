@@ -1558,24 +1558,31 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	TileCtx t;
 	tile_ctx_fix(tfx, t);
 	int sym2[2], flag2[2];
-	uint64_t w2[2], l2[2];                                     // issued before the barriers of group_setup
+	uint64_t w2[2]; P l2[2];                                   // issued before the barriers of group_setup
 	uint32_t araw[2];
 	const uint32_t fixw = tilefix_word(tf, tile);
+	// Every access of the tile is a wave-uniform base + a 32-bit offset, and every position is computed in the batch's storage width P
+	// (while positions are stored in 32 bits the sums below are exact modulo 2^32 and their results are below 2^32: half the integer
+	// instructions and registers of the 64-bit form -- the kernel issued 352 VALU per wave of 128 strings)
+	const uint32_t nval = (uint32_t)min((uint64_t)STILE, t.segend - t.base);   // strings in this tile
+	{
+		const uint64_t *Wb = W + t.base; const P *Lb = L + t.base; const uint8_t *Ab = A + t.base;
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		const uint64_t k = t.base + h * 256 + threadIdx.x;
-		w2[h] = 0; l2[h] = 0; araw[h] = 7;
-		if (k < t.segend) { w2[h] = W[k]; l2[h] = L[k]; araw[h] = A[k]; }
+		for (int h = 0; h < 2; ++h) {
+			const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
+			w2[h] = 0; l2[h] = 0; araw[h] = 7;
+			if (x < nval) { w2[h] = Wb[x]; l2[h] = Lb[x]; araw[h] = Ab[x]; }
+		}
 	}
 	// per tile and symbol: AC offset minus the directory prefix in front of the piece, and where the bucket's members that insert the
 	// symbol go -- six values each, looked up in LDS by every string instead of rebuilt from two directory loads and two table loads
-	__shared__ uint64_t s_acb[6], s_dst[6];
+	__shared__ P s_acb[6]; __shared__ uint32_t s_dst[6];       // (a batch has < 2^32 strings: places in the string arrays fit 32 bits)
 	const RopeDesc &nrp = ctl->rope[side ^ 1][t.b];
 	__shared__ uint32_t s_pr[6];                               // PEER transport: the rank a member that inserts the symbol moves to
 	if (threadIdx.x < 6) {
 		const int a6 = threadIdx.x;
-		s_acb[a6] = ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6);
-		s_dst[a6] = push ? ctl->pdst[t.b][a6] : ctl->dest[t.b][a6];
+		s_acb[a6] = (P)(ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6));
+		s_dst[a6] = (uint32_t)(push ? ctl->pdst[t.b][a6] : ctl->dest[t.b][a6]);
 		s_pr[a6] = push ? ctl->pdev[t.b][a6] : 0u;
 	}
 	// The gathers of the round -- the directory entries in front of my new symbol, its rank inside its leaf, the text of a cursor that ran
@@ -1586,30 +1593,33 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	// rank of a in front of my new symbol on the NEW rope = directory prefix of its leaf + count inside
 	// the leaf (k_merge); minus the PA new a's in front of it = rank on the old rope = what
 	// rope_insert_run returns (rope.c:147) before the a's of earlier groups (PGA) are added back
-	uint64_t rk[2], sz[2], wv[2];
+	P rk[2], sz[2]; uint64_t wv[2];
 	bool act0[2];
 	// the four (dense layout) loads of one rank, issued together and only added up when their sum is needed
-	struct RankRaw { uint64_t sbb; uint32_t sbr, meta, rkrel; };
-	auto rank_issue = [&](int h, int a, uint64_t slot, uint64_t F, bool flag, RankRaw &q) {
+	struct RankRaw { P sbb; uint32_t sbr, meta, rkrel; };
+	const LeafMeta *metab = newp.meta + nrp.leaf0; const SbRec *sbrb = newp.sbrec + nrp.sb0;   // the piece's first leaf / superblock (a piece starts on a superblock boundary)
+	const uint16_t *RKb = RKREL + t.segstart; const P *Eb = INS_E + t.segstart; const uint32_t *RLb = SPARSE ? RKLEAF + t.segstart : nullptr;
+	auto rank_issue = [&](int h, int a, uint32_t slot, P F, bool flag, RankRaw &q) {
 		if (SPARSE) {                                          // in-place rounds: the leaf comes from RKLEAF, the prefix from a directory row -- dependent loads, summed here
-			const uint64_t gl = RKLEAF[t.segstart + slot];     // where k_merge_leaf put my symbol
-			q.sbb = sb_cum(newp, gl / SB, a); q.sbr = 0; q.meta = dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)); q.rkrel = RKREL[t.segstart + slot];
+			const uint64_t gl = RLb[slot];                     // where k_merge_leaf put my symbol
+			q.sbb = (P)sb_cum(newp, gl / SB, a); q.sbr = 0; q.meta = dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)); q.rkrel = RKb[slot];
 			return;
 		}
-		const uint64_t f = ((!AE && flag) ? (uint64_t)INS_E[t.segstart + slot] : l2[h] - F) + slot;   // where my symbol went: e + slot; empty interval: e = l - F (k_prep)
-		const uint64_t gl = nrp.leaf0 + (f >> LEAF_SH), sb = gl / SB;
-		q.sbb = newp.sbbase[sb >> SCHUNK_SH].cum[a]; q.sbr = newp.sbrec[sb].cum[a]; q.meta = newp.meta[gl].c[a]; q.rkrel = RKREL[t.segstart + slot];
+		const P f = (P)(((!AE && flag) ? Eb[slot] : (P)(l2[h] - F)) + (P)slot);   // where my symbol went: e + slot; empty interval: e = l - F (k_prep)
+		const uint32_t lf = (uint32_t)(f >> LEAF_SH), sbq = (uint32_t)nrp.sb0 + lf / SB;      // its leaf of the piece (a piece has < 2^32 leaves), its superblock of the pool
+		const P *bb = (const P*)&newp.sbbase[sbq >> SCHUNK_SH].cum[a];                       // (little endian: the low half when positions are stored in 32 bits)
+		q.sbb = *bb; q.sbr = sbrb[lf / SB].cum[a]; q.meta = metab[lf].c[a]; q.rkrel = RKb[slot];
 	};
-	auto rank_sum = [](const RankRaw &q) -> uint64_t { return q.sbb + q.sbr + q.meta + q.rkrel; };
+	auto rank_sum = [](const RankRaw &q) -> P { return (P)(q.sbb + q.sbr + q.meta + q.rkrel); };
 	RankRaw rq[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {                              // speculative: slot = F = my index in the bucket
 		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
 		const int a = (int)(araw[h] & 7u);
-		act0[h] = t.base + x < t.segend && a != 0 && a != 7;
+		act0[h] = x < nval && a != 0 && a != 7;
 		rq[h].sbb = 0; rq[h].sbr = rq[h].meta = rq[h].rkrel = 0;
-		const uint64_t slot = t.lt * STILE + x;
-		if (act0[h]) rank_issue(h, a, slot, slot, (araw[h] & 0x40u) != 0, rq[h]);
+		const uint32_t slot = (uint32_t)t.lt * STILE + x;
+		if (act0[h]) rank_issue(h, a, slot, (P)slot, (araw[h] & 0x40u) != 0, rq[h]);
 	}
 	// a cursor that ran empty (one string in CUR_SYMS per round) is refilled from the batch text: the 16 bytes are asked for here, with the
 	// gathers -- by EVERY lane, the ones that need nothing read the first bytes of the text (one hot line): a load inside a branch of its
@@ -1636,12 +1646,12 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
-		act[h] = t.base + x < t.segend && sym2[h] != 0;         // sentinel inserted: string is done (mrope.c:310)
+		act[h] = (uint32_t)x < nval && sym2[h] != 0;            // sentinel inserted: string is done (mrope.c:310)
 		if (act[h]) mem[h] = group_member(G, t, x, sym2[h], orda);
 	}
 	if (!G.allsingle) {                                        // (block-uniform) some group of the tile has more than one member: the real slots
 #pragma unroll
-		for (int h = 0; h < 2; ++h) if (act[h]) rank_issue(h, sym2[h], mem[h].slot, mem[h].F, flag2[h] != 0, rq[h]);
+		for (int h = 0; h < 2; ++h) if (act[h]) rank_issue(h, sym2[h], mem[h].slot, (P)mem[h].F, flag2[h] != 0, rq[h]);
 	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
@@ -1653,26 +1663,26 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	}
 	if (!AE) {
 #pragma unroll
-		for (int h = 0; h < 2; ++h) if (act[h] && flag2[h]) sz[h] = SIZE[t.base + h * 256 + threadIdx.x];
+		for (int h = 0; h < 2; ++h) if (act[h] && flag2[h]) sz[h] = (SIZE + t.base)[(uint32_t)(h * 256) + threadIdx.x];
 	}
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		if (!act[h]) continue;
 		const int a = sym2[h];
 		const Member &m = mem[h];
-		const uint64_t l = s_acb[a] + rk[h] - m.pa + m.pga;
-		const uint64_t u = l + sz[h];
-		const uint64_t d = s_dst[a] + m.pa;
+		const P l = (P)(s_acb[a] + rk[h] - (P)m.pa + (P)m.pga);
+		const P u = (P)(l + sz[h]);
+		const uint32_t d = s_dst[a] + m.pa;
 		if (push) {                                            // sharded, PEER transport: straight into the next arrays of the owner of piece (a, b) (mrope.c:303-309: the scatter is a write)
 			const uint32_t pr = s_pr[a];
 			push->L2[pr][d] = l; push->W2[pr][d] = wv[h]; push->A2[pr][d] = (uint8_t)cur_sym(wv[h]);
 			push->U2[pr][d] = u;                                 // always: the owner may hold non-empty intervals of other senders next round and then reads U of every string
 			if (!AE && u != l) push->ctl[pr]->ne[(round & 1) ^ 1] = 1;   // (the owner's flag: its next round sees a non-empty interval)
 		} else if (send) {                                     // sharded, RCCL transport: the string travels as a record, cursor and all
-			send[ctl->sdest[t.b][a] + m.pa] = shard_pack(l, u - l, 0u, wv[h]);
+			send[ctl->sdest[t.b][a] + m.pa] = shard_pack((uint64_t)l, (uint64_t)(u - l), 0u, wv[h]);
 		} else {
-			L2[d] = (P)l; W2[d] = wv[h]; A2[d] = (uint8_t)cur_sym(wv[h]);
-			if (!AE) { U2[d] = (P)u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
+			L2[d] = l; W2[d] = wv[h]; A2[d] = (uint8_t)cur_sym(wv[h]);
+			if (!AE) { U2[d] = u; nz += (u != l); }            // AE: u == l for every string of the batch from here on; U is dead
 		}
 	}
 	if (!AE && !send && !push) {                               // does the next round see a non-empty interval?  (a flag: plain store, no atomic)
