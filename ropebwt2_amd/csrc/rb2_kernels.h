@@ -279,6 +279,7 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 // the tile is marked done (bit TILE_DONE of its `lh` record -> bit 1 of TileFix::nexthead) and k_prep<AE> returns at once for it.
 // (r04: k_prep<AE> was a second pass over the same strings at 2.3 TB/s: 0.18 ms per round of 42 M strings.)
 constexpr int32_t TILE_DONE = 0x10000;       // in TileRecs::lh (a head index is < STILE)
+constexpr int32_t TILE_SINGLE = 0x20000;     // ... every string of the tile is a group of its own and so is the string behind it (-> TileFix::nexthead bit 2: k_advance asks for its gathers before the barriers only then)
 template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __launch_bounds__(256) void k_sym(const Ctl *ctl, int side, int par, const P *L, const P *UU,
 		uint8_t *A /* in: the symbol every string inserts this round (k_init_strings / k_advance); out: + the group-head flag */, TileRecs trec, SplitArgs sp,
 		P *INS_E, uint8_t *INS_A)
@@ -335,7 +336,8 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		if (ln == 0) s_head[c] = hm;
 	}
 	if (has_next) single = single && un != uv[1];
-	const bool fused = __syncthreads_and((int)(ae && single)) != 0;   // (the barrier the tile summaries need anyway)
+	const bool allsingle = __syncthreads_and((int)single) != 0;   // (the barrier the tile summaries need anyway)
+	const bool fused = ae && allsingle;
 	if (fused) {
 		P *Eb = INS_E + t.base; uint8_t *Ib = INS_A + t.base;     // slot + segstart = t.base + x
 		const P slot0 = (P)(t.lt * STILE);
@@ -360,7 +362,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 			run += __popcll(bm);
 		}
 		trec.hist(s, tile) = run; trec.fhpre(s, tile) = fhpre; trec.lhpre(s, tile) = lhpre;
-		if (s == 0) { trec.fh(tile) = fh; trec.lh(tile) = lh | (fused ? TILE_DONE : 0); }   // (fused: every string is a head, lh >= 0)
+		if (s == 0) { trec.fh(tile) = fh; trec.lh(tile) = lh | (fused ? TILE_DONE : 0) | (allsingle ? TILE_SINGLE : 0); }   // (all-single: every string is a head, lh >= 0)
 	}
 	if (!STRIDE) return;
 	}
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const
 	}
 	f.fopen = hl ? (uint32_t)((lt - t0) * STILE + (trec.lh((uint32_t)lt) & (TILE_DONE - 1))) : 0u;
 	const int32_t mylh = trec.lh(tile);
-	f.b = (uint32_t)b; f.lt = tile - t0; f.nexthead = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u);
+	f.b = (uint32_t)b; f.lt = tile - t0; f.nexthead = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u) | ((mylh >= 0 && (mylh & TILE_SINGLE)) ? 4u : 0u);
 	f.segstart = sg.start[b]; f.segend = sg.start[b] + sg.cnt[b];
 	tf[tile] = f;
 }
@@ -715,7 +717,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 			}
 			f[18] = hl ? (uint32_t)((lt - (int)t0) * STILE + (trec.lh((uint32_t)lt) & (TILE_DONE - 1))) : 0u;          // fopen
 			const int32_t mylh = trec.lh(tile);
-			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u);   // nexthead | done
+			f[19] = (uint32_t)b; f[20] = tile - t0; f[21] = ((tile + 1 >= t1 || trec.fh(tile + 1) == 0) ? 1u : 0u) | ((mylh >= 0 && (mylh & TILE_DONE)) ? 2u : 0u) | ((mylh >= 0 && (mylh & TILE_SINGLE)) ? 4u : 0u);   // nexthead | done | single
 			const uint64_t ss = sg.start[b], se = ss + sg.cnt[b];
 			f[22] = (uint32_t)ss; f[23] = (uint32_t)(ss >> 32); f[24] = (uint32_t)se; f[25] = (uint32_t)(se >> 32);
 		}
@@ -1612,6 +1614,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	};
 	auto rank_sum = [](const RankRaw &q) -> P { return (P)(q.sbb + q.sbr + q.meta + q.rkrel); };
 	RankRaw rq[2];
+	const bool spec = (tfx.nexthead & 4u) != 0;                // k_sym saw a tile of one-member groups (tile-uniform): ask now; else after the groups are known
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {                              // speculative: slot = F = my index in the bucket
 		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
@@ -1619,7 +1622,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		act0[h] = x < nval && a != 0 && a != 7;
 		rq[h].sbb = 0; rq[h].sbr = rq[h].meta = rq[h].rkrel = 0;
 		const uint32_t slot = (uint32_t)t.lt * STILE + x;
-		if (act0[h]) rank_issue(h, a, slot, (P)slot, (araw[h] & 0x40u) != 0, rq[h]);
+		if (spec && act0[h]) rank_issue(h, a, slot, (P)slot, (araw[h] & 0x40u) != 0, rq[h]);
 	}
 	// a cursor that ran empty (one string in CUR_SYMS per round) is refilled from the batch text: the 16 bytes are asked for here, with the
 	// gathers -- by EVERY lane, the ones that need nothing read the first bytes of the text (one hot line): a load inside a branch of its
@@ -1649,7 +1652,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		act[h] = (uint32_t)x < nval && sym2[h] != 0;            // sentinel inserted: string is done (mrope.c:310)
 		if (act[h]) mem[h] = group_member(G, t, x, sym2[h], orda);
 	}
-	if (!G.allsingle) {                                        // (block-uniform) some group of the tile has more than one member: the real slots
+	if (!spec || !G.allsingle) {                               // (block-uniform) some group of the tile has more than one member: the real slots
 #pragma unroll
 		for (int h = 0; h < 2; ++h) if (act[h]) rank_issue(h, sym2[h], mem[h].slot, (P)mem[h].F, flag2[h] != 0, rq[h]);
 	}
