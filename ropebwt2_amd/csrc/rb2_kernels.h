@@ -761,11 +761,11 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 {
 	const int ln = lane_id(), w = wave_id();
 	if (threadIdx.x < TILEFIX_LDS_WORDS) ((uint32_t*)&G.fix)[threadIdx.x] = fixw;
+	const uint32_t nv = (uint32_t)min((uint64_t)STILE, t.segend - t.base);
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const uint64_t k = t.base + h * 256 + threadIdx.x;
 		int sym = 7, fl = 0; bool head = false;
-		if (k < t.segend) { const uint32_t a = araw[h]; sym = (int)(a & 7u); head = (a & 0x80u) != 0; fl = (int)(a & 0x40u); }
+		if ((uint32_t)(h * 256) + threadIdx.x < nv) { const uint32_t a = araw[h]; sym = (int)(a & 7u); head = (a & 0x80u) != 0; fl = (int)(a & 0x40u); }
 		sym2[h] = sym; flag2[h] = fl;
 		const int c = h * 4 + w;
 #pragma unroll
@@ -799,7 +799,7 @@ __device__ __forceinline__ void tile_ctx_fix(const TileFix &f, TileCtx &t)
 	t.base = t.segstart + t.lt * STILE;
 }
 
-struct Member { uint32_t pa, pga, slot; uint64_t F; int lead; };   // lead: first member of my group inside this tile
+struct Member { uint32_t pa, pga, slot, F; int lead; };   // lead: first member of my group inside this tile (F, like slot, is an index inside the bucket: a batch has < 2^32 strings)
 
 // string x of the tile, inserting a: pa = members of the bucket in front of it inserting a, pga = the same count
 // in front of its group, F = first member of its group, slot = its place in the bucket's insert list
@@ -821,16 +821,16 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 	Member m;
 	if (G.allsingle) {                                         // (block-uniform) a tile of one-member groups
 		m.pa = G.fix.tpre[a] + before(x, a);
-		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F; m.lead = x;
+		m.pga = m.pa; m.F = (uint32_t)t.lt * STILE + (uint32_t)x; m.slot = m.F; m.lead = x;
 		return m;
 	}
 	m.pa = G.fix.tpre[a] + before(x, a);
 	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
-		m.pga = m.pa; m.F = t.lt * STILE + x; m.slot = (uint32_t)m.F; m.lead = x;
+		m.pga = m.pa; m.F = (uint32_t)t.lt * STILE + (uint32_t)x; m.slot = m.F; m.lead = x;
 		return m;
 	}
 	m.pga = hpos >= 0 ? G.fix.tpre[a] + before(hpos, a) : G.fix.popen[a];
-	m.F = hpos >= 0 ? t.lt * STILE + hpos : (uint64_t)G.fix.fopen;
+	m.F = hpos >= 0 ? (uint32_t)t.lt * STILE + (uint32_t)hpos : G.fix.fopen;
 	uint32_t bef = 0;                                      // members of my group inserting a smaller symbol
 	const int oa = orda[a];
 	for (int s = 0; s < 6; ++s) {
@@ -839,7 +839,7 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 		const uint32_t pn = npos >= 0 ? G.fix.tpre[s] + before(npos, s) : G.fix.pnext[s];
 		bef += pn - pg;
 	}
-	m.slot = (uint32_t)(m.F + bef + (m.pa - m.pga));
+	m.slot = m.F + bef + (m.pa - m.pga);
 	m.lead = hpos >= 0 ? hpos : 0;
 	return m;
 }
@@ -879,11 +879,12 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	P l2[2], u2[2];                                            // issued before the barriers of group_setup (in the batch's storage width: half the registers while positions fit 32 bits)
 	uint32_t araw[2];
 	const uint32_t fixw = tilefix_word(tf, tile);
+	const uint32_t nval = (uint32_t)min((uint64_t)STILE, t.segend - t.base);   // strings in this tile; every access below: uniform base + 32-bit offset
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		const uint64_t k = t.base + h * 256 + threadIdx.x;
+		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
 		l2[h] = u2[h] = 0; araw[h] = 7;
-		if (k < t.segend) { l2[h] = L[k]; u2[h] = AE ? l2[h] : U[k]; araw[h] = A[k]; }
+		if (x < nval) { l2[h] = (L + t.base)[x]; u2[h] = AE ? l2[h] : (U + t.base)[x]; araw[h] = (A + t.base)[x]; }
 	}
 	group_setup(G, t, araw, fixw, sym2, flag2);
 	const RopeDesc &rp = ctl->rope[side][t.b];
@@ -892,12 +893,11 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			const int x = h * 256 + threadIdx.x;
-			const uint64_t k = t.base + x;
-			if (k >= t.segend) continue;
+			if ((uint32_t)x >= nval) continue;
 			const int a = sym2[h];
 			const Member m = group_member(G, t, x, a, orda);
-			INS_E[t.segstart + m.slot] = (P)(l2[h] - m.F);     // empty interval: the new symbol goes to l (pre-round coordinates)
-			INS_A[t.segstart + m.slot] = (uint8_t)a;
+			(INS_E + t.segstart)[m.slot] = (P)(l2[h] - (P)m.F);   // empty interval: the new symbol goes to l (pre-round coordinates)
+			(INS_A + t.segstart)[m.slot] = (uint8_t)a;
 		}
 		return true;
 	}
@@ -919,9 +919,8 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
-		const uint64_t k = t.base + x;
 		l0[h] = u0[h] = 0; mm[h].lead = -1;
-		if (k >= t.segend) continue;
+		if ((uint32_t)x >= nval) continue;
 		mm[h] = group_member(G, t, x, sym2[h], orda);
 		l0[h] = (P)(l2[h] - (P)mm[h].F); u0[h] = (P)(u2[h] - (P)mm[h].F);   // coordinates on the pre-round rope
 		if (mm[h].lead == x && u0[h] != l0[h]) {               // rope_rank2a (mrope.c:202)
@@ -948,8 +947,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
-		const uint64_t k = t.base + x;
-		if (k >= t.segend) continue;
+		if ((uint32_t)x >= nval) continue;
 		const int a = sym2[h];
 		P e = l0[h];
 		if (u0[h] != l0[h]) {
@@ -960,11 +958,11 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 				if (orda[s] < oa) e += d;
 				if (s == a) size = d;
 			}
-			SIZE[k] = (P)size;                                 // only non-empty intervals have one (flag 0x40 in A)
-			A[k] = (uint8_t)(a | 0x40 | (G.head[x >> 6] >> (x & 63) & 1 ? 0x80 : 0));
+			(SIZE + t.base)[x] = (P)size;                                 // only non-empty intervals have one (flag 0x40 in A)
+			(A + t.base)[x] = (uint8_t)(a | 0x40 | (G.head[x >> 6] >> (x & 63) & 1 ? 0x80 : 0));
 		}
-		INS_E[t.segstart + mm[h].slot] = (P)e;
-		INS_A[t.segstart + mm[h].slot] = (uint8_t)a;
+		(INS_E + t.segstart)[mm[h].slot] = (P)e;
+		(INS_A + t.segstart)[mm[h].slot] = (uint8_t)a;
 	}
 	return true;
 }
