@@ -451,11 +451,11 @@ __device__ __forceinline__ Loc locate_dense(const RopeDesc &rp, uint64_t p)
 // counts of all six symbols in [0,p) of a sub-rope on pool side `pv` (rope_rank1a, rope.h:45):
 // superblock prefix + leaf-relative prefix + popcounts over the groups of the leaf up to p
 // (the reference walks the runs of one leaf, rle.c:147-158).  SPARSE: leaves carry slack, the leaf is found by locate().
-template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
+template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, Q out[6])
 {
 	if (p >= rp.n) {
 #pragma unroll
-		for (int s = 0; s < 6; ++s) out[s] = rp.cnt[s];
+		for (int s = 0; s < 6; ++s) out[s] = (Q)rp.cnt[s];
 		return;
 	}
 	uint64_t gl; uint32_t off;
@@ -475,13 +475,15 @@ template <bool SPARSE = false> __device__ inline void rank_all(const PoolView &p
 	uint32_t c[6];
 	pl_finish(A, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = (Q)(sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s]);
 }
 
 // occurrences of the six symbols inside [l, u), l < u: what mr_insert_multi_aux needs from rope_rank2a (tu[] - tl[],
 // mrope.c:202-224).  When the interval lies in one leaf -- the common case: intervals are short -- this is a scan of the
 // interval itself, no directory and no prefix (rle_rank2a counts the same way, rle.c:134-191); else two full ranks.
-template <bool SPARSE = false> __device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
+// Q: the width the counts are wanted in (the difference of two ranks is exact modulo 2^32 when it is below 2^32: the string kernels ask for
+// uint32_t while positions are stored in 32 bits and keep half the registers)
+template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, Q d[6])
 {
 	uint64_t gl; uint32_t ol; bool one;
 	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
@@ -495,11 +497,11 @@ template <bool SPARSE = false> __device__ inline void range_counts(const PoolVie
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {
-		uint64_t cl[6], cu[6];
-		rank_all<SPARSE>(pv, rp, l, cl);
-		rank_all<SPARSE>(pv, rp, u, cu);
+		Q cl[6], cu[6];
+		rank_all<SPARSE, Q>(pv, rp, l, cl);
+		rank_all<SPARSE, Q>(pv, rp, u, cu);
 #pragma unroll
-		for (int s = 0; s < 6; ++s) d[s] = cu[s] - cl[s];
+		for (int s = 0; s < 6; ++s) d[s] = (Q)(cu[s] - cl[s]);
 	}
 }
 
@@ -562,11 +564,11 @@ __device__ __forceinline__ void wave_leaf_counts(const uint64_t *leaf, uint32_t 
 }
 
 // all 64 lanes call it with the same p
-template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, uint64_t out[6])
+template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wave_rank_all(const PoolView &pv, const RopeDesc &rp, uint64_t p, Q out[6])
 {
 	if (p >= rp.n) {
 #pragma unroll
-		for (int s = 0; s < 6; ++s) out[s] = rp.cnt[s];
+		for (int s = 0; s < 6; ++s) out[s] = (Q)rp.cnt[s];
 		return;
 	}
 	uint64_t gl; uint32_t off;
@@ -588,11 +590,11 @@ template <bool SPARSE> __device__ __forceinline__ void wave_rank_all(const PoolV
 	uint32_t c[6];
 	wave_leaf_counts(leaf_words(pv.data, gl), 0, off, c);
 #pragma unroll
-	for (int s = 0; s < 6; ++s) out[s] = sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s];
+	for (int s = 0; s < 6; ++s) out[s] = (Q)(sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s]);
 }
 
 // occurrences of the six symbols inside [l, u), l < u, by one wave (what range_counts does with one thread)
-template <bool SPARSE> __device__ __forceinline__ void wave_range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, uint64_t d[6])
+template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wave_range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, Q d[6])
 {
 	uint64_t gl; uint32_t ol; bool one;
 	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
@@ -603,11 +605,11 @@ template <bool SPARSE> __device__ __forceinline__ void wave_range_counts(const P
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {
-		uint64_t cl[6], cu[6];
-		wave_rank_all<SPARSE>(pv, rp, l, cl);
-		wave_rank_all<SPARSE>(pv, rp, u, cu);
+		Q cl[6], cu[6];
+		wave_rank_all<SPARSE, Q>(pv, rp, l, cl);
+		wave_rank_all<SPARSE, Q>(pv, rp, u, cu);
 #pragma unroll
-		for (int s = 0; s < 6; ++s) d[s] = cu[s] - cl[s];
+		for (int s = 0; s < 6; ++s) d[s] = (Q)(cu[s] - cl[s]);
 	}
 }
 

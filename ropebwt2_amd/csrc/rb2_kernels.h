@@ -932,16 +932,16 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < s_ns; i += 256) {
 		const int x = s_qs[i];
-		uint64_t d[6];
-		range_counts<SPARSE>(oldp, rp, s_d[x][0], s_d[x][1], d);
+		P d[6];
+		range_counts<SPARSE, P>(oldp, rp, s_d[x][0], s_d[x][1], d);
 		for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
 	}
 	for (uint32_t q = wave_id(); q < s_nw; q += 4) {           // wave-uniform loop
 		const int x = s_qw[q];
-		uint64_t d[6];
-		wave_range_counts<SPARSE>(oldp, rp, s_d[x][0], s_d[x][1], d);
+		P d[6];
+		wave_range_counts<SPARSE, P>(oldp, rp, s_d[x][0], s_d[x][1], d);
 		__builtin_amdgcn_wave_barrier();
-		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[x][s] = (P)d[s];
+		if (lane_id() == 0) for (int s = 0; s < 6; ++s) s_d[x][s] = d[s];
 	}
 	__syncthreads();
 #pragma unroll
