@@ -10,22 +10,25 @@
 // three 64-bit words, a leaf = 16 groups, plane-major: rb2_device.h), so the merge is a pure stream:
 // no run decoding, no re-encoding, no length-dependent paths, no divisions.  Run-length coding is
 // applied once, by k_export, when the host asks for the ropes (mr_sync_host -> .fmd/.fmr writers).
+// What rle_insert_cached gains by coding (fewer bytes per symbol than a fixed-width field, rle.h:53-75) is gained here by not
+// storing the third plane of a window where it almost never differs from what the other two imply (round 5: window formats).
 //
-// k_merge work decomposition: ONE WAVE PER OUTPUT WINDOW of 64 * GPL groups (WPL leaves), four
-// independent waves per block, no block-level barrier anywhere.  Lane l owns GPL consecutive groups:
-//   1. the new symbols of the window are OR-ed into position-indexed LDS words -- one flag word and
-//      three plane words per group -- one 64-bit LDS atomic per set bit; the old groups the window
-//      draws from are loaded at the same time (whole 128-byte lines) and staged in LDS
-//   2. one packed wave prefix sum (not-new count | new count) -> first old symbol each lane
-//      consumes; the old bits of each of its groups are an unaligned 64-bit window of each plane
-//   3. expand: open one 1-bit gap per new symbol in each plane (wave-uniform loop, 1-2 trips in
-//      steady state); the new symbols are already in place
-//   4. symbol counts per lane: five popcounts of dense words per group, three packed scans -> new
-//      LeafMeta of each leaf of the window
-//   5. RKREL: every new symbol gets the number of equal symbols before it INSIDE its leaf, one new
-//      symbol per lane (prefix of the owning lane + a masked plane compare of its group, both read back
-//      from LDS); k_advance adds the directory prefix of the new sub-rope to obtain the reference's
-//      return value of rope_insert_run.
+// k_merge work decomposition: ONE WAVE PER OUTPUT WINDOW of 64 groups (WPL = 4 leaves), lane = group, four independent waves
+// per block, no block-level barrier anywhere:
+//   1. the new symbols of the window are OR-ed into position-indexed LDS words -- one flag word and three plane words per group
+//      -- one 64-bit LDS atomic per set bit; the old groups the window draws from are loaded (whole 128-byte lines) and staged in
+//      LDS: three plane words of a PLAIN old window, two of a COMPACT one, whose third plane is OR-ed together from its list of
+//      exception positions ("window formats" below)
+//   2. one wave prefix sum of the not-new counts -> first old symbol each lane consumes; the old bits of its group are an
+//      unaligned 64-bit window of each staged plane (three dword reads, two funnel shifts)
+//   3. expand: open one 1-bit gap per new symbol in each plane (open_gaps: an addition per plane and gap; 1-2 trips in steady
+//      state); the new symbols are already in place
+//   4. symbol counts per lane: five popcounts of dense words, three packed scans inside the DPP row (= leaf) -> LeafMeta of each
+//      leaf, the format of the new window (its $ + N counts are its exceptions) and, for a compact one, its list
+//   5. RKREL: every new symbol gets the number of equal symbols before it INSIDE its leaf, one new symbol per lane (row prefix of
+//      the owning lane + a masked plane compare of its group, both read back from LDS); k_advance adds the directory prefix of the
+//      new sub-rope to obtain the reference's return value of rope_insert_run.
+// The kernel is bound by VALU issue as much as by HBM bytes: every step above is written for instruction count.
 #pragma once
 #include <type_traits>
 #include <utility>
