@@ -51,10 +51,11 @@ HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 GEN = os.path.join(ROOT, "ropebwt2_amd", "bin", "synth_reads")
 CLI = os.path.join(ROOT, "ropebwt2_amd", "bin", "ropebwt2")
 # the real reference on the FULL configs[1] job, same kind of box (profiles/r01_configs1_cli_vs_reference.json)
-CPU_FULL_CONFIG = {"value": 0.0294, "unit": "Gsymbols/s", "insert_s": 346.9, "real_s": 391.4, "threads": 5, "measured_in_round": 1, "constant": True,
-                   "age": "a constant from round 1 (four rounds old; the reference has not changed: /root/reference is read-only) -- the full job takes 6.5 min of host time, "
-                          "more than the default run may spend; `bench.py --cpu-full-config` re-measures it on this box",
-                   "source": "profiles/r01_configs1_cli_vs_reference.json (oracle/_ref/ropebwt2 -LRds -m4g on all 100 M reads, MI355X box host)"}
+CPU_FULL_CONFIG = {"value": 0.0293, "unit": "Gsymbols/s", "insert_s": 348.5, "real_s": 391.4, "threads": 5, "measured_in_round": 5, "constant": True,
+                   "age": "a constant: re-measured in round 5 on an MI355X box host (profiles/r05_cpu_full_config.json: 348.5 s of inserts; round 1 had 346.9 s, "
+                          "real time 391.4 s) -- the full job takes 6.5 min of host time, more than the default run may spend; `bench.py --cpu-full-config` "
+                          "measures it again on the box at hand",
+                   "source": "profiles/r05_cpu_full_config.json (oracle/_ref/ropebwt2 -L -R -b -s -m4g on all 100 M reads, MI355X box host)"}
 
 
 def batch_reads(mem_arg_bytes, read_len):
