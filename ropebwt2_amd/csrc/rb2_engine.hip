@@ -198,6 +198,8 @@ struct rb2_hip_s {
 	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
 	bool pair_valid = false;
 	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
+	double tl_base = 0, tl_last = 0;
+	int timeline = 0;                   // RB2_HIP_TIMELINE=1: host timestamps of the phases of a host-buffer insert on stderr (changes nothing else)
 	int lazy_insert = 1;                // RB2_HIP_LAZY_INSERT=0 / rb2_hip_set_lazy(h, 0): every insert returns only when the device is done
 	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
 	Ctl *ctl = nullptr;                 // device
@@ -392,6 +394,8 @@ bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, b
 		h->pool[h->pside].ensure(leaves_ub, true, st);
 		h->pool[h->pside ^ 1].ensure(leaves_ub, false, st);
 	}
+	if (!h->sparse) h->sbtot.ensure(leaves_ub / SB + 1);          // what build_directory will ask for by the batch's last round: growing it there, round by round, is a
+	                                                           // hipFree in the middle of the queued rounds -- a device-wide wait (r05: 2 x 30-100 ms of a host-buffer batch)
 	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64 + (uint64_t)(NR + WLC + 1) * STILE / 2));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
 	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
@@ -467,6 +471,13 @@ void maybe_widen(rb2_hip_t *h, BatchState &B, uint64_t r)
 // phase 1 of a round: next symbols, group heads, tile scans, the rows of the count matrix seen here
 // spec: queued while the verdict of the in-place round in front of it is still on its way (round_merge_sparse)
 // with_split: the k_sym launch also does the leaf splits of the in-place round in front of it and the verdict event follows it (round_merge_sparse)
+static inline void tl_slow(rb2_hip_t *h, const char *what)    // RB2_HIP_TIMELINE=2: which host call of a round took more than half a millisecond
+{
+	if (h->timeline < 2) return;
+	const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	if (h->tl_last != 0 && now - h->tl_last > 0.5) fprintf(stderr, "[rb2_hip] t = %8.3f ms  round %d: %.3f ms on the host up to and including %s\n", now - h->tl_base, h->cur_round, now - h->tl_last, what);
+	h->tl_last = now;
+}
 void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bool with_split = false)
 {
 	hipStream_t st = h->st;
@@ -474,6 +485,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	const int64_t units = (int64_t)B.m;
 	h->cur_round = (int)r;
 	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
+	tl_slow(h, "start of round_counts");
 	{ Scope sc(h, RB2_K_SYM, units);
 	  with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	    SplitArgs sp; memset(&sp, 0, sizeof(sp));
@@ -484,6 +496,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
 	    } else
 	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p); }); }
+	tl_slow(h, "k_sym");
 	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
 	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
@@ -500,6 +513,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt, do_setup, (int)h->sparse, (uint32_t)r,
 	                     h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)spec);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; } }
+	tl_slow(h, "tile scans");
 }
 
 // phase 2: with the global count matrix in h->gcnt: layout, ranks, merge, directory, new intervals.
@@ -526,22 +540,28 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
+	tl_slow(h, "k_prep");
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, h->pool_compact ? (const uint8_t*)oldp.xh : (const uint8_t*)nullptr); }   // (the formats of the old windows: only a pool side the compact-capable merge wrote has any but plain)
+	tl_slow(h, "k_part");
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(grid8(cdiv(wg, MW))), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0), (int)(r & 1)); }
 	});
+	tl_slow(h, "k_merge");
 	{ Scope sc(h, RB2_K_META, units);
 	  build_directory(h, sd ^ 1, h->pside ^ 1, std::min<uint64_t>(B.nsb_ub, n_new_ub / (LEAF * SB) + NR + 1), false, false, (uint64_t)wg * WPL / SB + NR + 1); }
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
+	tl_slow(h, "directory");
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true, P>), (k_advance<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true, P>), (k_advance<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
 			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]); }
 	});
+	tl_slow(h, "k_advance");
 	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());                                  // a refused launch (grid limits) must not go unnoticed until the end of the batch
+	tl_slow(h, "ne snapshot");
 	h->side ^= 1; h->pside ^= 1; B.cur ^= 1;
 	h->pool_compact = compact_out;
 	if (compact_out) ++h->n_compact_rounds;
@@ -777,6 +797,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 	// re-layout there and back per round); one dense phase of eight rounds costs two re-layouts for all of them.
 	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
+		if (h->timeline > 1 && (r < 4 || r % 10 == 0)) fprintf(stderr, "[rb2_hip] t = %8.3f ms  queueing round %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - h->tl_base, (unsigned long long)r);
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
 		maybe_widen(h, B, r);
 		choose_layout(h, B, r, B.m);
@@ -833,6 +854,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	if (getenv("RB2_COMPACT_STATS")) h->compact_stats = atoi(getenv("RB2_COMPACT_STATS"));
 	if (getenv("RB2_TS_MAX")) h->ts_max = std::max(0, std::min((int)TS_MAX, atoi(getenv("RB2_TS_MAX"))));
 	if (getenv("RB2_HIP_LAZY_INSERT")) h->lazy_insert = atoi(getenv("RB2_HIP_LAZY_INSERT"));
+	if (getenv("RB2_HIP_TIMELINE")) h->timeline = atoi(getenv("RB2_HIP_TIMELINE"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round
 	if (h->trace) h->prof = 1;
 	HIPCHK(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
@@ -951,6 +973,10 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 {
 	HIPCHK(hipSetDevice(h->dev));
 	if (len <= 0 || s[len - 1] != 0) { rb2_fatal("[rb2_hip] insert_multi: buffer must be non-empty and end with a sentinel\n"); }   // mrope.c:268
+	static const double tl0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+	h->tl_base = tl0;
+	auto tl = [&](const char *what) { if (h->timeline) fprintf(stderr, "[rb2_hip] t = %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tl0, what); };
+	tl("insert_multi: enter");
 	// The text goes into the SECOND text buffer on the copy stream -- the first may still be read by the rounds of the previous
 	// insert, which was allowed to return before they were done (finish_pending): a caller that inserts batch after batch has batch
 	// k + 1 cross PCIe while batch k is being inserted.  Whatever rb2_hip_prefetch has brought over already is not sent again.
@@ -970,15 +996,19 @@ void rb2_hip_insert_multi(rb2_hip_t *h, int64_t len, const uint8_t *s)
 		HIPCHK(hipMemsetAsync(h->pair_d, 0, 36 * 8, h->st_copy));  // the count matrix of the batch, from its text alone (rb2_hip_last_batch_counts)
 		hipLaunchKernelGGL(k_pair_hist, dim3((unsigned)std::min<uint64_t>(((uint64_t)len + 4095) / 4096, 8192)), dim3(256), 0, h->st_copy, (const uint8_t*)h->sbuf2.p, (uint64_t)len, h->pair_d);
 		HIPCHK(hipMemcpyAsync(h->pair_h, h->pair_d, 36 * 8, hipMemcpyDeviceToHost, h->st_copy));
+		tl("upload queued");
 		HIPCHK(hipStreamSynchronize(h->st_copy));
 		h->pair_valid = true;
+		tl("upload done");
 		finish_pending(h);                                       // the previous batch is done with sbuf: it becomes the target of the next upload
 		lk.lock();
 		std::swap(h->sbuf, h->sbuf2);
 		h->pf_busy = false;
 		h->pf_cv.notify_all();
 	}
+	tl("previous batch done");
 	insert_dev(h, len, h->sbuf.p, true);
+	tl("rounds queued");
 }
 
 /* what the last rb2_hip_insert_multi adds to the count matrix (d[b*6+a], layout of rb2_hip_get_counts), computed from the text of the
@@ -1355,6 +1385,7 @@ void rb2_hip_reserve(rb2_hip_t *h, int64_t batch_bytes, int64_t batch_strings, i
 		h->pool[h->pside].ensure(leaves, true, h->st);
 		h->pool[h->pside ^ 1].ensure(leaves, false, h->st);
 		h->LD.ensure(leaves + NR + 16);
+		if (!h->sparse) h->sbtot.ensure(leaves / SB + 1);
 	}
 }
 
