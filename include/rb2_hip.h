@@ -256,7 +256,9 @@ void rb2_hip_sync(rb2_hip_t *h);
  * of slack; the round was redone densely), out[2] rounds inserted in place, out[3] 1 when the index currently has the sparse layout */
 void rb2_hip_sparse_stats(rb2_hip_t *h, int64_t out[4]);
 /* the same four, then out[4] re-spreads among the re-layouts (sparse -> sparse: a superblock had no free slot for a split),
- * out[5] leaves split in place by k_split (the leaf split of rope.c:143-146); out[6..7] reserved */
+ * out[5] leaves split in place by k_split (the leaf split of rope.c:143-146); out[6] device buffers that had to grow while the rounds
+ * of a dense batch were being queued (each one is a device-wide wait in the middle of the batch: 0 unless a sizing rule is missing);
+ * out[7] reserved */
 void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8]);
 /* window formats of the dense layout (a window = 4 leaves = 4096 symbols; csrc/rb2_merge.h): out[0..3] = windows the dense merge wrote
  * plain (three bit planes) / compact with no, one, two lines of exception positions -- counted on the device only when the handle was

@@ -74,6 +74,10 @@ static bool vmm_enabled()
 	return g_vmm_ok == 1;
 }
 
+// set while insert_dev queues the rounds of a batch: DevBuf::ensure counts the buffers that have to grow there.  Growing one means a
+// hipFree (or new mappings) in the middle of the queued rounds -- the runtime waits for the whole device, the host thread with it
+// (r05: the superblock totals grew round by round; a host-buffer job lost 8 % to it).  Everything a batch needs is sized in batch_begin.
+static thread_local int64_t *t_grow_in_rounds = nullptr;
 template <typename T> struct DevBuf {
 	T *p = nullptr; size_t cap = 0;
 	bool vm = false;                                            // set by the owner before first use: grow in place
@@ -137,6 +141,7 @@ template <typename T> struct DevBuf {
 	}
 	void ensure(size_t n, bool keep = false, hipStream_t st = 0) {
 		if (n <= cap) return;
+		if (t_grow_in_rounds) ++*t_grow_in_rounds;              // (a buffer that grows while a batch's rounds are being queued: see rb2_hip_layout_stats out[6])
 		if (vm && vm_grow(n)) return;
 		size_t ncap = std::max(n, cap + cap / 2);
 		T *q = nullptr;
@@ -199,6 +204,7 @@ struct rb2_hip_s {
 	bool pair_valid = false;
 	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
 	double tl_base = 0, tl_last = 0;
+	int64_t n_grow_in_rounds = 0;       // device buffers that had to grow while the rounds of a dense batch were being queued (should stay 0)
 	int timeline = 0;                   // RB2_HIP_TIMELINE=1: host timestamps of the phases of a host-buffer insert on stderr (changes nothing else)
 	int lazy_insert = 1;                // RB2_HIP_LAZY_INSERT=0 / rb2_hip_set_lazy(h, 0): every insert returns only when the device is done
 	int64_t n_relayout = 0, n_void = 0, n_sparse_rounds = 0;
@@ -581,6 +587,7 @@ uint64_t slots_for(uint64_t n, bool sparse)
 void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 {
 	hipStream_t st = h->st;
+	struct NoWatch { int64_t *keep = t_grow_in_rounds; NoWatch() { t_grow_in_rounds = nullptr; } ~NoWatch() { t_grow_in_rounds = keep; } } nw;   // (a re-layout sizes its target pool here and waits for the device anyway)
 	const auto t_host0 = std::chrono::steady_clock::now();
 	const uint64_t cap_before[2] = { h->pool[0].cap_leaves, h->pool[1].cap_leaves };
 	const uint32_t F = to_sparse ? SP_FILL : LEAF, K = to_sparse ? SP_USED : SB;
@@ -796,6 +803,7 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 	// at a handful of positions in the sorted orders), round k touches ~4^k places.  A sparse index would void each of them (a
 	// re-layout there and back per round); one dense phase of eight rounds costs two re-layouts for all of them.
 	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
+	struct GrowWatch { GrowWatch(int64_t *c) { t_grow_in_rounds = c; } ~GrowWatch() { t_grow_in_rounds = nullptr; } } gw(&h->n_grow_in_rounds);
 	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
 		if (h->timeline > 1 && (r < 4 || r % 10 == 0)) fprintf(stderr, "[rb2_hip] t = %8.3f ms  queueing round %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - h->tl_base, (unsigned long long)r);
 		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
@@ -1401,7 +1409,7 @@ void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
 	HIPCHK(hipMemcpyAsync(&ns, &h->ctl->nsplit_total, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
-	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = out[7] = 0;
+	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = h->n_grow_in_rounds; out[7] = 0;
 }
 
 void rb2_hip_window_stats(rb2_hip_t *h, int64_t out[6])

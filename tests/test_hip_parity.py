@@ -146,6 +146,30 @@ def test_reserve_is_only_a_hint(hip):
         assert np.array_equal(dev.rope(b), o.rope(b))
 
 
+@pytest.mark.parametrize("reserve", [False, True])
+def test_no_buffer_grows_while_rounds_are_queued(hip, reserve):
+    """everything a dense batch needs is sized before its first round: a buffer that grows in the middle of the queued rounds is a
+    hipFree / a new mapping, i.e. a device-wide wait the host thread sits in (rb2_hip_layout_stats out[6]; r05: the superblock totals
+    grew round by round).  Three host-buffer batches on a growing index, with and without the capacity hint."""
+    codes = H.splitmix_bases(900_000, 101, seed=77)
+    bufs = [H.encode_batch_fixed(codes[i:i + 300_000]) for i in (0, 300_000, 600_000)]
+    old = os.environ.get("RB2_SPARSE_LAMBDA")
+    os.environ["RB2_SPARSE_LAMBDA"] = "0"                   # (dense rounds only: re-layouts size their pools themselves)
+    try:
+        dev = hip.HipBwt(1)
+    finally:
+        if old is None: os.environ.pop("RB2_SPARSE_LAMBDA", None)
+        else: os.environ["RB2_SPARSE_LAMBDA"] = old
+    if reserve:
+        dev.reserve(len(bufs[0]), 300_000, 3 * len(bufs[0]))
+    for buf in bufs:
+        dev.insert_multi(buf)
+    st = dev.layout_stats()
+    assert int(dev.counts().sum()) == sum(len(b) for b in bufs)
+    dev.close()
+    assert st["grown_in_rounds"] == 0, st
+
+
 @pytest.mark.parametrize("so", [0, 1])
 def test_sparse_inserts_into_large_index(hip, so):
     """steady state of a long job: a small batch into an index hundreds of merge windows long (few new symbols
