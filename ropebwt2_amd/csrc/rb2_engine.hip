@@ -253,6 +253,7 @@ struct rb2_hip_s {
 	int64_t n_compact_rounds = 0;       // dense rounds that were allowed to write compact windows
 	bool pool_compact = false;          // the last dense round wrote compact windows (only k_merge may read the pool now)
 	bool plain_next = false;            // choose_layout wants to leave the dense layout: this round writes plain windows
+	int ts_fold = SCHUNK;               // up to this many chunks of string tiles k_tscan3 scans the chunk totals itself (no k_tscan2 launch); RB2_TS_FOLD lowers it (tests)
 	int ts_max = TS_MAX;                // batches with fewer string tiles run their counting tail in one single-block launch (k_tscan_setup); RB2_TS_MAX lowers it (tests)
 	int trace = 0;                      // RB2_HIP_TRACE=1: per-round kernel times + merge path statistics on stderr
 };
@@ -513,8 +514,11 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);
 	  hipLaunchKernelGGL(k_tscan1, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p);
-	  hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
-	  hipLaunchKernelGGL(k_tscan3, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
+	  if (B.nsc <= (unsigned)h->ts_fold) hipLaunchKernelGGL(k_tscan3<true>, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);   // (the scan over the chunks folded in)
+	  else {
+	    hipLaunchKernelGGL(k_tscan2, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, h->cpart.p);
+	    hipLaunchKernelGGL(k_tscan3<false>, dim3(B.nsc), dim3(SCHUNK), 0, st, h->ctl, sd, trs, h->cpart.p, h->tsc.p);
+	  }
 	  const int do_setup = h->nranks == 1;                     // one GPU: k_setup of the round rides on block 0 of k_tfix (the local count matrix is the global one)
 	  hipLaunchKernelGGL(k_tfix, dim3(std::max<unsigned>(1u, cdiv(B.nst_ub, 256))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tsc.p, h->tfix.p, h->gcnt, do_setup, (int)h->sparse, (uint32_t)r,
 	                     h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)spec);
@@ -861,6 +865,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	if (getenv("RB2_COMPACT")) h->compact_ok = atoi(getenv("RB2_COMPACT"));
 	if (getenv("RB2_COMPACT_STATS")) h->compact_stats = atoi(getenv("RB2_COMPACT_STATS"));
 	if (getenv("RB2_TS_MAX")) h->ts_max = std::max(0, std::min((int)TS_MAX, atoi(getenv("RB2_TS_MAX"))));
+	if (getenv("RB2_TS_FOLD")) h->ts_fold = std::max(0, std::min((int)SCHUNK, atoi(getenv("RB2_TS_FOLD"))));   // tests: 0 = the scan over the chunks always as a launch of its own (k_tscan2)
 	if (getenv("RB2_HIP_LAZY_INSERT")) h->lazy_insert = atoi(getenv("RB2_HIP_LAZY_INSERT"));
 	if (getenv("RB2_HIP_TIMELINE")) h->timeline = atoi(getenv("RB2_HIP_TIMELINE"));
 	if (getenv("RB2_SPARSE_MAXPEN")) h->sp_maxpen = atoi(getenv("RB2_SPARSE_MAXPEN"));     // tests: 0 = retry the sparse layout after every dense fallback round

@@ -442,14 +442,28 @@ __global__ __launch_bounds__(SCHUNK) void k_tscan2(const Ctl *ctl, int side, Chu
 	}
 }
 
-__global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRecs trec, const ChunkPart *part, TileScan *tsc)
+// FOLD: at most SCHUNK chunks (2^20 tiles: every batch of up to 2^29 strings) -- no k_tscan2 launch between k_tscan1 and this kernel: `part`
+// holds the chunks' own totals and every block sums the ones in front of its chunk itself (a few KB of cache-resident reads against a
+// single-block launch that the whole round waits for)
+template <bool FOLD> __global__ __launch_bounds__(SCHUNK) void k_tscan3(const Ctl *ctl, int side, const TileRecs trec, const ChunkPart *part, TileScan *tsc)
 {
 	__shared__ uint32_t s_w[16]; __shared__ int s_wi[16];
 	const uint32_t nt = ctl->seg[side].tile0[NR];
 	const uint32_t t = blockIdx.x * SCHUNK + threadIdx.x;
 	if (blockIdx.x * SCHUNK >= nt) return;
 	const bool ok = t < nt;
-	const ChunkPart cp = part[blockIdx.x];
+	ChunkPart cp;
+	if (FOLD) {
+		const uint32_t nc = (nt + SCHUNK - 1) / SCHUNK, i = threadIdx.x;
+		ChunkPart p;
+		for (int s = 0; s < 6; ++s) p.sum[s] = 0;
+		p.mx = -1; p.mn = INT_MAX;
+		if (i < nc) p = part[i];
+		for (int s = 0; s < 6; ++s) { uint32_t tot; block_excl_add<uint32_t>(i < blockIdx.x ? p.sum[s] : 0u, s_w, &tot); cp.sum[s] = tot; }
+		cp.mx = block_all_max(i < blockIdx.x ? p.mx : -1, s_wi);
+		const int nmn = block_all_max((i > blockIdx.x && p.mn != INT_MAX) ? -p.mn : INT_MIN + 1, s_wi);
+		cp.mn = nmn == INT_MIN + 1 ? INT_MAX : -nmn;
+	} else cp = part[blockIdx.x];
 	TileScan o;
 	uint32_t h[6];
 	for (int s = 0; s < 6; ++s) {

@@ -170,6 +170,35 @@ def test_no_buffer_grows_while_rounds_are_queued(hip, reserve):
     assert st["grown_in_rounds"] == 0, st
 
 
+@pytest.mark.parametrize("fold", [None, 0])
+@pytest.mark.parametrize("so", [0, 1, 2])
+def test_tile_scan_over_several_chunks(hip, so, fold):
+    """1.2 M reads of 10 bp are 2344 string tiles = three chunks of the tile scan (k_tscan1 / k_tscan3, the many-tiles path forced by
+    RB2_TS_MAX): the chunk in the middle needs the totals in front of it and the next group head behind it; 4^10 possible reads make
+    groups that span tiles and chunks in the sorted orders.  With the scan over the chunk totals folded into k_tscan3 (default) and as
+    a launch of its own (RB2_TS_FOLD=0, what batches of more than 2^20 tiles get)."""
+    rng = np.random.default_rng(17 + so)
+    a = rng.integers(1, 5, size=(700_000, 10), dtype=np.uint8)
+    b = rng.integers(1, 5, size=(500_000, 10), dtype=np.uint8)
+    knobs = {"RB2_TS_MAX": "2"}
+    if fold is not None: knobs["RB2_TS_FOLD"] = str(fold)
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        dev, o = hip.HipBwt(so), H.Oracle(so)
+        for codes in (a, b):
+            buf = H.encode_batch_fixed(codes)
+            o.insert_multi(buf); dev.insert_multi(buf)
+        assert np.array_equal(dev.counts(), o.counts())
+        for r in range(6):
+            assert np.array_equal(dev.rope(r), o.rope(r)), "rope %d" % r
+        dev.close()
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
 @pytest.mark.parametrize("so", [0, 1])
 def test_sparse_inserts_into_large_index(hip, so):
     """steady state of a long job: a small batch into an index hundreds of merge windows long (few new symbols

@@ -51,7 +51,9 @@ def one(seed):
     if rng.rand() < 0.3: env.update(RB2_LEAF_PIPE=str(int(rng.choice([0, 64, 8192]))))
     if rng.rand() < 0.2: env.update(RB2_COMPACT="0")               # round 5: windows of the dense layout never compact
     if rng.rand() < 0.25: env.update(RB2_POS="64")                 # positions in 64-bit storage from the start
-    if rng.rand() < 0.2: env.update(RB2_TS_MAX="2")                # the many-tiles counting kernels for every batch of more than 1024 strings
+    if rng.rand() < 0.2:
+        env.update(RB2_TS_MAX="2")                                 # the many-tiles counting kernels for every batch of more than 1024 strings
+        if rng.rand() < 0.4: env.update(RB2_TS_FOLD="0")           # ... with the scan over the chunk totals as a launch of its own
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     nr = int(rng.choice([1, 1, 1, 2, 3, 8]))
