@@ -548,7 +548,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, false, true, P>), (k_prep<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, false, true, P>), (k_prep<true, false, false, P>), dim3(h->nranks > 1 ? tg : grid8(cdiv(tg, PREP_PT))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, oldp, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	tl_slow(h, "k_prep");
 	{ Scope sc(h, RB2_K_PART, units);
@@ -644,7 +644,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true, P>), (k_prep<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
-	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
+	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(h->nranks > 1 ? tg : grid8(cdiv(tg, PREP_PT))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }

@@ -861,11 +861,31 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep_tile(const uint32_t tile, const Ctl *ctl, int side, int par, int is_comp, const PoolView &oldp,
 		const P *L, const P *U, uint8_t *A, const TileFix *tf,
 		P *INS_E, uint8_t *INS_A, P *SIZE);                              // false: nothing (more) to do for this block
+constexpr int PREP_PT = 8;                  // string tiles per block of k_prep<AE> on one engine
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_prep(const Ctl *ctl, int side, int par, int is_comp, PoolView oldp,
 		const P *L, const P *U, uint8_t *A, const TileFix *tf,
 		P *INS_E, uint8_t *INS_A, P *SIZE)
 {
+	if (AE && !STRIDE) {
+		// all-empty rounds, one engine: k_sym has placed the new symbols of nearly every tile itself (TILE_DONE), and a launch of one block
+		// per tile was 22 us of blocks that read one word and left (82 K of them, 40 turns of the chip).  A block takes PREP_PT consecutive
+		// tiles: one vector load says which of them are still to do (none, as a rule); those go one after the other.
+		const uint32_t t0 = xcd_item() * PREP_PT, nt = ctl->seg[side].tile0[NR];
+		if (ctl->ne[par] != 0) return;
+		const uint32_t ln = (uint32_t)lane_id();
+		const bool mine = ln < (uint32_t)PREP_PT && t0 + ln < nt;
+		uint32_t nh = 2u;
+		if (mine) nh = tf[t0 + ln].nexthead;
+		uint64_t todo = __ballot(mine && !(nh & 2u));               // (the same in all four waves)
+		while (todo) {
+			const uint32_t k = (uint32_t)__builtin_ctzll(todo);
+			todo &= todo - 1;
+			prep_tile<AE, SPARSE, P>(t0 + k, ctl, side, par, is_comp, oldp, L, U, A, tf, INS_E, INS_A, SIZE);
+			if (todo) __syncthreads();
+		}
+		return;
+	}
 	// the first tile exactly as a one-tile-per-block kernel would run it (its loads are issued before anything is waited for);
 	// further tiles only when the grid is smaller than the number of tiles (grid stride: see k_sym)
 	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {
