@@ -16,7 +16,7 @@
 //                 The format of a window = LeafMeta::npre of its first leaf in own[] (0 = plain, what everything but k_merge expects).
 //   own[]         16 B per leaf (LeafMeta): its six own counts + fill, written by whoever writes the leaf (k_merge, k_relayout, the loader).
 //   meta[]        dense layout: 16 B per leaf, the counts of the preceding leaves of the same superblock (k_meta_sb, from own[]);
-//                 sparse layout: the same 512 bytes per superblock are eight rows of 32 u16 -- row 0 fills, rows 1-6 own counts, row 7 the
+//                 sparse layout: the same 512 bytes per superblock are eight rows of 32 u16 -- row 0 fills (+ bit 15: the leaf's third plane line is valid, see "two-plane leaves"), rows 1-6 own counts, row 7 the
 //                 claim word of k_split -- that an in-place insert updates by atomics on its own entries (dir_row / dir_commit).
 //   sparse layout the same arrays, but leaves carry SLACK (SP_FILL symbols after a re-layout, SP_USED of a superblock's 32 slots in use):
 //                 rounds that touch few leaves insert IN PLACE (k_merge_leaf), position -> leaf is a search (locate()), a leaf that fills
@@ -166,7 +166,7 @@ struct SpOrd {              // work order of one touched leaf in a sparse round,
 	uint32_t gl;            // leaf slot (32 bits in the sparse layout, like RKLEAF)
 	uint32_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL (a batch has < 2^32 strings)
 	uint32_t i0;            // piece position of the leaf's first symbol, low half (positions inside a leaf need no more)
-	uint16_t ni, nvalid;    // new symbols / symbols in the leaf after the round
+	uint16_t ni, nvalid;    // new symbols / symbols in the leaf after the round (bits 0-10); bit 15 of nvalid: the leaf has a plane-2 line (FILL_P2)
 };
 
 // The pool-wide prefix over the superblocks, two levels: what lies in front of superblock sb = base of its chunk of SCHUNK superblocks
@@ -350,14 +350,16 @@ __device__ __forceinline__ uint64_t bits_below(uint32_t n) { return n >= 64u ? ~
 // word pl * LEAFG + g of leaf slot gl
 __device__ __forceinline__ const uint64_t *leaf_words(const uint8_t *data, uint64_t gl) { return (const uint64_t*)data + gl * LEAFW; }
 // accumulate the symbols at [from, to) of one leaf, by one thread: the groups the interval touches, three words each
-__device__ inline void leaf_count(const uint64_t *lw, uint32_t from, uint32_t to, PlAcc &A)
+// p2: the leaf has a plane-2 line (always, in the dense layout; sparse layout: Loc::p2)
+__device__ inline void leaf_count(const uint64_t *lw, uint32_t from, uint32_t to, PlAcc &A, bool p2 = true)
 {
 	if (from >= to) return;
 	const uint32_t g0 = from >> 6, g1 = (to - 1) >> 6;
 	for (uint32_t g = g0; g <= g1; ++g) {
 		const uint32_t base = g << 6;
 		const uint32_t lo = from > base ? from - base : 0u, hi = min(to - base, 64u);
-		pl_acc(A, lw[g], lw[LEAFG + g], lw[2 * LEAFG + g], bits_below(hi) & ~bits_below(lo));
+		const uint64_t b0 = lw[g], b1 = lw[LEAFG + g];
+		pl_acc(A, b0, b1, p2 ? lw[2 * LEAFG + g] : ~(b0 | b1), bits_below(hi) & ~bits_below(lo));
 	}
 }
 
@@ -367,6 +369,18 @@ __device__ inline void leaf_count(const uint64_t *lw, uint32_t from, uint32_t to
 // An in-place insert changes the entries of its own leaf and nothing else -- there is no prefix behind it to move, which is
 // what keeps a round's cost proportional to the leaves it touches (the reference updates the counts along one root-to-leaf
 // path, rope.c:139-146); a query sums the row in front of its slot, one 48-byte read per symbol.
+// TWO-PLANE LEAVES.  With $ACGTN = 000 .. 101 a leaf that holds neither `$` nor `N` -- nine leaves in ten of a long-read index -- is told by
+// planes 0 and 1 alone: plane 2 marks T, and T is "neither bit set" (~(p0 | p1) on the valid positions).  Such a leaf's third line is
+// neither read nor written by an in-place insert (k_merge_leaf: two lines in, two lines out instead of three and three; the memory side
+// moves whole lines and a skipped line costs nothing, tools/ubench/leaf_rw2.hip: 140 -> 103 us per million leaves) and holds NOTHING that
+// may be looked at.  Bit 15 of the leaf's fill entry (row 0; a fill is at most LEAF = 2^10) says that the plane-2 line is valid: set by
+// whoever writes a leaf that holds a `$` or an `N` (k_meta_sb after a re-layout, k_split for both halves of such a leaf) and by the insert
+// that brings the first one (k_merge_leaf adds the bit with the fill, in the same atomic).  Every reader of sparse-layout leaf words goes
+// through leaf_p2() below; the dense layout always has three planes (and, between two merges, its own compact windows: rb2_merge.h).
+// What rle_insert_cached gains by run-length coding -- fewer bytes moved per insert than a fixed-width field costs (rle.c:63-86) -- is
+// gained here by not moving the plane that carries no information.
+constexpr uint32_t FILL_MASK = 0x7ffu, FILL_P2 = 0x8000u;
+__device__ __forceinline__ uint64_t leaf_p2(bool p2, uint64_t b0, uint64_t b1, uint64_t w2) { return p2 ? w2 : ~(b0 | b1); }   // (positions behind the fill: masked by whoever counts)
 constexpr int DIRW = 8 * SB;            // 16-bit values per superblock
 __device__ __forceinline__ uint16_t *dir_row(const PoolView &pv, uint64_t sb, int row) { return (uint16_t*)pv.meta + sb * DIRW + row * SB; }
 __device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, int row, uint32_t k)   // sum of slots [0, k) of a row, k <= SB
@@ -391,10 +405,10 @@ __device__ __forceinline__ uint32_t dir_prefix(const PoolView &pv, uint64_t sb, 
 // starts at or before p -- superblock by binary search over sbpos, leaf by binary search over the in-superblock prefixes.
 // A position on a leaf boundary goes to the RIGHT leaf, p == n to the last leaf in use (the reference sends boundaries to
 // the left child, rope.c:130; the BWT does not depend on it).  This is the descent of rope.c:119-134.
-struct Loc { uint64_t gl, s; uint32_t n; };   // leaf slot (pool-wide), piece position of its first symbol, its fill
+struct Loc { uint64_t gl, s; uint32_t n, p2; };   // leaf slot (pool-wide), piece position of its first symbol, its fill, "its plane-2 line is valid" (two-plane leaves)
 __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 {
-	Loc r; r.gl = rp.leaf0; r.s = 0; r.n = 0;
+	Loc r; r.gl = rp.leaf0; r.s = 0; r.n = 0; r.p2 = 0;        // (an empty slot has no plane-2 line either: the insert that brings a `$` / `N` says so)
 	if (rp.nleaves == 0) return r;
 	const uint64_t nsb = (rp.nleaves + SB - 1) / SB, base = sb_pos(pv, rp.sb0);
 	// superblocks hold about the same number of symbols each (a re-layout fills them evenly, inserts land at random), so start
@@ -427,15 +441,15 @@ __device__ inline Loc locate(const PoolView &pv, const RopeDesc &rp, uint64_t p)
 		const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
-			const uint32_t n = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
-			if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = n; }
+			const uint32_t e = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu, n = e & FILL_MASK;   // (bit 15: the leaf has a plane-2 line)
+			if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = e; }
 			run += n;
 		}
 	};
 #pragma unroll
 	for (int i = 0; i < SP_USED / 8; ++i) scan8(i);             // the slots a re-layout fills: three 16-byte loads, issued together
 	if (run <= rel) scan8(SP_USED / 8);                        // the reserve slots (leaf splits): only when the position lies behind the first 24
-	r.gl = l0 + klo; r.s = sbs + pre; r.n = nk;
+	r.gl = l0 + klo; r.s = sbs + pre; r.n = nk & FILL_MASK; r.p2 = nk >> 15;
 	return r;
 }
 
@@ -444,7 +458,7 @@ __device__ __forceinline__ Loc locate_dense(const RopeDesc &rp, uint64_t p)
 {
 	Loc r;
 	const uint64_t lf = rp.nleaves ? min(p >> LEAF_SH, rp.nleaves - 1) : 0;
-	r.gl = rp.leaf0 + lf; r.s = lf << LEAF_SH; r.n = (uint32_t)min((uint64_t)LEAF, rp.n - r.s);
+	r.gl = rp.leaf0 + lf; r.s = lf << LEAF_SH; r.n = (uint32_t)min((uint64_t)LEAF, rp.n - r.s); r.p2 = 1;
 	return r;
 }
 
@@ -458,8 +472,8 @@ template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void ran
 		for (int s = 0; s < 6; ++s) out[s] = (Q)rp.cnt[s];
 		return;
 	}
-	uint64_t gl; uint32_t off;
-	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
+	uint64_t gl; uint32_t off; bool p2 = true;
+	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); p2 = lc.p2 != 0; }
 	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
 	uint32_t pc[6];                                            // symbols of the superblock in front of the leaf
 	if (SPARSE) {
@@ -471,7 +485,7 @@ template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void ran
 		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
 	}
 	PlAcc A;
-	leaf_count(leaf_words(pv.data, gl), 0, off, A);
+	leaf_count(leaf_words(pv.data, gl), 0, off, A, p2);
 	uint32_t c[6];
 	pl_finish(A, off, c);
 #pragma unroll
@@ -485,13 +499,13 @@ template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void ran
 // uint32_t while positions are stored in 32 bits and keep half the registers)
 template <bool SPARSE = false, typename Q = uint64_t> __device__ inline void range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, Q d[6])
 {
-	uint64_t gl; uint32_t ol; bool one;
-	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
+	uint64_t gl; uint32_t ol; bool one, p2 = true;
+	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; p2 = lc.p2 != 0; }
 	else { const uint64_t lf = l >> LEAF_SH; gl = rp.leaf0 + lf; ol = (uint32_t)(l & (LEAF - 1)); one = ((u - 1) >> LEAF_SH) == lf; }
 	if (one) {
 		PlAcc A;
 		const uint32_t ou = ol + (uint32_t)(u - l);
-		leaf_count(leaf_words(pv.data, gl), ol, ou, A);
+		leaf_count(leaf_words(pv.data, gl), ol, ou, A, p2);
 		uint32_t c[6];
 		pl_finish(A, ou - ol, c);
 #pragma unroll
@@ -549,13 +563,14 @@ __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__buil
 // of the interval length (the single-thread scan of leaf_count is linear in it): this is what serves long intervals and intervals
 // that span leaves in k_prep, and every query of k_rank_batch.  (rle_rank2a, rle.c:134-191; rope_rank2a, rope.c:179-194.)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_leaf_counts(const uint64_t *leaf, uint32_t from, uint32_t to, uint32_t c[6])
+__device__ __forceinline__ void wave_leaf_counts(const uint64_t *leaf, uint32_t from, uint32_t to, uint32_t c[6], bool p2 = true)
 {
 	const uint32_t g = (uint32_t)lane_id(), b = g << 6;
 	PlAcc A;
 	if (g < (uint32_t)LEAFG) {
 		const uint32_t lo = from > b ? min(from - b, 64u) : 0u, hi = to > b ? min(to - b, 64u) : 0u;   // my symbols [lo, hi)
-		pl_acc(A, leaf[g], leaf[LEAFG + g], leaf[2 * LEAFG + g], bits_below(hi) & ~bits_below(lo));
+		const uint64_t b0 = leaf[g], b1 = leaf[LEAFG + g];
+		pl_acc(A, b0, b1, p2 ? leaf[2 * LEAFG + g] : ~(b0 | b1), bits_below(hi) & ~bits_below(lo));
 	}
 	const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
 	PlAcc T;
@@ -571,8 +586,8 @@ template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wa
 		for (int s = 0; s < 6; ++s) out[s] = (Q)rp.cnt[s];
 		return;
 	}
-	uint64_t gl; uint32_t off;
-	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); }
+	uint64_t gl; uint32_t off; bool p2 = true;
+	if (SPARSE) { const Loc lc = locate(pv, rp, p); gl = lc.gl; off = (uint32_t)(p - lc.s); p2 = lc.p2 != 0; }
 	else { gl = rp.leaf0 + (p >> LEAF_SH); off = (uint32_t)(p & (LEAF - 1)); }
 	uint32_t pc[6];
 	if (SPARSE) {                                              // lane j < k holds the counts of slot j: three packed wave sums
@@ -588,7 +603,7 @@ template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wa
 		for (int s = 0; s < 6; ++s) pc[s] = m.c[s];
 	}
 	uint32_t c[6];
-	wave_leaf_counts(leaf_words(pv.data, gl), 0, off, c);
+	wave_leaf_counts(leaf_words(pv.data, gl), 0, off, c, p2);
 #pragma unroll
 	for (int s = 0; s < 6; ++s) out[s] = (Q)(sb_cum(pv, gl / SB, s) - sb_cum(pv, rp.sb0, s) + pc[s] + c[s]);
 }
@@ -596,12 +611,12 @@ template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wa
 // occurrences of the six symbols inside [l, u), l < u, by one wave (what range_counts does with one thread)
 template <bool SPARSE, typename Q = uint64_t> __device__ __forceinline__ void wave_range_counts(const PoolView &pv, const RopeDesc &rp, uint64_t l, uint64_t u, Q d[6])
 {
-	uint64_t gl; uint32_t ol; bool one;
-	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; }
+	uint64_t gl; uint32_t ol; bool one, p2 = true;
+	if (SPARSE) { const Loc lc = locate(pv, rp, l); gl = lc.gl; ol = (uint32_t)(l - lc.s); one = u - lc.s <= lc.n; p2 = lc.p2 != 0; }
 	else { const uint64_t lf = l >> LEAF_SH; gl = rp.leaf0 + lf; ol = (uint32_t)(l & (LEAF - 1)); one = ((u - 1) >> LEAF_SH) == lf; }
 	if (one) {
 		uint32_t c[6];
-		wave_leaf_counts(leaf_words(pv.data, gl), ol, ol + (uint32_t)(u - l), c);
+		wave_leaf_counts(leaf_words(pv.data, gl), ol, ol + (uint32_t)(u - l), c, p2);
 #pragma unroll
 		for (int s = 0; s < 6; ++s) d[s] = c[s];
 	} else {

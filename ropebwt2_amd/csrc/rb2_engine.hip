@@ -200,6 +200,10 @@ struct rb2_hip_s {
 	uint64_t layout_epoch = 0;          // counts the re-layouts: what k_setup derived from the piece descriptors before one is stale after it
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
+	// in-place rounds: the prefix over the superblock totals (k_sbscan*) is needed by the NEXT round's descent only (k_advance takes its ranks
+	// from before the merge: RKOLD), so it runs on a stream of its own beside k_advance and the next round's counting phase
+	hipStream_t st_dir = nullptr; hipEvent_t ev_merge = nullptr, ev_dir = nullptr; bool dir_pending = false;
+	int dir_async = 1;                  // RB2_DIR_ASYNC=0: on the round's own stream, behind k_merge_leaf
 	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
 	bool pair_valid = false;
 	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
@@ -216,7 +220,7 @@ struct rb2_hip_s {
 	int pos_mode = getenv("RB2_POS") ? atoi(getenv("RB2_POS")) : 0;   // 0 auto, 64: never narrow; RB2_POS_WIDEN_AT=r: leave the narrow mode before round r (tests)
 	uint64_t pos_m0 = 0;                // largest piece when the batch began
 	DevBuf<uint16_t> RKREL;
-	DevBuf<uint32_t> RKLEAF;            // sparse rounds: leaf slot every new symbol went to
+	DevBuf<uint64_t> RKOLD;             // sparse rounds: rank of every new symbol on the rope as it was, in front of its leaf (k_part_sparse -> k_advance; stored in the positions' width)
 	DevBuf<uint32_t> SPL;               // sparse rounds: leaves to split at the end of the round (k_part_sparse -> k_split)
 	uint32_t split_epoch = 0;           // claim word of k_split: one value per in-place round, never repeated (rb2_kernels.h)
 	bool want_respread = false;         // k_split met a superblock without a free slot: re-spread (sparse -> sparse) before the next round
@@ -310,19 +314,28 @@ inline uint64_t rank_share(const rb2_hip_t *h, uint64_t whole)
 }
 
 // recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
-void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false, uint64_t nsb_grid = 0)
+// (the prefix rebuilt beside an in-place round must be there before anything else reads the directory: the next descent, a re-layout, the end of the batch)
+void dir_join(rb2_hip_t *h)
+{
+	if (!h->dir_pending) return;
+	HIPCHK(hipStreamWaitEvent(h->st, h->ev_dir, 0));
+	h->dir_pending = false;
+}
+
+void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false, uint64_t nsb_grid = 0, hipStream_t on = nullptr)
 {
 	if (nsb_ub == 0) return;
+	const hipStream_t st_ = on ? on : h->st;
 	if (nsb_grid == 0 || nsb_grid > nsb_ub) nsb_grid = nsb_ub;    // k_meta_sb walks the superblocks with a grid stride (rank_share); the scans need the true bound
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
 	h->sbtot.ensure(nsb_ub);
 	PoolView pv = h->pool[pool].view();
 	// leaves_done: an in-place round -- k_merge_leaf updated the entries of the leaves it rewrote and the superblock totals
 	// itself (h->sbtot lives on between rounds); what is left is the prefix over the totals
-	if (!leaves_done) RB2_LAUNCH_STRIDE(h, k_meta_sb<true>, k_meta_sb<false>, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, h->st, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
+	if (!leaves_done) RB2_LAUNCH_STRIDE(h, k_meta_sb<true>, k_meta_sb<false>, dim3(cdiv(nsb_grid, 8)), dim3(256), 0, st_, h->ctl, sd, pv, h->sbtot.p, (int)sparse);
 	// in-chunk prefixes (SbRec) + chunk totals in one pass over the totals, then the chunk bases (the in-chunk prefixes need no base: queries add it)
-	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK / SBT), 0, h->st, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv);
-	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SB2T), 0, h->st, (const Ctl*)h->ctl, pv.sbbase);
+	hipLaunchKernelGGL(k_sbscan3, dim3(nchunk), dim3(SCHUNK / SBT), 0, st_, (const Ctl*)h->ctl, (const SbTot*)h->sbtot.p, pv);
+	hipLaunchKernelGGL(k_sbscan2, dim3(1), dim3(SB2T), 0, st_, (const Ctl*)h->ctl, pv.sbbase);
 }
 
 void fetch_ropes(rb2_hip_t *h)
@@ -348,7 +361,7 @@ struct BatchState {
 void ensure_strings(rb2_hip_t *h, uint64_t m)
 {
 	for (int i = 0; i < 2; ++i) { h->L[i].ensure(m); h->U[i].ensure(m); h->W[i].ensure(m); }
-	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKLEAF.ensure(m); h->SPL.ensure(m + 64);
+	h->SIZE.ensure(m); h->INS_E.ensure(m); h->RKREL.ensure(m); h->RKOLD.ensure(m); h->SPL.ensure(m + 64);
 	h->A[0].ensure(m); h->A[1].ensure(m); h->INS_A.ensure(m); h->START.ensure(m + 1);
 	const uint64_t nst = cdiv(m, STILE) + NR;
 	h->trec.ensure(nst + 8 * XCD_RUN + 8); h->tsc.ensure(nst + 8 * XCD_RUN + 8); h->tfix.ensure(nst + 8 * XCD_RUN + 8); h->cpart.ensure(cdiv(nst, SCHUNK) + 1);
@@ -533,6 +546,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool compact_out = false)
 {
 	hipStream_t st = h->st;
+	dir_join(h);
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
@@ -564,9 +578,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	tl_slow(h, "directory");
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true, P>), (k_advance<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]);
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1]);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true, P>), (k_advance<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)nullptr, (const PushTab*)h->push[cur ^ 1]); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1]); }
 	});
 	tl_slow(h, "k_advance");
 	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
@@ -591,6 +605,7 @@ uint64_t slots_for(uint64_t n, bool sparse)
 void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 {
 	hipStream_t st = h->st;
+	dir_join(h);                                                // (the old layout's directory is read here)
 	struct NoWatch { int64_t *keep = t_grow_in_rounds; NoWatch() { t_grow_in_rounds = nullptr; } ~NoWatch() { t_grow_in_rounds = keep; } } nw;   // (a re-layout sizes its target pool here and waits for the device anyway)
 	const auto t_host0 = std::chrono::steady_clock::now();
 	const uint64_t cap_before[2] = { h->pool[0].cap_leaves, h->pool[1].cap_leaves };
@@ -640,26 +655,34 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)(h->push[0] != nullptr)); }
 	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
+	if (!B.known_ae) dir_join(h);                              // (k_prep<false> counts intervals on the rope: it walks the directory)
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true, P>), (k_prep<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(h->nranks > 1 ? tg : grid8(cdiv(tg, PREP_PT))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
+	dir_join(h);                                               // the descent needs the prefix the round before this one left
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu)); }
+	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), RB2_P(h->RKOLD.p)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
-	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(std::max<unsigned>(WLC / MW, (h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads) / (WLC / MW) * (WLC / MW))), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->RKLEAF.p, h->sbtot.p); }
+	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(std::max<unsigned>(WLC / MW, (h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads) / (WLC / MW) * (WLC / MW))), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->sbtot.p); }
 	});
 	{ Scope sc(h, RB2_K_META, units);
-	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
+	  if (h->dir_async) {                                      // beside k_advance and the next round's counting phase (joined in front of the next descent: dir_join)
+	    HIPCHK(hipEventRecord(h->ev_merge, st));
+	    HIPCHK(hipStreamWaitEvent(h->st_dir, h->ev_merge, 0));
+	    build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true, 0, h->st_dir);
+	    HIPCHK(hipEventRecord(h->ev_dir, h->st_dir));
+	    h->dir_pending = true;
+	  } else build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true, P>), (k_advance<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p, (const PushTab*)h->push[cur ^ 1]);
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1]);
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const uint32_t*)h->RKLEAF.p, (const PushTab*)h->push[cur ^ 1]); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1]); }
 	});
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h) --
 	// or, when the counting phase of round r + 1 is queued at once (spec), blocks of their own in its first launch (k_sym<.., SPLIT>)
@@ -687,6 +710,7 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 void batch_end(rb2_hip_t *h)
 {
 	h->cur_round = -1;
+	dir_join(h);
 	HIPCHK(hipGetLastError());
 	fetch_ropes(h);
 	drain_profile(h);
@@ -878,6 +902,9 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	memset(h->h_flag, 0, 64 + 8 * rb2_hip_s::NE_RING);
 	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
+	if (getenv("RB2_DIR_ASYNC")) h->dir_async = atoi(getenv("RB2_DIR_ASYNC"));
+	HIPCHK(hipStreamCreateWithFlags(&h->st_dir, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&h->ev_merge, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_dir, hipEventDisableTiming));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
@@ -893,12 +920,13 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	HIPCHK(hipSetDevice(h->dev));
 	if (h->own_stream) HIPCHK(hipStreamSynchronize(h->st)); else HIPCHK(hipDeviceSynchronize());   /* a caller's stream (rb2_hip_use_stream) may be gone already */
 	for (int i = 0; i < 2; ++i) { h->pool[i].release(); h->L[i].release(); h->U[i].release(); h->W[i].release(); }
-	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKLEAF.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
+	h->START.release(); h->SIZE.release(); h->INS_E.release(); h->RKREL.release(); h->RKOLD.release(); h->SPL.release(); h->qbuf.release(); h->zblk.release();
 	h->LD.release(); h->A[0].release(); h->A[1].release(); h->INS_A.release(); h->sbuf.release(); h->sbuf2.release();
 	if (h->st_copy) HIPCHK(hipStreamDestroy(h->st_copy));
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
+	HIPCHK(hipStreamSynchronize(h->st_dir)); HIPCHK(hipStreamDestroy(h->st_dir)); HIPCHK(hipEventDestroy(h->ev_merge)); HIPCHK(hipEventDestroy(h->ev_dir));
 	if (h->pair_d) { HIPCHK(hipFree(h->pair_d)); HIPCHK(hipHostFree(h->pair_h)); }
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
 	for (int i = 0; i < 2; ++i) if (h->xhost[i]) { HIPCHK(hipHostFree(h->xhost[i])); HIPCHK(hipHostFree(h->xtot[i])); HIPCHK(hipEventDestroy(h->xev[i])); }

@@ -1068,12 +1068,12 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap);
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD);
 
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD)
 {
 	for (uint32_t tile = blockIdx.x; ; ) {                      // (first tile as ever, then a grid stride: see k_prep)
-		if (!part_sparse_tile<P>(tile, ctl, side, oldp, INS_E, tf, LD, SPL, spl_cap)) return;
+		if (!part_sparse_tile<P>(tile, ctl, side, oldp, INS_E, INS_A, tf, LD, SPL, spl_cap, RKOLD)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1081,7 +1081,7 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	}
 }
 
-template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap)
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD)
 {
 	const TileFix &tfx = tf[tile];
 	if (tile >= ctl->seg[side].tile0[NR]) return false;
@@ -1096,14 +1096,24 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 	// it: three probes side by side (two of them share a line) instead of a gallop; anything else falls back to the search.
 	const uint64_t nsb = (rp.nleaves + SB - 1) / SB;
 	const uint64_t base = nsb ? sb_pos(oldp, rp.sb0) : 0;
+	// The rank of every insert's symbol on the rope AS IT IS (before the round) is taken here, on the way down -- the prefix in front of its
+	// superblock sits in the record the descent reads anyway, the row of own counts in the directory block whose fills it reads -- and
+	// handed to k_advance (RKOLD; k_merge_leaf adds the part inside the leaf: RKREL).  k_advance then needs nothing of the directory
+	// after the merge: no leaf slot per symbol, no gathers behind it, and the prefix over the superblock totals (k_sbscan*) has until
+	// the NEXT round's descent to be rebuilt (rope_insert_run returns the rank on its way down as well, rope.c:132-147).
+	__shared__ P s_cb[6];                                       // symbol counts in front of the piece (pool-wide prefix of its first superblock)
+	if (threadIdx.x < 6) s_cb[threadIdx.x] = nsb ? (P)sb_cum(oldp, rp.sb0, (int)threadIdx.x) : (P)0;
 	bool ok[2];
 	uint64_t p[2], pprev[2], sbi[2], sbs[2];
 	uint64_t pr[2][3];
+	uint32_t aq[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint64_t g = t.base + h * 256 + threadIdx.x;
 		ok[h] = g < t.segend;
 		p[h] = ok[h] ? (uint64_t)E[g] : 0;
+		aq[h] = ok[h] ? (uint32_t)INS_A[g] & 7u : 0u;
+		if (aq[h] > 5u) aq[h] = 0;
 		pprev[h] = (ok[h] && g > t.segstart) ? (uint64_t)E[g - 1] : ~0ull;   // ~0: no insert in front of mine in this piece
 	}
 #pragma unroll
@@ -1128,19 +1138,26 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		slow[h] = slow[h] && ok[h] && nsb;
 	}
 	Loc lc[2];
-	uint4 fr[2][4];
+	uint4 fr[2][4], cr[2][4];
+	uint64_t cum[2];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {                              // the fills of the superblock's 32 slots: one 64-byte line
-		const uint4 *q = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 0);
+	for (int h = 0; h < 2; ++h) {                              // the fills of the superblock's 32 slots: one 64-byte line; the own counts of my symbol: another
+		const uint4 *q = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 0), *qc = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 1 + (int)aq[h]);
 		const bool ld = ok[h] && nsb && !slow[h];
 #pragma unroll
-		for (int i = 0; i < 4; ++i) fr[h][i] = ld ? q[i] : make_uint4(0, 0, 0, 0);
+		for (int i = 0; i < 4; ++i) { fr[h][i] = ld ? q[i] : make_uint4(0, 0, 0, 0); cr[h][i] = ld ? qc[i] : make_uint4(0, 0, 0, 0); }
+		cum[h] = ld ? sb_cum(oldp, rp.sb0 + sbi[h], (int)aq[h]) : 0ull;
 	}
+	P rko[2] = { 0, 0 };                                      // my symbol in front of my leaf (without the piece's base: s_cb)
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
-		lc[h].gl = rp.leaf0; lc[h].s = 0; lc[h].n = 0;
+		lc[h].gl = rp.leaf0; lc[h].s = 0; lc[h].n = 0; lc[h].p2 = 0;
 		if (!ok[h] || !nsb) continue;
-		if (slow[h]) { lc[h] = locate(oldp, rp, p[h]); continue; }   // (rare: a piece that fills unevenly)
+		if (slow[h]) {                                             // (rare: a piece that fills unevenly)
+			lc[h] = locate(oldp, rp, p[h]);
+			rko[h] = (P)(sb_cum(oldp, lc[h].gl / SB, (int)aq[h]) + dir_prefix(oldp, lc[h].gl / SB, 1 + (int)aq[h], (uint32_t)(lc[h].gl % SB)));
+			continue;
+		}
 		const uint32_t rel = (uint32_t)(p[h] - sbs[h]);
 		uint32_t run = 0, klo = 0, pre = 0, nk = 0;
 #pragma unroll
@@ -1148,12 +1165,23 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 			const uint32_t w[4] = { fr[h][i].x, fr[h][i].y, fr[h][i].z, fr[h][i].w };
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
-				const uint32_t n = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu;
-				if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = n; }
+				const uint32_t e = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu, n = e & FILL_MASK;   // (bit 15: the leaf has a plane-2 line)
+				if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = e; }
 				run += n;
 			}
 		}
-		lc[h].gl = (rp.sb0 + sbi[h]) * SB + klo; lc[h].s = sbs[h] + pre; lc[h].n = nk;
+		lc[h].gl = (rp.sb0 + sbi[h]) * SB + klo; lc[h].s = sbs[h] + pre; lc[h].n = nk & FILL_MASK; lc[h].p2 = nk >> 15;
+		uint32_t acc = 0;                                          // own counts of the slots in front of klo: two 16-bit sums side by side (dir_prefix)
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const uint32_t w[4] = { cr[h][i].x, cr[h][i].y, cr[h][i].z, cr[h][i].w };
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t s0 = (uint32_t)(8 * i + 2 * j);
+				acc += w[j] & (klo > s0 + 1 ? 0xffffffffu : (klo == s0 + 1 ? 0xffffu : 0u));
+			}
+		}
+		rko[h] = (P)(cum[h] + (acc & 0xffffu) + (acc >> 16));
 	}
 	// first insert of its leaf: the insert in front of mine (ascending positions) lies in front of my leaf's first symbol -- a leaf is
 	// the LAST one in use that starts at or before the position, so two inserts share it exactly when the earlier one is not in front of it
@@ -1167,6 +1195,8 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 	if (threadIdx.x == 0) { const uint32_t ws = ctl->wstride, c = tile / (ws / STILE); s_base = c * ws + (tot ? atomicAdd(&ctl->wcnt[c * WLS], tot) : 0u); }   // my list (Ctl::wcnt)
 	__syncthreads();
 	off += s_base;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) if (ok[h]) RKOLD[t.base + h * 256 + threadIdx.x] = (P)(rko[h] - s_cb[aq[h]]);
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const int x = h * 256 + threadIdx.x;
@@ -1184,7 +1214,7 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		const uint64_t ni = q1 - g;
 		SpOrd d;
 		d.i0 = (uint32_t)lc[h].s; d.ins0 = (uint32_t)g; d.gl = (uint32_t)lc[h].gl;
-		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)min(lc[h].n + ni, (uint64_t)LEAF);
+		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)(min(lc[h].n + ni, (uint64_t)LEAF) | (lc[h].p2 ? FILL_P2 : 0u));
 		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = 1;  // the leaf cannot take them: void round
 		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)
 			const uint32_t e = atomicAdd(&ctl->nsplit, 1u);
@@ -1253,9 +1283,11 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 				if (a < b) {
 					const uint32_t op = taken + (a - off), og = op >> 6, sh = op & 63;
 					const uint64_t m = bits_below(b - a);
+					uint64_t ow[3];
+					ow[0] = lw[0]; ow[1] = lw[LEAFG]; ow[2] = lc.p2 ? lw[2 * LEAFG] : ~(ow[0] | ow[1]);   // (a two-plane leaf of the sparse layout: rb2_device.h)
 #pragma unroll
 					for (int pl = 0; pl < 3; ++pl) {
-						const uint64_t bits = (lw[pl * LEAFG] >> (a & 63)) & m;
+						const uint64_t bits = (ow[pl] >> (a & 63)) & m;
 						const uint64_t lo = bits << sh, hi = sh ? bits >> (64 - sh) : 0ull;
 						if (lo) atomicOr((unsigned long long*)&LX[pl * (LEAFG + 1) + og], (unsigned long long)lo);
 						if (hi) atomicOr((unsigned long long*)&LX[pl * (LEAFG + 1) + og + 1], (unsigned long long)hi);
@@ -1269,7 +1301,8 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 				if (!old_sparse) n2 = g2 < orp.leaf0 + orp.nleaves ? (uint32_t)min((uint64_t)LEAF, orp.n - (g2 - orp.leaf0) * LEAF) : 0u;
 				else {
 					if (g2 % SB != 0) n2 = dir_row(oldp, g2 / SB, 0)[g2 % SB];
-					if (n2 == 0) { g2 = (lc.gl / SB + 1) * SB; n2 = g2 < orp.leaf0 + orp.nleaves ? dir_row(oldp, g2 / SB, 0)[0] : 0u; }
+					if ((n2 & FILL_MASK) == 0) { g2 = (lc.gl / SB + 1) * SB; n2 = g2 < orp.leaf0 + orp.nleaves ? dir_row(oldp, g2 / SB, 0)[0] : 0u; }
+					lc.p2 = n2 >> 15; n2 &= FILL_MASK;
 				}
 				lc.gl = g2; lc.n = n2;
 				if (n2 == 0) break;                              // cannot happen on a consistent directory
@@ -1330,8 +1363,8 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 		uint16_t v[7];
 #pragma unroll
 		for (int r = 0; r < 7; ++r) v[r] = ln < SB ? dir_row(pool, sb, r)[ln] : (uint16_t)0;
-		const uint32_t used = (uint32_t)__popcll(__ballot(ln < SB && v[0] > 0));
-		uint32_t marked = (uint32_t)__ballot(ln < SB && v[0] > (uint16_t)(LEAF - SP_MARGIN));
+		const uint32_t used = (uint32_t)__popcll(__ballot(ln < SB && (v[0] & FILL_MASK) > 0));
+		uint32_t marked = (uint32_t)__ballot(ln < SB && (v[0] & FILL_MASK) > (uint32_t)(LEAF - SP_MARGIN));
 		if (marked == 0) continue;
 		const uint32_t room = SB - used;
 		if ((uint32_t)__popc(marked) > room) {
@@ -1362,7 +1395,7 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
 			const uint64_t w = W[k];
 			if (!((marked >> k) & 1u)) { if (nk != (uint32_t)k && wl) leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
-			const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)v[0], k);
+			const uint32_t nraw = (uint32_t)__builtin_amdgcn_readlane((int)v[0], k), n = nraw & FILL_MASK, p2f = nraw & FILL_P2;   // (both halves of a leaf with a plane-2 line keep one)
 			uint32_t ck[6];
 #pragma unroll
 			for (int s = 0; s < 6; ++s) ck[s] = (uint32_t)__builtin_amdgcn_readlane((int)v[1 + s], k);
@@ -1370,7 +1403,7 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 			// counts of the part that stays: the three planes of a group sit 16 lanes apart
 			const uint64_t w1 = (uint64_t)__shfl((unsigned long long)w, (ln + 16) & 63), w2 = (uint64_t)__shfl((unsigned long long)w, (ln + 32) & 63);
 			PlAcc A;
-			pl_acc(A, w, w1, w2, (ln < LEAFG && gq < hg) ? ~0ull : 0ull);
+			pl_acc(A, w, w1, leaf_p2(p2f != 0, w, w1, w2), (ln < LEAFG && gq < hg) ? ~0ull : 0ull);
 			const uint32_t r0 = lane63(dpp_incl_add(A.p0 | A.p1 << 16)), r1 = lane63(dpp_incl_add(A.p2 | A.p01 << 16)), r2 = lane63(dpp_incl_add(A.p02));
 			PlAcc T;
 			T.p0 = r0 & 0xffffu; T.p1 = r0 >> 16; T.p2 = r1 & 0xffffu; T.p01 = r1 >> 16; T.p02 = r2;
@@ -1382,7 +1415,7 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 				leaves[(uint64_t)nk * LEAFW + ln] = gq < hg ? w : 0ull;
 			}
 			if (ln == 0) {
-				R[0][nk] = (uint16_t)h; R[0][nk + 1] = (uint16_t)(n - h);
+				R[0][nk] = (uint16_t)(h | p2f); R[0][nk + 1] = (uint16_t)((n - h) | p2f);
 #pragma unroll
 				for (int s = 0; s < 6; ++s) { R[1 + s][nk] = (uint16_t)c1[s]; R[1 + s][nk + 1] = (uint16_t)(ck[s] - c1[s]); }
 			}
@@ -1444,7 +1477,7 @@ template <bool STRIDE> __global__ __launch_bounds__(256) void k_meta_sb(const Ct
 	if (sparse) {
 		if (live) {                                            // all 32 slots: an unused one must read as empty
 			uint16_t *dr = dir_row(newp, sb, 0) + (ln & 31);
-			dr[0] = m.n;
+			dr[0] = (uint16_t)(m.n | ((m.c[0] | m.c[5]) ? FILL_P2 : 0u));   // (a leaf without `$` and `N` is told by two planes: its third line is dead from here on)
 #pragma unroll
 			for (int s = 0; s < 6; ++s) dr[(1 + s) * SB] = m.c[s];
 			dr[7 * SB] = 0;                                        // spare row: the claim word of k_split
@@ -1562,15 +1595,15 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push);
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push);
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push)
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push)
 {
 	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {   // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
-		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKLEAF, push)) return;
+		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKOLD, push)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1581,7 +1614,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64
 template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool advance_tile(const uint32_t tile, const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, const PoolView &newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const uint32_t *RKLEAF, const PushTab *push)
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push)
 {
 	__shared__ GroupLds G;
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
@@ -1615,7 +1648,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	__shared__ uint32_t s_pr[6];                               // PEER transport: the rank a member that inserts the symbol moves to
 	if (threadIdx.x < 6) {
 		const int a6 = threadIdx.x;
-		s_acb[a6] = (P)(ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6));
+		s_acb[a6] = SPARSE ? (P)ctl->ac[t.b][a6] : (P)(ctl->ac[t.b][a6] - sb_cum(newp, nrp.sb0, a6));   // (in-place rounds: ranks come piece-relative, see rank_issue)
 		s_dst[a6] = (uint32_t)(push ? ctl->pdst[t.b][a6] : ctl->dest[t.b][a6]);
 		s_pr[a6] = push ? ctl->pdev[t.b][a6] : 0u;
 	}
@@ -1632,11 +1665,10 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	// the four (dense layout) loads of one rank, issued together and only added up when their sum is needed
 	struct RankRaw { P sbb; uint32_t sbr, meta, rkrel; };
 	const LeafMeta *metab = newp.meta + nrp.leaf0; const SbRec *sbrb = newp.sbrec + nrp.sb0;   // the piece's first leaf / superblock (a piece starts on a superblock boundary)
-	const uint16_t *RKb = RKREL + t.segstart; const P *Eb = INS_E + t.segstart; const uint32_t *RLb = SPARSE ? RKLEAF + t.segstart : nullptr;
+	const uint16_t *RKb = RKREL + t.segstart; const P *Eb = INS_E + t.segstart; const P *ROb = SPARSE ? RKOLD + t.segstart : nullptr;
 	auto rank_issue = [&](int h, int a, uint32_t slot, P F, bool flag, RankRaw &q) {
-		if (SPARSE) {                                          // in-place rounds: the leaf comes from RKLEAF, the prefix from a directory row -- dependent loads, summed here
-			const uint64_t gl = RLb[slot];                     // where k_merge_leaf put my symbol
-			q.sbb = (P)sb_cum(newp, gl / SB, a); q.sbr = 0; q.meta = dir_prefix(newp, gl / SB, 1 + a, (uint32_t)(gl % SB)); q.rkrel = RKb[slot];
+		if (SPARSE) {                                          // in-place rounds: the rank on the rope as it was BEFORE the round, taken on the way down: in front of the leaf (k_part_sparse) + inside it (k_merge_leaf)
+			q.sbb = ROb[slot]; q.sbr = 0; q.meta = 0; q.rkrel = RKb[slot];
 			return;
 		}
 		const P f = (P)(((!AE && flag) ? Eb[slot] : (P)(l2[h] - F)) + (P)slot);   // where my symbol went: e + slot; empty interval: e = l - F (k_prep)
@@ -1705,7 +1737,8 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		if (!act[h]) continue;
 		const int a = sym2[h];
 		const Member &m = mem[h];
-		const P l = (P)(s_acb[a] + rk[h] - (P)m.pa + (P)m.pga);
+		const P l = SPARSE ? (P)(s_acb[a] + rk[h] + (P)m.pga)    // old rank + the a's of earlier groups (mrope.c:226-229)
+		                   : (P)(s_acb[a] + rk[h] - (P)m.pa + (P)m.pga);   // dense rounds: the rank was taken on the NEW rope, the pa new a's in front of mine included
 		const P u = (P)(l + sz[h]);
 		const uint32_t d = s_dst[a] + m.pa;
 		if (push) {                                            // sharded, PEER transport: straight into the next arrays of the owner of piece (a, b) (mrope.c:303-309: the scatter is a write)

@@ -329,12 +329,14 @@ __device__ __forceinline__ void dir_commit(const PoolView &pool, SbTot *sbtot, u
 	if (role < 10 && val) atomicAdd(ptr, val);
 }
 // ... any number of new symbols, already counted: d01 | d23 | d45 packed like LeafMeta::c, same values in all lanes that act
-__device__ __forceinline__ void dir_add_packed(const PoolView &pool, SbTot *sbtot, uint64_t gl, int role, uint32_t d01, uint32_t d23, uint32_t d45)
+// fill_flag: FILL_P2 when this insert brings the leaf's first `$` / `N` -- the leaf has a plane-2 line from now on (rb2_device.h "two-plane
+// leaves"); the bit travels with the fill, in the same atomic (the entry has one writer per round, and a fill never carries into bit 15)
+__device__ __forceinline__ void dir_add_packed(const PoolView &pool, SbTot *sbtot, uint64_t gl, int role, uint32_t d01, uint32_t d23, uint32_t d45, uint32_t fill_flag = 0)
 {
 	const int s = role - 1;
 	const uint32_t dw = s < 2 ? d01 : (s < 4 ? d23 : d45);
 	uint32_t cnt = (dw >> ((uint32_t)(s & 1) * 16)) & 0xffffu;
-	if (role == 0) cnt = (d01 & 0xffffu) + (d01 >> 16) + (d23 & 0xffffu) + (d23 >> 16) + (d45 & 0xffffu) + (d45 >> 16);
+	if (role == 0) cnt = ((d01 & 0xffffu) + (d01 >> 16) + (d23 & 0xffffu) + (d23 >> 16) + (d45 & 0xffffu) + (d45 >> 16)) | fill_flag;
 	if (role >= 7) cnt = role == 7 ? d01 : (role == 8 ? d23 : d45);
 	dir_commit(pool, sbtot, gl, role, cnt);
 }
@@ -354,8 +356,9 @@ __device__ __forceinline__ void dir_add_packed(const PoolView &pool, SbTot *sbto
 // ---------------------------------------------------------------------------------------------
 constexpr int LROWS = 4;                    // leaves per wave step
 constexpr int LTURN = 8;                    // inserts a row takes per turn (lanes 0 .. LTURN - 1 of the row hold them)
-struct RowOrd { uint32_t gl, ins0, i0, ni; };                               // the row's work order (SpOrd, rb2_device.h), ni = 0: none
+struct RowOrd { uint32_t gl, ins0, i0, nn; };                               // the row's work order (SpOrd, rb2_device.h); nn = ni | nvalid << 16 (bit 31: the leaf has a plane-2 line), 0: none
 struct RowJob { uint64_t w[3]; uint32_t pj, aj; };
+__device__ __forceinline__ uint32_t ord_ni(const RowOrd &o) { return o.nn & 0xffffu; }
 
 __device__ __forceinline__ void row_ord_load(const SpOrd *LD, uint64_t g, uint32_t nwork, int ln, RowOrd &o)
 {
@@ -363,21 +366,22 @@ __device__ __forceinline__ void row_ord_load(const SpOrd *LD, uint64_t g, uint32
 	const bool ok = q < nwork;
 	const uint4 a = *(const uint4*)(LD + (ok ? q : g));         // behind the end: a duplicate of the quad's first order, loaded but never run
 	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z;
-	o.ni = ok ? (a.w & 0xffffu) : 0u;
+	o.nn = ok ? a.w : 0u;
 }
 template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const PoolView &pool, const P *INS_E, const uint8_t *INS_A, RowJob &J)
 {
 	const uint64_t *lw = (const uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
-#pragma unroll
-	for (int pl = 0; pl < 3; ++pl) J.w[pl] = RB2_LDNT(&lw[pl * LEAFG]);   // (nontemporal, like the stores: see the end of the loop)
-	// no branch and no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
+	J.w[0] = RB2_LDNT(&lw[0]); J.w[1] = RB2_LDNT(&lw[LEAFG]);   // (nontemporal, like the stores: see the end of the loop)
+	J.w[2] = 0;
+	if (o.nn >> 31) J.w[2] = RB2_LDNT(&lw[2 * LEAFG]);         // the third line only of a leaf that holds a `$` or an `N` (two-plane leaves, rb2_device.h)
+	// no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
 	// row's last insert again; they never use it)
-	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)o.ni, 1) - 1);
+	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)ord_ni(o), 1) - 1);
 	J.aj = INS_A[q]; J.pj = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];   // low half: positions inside a leaf need no more
 }
 
 template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
-		const P *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, uint32_t *RKLEAF, SbTot *sbtot)
+		const P *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, SbTot *sbtot)
 {
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id(), g = ln & 15;
@@ -406,15 +410,20 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 		asm volatile("" ::: "memory");
 		uint64_t w0 = J.w[0], w1 = J.w[1], w2 = J.w[2];
 		uint32_t pjr = J.pj, aj = J.aj;
-		const uint32_t nimax = max(max((uint32_t)__builtin_amdgcn_readlane((int)o.ni, 0), (uint32_t)__builtin_amdgcn_readlane((int)o.ni, 16)),
-				max((uint32_t)__builtin_amdgcn_readlane((int)o.ni, 32), (uint32_t)__builtin_amdgcn_readlane((int)o.ni, 48)));
-		uint32_t pg0 = 0;                                         // first group of the row that changes
+		const uint32_t oni = ord_ni(o);
+		bool p2 = (o.nn >> 31) != 0;                              // the leaf has a plane-2 line (row-uniform)
+		if (!p2) {                                                // two planes tell its symbols: T is "neither bit set", on the positions in use
+			const int nold = (int)((o.nn >> 16) & FILL_MASK) - (int)oni;
+			w2 = ~(w0 | w1) & bits_below((uint32_t)min(GSYM, max(0, nold - g * GSYM)));
+		}
+		const uint32_t nimax = max(max((uint32_t)__builtin_amdgcn_readlane((int)oni, 0), (uint32_t)__builtin_amdgcn_readlane((int)oni, 16)),
+				max((uint32_t)__builtin_amdgcn_readlane((int)oni, 32), (uint32_t)__builtin_amdgcn_readlane((int)oni, 48)));
 		for (uint32_t c0 = 0; c0 < nimax; c0 += LTURN) {            // turns of LTURN inserts per row (one turn, normally)
 			if (c0) {                                               // (rare) the row's next inserts
-				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(o.ni, 1u) - 1u);
+				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(oni, 1u) - 1u);
 				aj = INS_A[q]; pjr = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];
 			}
-			const uint32_t nic = o.ni > c0 ? min(o.ni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
+			const uint32_t nic = oni > c0 ? min(oni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
 			const uint32_t pj = pjr - o.i0 + c0 + (uint32_t)g;      // final position E[q] + q inside the leaf (lanes >= nic: unused)
 			const uint32_t ncmax = min(nimax - c0, (uint32_t)LTURN);
 			const bool mine = (uint32_t)g < nic;
@@ -425,11 +434,26 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 				uint32_t cs[6];
 #pragma unroll
 				for (int s = 0; s < 6; ++s) cs[s] = (uint32_t)__popc((uint32_t)(__ballot(mine && aj == (uint32_t)s) >> rsh) & 0xffffu);
-				dir_add_packed(pool, sbtot, o.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16);
-				if (mine) RKLEAF[(uint64_t)o.ins0 + c0 + g] = o.gl;
+				const bool first_x = !p2 && (cs[0] | cs[5]) != 0;       // the leaf's first `$` / `N`: it has a plane-2 line from here on
+				dir_add_packed(pool, sbtot, o.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16, first_x ? FILL_P2 : 0u);
+				p2 = p2 || first_x;
 			}
-			if (c0 == 0) pg0 = row_share<0>(pj) >> 6;
+			// RKREL = the rank of the symbol inside the leaf AS IT WAS before the round (what rope_insert_run's descent ends with: rle_insert_cached's
+			// count, rle.c:86-88; k_part_sparse took the part in front of the leaf from the directory before the round: RKOLD) = the rank in the
+			// leaf as it is when the symbol goes in, minus the inserts of the same symbol the leaf took before it this round: the ones of this
+			// turn are counted off as they go by, the ones of earlier turns (rare) are read again
 			uint32_t myrank = 0;
+			if (c0) {
+				const uint32_t rsh = (uint32_t)(ln & 48);
+				uint32_t cnt = 0;
+				for (uint32_t t0 = 0; t0 < c0; t0 += 16) {
+					const uint32_t idx = t0 + (uint32_t)g;
+					const uint32_t av = (idx < c0 && idx < oni) ? (uint32_t)INS_A[(uint64_t)o.ins0 + idx] : 7u;
+#pragma unroll
+					for (int s = 0; s < 6; ++s) { const uint32_t bm = (uint32_t)(__ballot(av == (uint32_t)s) >> rsh) & 0xffffu; if (aj == (uint32_t)s) cnt += (uint32_t)__popc(bm); }
+				}
+				myrank = 0u - cnt;
+			}
 			static_for<LTURN>([&](auto jc) {
 				constexpr int j = decltype(jc)::value;
 				if ((uint32_t)j >= ncmax) return;                     // wave-uniform
@@ -440,7 +464,8 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 				const uint64_t msk = (uint32_t)g < pg ? ~0ull : ((uint32_t)g == pg ? below : 0ull);
 				const uint32_t inc = row_incl_add((uint32_t)__popcll(pl_eq(w0, w1, w2, a) & msk));
 				const uint32_t r = row_share<15>(inc);                // a's in front of p, leaf as it is now
-				if (act && g == j) myrank = r;
+				if (act && g == j) myrank += r;
+				if (mine && g > j && aj == a) --myrank;               // (an insert of my symbol in front of mine)
 				const uint32_t top = (uint32_t)(w0 >> 63) | (uint32_t)(w1 >> 63) << 1 | (uint32_t)(w2 >> 63) << 2;
 				const uint32_t cprev = row_prev(top);                 // top symbol of the group below moves up
 				if (act) {
@@ -455,14 +480,14 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 			});
 			if (mine) RKREL[(uint64_t)o.ins0 + c0 + g] = (uint16_t)myrank;
 		}
-		// The WHOLE leaf goes back, three full 128-byte lines, with nontemporal stores behind nontemporal loads: the leaf streams through
-		// once and nothing of it has to wait in L2 for a partial line to be merged.  (Rounds 2-4 stored only the groups from the first
-		// changed one on, counting on the lines the load had left in L2: 1 M x 10 kbp 3.09-3.19 s, this way 2.72-2.75 s on one box.  Each
-		// half alone is no gain: whole lines with plain accesses 3.09, nontemporal accesses with partial lines 3.31-3.39.)
-		(void)pg0;
-		if (o.ni) {
+		// The WHOLE leaf goes back, full 128-byte lines -- two, or three when it holds a `$` or an `N` --, with nontemporal stores behind nontemporal
+		// loads: the leaf streams through once and nothing of it has to wait in L2 for a partial line to be merged.  (Rounds 2-4 stored only the
+		// groups from the first changed one on, counting on the lines the load had left in L2: 1 M x 10 kbp 3.09-3.19 s, this way 2.72-2.75 s
+		// on one box.  Each half alone is no gain: whole lines with plain accesses 3.09, nontemporal accesses with partial lines 3.31-3.39.)
+		if (oni) {
 			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
-			RB2_STNT(w0, &lw[0]); RB2_STNT(w1, &lw[LEAFG]); RB2_STNT(w2, &lw[2 * LEAFG]);
+			RB2_STNT(w0, &lw[0]); RB2_STNT(w1, &lw[LEAFG]);
+			if (p2) RB2_STNT(w2, &lw[2 * LEAFG]);
 		}
 		if (!more) return;
 		g0 = g1;
