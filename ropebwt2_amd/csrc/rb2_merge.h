@@ -360,13 +360,17 @@ struct RowOrd { uint32_t gl, ins0, i0, nn; };                               // t
 struct RowJob { uint64_t w[3]; uint32_t pj, aj; };
 __device__ __forceinline__ uint32_t ord_ni(const RowOrd &o) { return o.nn & 0xffffu; }
 
-__device__ __forceinline__ void row_ord_load(const SpOrd *LD, uint64_t g, uint32_t nwork, int ln, RowOrd &o)
+// (no use of the loaded words in here -- not even a select: the wave would wait for them, and with them for every load issued before, on the spot.
+// r05 and before: `ni = ok ? a.w : 0` behind the load made every step of k_merge_leaf wait for the leaf lines it had just asked for -- one
+// quad of leaves in flight per wave, nothing under way while it worked.  The caller clears nn of a row without an order when it takes the
+// order into use, a step later.)
+__device__ __forceinline__ bool row_ord_load(const SpOrd *LD, uint64_t g, uint32_t nwork, int ln, RowOrd &o)
 {
 	const uint64_t q = g + (uint32_t)(ln >> 4);
 	const bool ok = q < nwork;
 	const uint4 a = *(const uint4*)(LD + (ok ? q : g));         // behind the end: a duplicate of the quad's first order, loaded but never run
-	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z;
-	o.nn = ok ? a.w : 0u;
+	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z; o.nn = a.w;
+	return ok;
 }
 template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd &o, const int g, const PoolView &pool, const P *INS_E, const uint8_t *INS_A, RowJob &J)
 {
@@ -396,16 +400,18 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 	if (ctl->overflow || wi >= per || g0 >= nwork) return;
 	RowOrd o, on, onn;
 	RowJob J, Jn;
-	row_ord_load(LD, g0, nwork, ln, on);
-	row_ord_load(LD, g0 + stride < nwork ? g0 + stride : g0, nwork, ln, onn);
+	bool onn_ok;
+	if (!row_ord_load(LD, g0, nwork, ln, on)) on.nn = 0;
+	onn_ok = row_ord_load(LD, g0 + stride < nwork ? g0 + stride : g0, nwork, ln, onn);
 	row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);
 	for (;;) {
 		o = on; J = Jn; on = onn;
+		if (!onn_ok) on.nn = 0;                                   // (a row behind the end of the list)
 		const uint64_t g1 = g0 + stride, g2 = g1 + stride;
 		const bool more = g1 < nwork;
 		if (more) {
 			row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);       // next quad: in flight while this one is worked on
-			row_ord_load(LD, g2 < nwork ? g2 : g1, nwork, ln, onn);
+			onn_ok = row_ord_load(LD, g2 < nwork ? g2 : g1, nwork, ln, onn);
 		}
 		asm volatile("" ::: "memory");
 		uint64_t w0 = J.w[0], w1 = J.w[1], w2 = J.w[2];
@@ -422,6 +428,8 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 			if (c0) {                                               // (rare) the row's next inserts
 				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(oni, 1u) - 1u);
 				aj = INS_A[q]; pjr = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];
+				asm volatile("" : "+v"(aj), "+v"(pjr));             // waited for HERE, on the rare path: a wait at the first use, behind the join, would also make the common
+				                                                    // path wait -- for the next quad's leaf lines, which are to stay in flight while this quad is worked on
 			}
 			const uint32_t nic = oni > c0 ? min(oni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
 			const uint32_t pj = pjr - o.i0 + c0 + (uint32_t)g;      // final position E[q] + q inside the leaf (lanes >= nic: unused)
