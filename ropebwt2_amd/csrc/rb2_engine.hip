@@ -201,9 +201,8 @@ struct rb2_hip_s {
 	static constexpr int NE_RING = 32;
 	hipEvent_t ev_flag = nullptr;
 	// in-place rounds: the prefix over the superblock totals (k_sbscan*) is needed by the NEXT round's descent only (k_advance takes its ranks
-	// from before the merge: RKOLD), so it runs on a stream of its own beside k_advance and the next round's counting phase
-	hipStream_t st_dir = nullptr; hipEvent_t ev_merge = nullptr, ev_dir = nullptr; bool dir_pending = false;
-	int dir_async = 1;                  // RB2_DIR_ASYNC=0: on the round's own stream, behind k_merge_leaf
+	// from before the merge: RKOLD), so it rides in blocks of their own of the launches that follow the merge anyway (k_advance; k_sym / k_split)
+	int dir_ride = 1;                   // RB2_DIR_RIDE=0: two launches of its own behind k_merge_leaf, as in rounds 2-5
 	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
 	bool pair_valid = false;
 	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
@@ -314,18 +313,10 @@ inline uint64_t rank_share(const rb2_hip_t *h, uint64_t whole)
 }
 
 // recompute the rank directory (meta prefixes + superblock prefix) of pool side `sd`
-// (the prefix rebuilt beside an in-place round must be there before anything else reads the directory: the next descent, a re-layout, the end of the batch)
-void dir_join(rb2_hip_t *h)
-{
-	if (!h->dir_pending) return;
-	HIPCHK(hipStreamWaitEvent(h->st, h->ev_dir, 0));
-	h->dir_pending = false;
-}
-
-void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false, uint64_t nsb_grid = 0, hipStream_t on = nullptr)
+void build_directory(rb2_hip_t *h, int sd /* descriptors */, int pool /* arrays */, uint64_t nsb_ub, bool sparse = false, bool leaves_done = false, uint64_t nsb_grid = 0)
 {
 	if (nsb_ub == 0) return;
-	const hipStream_t st_ = on ? on : h->st;
+	const hipStream_t st_ = h->st;
 	if (nsb_grid == 0 || nsb_grid > nsb_ub) nsb_grid = nsb_ub;    // k_meta_sb walks the superblocks with a grid stride (rank_share); the scans need the true bound
 	const unsigned nchunk = cdiv(nsb_ub, SCHUNK);
 	h->sbtot.ensure(nsb_ub);
@@ -513,7 +504,8 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	      constexpr unsigned NSPLITB = 64;
 	      sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
 	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
-	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
+	      sp.scan2 = h->dir_ride ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
+	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB + (sp.scan2 ? 1u : 0u)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
 	    } else
 	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p); }); }
 	tl_slow(h, "k_sym");
@@ -546,7 +538,6 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool compact_out = false)
 {
 	hipStream_t st = h->st;
-	dir_join(h);
 	const int sd = h->side, cur = B.cur, is_comp = h->so == RB2_SO_RCLO;
 	const int64_t units = (int64_t)B.m;
 	PoolView oldp = h->pool[h->pside].view(), newp = h->pool[h->pside ^ 1].view();
@@ -578,9 +569,9 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	tl_slow(h, "directory");
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, false, true, P>), (k_advance<false, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1]);
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1], ScanRide{ nullptr, 0u });
 	  RB2_LAUNCH_STRIDE(h, (k_advance<true, false, true, P>), (k_advance<true, false, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, newp, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1]); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)nullptr, (const PushTab*)h->push[cur ^ 1], ScanRide{ nullptr, 0u }); }
 	});
 	tl_slow(h, "k_advance");
 	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
@@ -605,7 +596,6 @@ uint64_t slots_for(uint64_t n, bool sparse)
 void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 {
 	hipStream_t st = h->st;
-	dir_join(h);                                                // (the old layout's directory is read here)
 	struct NoWatch { int64_t *keep = t_grow_in_rounds; NoWatch() { t_grow_in_rounds = nullptr; } ~NoWatch() { t_grow_in_rounds = keep; } } nw;   // (a re-layout sizes its target pool here and waits for the device anyway)
 	const auto t_host0 = std::chrono::steady_clock::now();
 	const uint64_t cap_before[2] = { h->pool[0].cap_leaves, h->pool[1].cap_leaves };
@@ -655,41 +645,39 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)(h->push[0] != nullptr)); }
 	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
-	if (!B.known_ae) dir_join(h);                              // (k_prep<false> counts intervals on the rope: it walks the directory)
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true, P>), (k_prep<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p));
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(h->nranks > 1 ? tg : grid8(cdiv(tg, PREP_PT))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
-	dir_join(h);                                               // the descent needs the prefix the round before this one left
 	{ Scope sc(h, RB2_K_PART, units);
 	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), RB2_P(h->RKOLD.p)); }
 	{ Scope sc(h, RB2_K_MERGE, units);
 	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
 	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(std::max<unsigned>(WLC / MW, (h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads) / (WLC / MW) * (WLC / MW))), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->sbtot.p); }
 	});
+	// the prefix over the superblock totals: in blocks of their own of the k_advance launch and of the launch behind it (rb2_kernels.h "the directory rides along")
+	const bool ride = h->dir_ride != 0;
+	const ScanRide sr = { (const SbTot*)h->sbtot.p, ride ? cdiv(h->sp_nsb, SCHUNK) : 0u };
+	const ScanRide sr0 = { nullptr, 0u };
+	if (!ride)
 	{ Scope sc(h, RB2_K_META, units);
-	  if (h->dir_async) {                                      // beside k_advance and the next round's counting phase (joined in front of the next descent: dir_join)
-	    HIPCHK(hipEventRecord(h->ev_merge, st));
-	    HIPCHK(hipStreamWaitEvent(h->st_dir, h->ev_merge, 0));
-	    build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true, 0, h->st_dir);
-	    HIPCHK(hipEventRecord(h->ev_dir, h->st_dir));
-	    h->dir_pending = true;
-	  } else build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
+	  build_directory(h, sd ^ 1, h->pside, h->sp_nsb, true, true); }
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_ADVANCE, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_advance<false, true, true, P>), (k_advance<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1]);
-	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
-			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1]); }
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1], sr0);
+	  RB2_LAUNCH_STRIDE(h, (k_advance<true, true, true, P>), (k_advance<true, true, false, P>), dim3(tg + sr.nscan), dim3(256), 0, st, h->ctl, sd, is_comp, (uint32_t)r, B.s, pv, h->A[cur ^ 1].p, h->A[cur].p, h->tfix.p,
+			RB2_P(h->SIZE.p), RB2_P(h->INS_E.p), h->RKREL.p, RB2_P(h->L[cur].p), h->W[cur].p, RB2_P(h->L[cur ^ 1].p), RB2_P(h->U[cur ^ 1].p), h->W[cur ^ 1].p, send, (const P*)h->RKOLD.p, (const PushTab*)h->push[cur ^ 1], sr); }   // (this launch always runs: the scan blocks ride here)
 	});
 	// leaves that came close to full get a second slot of their superblock now: the last kernel of the round (k_split, rb2_kernels.h) --
 	// or, when the counting phase of round r + 1 is queued at once (spec), blocks of their own in its first launch (k_sym<.., SPLIT>)
 	const bool sp = spec && r + 1 <= B.max_len;
 	if (!sp)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
-	  hipLaunchKernelGGL(k_split, dim3(256), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag); }
+	  hipLaunchKernelGGL(k_split, dim3(256 + (ride ? 1 : 0)), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag,
+	                     ride ? pv.sbbase : (SbBase*)nullptr); }
 	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
 	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
 	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
@@ -710,7 +698,6 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 void batch_end(rb2_hip_t *h)
 {
 	h->cur_round = -1;
-	dir_join(h);
 	HIPCHK(hipGetLastError());
 	fetch_ropes(h);
 	drain_profile(h);
@@ -902,9 +889,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	memset(h->h_flag, 0, 64 + 8 * rb2_hip_s::NE_RING);
 	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
-	if (getenv("RB2_DIR_ASYNC")) h->dir_async = atoi(getenv("RB2_DIR_ASYNC"));
-	HIPCHK(hipStreamCreateWithFlags(&h->st_dir, hipStreamNonBlocking));
-	HIPCHK(hipEventCreateWithFlags(&h->ev_merge, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_dir, hipEventDisableTiming));
+	if (getenv("RB2_DIR_RIDE")) h->dir_ride = atoi(getenv("RB2_DIR_RIDE"));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));
@@ -926,7 +911,7 @@ void rb2_hip_destroy(rb2_hip_t *h)
 	h->trec.release(); h->tsc.release(); h->tfix.release(); h->cpart.release(); h->sbtot.release();
 	for (auto e : h->evpool) hipEventDestroy(e);
 	HIPCHK(hipHostFree(h->h_flag)); HIPCHK(hipEventDestroy(h->ev_flag));
-	HIPCHK(hipStreamSynchronize(h->st_dir)); HIPCHK(hipStreamDestroy(h->st_dir)); HIPCHK(hipEventDestroy(h->ev_merge)); HIPCHK(hipEventDestroy(h->ev_dir));
+
 	if (h->pair_d) { HIPCHK(hipFree(h->pair_d)); HIPCHK(hipHostFree(h->pair_h)); }
 	HIPCHK(hipFree(h->ctl)); HIPCHK(hipFree(h->d_tmp)); HIPCHK(hipFree(h->gcnt)); h->xstage.release(); h->xnb.release(); h->xpack.release(); h->xoff.release();
 	for (int i = 0; i < 2; ++i) if (h->xhost[i]) { HIPCHK(hipHostFree(h->xhost[i])); HIPCHK(hipHostFree(h->xtot[i])); HIPCHK(hipEventDestroy(h->xev[i])); }

@@ -270,7 +270,9 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // SPLIT: the launch that follows an in-place round on one GPU also does that round's leaf splits (k_split), in nsplitb blocks of its own
 // in front of the tile blocks: k_sym reads string arrays only, the splits touch the pool only -- one launch instead of two, the two running
 // side by side; the verdict of the round reaches the host behind this launch.
-struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb; };
+struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb;
+	SbBase *scan2; };   // scan2 != null: one more block, behind the split blocks, turns the chunk totals k_advance's scan blocks left into chunk bases (sbscan2_body; "the directory rides along", below)
+template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64]);
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
 		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB]);
 // Fused k_prep: in a round whose intervals are all empty (ctl->ne[par] == 0) a tile in which every string is a group of its own -- the
@@ -290,10 +292,11 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
 		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
 		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row); return; }
+		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, sp.scan2, s_w2); return; }
 	}
 	const bool ae = ctl->ne[par] == 0;
 	const P *U = ae ? L : UU;
-	for (uint32_t tile = (STRIDE || SPLIT) ? blockIdx.x - (SPLIT ? sp.nsplitb : 0u) : xcd_item(); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
+	for (uint32_t tile = (STRIDE || SPLIT) ? blockIdx.x - (SPLIT ? sp.nsplitb + (sp.scan2 ? 1u : 0u) : 0u) : xcd_item(); ; tile += gridDim.x) {     // the first tile as ever (its loads issue at once); the bound ends the walk
 	if (STRIDE && tile != blockIdx.x) __syncthreads();          // the LDS tables of the previous tile are done with (STRIDE and SPLIT never come together)
 	TileCtx t;
 	if (!tile_ctx(ctl->seg[side], tile, t)) return;
@@ -1430,10 +1433,12 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // R is reused by the wave's next entry
 	}
 }
-__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv)
+__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv, SbBase *scan2)
 {
 	__shared__ uint16_t s_row[MW][7][SB];
-	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, gridDim.x, s_row);
+	const uint32_t nb = gridDim.x - (scan2 ? 1u : 0u);         // (the last block: the chunk bases of the directory, see SplitArgs::scan2)
+	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, scan2, s_w2); return; }
+	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, nb, s_row);
 }
 
 } // namespace rb2
@@ -1506,10 +1511,10 @@ constexpr int SBT = 4;                      // superblocks per thread in k_sbsca
 // exclusive prefix over the chunk totals, in place (one block): a thread takes eight consecutive chunks, the wave and block levels are
 // shuffles and one LDS exchange -- one pass for up to 8192 chunks (270 G symbols); more: with a running total
 constexpr int SB2T = 512;                   // threads of k_sbscan2 (its one block)
-__global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
+template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64])
 {
-	__shared__ uint64_t s_w[6][SB2T / 64];
-	constexpr int CT = 8;                                       // chunks per thread: 4096 per pass, all six columns in flight at once
+	constexpr int SB2T = NT;
+	constexpr int CT = 8;                                       // chunks per thread: 4096 per pass (512 threads), all six columns in flight at once
 	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	uint64_t run[6] = {0, 0, 0, 0, 0, 0};
@@ -1547,11 +1552,16 @@ __global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
 		__syncthreads();
 	}
 }
-__global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, PoolView newp)
+__global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
 {
-	__shared__ uint32_t s_p[6][4];
-	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SBT;
-	if ((uint64_t)blockIdx.x * SCHUNK >= n) return;
+	__shared__ uint64_t s_w[6][SB2T / 64];
+	sbscan2_body<SB2T>(ctl, base, s_w);
+}
+// (the body: k_sbscan3 proper, and blocks of their own in the k_advance launch of an in-place round -- "the directory rides along", k_advance)
+__device__ __forceinline__ void sbscan3_body(const Ctl *ctl, const SbTot *sbtot, const PoolView &newp, const uint32_t blk, uint32_t (*s_p)[4])
+{
+	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blk * SCHUNK + (uint64_t)threadIdx.x * SBT;
+	if ((uint64_t)blk * SCHUNK >= n) return;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	uint32_t e[SBT][6], tot[6] = {0, 0, 0, 0, 0, 0};           // exclusive inside the thread, the thread's totals
 #pragma unroll
@@ -1575,7 +1585,7 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 		b0[s] = off + inc[s] - tot[s];
 	}
 	// the chunk's totals, for k_sbscan2 behind this kernel (a kernel of its own read every total a second time for them)
-	if (threadIdx.x < 6) newp.sbbase[blockIdx.x].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
+	if (threadIdx.x < 6) newp.sbbase[blk].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
 #pragma unroll
 	for (int k = 0; k < SBT; ++k) if (i0 + k < n) {             // one 32-byte record per superblock: 128 contiguous bytes per lane
 		uint32_t o[6];
@@ -1585,6 +1595,11 @@ __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const 
 		q[0] = make_uint4(o[0], o[1], o[2], o[3]);
 		q[1] = make_uint4(o[4], o[5], o[0] + o[1] + o[2] + o[3] + o[4] + o[5], 0u);
 	}
+}
+__global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, PoolView newp)
+{
+	__shared__ uint32_t s_p[6][4];
+	sbscan3_body(ctl, sbtot, newp, blockIdx.x, s_p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1596,16 +1611,28 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
 		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push);
+struct ScanRide { const SbTot *sbtot; uint32_t nscan; };     // in-place rounds: the first nscan blocks of the k_advance launch do k_sbscan3's work (see k_advance)
 
 template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64_t> __global__ __launch_bounds__(256) void k_advance(const Ctl *ctl, int side, int is_comp, uint32_t round, const uint8_t *s, PoolView newp,
 		uint8_t *A2, const uint8_t *A, const TileFix *tf,
 		const P *SIZE, const P *INS_E, const uint16_t *RKREL, const P *L, const uint64_t *W,
-		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push)
+		P *L2, P *U2, uint64_t *W2, ShardRec *send, const P *RKOLD, const PushTab *push, ScanRide sr)
 {
-	for (uint32_t tile = STRIDE ? blockIdx.x : xcd_item(); ; ) {   // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
+	// THE DIRECTORY RIDES ALONG.  An in-place round leaves the superblock totals current (k_merge_leaf); what is left is the prefix over them
+	// (k_sbscan3 + k_sbscan2: two launches, 12 us per round at 10 G symbols, ~100 us at 90 G -- the one part of the round that reads every
+	// superblock).  Nothing in this kernel reads the directory in an in-place round any more (ranks come from before the merge: RKOLD), and
+	// the next reader is the next round's descent -- so the first sr.nscan blocks of this launch ARE k_sbscan3 (one chunk of superblocks
+	// each), beside the tile blocks, and the chunk bases follow in one block of the next launch (k_sym<.., SPLIT> / k_split: SplitArgs::scan2).
+	// No launch, no event, no second stream; the latency-bound tile blocks leave the memory system to the scan.
+	uint32_t nsc = 0;
+	if (SPARSE) {
+		nsc = sr.nscan;
+		if (blockIdx.x < nsc) { __shared__ uint32_t s_p[6][4]; sbscan3_body(ctl, sr.sbtot, newp, blockIdx.x, s_p); return; }
+	}
+	for (uint32_t tile = (SPARSE && nsc) ? blockIdx.x - nsc : (STRIDE ? blockIdx.x : xcd_item()); ; ) {   // first tile as a one-tile-per-block kernel would run it, then a grid stride (see k_prep)
 		if (!advance_tile<AE, SPARSE, P>(tile, ctl, side, is_comp, round, s, newp, A2, A, tf, SIZE, INS_E, RKREL, L, W, L2, U2, W2, send, RKOLD, push)) return;
 		if (!STRIDE) return;
-		tile += gridDim.x;
+		tile += gridDim.x - nsc;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
 		__syncthreads();
 	}
