@@ -203,6 +203,12 @@ struct rb2_hip_s {
 	// in-place rounds: the prefix over the superblock totals (k_sbscan*) is needed by the NEXT round's descent only (k_advance takes its ranks
 	// from before the merge: RKOLD), so it rides in blocks of their own of the launches that follow the merge anyway (k_advance; k_sym / k_split)
 	int dir_ride = 1;                   // RB2_DIR_RIDE=0: two launches of its own behind k_merge_leaf, as in rounds 2-5
+	// in-place rounds of one engine are queued without waiting for their verdict (a void round is sticky on the device: rb2_kernels.h k_part_sparse);
+	// spec_rounds = in-place rounds queued since the host last looked with the stream drained (verdict_check)
+	int lazy_verdict = 1;               // RB2_LAZY_VERDICT=0: an event and a wait per in-place round, as in rounds 2-5
+	uint64_t spec_rounds = 0;
+	int run_ahead = 3;                  // ... and at most this many in-place rounds ahead of what the device reports done (h_flag[2]): a re-spread asked for by round r takes place this
+	                                    // many rounds late at worst (RB2_RUN_AHEAD)
 	unsigned long long *pair_d = nullptr, *pair_h = nullptr;   // k_pair_hist: what the batch just uploaded adds to the count matrix (device, pinned host)
 	bool pair_valid = false;
 	bool pending_end = false;           // rb2_hip_insert_multi returned with the batch queued but not awaited (finish_pending); lazy_insert: it may
@@ -343,6 +349,7 @@ struct BatchState {
 	unsigned nst_ub = 0, nsc = 0;
 	int cur = 0;                            // string array side
 	bool known_ae = false;                  // the host can tell that every interval of the batch is empty: input order, or an empty index
+	bool known_ae0 = false;                 // ... from the start of the batch (what a rollback falls back to: insert_dev)
 	uint64_t counted = (uint64_t)-1;        // round whose counting phase (round_counts) is already queued
 	uint64_t setup_round = (uint64_t)-1;    // round whose k_setup ran inside its counting phase (k_tscan_setup) ...
 	bool setup_sparse = false; uint64_t setup_epoch = 0;   // ... for this layout, at this layout epoch (a re-layout in between: k_setup runs again)
@@ -409,7 +416,7 @@ bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, b
 	                                                           // hipFree in the middle of the queued rounds -- a device-wide wait (r05: 2 x 30-100 ms of a host-buffer batch)
 	h->LD.ensure(std::max<uint64_t>(leaves_ub + NR + 16, m + 64 + (uint64_t)(NR + WLC + 1) * STILE / 2));   // dense: one work order per output window; sparse: at most one per string (+ the slots the last workgroup of k_merge_leaf reads past them)
 	B.s = s; B.len = len; B.m = m; B.n_tot = n_tot; B.nsb_ub = leaves_ub / SB + 1; B.cur = 0;
-	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = !is_srt || n0 == 0; }
+	{ uint64_t n0 = 0; for (int b = 0; b < NR; ++b) n0 += h->h_rope[b].cnt[0]; B.known_ae = B.known_ae0 = !is_srt || n0 == 0; }
 	{	// storage width of the positions: narrow while no piece can hold 2^32 symbols (checked again every round: maybe_widen)
 		uint64_t mx = 0;
 		for (int b = 0; b < NR; ++b) mx = std::max<uint64_t>(mx, h->h_rope[b].n);
@@ -417,6 +424,7 @@ bool batch_begin(rb2_hip_t *h, BatchState &B, int64_t len64, const uint8_t *s, b
 		h->pos32 = h->want_pos32 && h->pos_mode != 64 && mx + 2 * m < POS32_LIMIT;
 		h->want_pos32 = false;
 		((volatile unsigned long long*)(h->h_flag + 4))[0] = 0;  // (round, largest piece) as k_setup last reported it: nothing yet
+		((volatile uint32_t*)h->h_flag)[2] = 0;                   // (in-place rounds the device has come through: none of this batch)
 	}
 	{
 		Scope sc(h, RB2_K_INIT, 0);
@@ -456,6 +464,7 @@ bool ne_all_empty_from(rb2_hip_t *h, uint64_t r)               // may round r (a
 template <class F> inline void with_pos(rb2_hip_t *h, F f) { if (h->pos32) f((uint32_t*)nullptr); else f((uint64_t*)nullptr); }
 #define RB2_P(x) ((P*)(x))
 
+uint32_t verdict_check(rb2_hip_t *h, bool drain);
 // Leave the narrow storage mode when a piece could reach POS32_LIMIT symbols in round r.  What the host knows: the largest piece as
 // k_setup last reported it to pinned memory, for some round q < r (lock-free, possibly many rounds stale -- the host queues rounds
 // ahead of the device), and that a piece grows by at most the m strings of the batch per round.
@@ -467,6 +476,7 @@ void maybe_widen(rb2_hip_t *h, BatchState &B, uint64_t r)
 	if (v != 0) { known = v & ((1ull << 40) - 1); const uint64_t q = v >> 40; since = r >= q ? r - q : r + 1; }   // (the report of round q is the size AFTER round q)
 	const char *e = getenv("RB2_POS_WIDEN_AT");
 	if (known + (since + 1) * B.m < POS32_LIMIT && !(e && (uint64_t)atoll(e) == r)) return;
+	if (verdict_check(h, true)) return;                        // (an in-place round queued behind is void: the caller rolls back first and comes here again)
 	// widen L and U of the current side (what the next kernels read); scratch arrays are per round
 	hipStream_t st = h->st;
 	const int cur = B.cur;
@@ -489,7 +499,7 @@ static inline void tl_slow(rb2_hip_t *h, const char *what)    // RB2_HIP_TIMELIN
 	if (h->tl_last != 0 && now - h->tl_last > 0.5) fprintf(stderr, "[rb2_hip] t = %8.3f ms  round %d: %.3f ms on the host up to and including %s\n", now - h->tl_base, h->cur_round, now - h->tl_last, what);
 	h->tl_last = now;
 }
-void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bool with_split = false)
+void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bool with_split = false, bool with_event = true)
 {
 	hipStream_t st = h->st;
 	const int sd = h->side, cur = B.cur;
@@ -504,12 +514,13 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	      constexpr unsigned NSPLITB = 64;
 	      sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
 	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
+	      sp.round1 = (uint32_t)r;                               // (the splits of round r - 1)
 	      sp.scan2 = h->dir_ride ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
 	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB + (sp.scan2 ? 1u : 0u)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
 	    } else
 	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p); }); }
 	tl_slow(h, "k_sym");
-	if (with_split) HIPCHK(hipEventRecord(h->ev_flag, st));      // (the splits left the verdict in pinned memory)
+	if (with_split && with_event) HIPCHK(hipEventRecord(h->ev_flag, st));   // (the splits left the verdict in pinned memory)
 	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
@@ -644,7 +655,16 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	if (!(B.setup_round == r && B.setup_sparse && B.setup_epoch == h->layout_epoch))
 	{ Scope sc(h, RB2_K_TSCAN, 0);
 	  hipLaunchKernelGGL(k_setup<true>, dim3(1), dim3(64), 0, st, h->ctl, sd, h->gcnt, (int)(r & 1), (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, (int)(h->push[0] != nullptr)); }
-	h->h_flag[0] = h->h_flag[1] = 0;                           // the verdict words k_split writes
+	const bool lazy = spec && h->lazy_verdict && h->nranks == 1;   // no verdict read here: the caller polls (insert_dev)
+	if (!lazy) h->h_flag[0] = h->h_flag[1] = 0;                // the verdict words k_split writes
+	else if (h->spec_rounds > (uint64_t)h->run_ahead) {          // not too far ahead of the device: it reports the round whose splits it has reached (split_body -> h_flag[2] = round + 1)
+		const volatile uint32_t *prog = (const volatile uint32_t*)h->h_flag + 2;
+		const uint32_t want = (uint32_t)r - (uint32_t)h->run_ahead;   // round `want - 1` at least must be over
+		for (uint32_t spins = 0; (int32_t)(*prog - want) < 0 && !((const volatile uint32_t*)h->h_flag)[0]; ++spins) {
+			if ((spins & 1023u) == 1023u) { if (hipStreamQuery(st) == hipSuccess) break; }   // (everything queued is done: nothing more will be reported)
+			__builtin_ia32_pause();
+		}
+	}
 	with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	{ Scope sc(h, RB2_K_PREP, units);
 	  if (!B.known_ae) RB2_LAUNCH_STRIDE(h, (k_prep<false, true, true, P>), (k_prep<false, true, false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
@@ -652,9 +672,9 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	  RB2_LAUNCH_STRIDE(h, (k_prep<true, true, true, P>), (k_prep<true, true, false, P>), dim3(h->nranks > 1 ? tg : grid8(cdiv(tg, PREP_PT))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), is_comp, pv, RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p,
 			h->tfix.p, RB2_P(h->INS_E.p), h->INS_A.p, RB2_P(h->SIZE.p)); }
 	{ Scope sc(h, RB2_K_PART, units);
-	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), RB2_P(h->RKOLD.p)); }
+	  RB2_LAUNCH_STRIDE(h, (k_part_sparse<true, P>), (k_part_sparse<false, P>), dim3(tg), dim3(256), 0, st, h->ctl, sd, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->tfix.p, (SpOrd*)h->LD.p, h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), RB2_P(h->RKOLD.p), (uint32_t)r); }
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS);   // a wave takes four work orders per step (one leaf per DPP row) and walks the list with a grid stride
+	  const unsigned quads = cdiv(rank_share(h, B.m), MW * LROWS * LQ);   // a wave takes LQ x four work orders per step (one leaf per DPP row) and walks the list with a grid stride
 	  hipLaunchKernelGGL(k_merge_leaf<P>, dim3(std::max<unsigned>(WLC / MW, (h->leaf_pipe > 0 ? std::min<unsigned>(quads, (unsigned)h->leaf_pipe) : quads) / (WLC / MW) * (WLC / MW))), dim3(256), 0, st, (const Ctl*)h->ctl, (const SpOrd*)h->LD.p, pv, (const P*)h->INS_E.p, (const uint8_t*)h->INS_A.p, h->RKREL.p, h->sbtot.p); }
 	});
 	// the prefix over the superblock totals: in blocks of their own of the k_advance launch and of the launch behind it (rb2_kernels.h "the directory rides along")
@@ -677,22 +697,43 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	if (!sp)
 	{ Scope sc(h, RB2_K_SPLIT, 0);
 	  hipLaunchKernelGGL(k_split, dim3(256 + (ride ? 1 : 0)), dim3(256), 0, st, h->ctl, pv, (const uint32_t*)h->SPL.p, (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu), h->split_epoch, (volatile uint32_t*)h->d_flag,
-	                     ride ? pv.sbbase : (SbBase*)nullptr); }
+	                     ride ? pv.sbbase : (SbBase*)nullptr, (uint32_t)r + 1u); }
 	// The verdict of the round (did every leaf fit?  did every split find a slot?) travels to pinned host memory behind the last
 	// kernel.  While it is on its way the host already queues the counting phase of round r + 1 -- it only writes per-round scratch,
 	// and a void round r is redone from its own counting phase anyway -- so the GPU has work while the host waits and then queues
 	// the next merge.
 	if (!B.known_ae && !send && h->nranks == 1) ne_snapshot(h, r);
 	HIPCHK(hipGetLastError());
-	if (!sp) HIPCHK(hipEventRecord(h->ev_flag, st));           // (k_split left the verdict in pinned memory)
+	if (!sp && !lazy) HIPCHK(hipEventRecord(h->ev_flag, st));  // (k_split left the verdict in pinned memory)
 	h->side ^= 1; B.cur ^= 1;
-	if (sp) round_counts(h, B, r + 1, true, true);             // (records the event behind its first launch)
+	if (sp) round_counts(h, B, r + 1, true, true, !lazy);      // (records the event behind its first launch)
+	if (lazy) {                                                // one engine: nobody waits; a void round makes every kernel queued behind it return (sticky: k_part_sparse)
+		B.counted = sp ? r + 1 : (uint64_t)-1;
+		++h->n_sparse_rounds; ++h->spec_rounds;
+		return true;
+	}
 	HIPCHK(hipEventSynchronize(h->ev_flag));
-	if (h->h_flag[0]) { h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1; return false; }
+	if (h->h_flag[0]) {                                         // void: nothing was changed; the flag comes down here, with nothing queued behind the round
+		h->side ^= 1; B.cur ^= 1; B.counted = (uint64_t)-1;
+		HIPCHK(hipMemsetAsync(&h->ctl->overflow, 0, 4, st));
+		return false;
+	}
 	if (h->h_flag[1]) h->want_respread = true;
 	B.counted = sp ? r + 1 : (uint64_t)-1;
 	++h->n_sparse_rounds;
 	return true;
+}
+
+// Has an in-place round queued since the last look been void (returns round + 1, else 0)?  drain: wait for everything queued first -- the
+// answer is then final; else whatever has landed in pinned memory so far.  A superblock that ran out of slots asks for a re-spread.
+uint32_t verdict_check(rb2_hip_t *h, bool drain)
+{
+	if (!h->spec_rounds) return 0;
+	if (drain) HIPCHK(hipStreamSynchronize(h->st));
+	const uint32_t v = ((volatile uint32_t*)h->h_flag)[0];
+	if (((volatile uint32_t*)h->h_flag)[1]) { h->want_respread = true; if (drain) h->h_flag[1] = 0; }
+	if (drain && !v) h->spec_rounds = 0;
+	return v;
 }
 
 void batch_end(rb2_hip_t *h)
@@ -707,7 +748,8 @@ void batch_end(rb2_hip_t *h)
 // in-place round ~ the touched leaves (+ a search per string).  The host only knows upper bounds of both; that is enough.
 // m_eff: the strings this handle expects per round (the batch on one GPU; its share of it on a rank of a sharded index).
 // Changes the layout when the regime changes (dense <-> sparse) and re-spreads a sparse index whose superblocks ran out of slots.
-void choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
+// false: an in-place round queued earlier turned out void (found when the stream was drained in front of a re-layout): nothing was done, the caller rolls back
+bool choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
 {
 	const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);            // symbols in the index before this round
 	const double lambda = (double)m_eff / ((double)n_ub / LEAF + 1.0);
@@ -729,26 +771,36 @@ void choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
 			if (h->trace) fprintf(stderr, "[rb2_hip] not enough free device memory for the sparse layout (%.1f GB needed, %.1f GB free): staying dense\n", bytes / 1e9, fr / 1e9);
 		}
 	}
+	if (want != h->sparse || (h->sparse && h->want_respread)) {
+		if (verdict_check(h, true)) return false;              // (a re-layout copies the index as it is: every in-place round queued so far must have taken place)
+	}
 	if (want != h->sparse) { relayout(h, want, n_ub, B.n_tot + B.len); h->want_respread = false; }
 	else if (h->sparse && h->want_respread) {               // a superblock ran out of slots: spread the index over fresh superblocks (sparse -> sparse)
 		if (h->trace) fprintf(stderr, "[rb2_hip] round %llu: re-spread (a superblock has no free slot left)\n", (unsigned long long)r);
 		relayout(h, true, n_ub, B.n_tot + B.len);
 		h->want_respread = false; ++h->n_respread;
 	}
+	return true;
 }
 
 // the merge phase of round r in whatever layout the index has (its counting phase is queued); a void in-place round is redone densely
+// round r could not be done in place (nothing was changed): back to the dense layout, stay dense for a while (doubling: hot spots tend to persist)
+void void_to_dense(rb2_hip_t *h, BatchState &B, uint64_t r)
+{
+	++h->n_void;
+	if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
+	const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);
+	relayout(h, false, n_ub, B.n_tot + B.len);
+	h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
+	h->sp_backoff = 1 << h->sp_penalty;
+}
+
 void round_merge_any(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool spec)
 {
 	if (h->sparse) {
 		if (round_merge_sparse(h, B, r, send, spec)) { if (h->sp_penalty > 0 && (h->n_sparse_rounds & 63) == 0) --h->sp_penalty; return; }
-		// void round: back to the dense layout, redo it there, stay dense for a while (doubling: hot spots tend to persist)
-		++h->n_void;
-		if (h->trace) fprintf(stderr, "[rb2_hip] void round %llu (penalty %d)\n", (unsigned long long)r, h->sp_penalty);
-		const uint64_t n_ub = B.n_tot + std::min<uint64_t>(B.len, r * B.m);
-		relayout(h, false, n_ub, B.n_tot + B.len);
-		h->sp_penalty = std::min(h->sp_penalty + 1, h->sp_maxpen);
-		h->sp_backoff = 1 << h->sp_penalty;
+		// void round: redone on the dense layout
+		void_to_dense(h, B, r);
 		if (spec) round_counts(h, B, r);                       // the scratch of this round's counting phase was reused by the look-ahead
 	}
 	// compact windows (rb2_merge.h) while k_merge is the only reader of the pool until the next rewrite: every interval of the batch is
@@ -819,13 +871,42 @@ void insert_dev(rb2_hip_t *h, int64_t len64, const uint8_t *s, bool lazy = false
 	// re-layout there and back per round); one dense phase of eight rounds costs two re-layouts for all of them.
 	if (h->sparse && h->sp_backoff < h->sp_head) h->sp_backoff = h->sp_head;
 	struct GrowWatch { GrowWatch(int64_t *c) { t_grow_in_rounds = c; } ~GrowWatch() { t_grow_in_rounds = nullptr; } } gw(&h->n_grow_in_rounds);
-	for (uint64_t r = 0; r <= B.max_len; ++r) {                // one round per string position, last symbol first (mrope.c:285, 299-342)
-		if (h->timeline > 1 && (r < 4 || r % 10 == 0)) fprintf(stderr, "[rb2_hip] t = %8.3f ms  queueing round %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - h->tl_base, (unsigned long long)r);
-		if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
-		maybe_widen(h, B, r);
-		choose_layout(h, B, r, B.m);
+	for (uint64_t r = 0; ; ) {                                 // one round per string position, last symbol first (mrope.c:285, 299-342)
+		// In-place rounds are queued without a look at their verdict.  The host looks here -- at what has landed in pinned memory when it queues
+		// the next round, with the stream drained at the end of the batch and in front of anything that is not an in-place round (a re-layout,
+		// a widening of the positions: they come back with rv set) -- and takes a void round back: every kernel queued behind it returned at
+		// once (rb2_kernels.h k_part_sparse), so the device is where it was in front of that round and only the host's own bookkeeping rewinds.
+		uint32_t rv = verdict_check(h, r > B.max_len);
+		if (!rv && r > B.max_len) break;
+		if (!rv) {
+			if (h->timeline > 1 && (r < 4 || r % 10 == 0)) fprintf(stderr, "[rb2_hip] t = %8.3f ms  queueing round %llu\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - h->tl_base, (unsigned long long)r);
+			if (!B.known_ae && r > 0 && ne_all_empty_from(h, r)) B.known_ae = true;
+			maybe_widen(h, B, r);
+			if (!(rv = verdict_check(h, false)) && !choose_layout(h, B, r, B.m)) rv = verdict_check(h, true);
+		}
+		if (rv) {
+			rv = verdict_check(h, true);                           // (final: everything queued has run -- or returned)
+			const uint64_t r_void = rv - 1;
+			if (r_void >= r || r - r_void > h->spec_rounds) { rb2_fatal("[rb2_hip] internal: void round %llu reported while queueing round %llu (%llu in flight)\n", (unsigned long long)r_void, (unsigned long long)r, (unsigned long long)h->spec_rounds); }
+			if ((r - r_void) & 1) { h->side ^= 1; B.cur ^= 1; }     // every in-place round queued from r_void on flipped the descriptor and array sides once
+			h->n_sparse_rounds -= (int64_t)(r - r_void);
+			h->spec_rounds = 0; h->h_flag[0] = 0;
+			HIPCHK(hipMemsetAsync(&h->ctl->overflow, 0, 4, h->st));
+			B.counted = (uint64_t)-1; B.setup_round = (uint64_t)-1;
+			// the "every interval is empty from here on" snapshots of the void round and of the rounds behind it are not what those rounds leave
+			// when they really run (the void round's k_advance never set the flag): forget them, and what the host concluded from them
+			B.known_ae = B.known_ae0;
+			for (int q = 0; q < 2 * rb2_hip_s::NE_RING; ++q) h->h_flag[16 + q] = 0xffffffffu;
+			r = r_void;
+			void_to_dense(h, B, r);
+			round_counts(h, B, r);
+			round_merge_any(h, B, r, nullptr, true);
+			++r;
+			continue;
+		}
 		if (B.counted != r) round_counts(h, B, r);
 		round_merge_any(h, B, r, nullptr, true);
+		++r;
 	}
 	if (lazy && h->lazy_insert && !h->prof && !h->debug) { h->cur_round = -1; HIPCHK(hipGetLastError()); h->pending_end = true; return; }
 	batch_end(h);
@@ -890,6 +971,8 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
 	if (getenv("RB2_DIR_RIDE")) h->dir_ride = atoi(getenv("RB2_DIR_RIDE"));
+	if (getenv("RB2_LAZY_VERDICT")) h->lazy_verdict = atoi(getenv("RB2_LAZY_VERDICT"));
+	if (getenv("RB2_RUN_AHEAD")) h->run_ahead = std::max(1, atoi(getenv("RB2_RUN_AHEAD")));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }
 	HIPCHK(hipMemsetAsync(h->d_tmp, 0, 256, h->st));
 	memset(h->h_rope, 0, sizeof(h->h_rope));

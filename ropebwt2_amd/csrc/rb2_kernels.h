@@ -271,10 +271,11 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 // in front of the tile blocks: k_sym reads string arrays only, the splits touch the pool only -- one launch instead of two, the two running
 // side by side; the verdict of the round reaches the host behind this launch.
 struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb;
+	uint32_t round1;    // the in-place round whose splits these are, + 1: reported to the host (hv[2]) -- it queues in-place rounds without waiting for them, but only a few ahead
 	SbBase *scan2; };   // scan2 != null: one more block, behind the split blocks, turns the chunk totals k_advance's scan blocks left into chunk bases (sbscan2_body; "the directory rides along", below)
 template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64]);
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
-		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB]);
+		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB], uint32_t round1);
 // Fused k_prep: in a round whose intervals are all empty (ctl->ne[par] == 0) a tile in which every string is a group of its own -- the
 // rule from round ~14 of a batch on -- needs nothing from the tile scans to place its new symbols: slot = the string's index in its
 // bucket, e = l - slot (prep_tile's all-single path).  k_sym has l in hand (it reads L in U's place) and writes INS_E / INS_A itself;
@@ -291,7 +292,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		__shared__ uint16_t s_row[MW][7][SB];
 		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
 		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
-		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row); return; }
+		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row, sp.round1); return; }
 		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, sp.scan2, s_w2); return; }
 	}
 	const bool ae = ctl->ne[par] == 0;
@@ -876,6 +877,7 @@ template <bool AE, bool SPARSE = false, bool STRIDE = false, typename P = uint64
 		// tiles: one vector load says which of them are still to do (none, as a rule); those go one after the other.
 		const uint32_t t0 = xcd_item() * PREP_PT, nt = ctl->seg[side].tile0[NR];
 		if (ctl->ne[par] != 0) return;
+		if (SPARSE && ctl->overflow) return;                        // (queued behind a void in-place round: its tile records are not this round's -- k_part_sparse, "a void round is sticky")
 		const uint32_t ln = (uint32_t)lane_id();
 		const bool mine = ln < (uint32_t)PREP_PT && t0 + ln < nt;
 		uint32_t nh = 2u;
@@ -908,6 +910,7 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool prep
 	const TileFix &tfx = tf[tile];                              // issued together with the mode and tile-count loads
 	const SegDesc &sg = ctl->seg[side];
 	if ((ctl->ne[par] == 0) != AE) return false;
+	if (SPARSE && ctl->overflow) return false;                 // (queued behind a void in-place round: its tile records are not this round's)
 	if (tile >= sg.tile0[NR]) return false;
 	if (AE && (tfx.nexthead & 2u)) return true;                // k_sym placed this tile's new symbols itself (all-single tile)
 	TileCtx t;
@@ -1071,12 +1074,19 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 // One block per string tile (slots and strings of a bucket share the index range).
 // ---------------------------------------------------------------------------------------------
 
-template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD);
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD, uint32_t round);
 
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD)
+// A VOID ROUND IS STICKY.  ctl->overflow = (the round that could not be done in place) + 1 stays set until the HOST has dealt with it: every
+// kernel of an in-place round returns at once while it is set (this one, k_merge_leaf, k_advance<SPARSE>, the leaf splits; the counting
+// phases queued behind it: k_tscan_setup / k_tfix with spec), so the device state stays what it was in front of the void round however
+// many rounds the host has queued behind it.  That is what lets one engine queue in-place rounds WITHOUT reading a verdict per round
+// (rounds 2-5: an event and a host round trip in every round, 14 us of an otherwise 230 us round with nothing on the device): the host
+// polls the verdict word in pinned memory when it queues a round, and finds out at the latest at the end of the batch (insert_dev).
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_part_sparse(Ctl *ctl, int side, PoolView oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD, uint32_t round)
 {
+	if (ctl->overflow) return;                                  // (an earlier round is void -- or a block of this launch just found this one to be)
 	for (uint32_t tile = blockIdx.x; ; ) {                      // (first tile as ever, then a grid stride: see k_prep)
-		if (!part_sparse_tile<P>(tile, ctl, side, oldp, INS_E, INS_A, tf, LD, SPL, spl_cap, RKOLD)) return;
+		if (!part_sparse_tile<P>(tile, ctl, side, oldp, INS_E, INS_A, tf, LD, SPL, spl_cap, RKOLD, round)) return;
 		if (!STRIDE) return;
 		tile += gridDim.x;
 		if (tile >= ctl->seg[side].tile0[NR]) return;
@@ -1084,7 +1094,7 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	}
 }
 
-template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD)
+template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uint32_t tile, Ctl *ctl, int side, const PoolView &oldp, const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, const TileFix *tf, SpOrd *LD, uint32_t *SPL, uint32_t spl_cap, P *RKOLD, uint32_t round)
 {
 	const TileFix &tfx = tf[tile];
 	if (tile >= ctl->seg[side].tile0[NR]) return false;
@@ -1218,7 +1228,7 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		SpOrd d;
 		d.i0 = (uint32_t)lc[h].s; d.ins0 = (uint32_t)g; d.gl = (uint32_t)lc[h].gl;
 		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)(min(lc[h].n + ni, (uint64_t)LEAF) | (lc[h].p2 ? FILL_P2 : 0u));
-		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = 1;  // the leaf cannot take them: void round
+		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = round + 1u;  // the leaf cannot take them: void round (every block that finds one writes the same value)
 		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)
 			const uint32_t e = atomicAdd(&ctl->nsplit, 1u);
 			if (e < spl_cap) SPL[e] = (uint32_t)lc[h].gl;
@@ -1351,9 +1361,10 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 // zeroes both words before it queues the round): no copy command behind the last kernel.
 // (the body: k_split proper, and the last blocks of the k_sym launch that follows an in-place round -- k_sym<.., SPLIT> -- run it: bidx of nblk)
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */, volatile uint32_t *hv,
-		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB])
+		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB], uint32_t round1)
 {
-	if (ctl->overflow) { if (bidx == 0 && threadIdx.x == 0) hv[0] = 1; return; }   // void round: nothing was inserted
+	if (bidx == 0 && threadIdx.x == 0) hv[2] = round1;          // how far the device has come (the host stays a few rounds ahead of this: insert_dev)
+	if (ctl->overflow) { if (bidx == 0 && threadIdx.x == 0) hv[0] = ctl->overflow; return; }   // void round (this one or one in front of it): nothing was inserted; the host learns which
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
 	const uint32_t nsp_all = min(ctl->nsplit, spl_cap);
@@ -1433,12 +1444,12 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();   // R is reused by the wave's next entry
 	}
 }
-__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv, SbBase *scan2)
+__global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv, SbBase *scan2, uint32_t round1)
 {
 	__shared__ uint16_t s_row[MW][7][SB];
 	const uint32_t nb = gridDim.x - (scan2 ? 1u : 0u);         // (the last block: the chunk bases of the directory, see SplitArgs::scan2)
 	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, scan2, s_w2); return; }
-	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, nb, s_row);
+	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, nb, s_row, round1);
 }
 
 } // namespace rb2

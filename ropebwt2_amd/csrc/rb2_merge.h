@@ -368,7 +368,7 @@ __device__ __forceinline__ bool row_ord_load(const SpOrd *LD, uint64_t g, uint32
 {
 	const uint64_t q = g + (uint32_t)(ln >> 4);
 	const bool ok = q < nwork;
-	const uint4 a = *(const uint4*)(LD + (ok ? q : g));         // behind the end: a duplicate of the quad's first order, loaded but never run
+	const uint4 a = *(const uint4*)(LD + (ok ? q : 0));         // behind the end: a duplicate of the list's first order, loaded but never run
 	o.gl = a.x; o.ins0 = a.y; o.i0 = a.z; o.nn = a.w;
 	return ok;
 }
@@ -384,7 +384,21 @@ template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd 
 	J.aj = INS_A[q]; J.pj = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];   // low half: positions inside a leaf need no more
 }
 
-template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
+#ifndef RB2_LQ
+#define RB2_LQ 2
+#endif
+constexpr int LQ = RB2_LQ;                  // quads (of LROWS leaves) a wave has in flight per step
+#ifndef RB2_LEAF_WAVES
+#define RB2_LEAF_WAVES 6
+#endif
+// What bounds the kernel is how many leaf lines a wave keeps IN FLIGHT, not its instructions (77 VALU per quad) and not yet the bytes: on
+// gfx9 one counter (vmcnt) covers loads AND stores, loads return in order but stores and atomics complete out of order with them, so every
+// wait for a load is a wait for everything outstanding (s_waitcnt vmcnt(0)) -- a software pipeline that keeps the NEXT quad's loads in
+// flight across this quad's stores (rounds 4-5) ends every step waiting for its own stores to be acknowledged, about as long as a load
+// takes: one quad per memory round trip and wave, 127 us per million leaves.  A step now asks for LQ quads at once -- their leaf lines,
+// their insert records, the work orders of the step after -- waits ONCE, and works the quads off one after the other; the stores of a
+// step drain while the next step's loads are under way.  Per quad: a round trip / LQ + the work.
+template <typename P = uint64_t> __global__ __launch_bounds__(256, RB2_LEAF_WAVES) void k_merge_leaf(const Ctl *ctl, const SpOrd *__restrict__ LD, PoolView pool,
 		const P *INS_E, const uint8_t *INS_A /* not __restrict__: the loads are to stay where they are issued */, uint16_t *RKREL, SbTot *sbtot)
 {
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -393,46 +407,56 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 	// share it -- one counter to read per wave, and no search for "the q-th order of the round"
 	const uint32_t gw = blockIdx.x * MW + (uint32_t)wv, per = gridDim.x * MW / WLC;   // (the host launches at least WLC waves)
 	const uint32_t lc = gw % WLC, wi = gw / WLC;
-	const uint64_t stride = (uint64_t)per * LROWS;
-	uint64_t g0 = (uint64_t)wi * LROWS;
+	const uint64_t stride = (uint64_t)per * (LROWS * LQ);       // a wave takes LROWS * LQ consecutive orders of its list per step
+	uint64_t g0 = (uint64_t)wi * (LROWS * LQ);
 	const uint32_t nwork = ctl->wcnt[lc * WLS];
 	LD += (uint64_t)lc * ctl->wstride;
 	if (ctl->overflow || wi >= per || g0 >= nwork) return;
-	RowOrd o, on, onn;
-	RowJob J, Jn;
-	bool onn_ok;
-	if (!row_ord_load(LD, g0, nwork, ln, on)) on.nn = 0;
-	onn_ok = row_ord_load(LD, g0 + stride < nwork ? g0 + stride : g0, nwork, ln, onn);
-	row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);
+	RowOrd o[LQ], on[LQ];
+	RowJob J[LQ];
+	bool on_ok[LQ];
+#pragma unroll
+	for (int k = 0; k < LQ; ++k) on_ok[k] = row_ord_load(LD, g0 + (uint64_t)(k * LROWS), nwork, ln, on[k]);
+	// (waited for here: left pending into the loop, the compiler guards the loop's first use of on[] with a wait that -- coming round again -- is a wait for
+	// the stores of the step before)
+#pragma unroll
+	for (int k = 0; k < LQ; ++k) asm volatile("" : "+v"(on[k].gl), "+v"(on[k].ins0), "+v"(on[k].i0), "+v"(on[k].nn));
 	for (;;) {
-		o = on; J = Jn; on = onn;
-		if (!onn_ok) on.nn = 0;                                   // (a row behind the end of the list)
-		const uint64_t g1 = g0 + stride, g2 = g1 + stride;
+		// the orders of this step arrived with the loads of the step before (or in front of the loop: the first use waits for them)
+#pragma unroll
+		for (int k = 0; k < LQ; ++k) { o[k] = on[k]; if (!on_ok[k]) o[k].nn = 0; }   // (nn = 0: a row behind the end of the list)
+		const uint64_t g1 = g0 + stride;
 		const bool more = g1 < nwork;
+#pragma unroll
+		for (int k = 0; k < LQ; ++k) row_job_load<P>(o[k], g, pool, INS_E, INS_A, J[k]);
 		if (more) {
-			row_job_load<P>(on, g, pool, INS_E, INS_A, Jn);       // next quad: in flight while this one is worked on
-			onn_ok = row_ord_load(LD, g2 < nwork ? g2 : g1, nwork, ln, onn);
+#pragma unroll
+			for (int k = 0; k < LQ; ++k) on_ok[k] = row_ord_load(LD, g1 + (uint64_t)(k * LROWS), nwork, ln, on[k]);
 		}
-		asm volatile("" ::: "memory");
-		uint64_t w0 = J.w[0], w1 = J.w[1], w2 = J.w[2];
-		uint32_t pjr = J.pj, aj = J.aj;
-		const uint32_t oni = ord_ni(o);
-		bool p2 = (o.nn >> 31) != 0;                              // the leaf has a plane-2 line (row-uniform)
+		// ONE wait for everything asked for above (the first look at any loaded word waits for all of them: see the head of the kernel)
+#pragma unroll
+		for (int k = 0; k < LQ; ++k) asm volatile("" : "+v"(J[k].w[0]), "+v"(J[k].w[1]), "+v"(J[k].w[2]), "+v"(J[k].pj), "+v"(J[k].aj));
+#pragma unroll
+		for (int k = 0; k < LQ; ++k) {
+		const RowOrd &oo = o[k];
+		uint64_t w0 = J[k].w[0], w1 = J[k].w[1], w2 = J[k].w[2];
+		uint32_t pjr = J[k].pj, aj = J[k].aj;
+		const uint32_t oni = ord_ni(oo);
+		bool p2 = (oo.nn >> 31) != 0;                             // the leaf has a plane-2 line (row-uniform)
 		if (!p2) {                                                // two planes tell its symbols: T is "neither bit set", on the positions in use
-			const int nold = (int)((o.nn >> 16) & FILL_MASK) - (int)oni;
+			const int nold = (int)((oo.nn >> 16) & FILL_MASK) - (int)oni;
 			w2 = ~(w0 | w1) & bits_below((uint32_t)min(GSYM, max(0, nold - g * GSYM)));
 		}
 		const uint32_t nimax = max(max((uint32_t)__builtin_amdgcn_readlane((int)oni, 0), (uint32_t)__builtin_amdgcn_readlane((int)oni, 16)),
 				max((uint32_t)__builtin_amdgcn_readlane((int)oni, 32), (uint32_t)__builtin_amdgcn_readlane((int)oni, 48)));
 		for (uint32_t c0 = 0; c0 < nimax; c0 += LTURN) {            // turns of LTURN inserts per row (one turn, normally)
 			if (c0) {                                               // (rare) the row's next inserts
-				const uint64_t q = (uint64_t)o.ins0 + min(c0 + (uint32_t)g, max(oni, 1u) - 1u);
+				const uint64_t q = (uint64_t)oo.ins0 + min(c0 + (uint32_t)g, max(oni, 1u) - 1u);
 				aj = INS_A[q]; pjr = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];
-				asm volatile("" : "+v"(aj), "+v"(pjr));             // waited for HERE, on the rare path: a wait at the first use, behind the join, would also make the common
-				                                                    // path wait -- for the next quad's leaf lines, which are to stay in flight while this quad is worked on
+				asm volatile("" : "+v"(aj), "+v"(pjr));             // waited for HERE, on the rare path: a wait at the first use, behind the join, would make the common path wait as well
 			}
 			const uint32_t nic = oni > c0 ? min(oni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
-			const uint32_t pj = pjr - o.i0 + c0 + (uint32_t)g;      // final position E[q] + q inside the leaf (lanes >= nic: unused)
+			const uint32_t pj = pjr - oo.i0 + c0 + (uint32_t)g;     // final position E[q] + q inside the leaf (lanes >= nic: unused)
 			const uint32_t ncmax = min(nimax - c0, (uint32_t)LTURN);
 			const bool mine = (uint32_t)g < nic;
 			// what a leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
@@ -443,7 +467,9 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 #pragma unroll
 				for (int s = 0; s < 6; ++s) cs[s] = (uint32_t)__popc((uint32_t)(__ballot(mine && aj == (uint32_t)s) >> rsh) & 0xffffu);
 				const bool first_x = !p2 && (cs[0] | cs[5]) != 0;       // the leaf's first `$` / `N`: it has a plane-2 line from here on
-				dir_add_packed(pool, sbtot, o.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16, first_x ? FILL_P2 : 0u);
+#ifndef RB2_EXP_NOATOM
+				dir_add_packed(pool, sbtot, oo.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16, first_x ? FILL_P2 : 0u);
+#endif
 				p2 = p2 || first_x;
 			}
 			// RKREL = the rank of the symbol inside the leaf AS IT WAS before the round (what rope_insert_run's descent ends with: rle_insert_cached's
@@ -456,7 +482,8 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 				uint32_t cnt = 0;
 				for (uint32_t t0 = 0; t0 < c0; t0 += 16) {
 					const uint32_t idx = t0 + (uint32_t)g;
-					const uint32_t av = (idx < c0 && idx < oni) ? (uint32_t)INS_A[(uint64_t)o.ins0 + idx] : 7u;
+					uint32_t av = 7u;
+					if (idx < c0 && idx < oni) { av = (uint32_t)INS_A[(uint64_t)oo.ins0 + idx]; asm volatile("" : "+v"(av)); }
 #pragma unroll
 					for (int s = 0; s < 6; ++s) { const uint32_t bm = (uint32_t)(__ballot(av == (uint32_t)s) >> rsh) & 0xffffu; if (aj == (uint32_t)s) cnt += (uint32_t)__popc(bm); }
 				}
@@ -486,16 +513,21 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, 7) void k_mer
 					}
 				}
 			});
-			if (mine) RKREL[(uint64_t)o.ins0 + c0 + g] = (uint16_t)myrank;
+			if (mine) RKREL[(uint64_t)oo.ins0 + c0 + g] = (uint16_t)myrank;
 		}
 		// The WHOLE leaf goes back, full 128-byte lines -- two, or three when it holds a `$` or an `N` --, with nontemporal stores behind nontemporal
 		// loads: the leaf streams through once and nothing of it has to wait in L2 for a partial line to be merged.  (Rounds 2-4 stored only the
 		// groups from the first changed one on, counting on the lines the load had left in L2: 1 M x 10 kbp 3.09-3.19 s, this way 2.72-2.75 s
 		// on one box.  Each half alone is no gain: whole lines with plain accesses 3.09, nontemporal accesses with partial lines 3.31-3.39.)
 		if (oni) {
-			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)o.gl * LEAFW + g;
+			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)oo.gl * LEAFW + g;
+#ifndef RB2_EXP_NOSTORE
 			RB2_STNT(w0, &lw[0]); RB2_STNT(w1, &lw[LEAFG]);
 			if (p2) RB2_STNT(w2, &lw[2 * LEAFG]);
+#else
+			if (w0 == 0x123456789ull) RB2_STNT(w0, &lw[0]);
+#endif
+		}
 		}
 		if (!more) return;
 		g0 = g1;
