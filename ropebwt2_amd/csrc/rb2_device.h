@@ -174,7 +174,8 @@ struct SpOrd {              // work order of one touched leaf in a sparse round,
 // record per superblock instead of the 48 + 8 bytes of 64-bit values of rounds 1-3: the scan that rebuilds them every round -- the one part
 // of an in-place round that reads every superblock -- moves 48 bytes per superblock instead of 72, in whole lines.
 constexpr int SCHUNK_SH = 10;          // log2(SCHUNK)
-struct SbRec { uint32_t cum[6]; uint32_t pos; uint32_t pad; };     // inside the chunk: symbol counts / symbols in front of the superblock
+struct SbRec { uint32_t cum[6]; uint32_t pos; uint32_t tot; };     // inside the chunk: symbol counts / symbols in front of the superblock; tot: the symbols it holds itself (its second
+                                                                   // 16 bytes -- cum[4], cum[5], pos, tot -- are all one probe of an in-place round's descent needs: k_part_sparse)
 struct SbBase { uint64_t cum[6]; uint64_t pos; uint64_t pad; };    // in front of the chunk
 struct PoolView { uint8_t *data; LeafMeta *meta; SbRec *sbrec; LeafMeta *own; SbBase *sbbase; uint8_t *xh; };   // xh: one byte per window (4 leaf slots), the format k_merge wrote it in (rb2_merge.h)
 __device__ __forceinline__ uint64_t sb_pos(const PoolView &pv, uint64_t sb) { return pv.sbbase[sb >> SCHUNK_SH].pos + pv.sbrec[sb].pos; }   // symbols in front of superblock sb (pool-wide)

@@ -1105,8 +1105,7 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 	__shared__ uint32_t s_w[4], s_base;
 	// The descent (locate(), rb2_device.h) of the thread's TWO inserts, level by level, the loads of a level issued together: a thread
 	// that ran one locate() after the other (and thread 0 a third one for the tile's left neighbour) had eight to twelve dependent
-	// round trips to memory in a row.  Superblocks fill evenly, so the one that holds p is the interpolated guess or a neighbour of
-	// it: three probes side by side (two of them share a line) instead of a gallop; anything else falls back to the search.
+	// round trips to memory in a row.
 	const uint64_t nsb = (rp.nleaves + SB - 1) / SB;
 	const uint64_t base = nsb ? sb_pos(oldp, rp.sb0) : 0;
 	// The rank of every insert's symbol on the rope AS IT IS (before the round) is taken here, on the way down -- the prefix in front of its
@@ -1118,7 +1117,6 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 	if (threadIdx.x < 6) s_cb[threadIdx.x] = nsb ? (P)sb_cum(oldp, rp.sb0, (int)threadIdx.x) : (P)0;
 	bool ok[2];
 	uint64_t p[2], pprev[2], sbi[2], sbs[2];
-	uint64_t pr[2][3];
 	uint32_t aq[2];
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
@@ -1129,38 +1127,69 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		if (aq[h] > 5u) aq[h] = 0;
 		pprev[h] = (ok[h] && g > t.segstart) ? (uint64_t)E[g - 1] : ~0ull;   // ~0: no insert in front of mine in this piece
 	}
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		uint64_t g = (rp.n && nsb) ? (uint64_t)((double)p[h] / (double)rp.n * (double)nsb) : 0;
-		if (nsb && g >= nsb) g = nsb - 1;
-		sbi[h] = g;
-		const bool on = ok[h] && nsb;
-		pr[h][0] = (on && g > 0) ? sb_pos(oldp, rp.sb0 + g - 1) - base : 0;
-		pr[h][1] = on ? sb_pos(oldp, rp.sb0 + g) - base : 0;
-		pr[h][2] = (on && g + 1 < nsb) ? sb_pos(oldp, rp.sb0 + g + 1) - base : ~0ull;
-	}
+	// Level 1: the interpolated superblock.  ONE 16-byte load of its record says where it starts and how many symbols it holds (SbRec: cum[4],
+	// cum[5], pos, tot), a 4-byte one my symbol's count in front of it.  Superblocks fill evenly: seven times in ten that is the superblock,
+	// else the neighbour on the side the position lies (one more probe), else -- a piece that fills unevenly -- the search (locate()).
+	// (Every one of these gathers costs what its sectors cost at the CU's address unit -- one 32-byte sector per clock, tools/ubench/gather_rate.hip --,
+	// whatever it hits: r05 probed three records side by side and read both 64-byte rows whole, twelve such loads per insert; now seven to eight.)
 	bool slow[2];
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		slow[h] = false;
-		if (pr[h][1] <= p[h]) {
-			if (pr[h][2] > p[h]) sbs[h] = pr[h][1];
-			else slow[h] = true;
-		} else if (sbi[h] > 0 && pr[h][0] <= p[h]) { sbs[h] = pr[h][0]; --sbi[h]; }
-		else slow[h] = true;
-		slow[h] = slow[h] && ok[h] && nsb;
-	}
-	Loc lc[2];
-	uint4 fr[2][4], cr[2][4];
 	uint64_t cum[2];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {                              // the fills of the superblock's 32 slots: one 64-byte line; the own counts of my symbol: another
-		const uint4 *q = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 0), *qc = (const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 1 + (int)aq[h]);
-		const bool ld = ok[h] && nsb && !slow[h];
+	for (int h = 0; h < 2; ++h) { slow[h] = false; sbs[h] = 0; cum[h] = 0; sbi[h] = 0; }
+	{
+		uint4 hi[2]; uint32_t cg[2]; uint64_t bp[2], bc[2];
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { fr[h][i] = ld ? q[i] : make_uint4(0, 0, 0, 0); cr[h][i] = ld ? qc[i] : make_uint4(0, 0, 0, 0); }
-		cum[h] = ld ? sb_cum(oldp, rp.sb0 + sbi[h], (int)aq[h]) : 0ull;
+		for (int h = 0; h < 2; ++h) {
+			uint64_t g = (rp.n && nsb) ? (uint64_t)((double)p[h] / (double)rp.n * (double)nsb) : 0;
+			if (nsb && g >= nsb) g = nsb - 1;
+			sbi[h] = g;
+			const bool on = ok[h] && nsb;
+			const SbRec *rec = oldp.sbrec + (on ? rp.sb0 + g : 0);
+			const SbBase *bb = oldp.sbbase + (on ? (rp.sb0 + g) >> SCHUNK_SH : 0);
+			hi[h] = *(const uint4*)&rec->cum[4];
+			cg[h] = rec->cum[aq[h] & 3u];
+			bp[h] = bb->pos; bc[h] = bb->cum[aq[h]];
+		}
+		uint64_t g2[2]; bool again[2];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const bool on = ok[h] && nsb;
+			const uint64_t P0 = bp[h] + hi[h].z - base;
+			const bool in = P0 <= p[h] && (p[h] < P0 + hi[h].w || sbi[h] + 1 >= nsb);   // (the piece's last superblock takes everything behind it: p == n)
+			again[h] = on && !in;
+			g2[h] = p[h] < P0 ? sbi[h] - 1 : sbi[h] + 1;           // (in range: the first superblock starts at 0, the last one takes the rest)
+			sbs[h] = P0;
+			cum[h] = bc[h] + (aq[h] < 4u ? cg[h] : (aq[h] == 4u ? hi[h].x : hi[h].y));
+		}
+		if (again[0] || again[1]) {                                // the neighbour
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const SbRec *rec = oldp.sbrec + (again[h] ? rp.sb0 + g2[h] : 0);
+				const SbBase *bb = oldp.sbbase + (again[h] ? (rp.sb0 + g2[h]) >> SCHUNK_SH : 0);
+				if (again[h]) { hi[h] = *(const uint4*)&rec->cum[4]; cg[h] = rec->cum[aq[h] & 3u]; bp[h] = bb->pos; bc[h] = bb->cum[aq[h]]; }
+			}
+#pragma unroll
+			for (int h = 0; h < 2; ++h) if (again[h]) {
+				const uint64_t P0 = bp[h] + hi[h].z - base;
+				const bool in = P0 <= p[h] && (p[h] < P0 + hi[h].w || g2[h] + 1 >= nsb);
+				slow[h] = !in;
+				sbi[h] = g2[h]; sbs[h] = P0;
+				cum[h] = bc[h] + (aq[h] < 4u ? cg[h] : (aq[h] == 4u ? hi[h].x : hi[h].y));
+			}
+		}
 	}
+	// Level 2: the fills of the superblock's slots (row 0 of its directory block) and the own counts of my symbol (row 1 + a): the 48 bytes of the 24 slots a
+	// re-layout fills, each; the reserve slots (leaf splits) only when the position lies behind the first 24
+	Loc lc[2];
+	uint4 fr[2][3], cr[2][3];
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const bool ld = ok[h] && nsb && !slow[h];
+		const uint4 *q = (const uint4*)dir_row(oldp, ld ? rp.sb0 + sbi[h] : 0, 0), *qc = (const uint4*)dir_row(oldp, ld ? rp.sb0 + sbi[h] : 0, 1 + (int)aq[h]);
+#pragma unroll
+		for (int i = 0; i < 3; ++i) { fr[h][i] = q[i]; cr[h][i] = qc[i]; }
+	}
+	static_assert(SP_USED == 24, "three 16-byte pieces of a directory row are the slots a re-layout fills");
 	P rko[2] = { 0, 0 };                                      // my symbol in front of my leaf (without the piece's base: s_cb)
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
@@ -1173,27 +1202,33 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		}
 		const uint32_t rel = (uint32_t)(p[h] - sbs[h]);
 		uint32_t run = 0, klo = 0, pre = 0, nk = 0;
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const uint32_t w[4] = { fr[h][i].x, fr[h][i].y, fr[h][i].z, fr[h][i].w };
+		auto scan8 = [&](const uint4 &v, int i) {
+			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int j = 0; j < 8; ++j) {
 				const uint32_t e = (j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffffu, n = e & FILL_MASK;   // (bit 15: the leaf has a plane-2 line)
 				if (n > 0 && run <= rel) { klo = (uint32_t)(8 * i + j); pre = run; nk = e; }
 				run += n;
 			}
-		}
-		lc[h].gl = (rp.sb0 + sbi[h]) * SB + klo; lc[h].s = sbs[h] + pre; lc[h].n = nk & FILL_MASK; lc[h].p2 = nk >> 15;
-		uint32_t acc = 0;                                          // own counts of the slots in front of klo: two 16-bit sums side by side (dir_prefix)
+		};
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			const uint32_t w[4] = { cr[h][i].x, cr[h][i].y, cr[h][i].z, cr[h][i].w };
+		for (int i = 0; i < 3; ++i) scan8(fr[h][i], i);
+		uint32_t acc = 0;                                          // own counts of the slots in front of klo: two 16-bit sums side by side (dir_prefix)
+		auto add8 = [&](const uint4 &v, int i) {
+			const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				const uint32_t s0 = (uint32_t)(8 * i + 2 * j);
 				acc += w[j] & (klo > s0 + 1 ? 0xffffffffu : (klo == s0 + 1 ? 0xffffu : 0u));
 			}
+		};
+		if (run <= rel) {                                          // behind the 24 slots a re-layout fills: the reserve slots
+			scan8(((const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 0))[3], 3);
+			if (klo > 24u) add8(((const uint4*)dir_row(oldp, rp.sb0 + sbi[h], 1 + (int)aq[h]))[3], 3);
 		}
+#pragma unroll
+		for (int i = 0; i < 3; ++i) add8(cr[h][i], i);
+		lc[h].gl = (rp.sb0 + sbi[h]) * SB + klo; lc[h].s = sbs[h] + pre; lc[h].n = nk & FILL_MASK; lc[h].p2 = nk >> 15;
 		rko[h] = (P)(cum[h] + (acc & 0xffffu) + (acc >> 16));
 	}
 	// first insert of its leaf: the insert in front of mine (ascending positions) lies in front of my leaf's first symbol -- a leaf is
@@ -1574,12 +1609,13 @@ __device__ __forceinline__ void sbscan3_body(const Ctl *ctl, const SbTot *sbtot,
 	const uint64_t n = ctl->nsb_total, i0 = (uint64_t)blk * SCHUNK + (uint64_t)threadIdx.x * SBT;
 	if ((uint64_t)blk * SCHUNK >= n) return;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint32_t e[SBT][6], tot[6] = {0, 0, 0, 0, 0, 0};           // exclusive inside the thread, the thread's totals
+	uint32_t e[SBT][6], tot[6] = {0, 0, 0, 0, 0, 0}, own[SBT];  // exclusive inside the thread, the thread's totals; the symbols of each superblock
 #pragma unroll
 	for (int k = 0; k < SBT; ++k) {
 		SbTot t; t.p01 = t.p23 = t.p45 = t.pad = 0;
 		if (i0 + k < n) t = sbtot[i0 + k];
 		const uint32_t v[6] = { t.p01 & 0xffffu, t.p01 >> 16, t.p23 & 0xffffu, t.p23 >> 16, t.p45 & 0xffffu, t.p45 >> 16 };
+		own[k] = v[0] + v[1] + v[2] + v[3] + v[4] + v[5];
 #pragma unroll
 		for (int s = 0; s < 6; ++s) { e[k][s] = tot[s]; tot[s] += v[s]; }
 	}
@@ -1604,7 +1640,7 @@ __device__ __forceinline__ void sbscan3_body(const Ctl *ctl, const SbTot *sbtot,
 		for (int s = 0; s < 6; ++s) o[s] = b0[s] + e[k][s];
 		uint4 *q = (uint4*)&newp.sbrec[i0 + k];
 		q[0] = make_uint4(o[0], o[1], o[2], o[3]);
-		q[1] = make_uint4(o[4], o[5], o[0] + o[1] + o[2] + o[3] + o[4] + o[5], 0u);
+		q[1] = make_uint4(o[4], o[5], o[0] + o[1] + o[2] + o[3] + o[4] + o[5], own[k]);   // (pos, tot: what one probe of the descent reads: k_part_sparse)
 	}
 }
 __global__ __launch_bounds__(SCHUNK / SBT) void k_sbscan3(const Ctl *ctl, const SbTot *sbtot, PoolView newp)
