@@ -1138,12 +1138,36 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 	for (int h = 0; h < 2; ++h) { slow[h] = false; sbs[h] = 0; cum[h] = 0; sbi[h] = 0; }
 	{
 		uint4 hi[2]; uint32_t cg[2]; uint64_t bp[2], bc[2];
+		// The guess, in two steps: the piece's superblocks as a whole, then -- with the chunk bases (SbBase: one 64-byte record per 1024 superblocks, a few
+		// thousand of them, cache-resident, neighbouring lanes read the same ones) -- the part of the guessed chunk that belongs to the piece.  What a
+		// straight line over the WHOLE piece misses grows with its length (inserts land at random: the position of superblock g strays from g / nsb of
+		// the piece like sqrt(g)): at 90 G symbols, 160 k superblocks per piece, it was off by one more often than not and off by two often enough that
+		// the fallback search took most of the kernel (38 -> 114 us per round from the first to the ninth batch of configs[3]).
+		uint64_t gq[2], c0p[2], c1p[2];
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
 			uint64_t g = (rp.n && nsb) ? (uint64_t)((double)p[h] / (double)rp.n * (double)nsb) : 0;
 			if (nsb && g >= nsb) g = nsb - 1;
-			sbi[h] = g;
+			gq[h] = g;
 			const bool on = ok[h] && nsb;
+			const uint64_t c = on ? (rp.sb0 + g) >> SCHUNK_SH : 0;
+			c0p[h] = oldp.sbbase[c].pos; c1p[h] = oldp.sbbase[c + 1].pos;   // (the bases reach one entry past the last chunk in use: k_sbscan2)
+		}
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			uint64_t g = gq[h];
+			const bool on = ok[h] && nsb;
+			if (on) {
+				const uint64_t c = (rp.sb0 + g) >> SCHUNK_SH, pa = base + p[h];
+				const uint64_t s_lo = max(c << SCHUNK_SH, rp.sb0), s_hi = min((c + 1) << SCHUNK_SH, rp.sb0 + nsb);   // the chunk's superblocks of this piece
+				const uint64_t p_lo = (c << SCHUNK_SH) >= rp.sb0 ? c0p[h] : base, p_hi = ((c + 1) << SCHUNK_SH) <= rp.sb0 + nsb ? c1p[h] : base + rp.n;
+				if (pa >= p_lo && pa < p_hi && p_hi > p_lo) {          // (else: the straight line's chunk was wrong -- keep its guess, the probes below sort it out)
+					uint64_t g2 = s_lo + (uint64_t)((double)(pa - p_lo) / (double)(p_hi - p_lo) * (double)(s_hi - s_lo));
+					if (g2 >= s_hi) g2 = s_hi - 1;
+					g = g2 - rp.sb0;
+				}
+			}
+			sbi[h] = g;
 			const SbRec *rec = oldp.sbrec + (on ? rp.sb0 + g : 0);
 			const SbBase *bb = oldp.sbbase + (on ? (rp.sb0 + g) >> SCHUNK_SH : 0);
 			hi[h] = *(const uint4*)&rec->cum[4];
@@ -1596,6 +1620,13 @@ template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, S
 			base[j0 + k] = o;
 		}
 		__syncthreads();
+	}
+	if (threadIdx.x == 0) {                                     // one entry past the last chunk: the pool's totals (the descent of an in-place round reads base[c + 1] as the end of chunk c)
+		SbBase o;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) o.cum[s] = run[s];
+		o.pos = run[0] + run[1] + run[2] + run[3] + run[4] + run[5]; o.pad = 0;
+		base[nc] = o;
 	}
 }
 __global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
