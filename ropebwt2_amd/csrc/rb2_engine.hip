@@ -260,6 +260,7 @@ struct rb2_hip_s {
 	int compact_ok = 1;                 // RB2_COMPACT=0: dense rounds always write plain (three-plane) windows
 	int compact_stats = 0;              // RB2_COMPACT_STATS=1: k_merge counts the windows it writes per format (rb2_hip_window_stats)
 	int64_t n_compact_rounds = 0;       // dense rounds that were allowed to write compact windows
+	int64_t n_plain_handover = 0;       // dense rounds that wrote plain windows over compact ones because a re-layout was pending (plain_next): rb2_hip_layout_stats out[7]
 	bool pool_compact = false;          // the last dense round wrote compact windows (only k_merge may read the pool now)
 	bool plain_next = false;            // choose_layout wants to leave the dense layout: this round writes plain windows
 	int ts_fold = SCHUNK;               // up to this many chunks of string tiles k_tscan3 scans the chunk totals itself (no k_tscan2 launch); RB2_TS_FOLD lowers it (tests)
@@ -600,6 +601,14 @@ uint64_t slots_for(uint64_t n, bool sparse)
 	return (n / ((uint64_t)SP_FILL * SP_USED) + NR + 1) * SB;
 }
 
+// Compact windows (rb2_merge.h "window formats") may only be met by k_merge: whoever else is about to read leaf words of the dense layout -- a
+// re-layout, the export, rank queries, the checksums -- says so here.  The round loop keeps the promise (the last round of a batch and the round in
+// front of a re-layout write plain windows: round_merge_any, choose_layout); this makes a new reader that forgets about it fail loudly.
+void require_plain(rb2_hip_t *h, const char *who)
+{
+	if (!h->sparse && h->pool_compact) { rb2_fatal("[rb2_hip] internal: %s would read a pool that holds compact windows\n", who); }
+}
+
 // copy the index pool[pside] -> pool[pside ^ 1] in the other layout (or the same one, re-spread); descriptors of
 // ctl->rope[side] are rewritten in place.  n_ub: upper bound of the symbols held now.
 // n_grow: what the index may grow to while it stays in the new layout's pools (dense rounds ping-pong between both pools
@@ -607,6 +616,7 @@ uint64_t slots_for(uint64_t n, bool sparse)
 void relayout(rb2_hip_t *h, bool to_sparse, uint64_t n_ub, uint64_t n_grow)
 {
 	hipStream_t st = h->st;
+	require_plain(h, "a re-layout");
 	struct NoWatch { int64_t *keep = t_grow_in_rounds; NoWatch() { t_grow_in_rounds = nullptr; } ~NoWatch() { t_grow_in_rounds = keep; } } nw;   // (a re-layout sizes its target pool here and waits for the device anyway)
 	const auto t_host0 = std::chrono::steady_clock::now();
 	const uint64_t cap_before[2] = { h->pool[0].cap_leaves, h->pool[1].cap_leaves };
@@ -757,7 +767,7 @@ bool choose_layout(rb2_hip_t *h, BatchState &B, uint64_t r, uint64_t m_eff)
 	if (h->sparse && !want && lambda < 2 * h->sp_lambda && h->sp_backoff == 0) want = true;   // hysteresis
 	if (h->sp_backoff > 0) --h->sp_backoff;
 	h->plain_next = false;
-	if (want && !h->sparse && h->pool_compact) { want = false; h->plain_next = true; }   // the re-layout reads plain windows: this round writes them, the next one switches
+	if (want && !h->sparse && h->pool_compact) { want = false; h->plain_next = true; ++h->n_plain_handover; }   // the re-layout reads plain windows: this round writes them, the next one switches
 	if (want && !h->sparse) {                              // the sparse pool is 1.8x one dense side and lives next to both: only if it fits
 		const uint64_t need = slots_for(n_ub, true);        // both pools take turns as the target of a re-layout: both must be able to grow
 		const int grow = (need > h->pool[0].cap_leaves) + (need > h->pool[1].cap_leaves);
@@ -1154,6 +1164,7 @@ static void ensure_dense(rb2_hip_t *h)          /* k_export streams flat pieces:
  * host buffers -- while the host consumes one (dst copy / one callback per staging round), the device fills the other. */
 static int64_t export_piece(rb2_hip_t *h, int r, uint8_t *dst, rb2_hip_run_cb cb = nullptr, void *user = nullptr)
 {
+	require_plain(h, "the export");
 	const uint64_t CH = 32768;                       // export chunks (XCHUNK symbols each) per staging round: at most 32 MiB of run bytes
 	const RopeDesc &d = h->h_rope[r];
 	const uint64_t nchunks = (d.n + XCHUNK - 1) / XCHUNK;
@@ -1398,6 +1409,7 @@ void rb2_hip_rank_batch(rb2_hip_t *h, int b, int64_t n, const int64_t *x, int64_
 	for (int64_t i0 = 0; i0 < n; i0 += CH) {
 		const int64_t nc = std::min(CH, n - i0);
 		HIPCHK(hipMemcpyAsync(h->qbuf.p, x + i0, (size_t)nc * 8, hipMemcpyHostToDevice, h->st));
+		require_plain(h, "a rank query");
 		hipLaunchKernelGGL(k_rank_batch, dim3(cdiv((uint64_t)nc, MW)), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), b,
 				(const uint64_t*)h->qbuf.p, (uint64_t)nc, h->qbuf.p + nc, (int)h->sparse);
 		HIPCHK(hipGetLastError());
@@ -1420,6 +1432,7 @@ static uint64_t piece_hash(rb2_hip_t *h, int r)
 	if (h->h_rope[r].n == 0) return 0;
 	h->qbuf.ensure(8);
 	HIPCHK(hipMemsetAsync(h->qbuf.p, 0, 8, h->st));
+	require_plain(h, "a checksum");
 	hipLaunchKernelGGL(k_piece_hash, dim3(2048), dim3(256), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), r, (unsigned long long*)h->qbuf.p);
 	HIPCHK(hipGetLastError());
 	uint64_t v = 0;
@@ -1445,6 +1458,7 @@ static void rank_piece(rb2_hip_t *h, int r, int64_t p, int64_t out[6])
 {
 	HIPCHK(hipSetDevice(h->dev));
 	h->qbuf.ensure(8);
+	require_plain(h, "a rank query");
 	hipLaunchKernelGGL(k_rank_piece, dim3(1), dim3(64), 0, h->st, (const Ctl*)h->ctl, h->side, h->pool[h->pside].view(), r, (uint64_t)p, h->qbuf.p, (int)h->sparse);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(out, h->qbuf.p, 48, hipMemcpyDeviceToHost, h->st));
@@ -1510,7 +1524,7 @@ void rb2_hip_layout_stats(rb2_hip_t *h, int64_t out[8])
 	HIPCHK(hipMemcpyAsync(&ns, &h->ctl->nsplit_total, 8, hipMemcpyDeviceToHost, h->st));
 	HIPCHK(hipStreamSynchronize(h->st));
 	out[0] = h->n_relayout; out[1] = h->n_void; out[2] = h->n_sparse_rounds; out[3] = h->sparse ? 1 : 0;
-	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = h->n_grow_in_rounds; out[7] = 0;
+	out[4] = h->n_respread; out[5] = (int64_t)ns; out[6] = h->n_grow_in_rounds; out[7] = h->n_plain_handover;
 }
 
 void rb2_hip_window_stats(rb2_hip_t *h, int64_t out[6])

@@ -541,42 +541,55 @@ void rb2_hip_default_owners(int nranks, int owner[])
 }
 
 /* Build a small job across the ranks of m and compare what every LOCAL rank holds with the same job on one engine: sub-rope by
- * sub-rope, device-side checksums of the symbols + the count matrix.  Collective over the ranks of the group (every process of an
- * RCCL group runs it at the same point).  Fatal on a mismatch -- a first run on hardware this build has not seen either works or
- * says where it does not.  Leaves the handle empty. */
-static void multi_selftest(rb2_hip_multi_t *m)
+ * sub-rope, device-side checksums of the symbols + the count matrix.  Two batches: the second one goes on top of an index that holds
+ * reads, in whatever order the handle sorts -- rounds with non-empty intervals (both kernel variants, U and SIZE travelling with the
+ * strings), the next-round flag set by the senders, copies of reads (groups of more than one string).  Collective over the ranks of the
+ * group (every process of an RCCL group runs it at the same point).  soft = false: fatal on a mismatch -- a first run on hardware this
+ * build has not seen either works or says where it does not; soft = true: says so and returns false (rb2_hip_multi_create then falls
+ * back from the PEER transport to RCCL).  Leaves the handle empty. */
+static bool multi_selftest(rb2_hip_multi_t *m, bool soft = false)
 {
 	const int n_reads = 2000, L = 48;
-	std::vector<uint8_t> s;
-	s.reserve((size_t)n_reads * (L + 1));
-	uint64_t x = 0x9E3779B97F4A7C15ull;
-	for (int i = 0; i < n_reads; ++i) {                          // reversed nt6 strings, 0-terminated (mrope.h:46-54); every 7th a copy of its neighbour
-		const size_t at = s.size();
-		for (int j = 0; j < L; ++j) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; s.push_back((uint8_t)(1 + (x >> 60) % 4)); }
-		if (i % 7 == 6) memcpy(&s[at], &s[at - (L + 1)], L);
-		s.push_back(0);
-	}
-	const int64_t len = (int64_t)s.size();
-	rb2_hip_multi_insert_multi(m, len, s.data());
+	char why[256] = "";
 	rb2_hip_t *one = rb2_hip_create(m->rk[0].dev, m->so);
-	rb2_hip_insert_multi(one, len, s.data());
-	rb2_hip_wait(one);
-	int64_t cm[36], c1[36];
-	rb2_hip_multi_get_counts(m, cm); rb2_hip_get_counts(one, c1);
-	if (memcmp(cm, c1, sizeof(cm)) != 0) rb2_fatal("[rb2_hip] multi self-test: the count matrix of %d ranks (%s transport) differs from one engine's\n", m->world, m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL");
-	for (int r = 0; r < NR; ++r) {
-		const int o = m->owner[r] - m->rank0;
-		if (o < 0 || o >= m->n) continue;                        /* another process holds (and checks) it */
-		const uint64_t a = piece_hash(m->rk[o].h, r), b = piece_hash(one, r);
-		if (a != b || m->rk[o].h->h_rope[r].n != one->h_rope[r].n)
-			rb2_fatal("[rb2_hip] multi self-test: sub-rope %d held by rank %d on device %d (%s transport) differs from the one-engine build (%llu vs %llu symbols)\n", r, m->owner[r], m->rk[o].dev,
-					m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL", (unsigned long long)m->rk[o].h->h_rope[r].n, (unsigned long long)one->h_rope[r].n);
+	uint64_t x = 0x9E3779B97F4A7C15ull;
+	for (int batch = 0; batch < 2 && !why[0]; ++batch) {
+		std::vector<uint8_t> s;
+		s.reserve((size_t)n_reads * (L + 1));
+		for (int i = 0; i < n_reads; ++i) {                      // reversed nt6 strings, 0-terminated (mrope.h:46-54); every 7th a copy of its neighbour
+			const size_t at = s.size();
+			for (int j = 0; j < L; ++j) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; s.push_back((uint8_t)(1 + (x >> 60) % 4)); }
+			if (i % 7 == 6) memcpy(&s[at], &s[at - (L + 1)], L);
+			s.push_back(0);
+		}
+		const int64_t len = (int64_t)s.size();
+		rb2_hip_multi_insert_multi(m, len, s.data());
+		rb2_hip_insert_multi(one, len, s.data());
+		rb2_hip_wait(one);
+		int64_t cm[36], c1[36];
+		rb2_hip_multi_get_counts(m, cm); rb2_hip_get_counts(one, c1);
+		if (memcmp(cm, c1, sizeof(cm)) != 0) snprintf(why, sizeof(why), "the count matrix of %d ranks differs from one engine's after batch %d", m->world, batch);
+		for (int r = 0; r < NR && !why[0]; ++r) {
+			const int o = m->owner[r] - m->rank0;
+			if (o < 0 || o >= m->n) continue;                    /* another process holds (and checks) it */
+			const uint64_t a = piece_hash(m->rk[o].h, r), b = piece_hash(one, r);
+			if (a != b || m->rk[o].h->h_rope[r].n != one->h_rope[r].n)
+				snprintf(why, sizeof(why), "sub-rope %d held by rank %d on device %d differs from the one-engine build after batch %d (%llu vs %llu symbols)", r, m->owner[r], m->rk[o].dev, batch,
+						(unsigned long long)m->rk[o].h->h_rope[r].n, (unsigned long long)one->h_rope[r].n);
+		}
 	}
 	rb2_hip_destroy(one);
+	const char *tn = m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL";
+	if (why[0]) {
+		if (!soft) rb2_fatal("[rb2_hip] multi self-test (%s transport): %s\n", tn, why);
+		fprintf(stderr, "[rb2_hip] multi self-test (%s transport): %s\n", tn, why);
+		return false;
+	}
 	rb2_hip_multi_reset(m);
 	m->n_sync = m->n_rounds = m->n_batches = 0;
 	for (auto &R : m->rk) { R.h->n_sparse_rounds = R.h->n_void = R.h->n_relayout = R.h->n_respread = 0; }
-	if (m->trace) fprintf(stderr, "[rb2_hip] multi self-test passed: %d ranks, %s transport\n", m->world, m->transport == RB2_TRANSPORT_PEER ? "PEER" : "RCCL");
+	if (m->trace) fprintf(stderr, "[rb2_hip] multi self-test passed: %d ranks, %s transport\n", m->world, tn);
+	return true;
 }
 static bool multi_want_selftest(int distinct_devices, int world)
 {
@@ -605,20 +618,35 @@ rb2_hip_multi_t *rb2_hip_multi_create(int n, const int *devices, int sorting_ord
 			transport = RB2_TRANSPORT_RCCL;
 		}
 	}
-	rb2_hip_multi_t *m = multi_new(n, devices, n, 0, sorting_order, transport, owner);
-	if (transport == RB2_TRANSPORT_RCCL && n > 1) {
-		for (int k = 0; k < n; ++k) for (int p = 0; p < k; ++p)
-			if (devices[k] == devices[p]) rb2_fatal("[rb2_hip] multi: RCCL needs one device per rank (device %d is listed twice); several ranks on one device run on the PEER transport\n", devices[k]);
-		std::vector<ncclComm_t> comms(n);
-		NCCLCHK(rccl().CommInitAll(comms.data(), n, devices));
-		for (int k = 0; k < n; ++k) m->rk[k].comm = comms[k];
-	} else if (transport == RB2_TRANSPORT_RCCL) {               // a group of one: the same calls on a one-rank communicator
-		ncclUniqueId id;
-		HIPCHK(hipSetDevice(devices[0]));
-		NCCLCHK(rccl().GetUniqueId(&id));
-		NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, 1, id, 0));
+	auto make = [&](int tr) {
+		rb2_hip_multi_t *m = multi_new(n, devices, n, 0, sorting_order, tr, owner);
+		if (tr == RB2_TRANSPORT_RCCL && n > 1) {
+			for (int k = 0; k < n; ++k) for (int p = 0; p < k; ++p)
+				if (devices[k] == devices[p]) rb2_fatal("[rb2_hip] multi: RCCL needs one device per rank (device %d is listed twice); several ranks on one device run on the PEER transport\n", devices[k]);
+			std::vector<ncclComm_t> comms(n);
+			NCCLCHK(rccl().CommInitAll(comms.data(), n, devices));
+			for (int k = 0; k < n; ++k) m->rk[k].comm = comms[k];
+		} else if (tr == RB2_TRANSPORT_RCCL) {                    // a group of one: the same calls on a one-rank communicator
+			ncclUniqueId id;
+			HIPCHK(hipSetDevice(devices[0]));
+			NCCLCHK(rccl().GetUniqueId(&id));
+			NCCLCHK(rccl().CommInitRank(&m->rk[0].comm, 1, id, 0));
+		}
+		return m;
+	};
+	rb2_hip_multi_t *m = make(transport);
+	if (multi_want_selftest(distinct, n)) {
+		// PEER between PHYSICAL devices (strings stored straight into the owner's arrays over xGMI, ordered by events only) has never run on the
+		// hardware this was built on -- every box had one GPU: if the job it builds there differs from one engine's, the records + RCCL
+		// transport (the owner fetches, unpacks in a pass of its own: k_munpack) takes over, and has to pass the same test
+		const bool fallback = transport == RB2_TRANSPORT_PEER && distinct == n && n > 1;
+		if (!multi_selftest(m, fallback)) {
+			fprintf(stderr, "[rb2_hip] multi: the PEER transport failed its start-up test on these devices: using the RCCL transport\n");
+			rb2_hip_multi_destroy(m);
+			m = make(RB2_TRANSPORT_RCCL);
+			multi_selftest(m, false);
+		}
 	}
-	if (multi_want_selftest(distinct, n)) multi_selftest(m);
 	return m;
 }
 

@@ -266,7 +266,7 @@ class HipBwt:
         a = np.zeros(8, np.int64)
         self.L.rb2_hip_layout_stats(self.h, a.ctypes.data)
         return {"relayouts": int(a[0]), "void_rounds": int(a[1]), "sparse_rounds": int(a[2]), "sparse_now": bool(a[3]),
-                "respreads": int(a[4]), "leaf_splits": int(a[5]), "grown_in_rounds": int(a[6])}
+                "respreads": int(a[4]), "leaf_splits": int(a[5]), "grown_in_rounds": int(a[6]), "plain_handovers": int(a[7])}
 
     def window_stats(self):
         a = np.zeros(6, np.int64)

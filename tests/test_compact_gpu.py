@@ -85,21 +85,56 @@ def test_compact_off_is_the_same_index(hip, so):
     assert st["compact_rounds"] == 0 and st["compact0"] + st["compact1"] + st["compact2"] == 0, st
 
 
-def test_leaving_the_dense_layout_from_compact_windows(hip):
-    """long reads: a few dense rounds at the head of a batch (compact), then the switch to the in-place layout -- the round before
-    it writes plain windows for the re-layout to read -- and back when the next batch starts"""
+def _handover(hip, make, so, lam):
+    """two batches of long reads with the switch to the in-place layout in the MIDDLE of each: RB2_SPARSE_LAMBDA = lam makes a batch of m reads
+    run dense (compact windows: every interval is empty) until the index holds about 1024 m / lam symbols per read set, then one round
+    that writes PLAIN windows over the compact ones (the re-layout reads plain leaves), then the re-layout and in-place rounds"""
     a = H.splitmix_bases(300, 3000, seed=51)
     b = H.splitmix_bases(300, 2500, seed=52)
-    with Env(RB2_COMPACT_STATS=1, RB2_SPARSE_LAMBDA="1e18"):
-        for so in (0, 1):
-            dev, o = hip.HipBwt(so), H.Oracle(so)
-            for buf in (H.encode_batch_fixed(a), H.encode_batch_fixed(b)):
-                o.insert_multi(buf); dev.insert_multi(buf)
-                _same(dev, o)
-            st, ls = dev.window_stats(), dev.layout_stats()
-            dev.close()
-            assert ls["sparse_rounds"] > 4000 and ls["relayouts"] >= 3, ls
-            assert st["compact_rounds"] >= 0, st
+    with Env(RB2_COMPACT_STATS=1, RB2_SPARSE_LAMBDA=lam):
+        dev, o = make(so), H.Oracle(so)
+        for buf in (H.encode_batch_fixed(a), H.encode_batch_fixed(b)):
+            o.insert_multi(buf); dev.insert_multi(buf)
+            _same(dev, o)                                          # after every batch
+        st, ls = dev.window_stats(), dev.layout_stats()
+        dev.close()
+    return st, ls
+
+
+@pytest.mark.parametrize("so", [0, 1])
+def test_leaving_the_dense_layout_from_compact_windows(hip, so):
+    st, ls = _handover(hip, hip.HipBwt, so, "20")
+    # ~50 dense rounds at the head of the first batch, 8 at the head of the second (the index is in the in-place layout when it starts): compact windows
+    # were written and read back (compact0: the first batch has no `$` until its last round), each switch went through a round of plain windows
+    assert st["compact_rounds"] >= 20 and st["compact0"] + st["compact1"] > 0, st
+    assert ls["plain_handovers"] >= 2, ls
+    assert ls["sparse_rounds"] > 4000 and ls["relayouts"] >= 3, ls
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_leaving_the_dense_layout_from_compact_windows_on_virtual_ranks(hip, n):
+    """the same hand-over on every rank of a sharded index (ranks decide on their own layout: their share of the strings against their leaves)"""
+    from ropebwt2_amd.hipbwt import MultiBwt
+    a = H.splitmix_bases(300, 3000, seed=51)
+    b = H.splitmix_bases(300, 2500, seed=52)
+    with Env(RB2_COMPACT_STATS=1, RB2_SPARSE_LAMBDA="20"):
+        m, o = MultiBwt(0, [0] * n, "peer"), H.Oracle(0)
+        for buf in (H.encode_batch_fixed(a), H.encode_batch_fixed(b)):
+            o.insert_multi(buf); m.insert_multi(buf)
+            assert np.array_equal(m.counts(), o.counts())
+            for r in range(6):
+                assert np.array_equal(m.rope(r), o.rope(r)), "rope %d" % r
+        ws = [m.engine(k).window_stats() for k in range(n)]
+        ls = [m.engine(k).layout_stats() for k in range(n)]
+        m.close()
+    assert sum(w["compact_rounds"] for w in ws) >= 20 and sum(w["compact0"] + w["compact1"] for w in ws) > 0, ws
+    assert sum(l["plain_handovers"] for l in ls) >= 2 and sum(l["sparse_rounds"] for l in ls) > 4000, ls
+
+
+def test_compact_windows_are_never_reached_when_the_layout_switches_at_once(hip):
+    """(the round-5 form of the test above: with RB2_SPARSE_LAMBDA = 1e18 the index leaves the dense layout in its first round, before a compact window exists)"""
+    st, ls = _handover(hip, hip.HipBwt, 0, "1e18")
+    assert ls["sparse_rounds"] > 4000 and ls["plain_handovers"] == 0, (st, ls)
 
 
 def test_configs1_shape_2M_reads_compact(hip):
