@@ -118,8 +118,8 @@ struct Ctl {
 	uint32_t wstride;       // work orders of a sparse round: WLC lists of at most wstride entries each, list c at LD[c * wstride ..) (see wcnt)
 	uint32_t overflow;      // some touched leaf cannot take its inserts: the round is void (every later kernel returns) and the host redoes it densely
 	uint32_t sbfull;        // (same 8-byte verdict word) k_split found a leaf to split in a superblock without a free slot: the host re-spreads the index before the next round
-	uint32_t nsplit;        // leaves that came within SP_MARGIN of LEAF this round (k_part_sparse appends them, k_split splits them)
-	uint32_t pad_sp;
+	uint32_t nsplit2[2];    // [round & 1]: leaves that came within SP_MARGIN of LEAF in that round (k_part_sparse appends them, the splits -- queued with the NEXT round's counting
+	                        // phase, beside its k_setup, which clears the counter of ITS round -- read them: two counters, no race)
 	uint64_t nsplit_total;  // leaves split since the handle was created (statistics)
 	RopeDesc relay_old[NR]; // k_relayout: the layout being read while rope[side] already describes the one being written
 	// ---- rope sharding across GPUs (single GPU: own[] all 1, sdest unused)

@@ -203,6 +203,7 @@ struct rb2_hip_s {
 	// in-place rounds: the prefix over the superblock totals (k_sbscan*) is needed by the NEXT round's descent only (k_advance takes its ranks
 	// from before the merge: RKOLD), so it rides in blocks of their own of the launches that follow the merge anyway (k_advance; k_sym / k_split)
 	int dir_ride = 1;                   // RB2_DIR_RIDE=0: two launches of its own behind k_merge_leaf, as in rounds 2-5
+	int ts_blocks = TSB;                // RB2_TS_BLOCKS=1: the single-launch counting tail on one block, as in rounds 4-5 (A/B)
 	// in-place rounds of one engine are queued without waiting for their verdict (a void round is sticky on the device: rb2_kernels.h k_part_sparse);
 	// spec_rounds = in-place rounds queued since the host last looked with the stream drained (verdict_check)
 	int lazy_verdict = 1;               // RB2_LAZY_VERDICT=0: an event and a wait per in-place round, as in rounds 2-5
@@ -508,25 +509,28 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	h->cur_round = (int)r;
 	const TileRecs trs = { (uint32_t*)h->trec.p, (uint32_t)(h->trec.cap & ~(size_t)3) };   // (20 columns of cap words in the 80-byte records' space)
 	tl_slow(h, "start of round_counts");
+	const bool one_launch_tail = B.nst_ub < (unsigned)h->ts_max;  // few tiles (long reads): the counting tail is one launch (k_tscan_setup)
+	SplitArgs sp; memset(&sp, 0, sizeof(sp));
+	if (with_split) {
+	  sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
+	  sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = 64;
+	  sp.round1 = (uint32_t)r;                                   // (the splits of round r - 1)
+	  sp.scan2 = h->dir_ride ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
+	}
 	{ Scope sc(h, RB2_K_SYM, units);
 	  with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
-	    SplitArgs sp; memset(&sp, 0, sizeof(sp));
 	    if (with_split) {
-	      constexpr unsigned NSPLITB = 64;
-	      sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
-	      sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = NSPLITB;
-	      sp.round1 = (uint32_t)r;                               // (the splits of round r - 1)
-	      sp.scan2 = h->dir_ride ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
-	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + NSPLITB + (sp.scan2 ? 1u : 0u)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
+	      hipLaunchKernelGGL((k_sym<false, P, true>), dim3((unsigned)rank_share(h, B.nst_ub) + sp.nsplitb + (sp.scan2 ? 1u : 0u)), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p);
 	    } else
 	    RB2_LAUNCH_STRIDE(h, (k_sym<true, P>), (k_sym<false, P>), dim3(grid8((unsigned)rank_share(h, B.nst_ub))), dim3(256), 0, st, h->ctl, sd, (int)(r & 1), RB2_P(h->L[cur].p), RB2_P(h->U[cur].p), h->A[cur].p, trs, sp, RB2_P(h->INS_E.p), h->INS_A.p); }); }
 	tl_slow(h, "k_sym");
 	if (with_split && with_event) HIPCHK(hipEventRecord(h->ev_flag, st));   // (the splits left the verdict in pinned memory)
-	if (B.nst_ub < (unsigned)h->ts_max) {                      // few tiles (long reads): one single-block launch instead of six, k_setup included (one GPU)
+	if (one_launch_tail) {                                      // one launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
-	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
-	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(1), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	  const unsigned grid = (unsigned)std::max(1, std::min<int>(TSB, h->ts_blocks));
+	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; }
 	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);
@@ -981,6 +985,7 @@ rb2_hip_t *rb2_hip_create(int device, int sorting_order)
 	HIPCHK(hipHostGetDevicePointer((void**)&h->d_flag, h->h_flag, 0));
 	HIPCHK(hipEventCreateWithFlags(&h->ev_flag, hipEventDisableTiming));
 	if (getenv("RB2_DIR_RIDE")) h->dir_ride = atoi(getenv("RB2_DIR_RIDE"));
+	if (getenv("RB2_TS_BLOCKS")) h->ts_blocks = atoi(getenv("RB2_TS_BLOCKS"));
 	if (getenv("RB2_LAZY_VERDICT")) h->lazy_verdict = atoi(getenv("RB2_LAZY_VERDICT"));
 	if (getenv("RB2_RUN_AHEAD")) h->run_ahead = std::max(1, atoi(getenv("RB2_RUN_AHEAD")));
 	{ Ctl *hc = (Ctl*)calloc(1, sizeof(Ctl)); for (int b = 0; b < NR; ++b) hc->own[b] = 1; HIPCHK(hipMemcpy(h->ctl, hc, sizeof(Ctl), hipMemcpyHostToDevice)); free(hc); }

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_tfix(Ctl *ctl, int side, int par, const
 template <bool SPARSE> __device__ __forceinline__ void setup_body(Ctl *ctl, int side, const uint64_t *gcnt /* global or LDS */, int par, uint32_t round, volatile unsigned long long *hmax, bool keep_ne)
 {
 	const int r = lane_id();
-	if (r == 0) { if (!keep_ne) ctl->ne[par ^ 1] = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit = 0; }   // ne: k_advance / k_munpack of this round count into it
+	if (r == 0) { if (!keep_ne) ctl->ne[par ^ 1] = 0; ctl->overflow = 0; ctl->sbfull = 0; ctl->nsplit2[round & 1u] = 0; }   // ne: k_advance / k_munpack of this round count into it
 	if (r < WLC) ctl->wcnt[r * WLS] = 0;                       // the work lists of a sparse round
 	if (r == 0) ctl->wstride = max(1u, (ctl->seg[side].tile0[NR] + WLC - 1) / WLC) * STILE;   // wstride / STILE consecutive tiles share a list, a tile appends at most STILE orders
 	const bool ok = r < NR;
@@ -633,6 +633,12 @@ template <bool SPARSE> __global__ __launch_bounds__(64) void k_setup(Ctl *ctl, i
 constexpr int TS_MAX = 4 * SCHUNK;          // string tiles the single-block path takes
 constexpr int TFW = 26;                     // dwords of a TileFix
 static_assert(sizeof(TileFix) == TFW * 4, "TileFix is written out as 26 dwords");
+// More than one block (round 6).  The launch sat on ONE compute unit for 19.5 us of every long-read round.  Now TSB blocks each run the scan (the tile
+// records are 160 KB, read from L2) and write a share of the TileFix records -- the part that took most of the time: three passes of 960 tiles for
+// one block, one pass for four --; block 0 alone publishes the count matrix and runs k_setup.  (Tried: the leaf splits of the round before and the
+// directory's chunk bases as further blocks of this launch instead of the k_sym launch's -- 1024-thread blocks cap the kernel at 128 VGPRs, the
+// splits keep a superblock's 32 leaves in 64 of them: 215 spilled registers, the job 8 % slower.)
+constexpr int TSB = 4;                      // blocks of k_tscan_setup
 template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(Ctl *ctl, int side, int par, const TileRecs trec, TileFix *tf, uint64_t *gcnt, int do_setup, int spec,
 		uint32_t round, volatile unsigned long long *hmax)
 {
@@ -689,20 +695,23 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	}
 	__syncthreads();
 	const uint32_t nt = s_t0[NR];
+	const bool lead = blockIdx.x == 0;                          // the block that publishes the count matrix and runs k_setup
 	if (threadIdx.x < NR * 6) {                                 // the rows of the count matrix seen here (k_tfix's block 0 in the many-tiles path)
 		const int b = threadIdx.x / 6, a = threadIdx.x % 6;
 		const uint64_t v = nt ? (uint64_t)(s_pre[a][s_t0[b + 1]] - s_pre[a][s_t0[b]]) : 0ull;
-		s_g[threadIdx.x] = v; gcnt[threadIdx.x] = v;
+		s_g[threadIdx.x] = v; if (lead) gcnt[threadIdx.x] = v;
 	}
-	if (threadIdx.x == NR * 6) gcnt[NR * 6] = ctl->ne[par];     // (GCN, rb2_device.h)
+	if (lead && threadIdx.x == NR * 6) gcnt[NR * 6] = ctl->ne[par];     // (GCN, rb2_device.h)
 	__syncthreads();
-	// k_setup of the round (one GPU) runs on the LAST wave while the others write the tile records: it needs the count matrix only,
+	// k_setup of the round (one GPU) runs on the LAST wave of block 0 while the others write the tile records: it needs the count matrix only,
 	// and its ten 64-bit wave scans in a row were 4 us at the end of the kernel with fifteen waves waiting
 	constexpr int NWV = SCHUNK / 64;
-	const int tw = do_setup ? NWV - 1 : NWV;                    // waves that write tile records
-	if (do_setup && wv == NWV - 1) { setup_body<SPARSE>(ctl, side, s_g, par, round, hmax); return; }
+	const int tw0 = (do_setup ? NWV - 1 : NWV);                 // waves of block 0 that write tile records
+	if (lead && do_setup && wv == NWV - 1) { setup_body<SPARSE>(ctl, side, s_g, par, round, hmax); return; }
+	const uint32_t nscanb = min((uint32_t)TSB, gridDim.x);      // (a launch of one block: everything here)
+	const uint32_t wid = lead ? (uint32_t)wv : (uint32_t)tw0 + (blockIdx.x - 1u) * NWV + (uint32_t)wv, tw = (uint32_t)tw0 + (nscanb - 1u) * NWV;   // my number among the writing waves / how many there are
 	uint32_t *so = s_out[wv];
-	for (uint32_t tb = (uint32_t)wv * 64; tb < nt; tb += (uint32_t)tw * 64) {   // k_tfix: a wave takes 64 consecutive tiles
+	for (uint32_t tb = wid * 64; tb < nt; tb += tw * 64) {      // k_tfix: a wave takes 64 consecutive tiles
 		const uint32_t tile = tb + (uint32_t)ln;
 		const bool live = tile < nt;
 		uint32_t f[TFW];
@@ -1289,7 +1298,7 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)(min(lc[h].n + ni, (uint64_t)LEAF) | (lc[h].p2 ? FILL_P2 : 0u));
 		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = round + 1u;  // the leaf cannot take them: void round (every block that finds one writes the same value)
 		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)
-			const uint32_t e = atomicAdd(&ctl->nsplit, 1u);
+			const uint32_t e = atomicAdd(&ctl->nsplit2[round & 1u], 1u);
 			if (e < spl_cap) SPL[e] = (uint32_t)lc[h].gl;
 		}
 		LD[off++] = d;
@@ -1422,12 +1431,14 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch /* != 0, never repeats */, volatile uint32_t *hv,
 		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB], uint32_t round1)
 {
-	if (bidx == 0 && threadIdx.x == 0) hv[2] = round1;          // how far the device has come (the host stays a few rounds ahead of this: insert_dev)
-	if (ctl->overflow) { if (bidx == 0 && threadIdx.x == 0) hv[0] = ctl->overflow; return; }   // void round (this one or one in front of it): nothing was inserted; the host learns which
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t tid = threadIdx.x & 255u;                    // (a 1024-thread block of k_tscan_setup is four of these "blocks": bidx says which)
+	if (bidx == 0 && tid == 0) hv[2] = round1;                  // how far the device has come (the host stays a few rounds ahead of this: insert_dev)
+	if (ctl->overflow) { if (bidx == 0 && tid == 0) hv[0] = ctl->overflow; return; }   // void round (this one or one in front of it): nothing was inserted; the host learns which
+	const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int ln = lane_id();
-	const uint32_t nsp_all = min(ctl->nsplit, spl_cap);
-	if (ctl->nsplit > spl_cap && bidx == 0 && threadIdx.x == 0) { ctl->sbfull = 1; hv[1] = 1; }   // list overflow (never in practice): re-spread
+	const uint32_t nsp_raw = ctl->nsplit2[(round1 - 1u) & 1u];  // (the counter of the round whose splits these are)
+	const uint32_t nsp_all = min(nsp_raw, spl_cap);
+	if (nsp_raw > spl_cap && bidx == 0 && tid == 0) { ctl->sbfull = 1; hv[1] = 1; }   // list overflow (never in practice): re-spread
 	for (uint32_t e = bidx * MW + wv; e < nsp_all; e += nblk * MW) {
 		const uint64_t gl = SPL[e], sb = gl / SB;
 		uint32_t mine = 0;
