@@ -515,8 +515,10 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	  sp.ctl = h->ctl; sp.pool = h->pool[h->pside].view(); sp.SPL = h->SPL.p; sp.spl_cap = (uint32_t)std::min<uint64_t>(h->SPL.cap, 0xffffffffu); sp.epoch = h->split_epoch;
 	  sp.hv = (volatile uint32_t*)h->d_flag; sp.nsplitb = 64;
 	  sp.round1 = (uint32_t)r;                                   // (the splits of round r - 1)
-	  sp.scan2 = h->dir_ride ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
+	  sp.scan2 = (h->dir_ride && !one_launch_tail) ? sp.pool.sbbase : (SbBase*)nullptr;   // the chunk bases of the directory the k_advance launch in front of this one left half-built
+	                                                             // (in a block of this launch -- or, when the counting tail is one launch, of that one: see below)
 	}
+	SbBase *scan2_tail = (with_split && h->dir_ride && one_launch_tail) ? h->pool[h->pside].view().sbbase : (SbBase*)nullptr;
 	{ Scope sc(h, RB2_K_SYM, units);
 	  with_pos(h, [&](auto *tg_) { using P = std::remove_pointer_t<decltype(tg_)>;
 	    if (with_split) {
@@ -528,9 +530,9 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	if (one_launch_tail) {                                      // one launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
-	  const unsigned grid = (unsigned)std::max(1, std::min<int>(TSB, h->ts_blocks));
-	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
-	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr);
+	  const unsigned grid = (unsigned)std::max(1, std::min<int>(TSB, h->ts_blocks)) + (scan2_tail ? 1u : 0u);
+	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, scan2_tail);
+	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, scan2_tail);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; }
 	} else
 	{ Scope sc(h, RB2_K_TSCAN, units);

@@ -273,7 +273,7 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb;
 	uint32_t round1;    // the in-place round whose splits these are, + 1: reported to the host (hv[2]) -- it queues in-place rounds without waiting for them, but only a few ahead
 	SbBase *scan2; };   // scan2 != null: one more block, behind the split blocks, turns the chunk totals k_advance's scan blocks left into chunk bases (sbscan2_body; "the directory rides along", below)
-template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64]);
+template <int NT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w /* NT / 64 words */);
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
 		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB], uint32_t round1);
 // Fused k_prep: in a round whose intervals are all empty (ctl->ne[par] == 0) a tile in which every string is a group of its own -- the
@@ -293,7 +293,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
 		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
 		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row, sp.round1); return; }
-		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, sp.scan2, s_w2); return; }
+		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256>(ctl, sp.scan2, s_w2); return; }
 	}
 	const bool ae = ctl->ne[par] == 0;
 	const P *U = ae ? L : UU;
@@ -640,7 +640,7 @@ static_assert(sizeof(TileFix) == TFW * 4, "TileFix is written out as 26 dwords")
 // splits keep a superblock's 32 leaves in 64 of them: 215 spilled registers, the job 8 % slower.)
 constexpr int TSB = 4;                      // blocks of k_tscan_setup
 template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(Ctl *ctl, int side, int par, const TileRecs trec, TileFix *tf, uint64_t *gcnt, int do_setup, int spec,
-		uint32_t round, volatile unsigned long long *hmax)
+		uint32_t round, volatile unsigned long long *hmax, SbBase *scan2)
 {
 	__shared__ uint32_t s_pre[6][TS_MAX + 4];                    // exclusive prefix of hist over all tiles; [.][nt] = total
 	__shared__ uint32_t s_out[SCHUNK / 64][32 * TFW];            // per wave: 32 TileFix records on their way out (coalesced stores)
@@ -648,6 +648,9 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	__shared__ uint32_t s_p[6][16];
 	__shared__ uint32_t s_t0[NR + 1];
 	__shared__ uint64_t s_g[NR * 6];
+	// behind an in-place round: one more block turns the chunk totals the k_advance launch left into the directory's chunk bases ("the directory rides
+	// along", k_advance) -- here and not in the k_sym launch in front of this one, whose two thousand tile blocks its registers would hold back
+	if (scan2 && blockIdx.x + 1 == gridDim.x) { sbscan2_lean<SCHUNK>(ctl, scan2, (uint64_t*)s_out); return; }
 	if (spec && ctl->overflow) return;
 	const SegDesc &sg = ctl->seg[side];
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -708,7 +711,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	constexpr int NWV = SCHUNK / 64;
 	const int tw0 = (do_setup ? NWV - 1 : NWV);                 // waves of block 0 that write tile records
 	if (lead && do_setup && wv == NWV - 1) { setup_body<SPARSE>(ctl, side, s_g, par, round, hmax); return; }
-	const uint32_t nscanb = min((uint32_t)TSB, gridDim.x);      // (a launch of one block: everything here)
+	const uint32_t nscanb = gridDim.x - (scan2 ? 1u : 0u);      // (a launch of one block: everything here)
 	const uint32_t wid = lead ? (uint32_t)wv : (uint32_t)tw0 + (blockIdx.x - 1u) * NWV + (uint32_t)wv, tw = (uint32_t)tw0 + (nscanb - 1u) * NWV;   // my number among the writing waves / how many there are
 	uint32_t *so = s_out[wv];
 	for (uint32_t tb = wid * 64; tb < nt; tb += tw * 64) {      // k_tfix: a wave takes 64 consecutive tiles
@@ -1465,19 +1468,25 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 			for (int r = 0; r < 7; ++r) R[r][nj] = v[r];
 		}
 		uint64_t *leaves = (uint64_t*)pool.data + sb * SB * LEAFW;
-		// every leaf from the first split one on moves (or splits): all of them are LOADED first, back to back (lane = word: plane
-		// ln >> 4 of group ln & 15, up to 32 words per lane in registers), then stored at their new slots -- one round trip to memory
-		// for the whole superblock instead of one per slot (a wave that moved slot after slot spent 60 us on a full superblock)
+		// every leaf from the first split one on moves (or splits).  Eight slots at a time, FROM THE TOP DOWN: the eight are loaded back to back
+		// (lane = word: plane ln >> 4 of group ln & 15), then stored at their new slots -- a slot moves up, never down, so nothing a later
+		// (lower) eight still has to read is overwritten, and no two slots share a destination: at most four round trips to memory per
+		// superblock (a wave that moved slot after slot spent 60 us on a full one).  (Rounds 4-5 loaded all 32 slots at once into 64 registers
+		// per lane: the 99 VGPRs of these few blocks held the k_sym launch they ride in -- two thousand tile blocks of 16 VGPRs -- to five
+		// workgroups per CU.)
 		const bool wl = ln < LEAFW;                              // 48 words per leaf
 		const uint32_t gq = (uint32_t)(ln & 15);                 // my group
-		uint64_t W[SB];
+		for (int c0 = SB - 8; c0 >= 0; c0 -= 8) {
+		if ((uint32_t)(c0 + 8) <= first || (uint32_t)c0 >= used) continue;   // (wave-uniform)
+		uint64_t W[8];
 #pragma unroll
-		for (int k = 0; k < SB; ++k) W[k] = (wl && (uint32_t)k >= first && (uint32_t)k < used) ? leaves[(uint64_t)k * LEAFW + ln] : 0ull;
+		for (int j = 0; j < 8; ++j) { const uint32_t k = (uint32_t)(c0 + j); W[j] = (wl && k >= first && k < used) ? leaves[(uint64_t)k * LEAFW + ln] : 0ull; }
 #pragma unroll
-		for (int k = 0; k < SB; ++k) {
+		for (int j = 0; j < 8; ++j) {
+			const int k = c0 + j;
 			if ((uint32_t)k < first || (uint32_t)k >= used) continue;   // wave-uniform
 			const uint32_t nk = (uint32_t)k + (uint32_t)__popc(marked & ((1u << k) - 1u));
-			const uint64_t w = W[k];
+			const uint64_t w = W[j];
 			if (!((marked >> k) & 1u)) { if (nk != (uint32_t)k && wl) leaves[(uint64_t)nk * LEAFW + ln] = w; continue; }
 			const uint32_t nraw = (uint32_t)__builtin_amdgcn_readlane((int)v[0], k), n = nraw & FILL_MASK, p2f = nraw & FILL_P2;   // (both halves of a leaf with a plane-2 line keep one)
 			uint32_t ck[6];
@@ -1504,6 +1513,7 @@ __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const
 				for (int s = 0; s < 6; ++s) { R[1 + s][nk] = (uint16_t)c1[s]; R[1 + s][nk + 1] = (uint16_t)(ck[s] - c1[s]); }
 			}
 		}
+		}
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 		const uint32_t nused = used + (uint32_t)__popc(marked);
 		if (ln == 0) atomicAdd((unsigned long long*)&ctl->nsplit_total, (unsigned long long)__popc(marked));
@@ -1518,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 {
 	__shared__ uint16_t s_row[MW][7][SB];
 	const uint32_t nb = gridDim.x - (scan2 ? 1u : 0u);         // (the last block: the chunk bases of the directory, see SplitArgs::scan2)
-	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[6][4]; sbscan2_body<256>(ctl, scan2, s_w2); return; }
+	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256>(ctl, scan2, s_w2); return; }
 	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, nb, s_row, round1);
 }
 
@@ -1638,6 +1648,41 @@ template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, S
 		for (int s = 0; s < 6; ++s) o.cum[s] = run[s];
 		o.pos = run[0] + run[1] + run[2] + run[3] + run[4] + run[5]; o.pad = 0;
 		base[nc] = o;
+	}
+}
+// the same, for a block that rides in another kernel's launch ("the directory rides along", k_advance): one column at a time, two chunks per thread -- two dozen
+// registers instead of a hundred (all six columns of eight chunks in flight, 64-bit values: what the riding block needs, its host kernel is compiled for);
+// the chunk totals are a few thousand records, cache-resident, and nothing waits for this block but the launch it rides in
+template <int NT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w)
+{
+	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;
+	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll 1
+	for (int s = 0; s < 6; ++s) {
+		uint64_t run = 0;
+#pragma unroll 1
+		for (uint64_t i0 = 0; i0 < nc; i0 += 2 * NT) {
+			const uint64_t j0 = i0 + (uint64_t)threadIdx.x * 2;
+			const uint64_t v0 = j0 < nc ? base[j0].cum[s] : 0ull, v1 = j0 + 1 < nc ? base[j0 + 1].cum[s] : 0ull;
+			const uint64_t inc = dpp_incl_add64(v0 + v1);
+			if (ln == 63) s_w[wv] = inc;
+			__syncthreads();
+			uint64_t off = 0, all = 0;
+			for (int w = 0; w < NT / 64; ++w) { const uint64_t x = s_w[w]; if (w < wv) off += x; all += x; }
+			const uint64_t b0 = run + off + inc - (v0 + v1);
+			if (j0 < nc) base[j0].cum[s] = b0;
+			if (j0 + 1 < nc) base[j0 + 1].cum[s] = b0 + v0;
+			run += all;
+			__syncthreads();
+		}
+		if (threadIdx.x == 0) base[nc].cum[s] = run;                // one entry past the last chunk: the pool's totals
+	}
+	__syncthreads();                                            // (each thread reads back what it wrote itself -- but for entry nc, thread 0's)
+	for (uint64_t j = threadIdx.x; j <= nc; j += NT) {
+		uint64_t p = 0;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) p += base[j].cum[s];
+		base[j].pos = p; base[j].pad = 0;
 	}
 }
 __global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
