@@ -1298,6 +1298,7 @@ template <typename P> __device__ __forceinline__ bool part_sparse_tile(const uin
 		const uint64_t ni = q1 - g;
 		SpOrd d;
 		d.i0 = (uint32_t)lc[h].s; d.ins0 = (uint32_t)g; d.gl = (uint32_t)lc[h].gl;
+		if (ni == 1) d.i0 = (uint32_t)(p[h] - lc[h].s) | aq[h] << 12;   // the one insert of the leaf rides in its order (nineteen leaves in twenty of a long-read round): place inside the leaf + symbol, no gathers in k_merge_leaf
 		d.ni = (uint16_t)min(ni, (uint64_t)LEAF); d.nvalid = (uint16_t)(min(lc[h].n + ni, (uint64_t)LEAF) | (lc[h].p2 ? FILL_P2 : 0u));
 		if (lc[h].n + ni > (uint64_t)LEAF) ctl->overflow = round + 1u;  // the leaf cannot take them: void round (every block that finds one writes the same value)
 		else if (lc[h].n + ni > (uint64_t)(LEAF - SP_MARGIN)) {  // close to full after this round: k_split gives it a second slot (rare: one atomic each)

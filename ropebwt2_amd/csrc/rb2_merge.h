@@ -380,8 +380,10 @@ template <typename P> __device__ __forceinline__ void row_job_load(const RowOrd 
 	if (o.nn >> 31) J.w[2] = RB2_LDNT(&lw[2 * LEAFG]);         // the third line only of a leaf that holds a `$` or an `N` (two-plane leaves, rb2_device.h)
 	// no use of a loaded value in here: the loads of the quad are to be in flight together (lanes >= ni load the
 	// row's last insert again; they never use it)
+	// (a leaf that takes ONE symbol has it in its order: SpOrd::i0 -- no gather, no sector of INS_E / INS_A moved for it)
 	const uint64_t q = (uint64_t)o.ins0 + (uint32_t)min(g, max((int)ord_ni(o), 1) - 1);
-	J.aj = INS_A[q]; J.pj = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];   // low half: positions inside a leaf need no more
+	J.aj = (o.i0 >> 12) & 7u; J.pj = o.i0 & 0xfffu;
+	if (ord_ni(o) > 1u) { J.aj = INS_A[q]; J.pj = (sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q]) - o.i0 + (uint32_t)g; }   // low half: positions inside a leaf need no more; pj = E[q] + q - (leaf start + first slot)
 }
 
 #ifndef RB2_LQ
@@ -454,9 +456,10 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, RB2_LEAF_WAVE
 				const uint64_t q = (uint64_t)oo.ins0 + min(c0 + (uint32_t)g, max(oni, 1u) - 1u);
 				aj = INS_A[q]; pjr = sizeof(P) == 4 ? ((const uint32_t*)INS_E)[q] : ((const uint32_t*)INS_E)[2 * q];
 				asm volatile("" : "+v"(aj), "+v"(pjr));             // waited for HERE, on the rare path: a wait at the first use, behind the join, would make the common path wait as well
+				pjr = pjr - oo.i0 + c0 + (uint32_t)g;
 			}
 			const uint32_t nic = oni > c0 ? min(oni - c0, (uint32_t)LTURN) : 0u;   // what my row inserts in this turn (row-uniform)
-			const uint32_t pj = pjr - oo.i0 + c0 + (uint32_t)g;     // final position E[q] + q inside the leaf (lanes >= nic: unused)
+			const uint32_t pj = pjr;                                // final position E[q] + q inside the leaf (lanes >= nic: unused)
 			const uint32_t ncmax = min(nimax - c0, (uint32_t)LTURN);
 			const bool mine = (uint32_t)g < nic;
 			// what a leaf receives is known before the first symbol is placed: the directory atomics go out first and are under way
