@@ -374,7 +374,11 @@ def secondary_configs3(reads=1_000_000, L=10_000, batch_gib=10.0):
         b.dev_free(buf)
     finally:
         b.close()
+    # roofline of the whole job: the algorithmic bytes of an inserted symbol (50 B) over the wall time against the 8 TB/s peak -- the in-place rounds
+    # move a leaf (two or three 128-byte lines in and out), the directory lines around it and 50 B of string state per symbol; there is no single dominant launch
     return {"value": total / dt / 1e9, "unit": "Gsymbols/s", "insert_s": dt, "rounds": L + 1, "us_per_round": dt / (L + 1) * 1e6, "counts_ok": bool(ok), "layout": st,
+            "roofline_frac": round(50.0 * total / dt / 8e12, 4), "roofline": {"bound": "hbm", "achieved": round(50.0 * total / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                                              "basis": "50 algorithmic bytes per inserted symbol over the wall time of the job (all kernels, all rounds)"},
             "what": "configs[3] shape at one tenth on 1 GPU: %d x %d bp, input order, forward strand, one -m10g batch (%.1f G symbols), inputs generated on the device, insert timed"
                     % (reads, L, total / 1e9)}
 

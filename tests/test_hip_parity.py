@@ -490,6 +490,41 @@ def test_sparse_forced_long_reads(hip, golden, so):
 
 
 @pytest.mark.parametrize("so", [0, 1, 2])
+def test_sparse_forced_two_and_three_plane_leaves(hip, so):
+    """long reads with runs of N, three batches, every round in place: leaves without `$` / `N` are two-plane leaves (their third line is neither read
+    nor written: rb2_device.h), the ones the N runs and the sentinels of earlier batches fall into keep three -- both kinds next to each other in every
+    superblock, leaves that get their first `$` / `N` in the middle of a batch (the flag travels with the fill), leaf splits of both kinds, re-spreads.
+    Ropes and counts against the oracle after every batch, then rank queries answered from the in-place layout (the readers of leaf words other
+    than the merge: leaf_count / wave_leaf_counts with and without a plane-2 line)"""
+    rng = np.random.RandomState(77 + so)
+    reads = []
+    for i in range(360):
+        r = list(rng.randint(1, 5, size=int(rng.randint(1500, 2600))))
+        for _ in range(int(rng.randint(0, 3))):                            # 0-2 runs of N per read
+            at, n = int(rng.randint(0, len(r) - 1)), int(rng.randint(1, 300))
+            r[at:at + n] = [5] * len(r[at:at + n])
+        reads.append(r)
+    with _ForcedSparse():
+        o, dev = H.Oracle(so), hip.HipBwt(so)
+        for i, buf in enumerate([H.encode_batch(reads[:150]), H.encode_batch(reads[150:270]), H.encode_batch(reads[270:], True, so == 2)]):
+            o.insert_multi(buf); dev.insert_multi(buf)
+            assert np.array_equal(o.counts(), dev.counts()), "count matrix differs after batch %d" % i
+            st = dev.layout_stats()
+            assert st["sparse_now"], st                                     # the queries below are answered from the in-place layout
+            for b in range(1, 6):
+                r = o.rope(b)
+                xs = np.concatenate([[0, 1, len(r) - 1, len(r)], rng.randint(0, len(r) + 1, size=100)])
+                got = dev.rank_batch(b, xs)
+                cum = np.zeros((len(r) + 1, 6), np.int64)
+                for s in range(6):
+                    cum[1:, s] = np.cumsum(r == s)
+                assert np.array_equal(got, cum[np.minimum(xs, len(r))]), "rank on rope %d after batch %d" % (b, i)
+        assert dev.layout_stats()["sparse_rounds"] > 3000
+        for b in range(6):                                                  # (the export leaves the in-place layout: last)
+            assert np.array_equal(o.rope(b), dev.rope(b)), "rope %d" % b
+
+
+@pytest.mark.parametrize("so", [0, 1, 2])
 def test_sparse_forced_edge_shapes(hip, so):
     lay = hip.HipBwt.layout()
     n = lay["leaf_syms"] * lay["tile_leaves"] + 37
