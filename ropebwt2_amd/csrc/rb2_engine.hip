@@ -676,8 +676,12 @@ bool round_merge_sparse(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send 
 	else if (h->spec_rounds > (uint64_t)h->run_ahead) {          // not too far ahead of the device: it reports the round whose splits it has reached (split_body -> h_flag[2] = round + 1)
 		const volatile uint32_t *prog = (const volatile uint32_t*)h->h_flag + 2;
 		const uint32_t want = (uint32_t)r - (uint32_t)h->run_ahead;   // round `want - 1` at least must be over
+		const auto t_spin = std::chrono::steady_clock::now();
 		for (uint32_t spins = 0; (int32_t)(*prog - want) < 0 && !((const volatile uint32_t*)h->h_flag)[0]; ++spins) {
-			if ((spins & 1023u) == 1023u) { if (hipStreamQuery(st) == hipSuccess) break; }   // (everything queued is done: nothing more will be reported)
+			if ((spins & 1023u) == 1023u) {
+				if (hipStreamQuery(st) == hipSuccess) break;         // (everything queued is done: nothing more will be reported)
+				if (std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(2)) { HIPCHK(hipStreamSynchronize(st)); break; }   // (a report that does not come: wait the plain way)
+			}
 			__builtin_ia32_pause();
 		}
 	}
