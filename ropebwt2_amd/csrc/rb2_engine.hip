@@ -530,7 +530,7 @@ void round_counts(rb2_hip_t *h, BatchState &B, uint64_t r, bool spec = false, bo
 	if (one_launch_tail) {                                      // one launch instead of six, k_setup included (one GPU)
 	  Scope sc(h, RB2_K_TSCAN, units);
 	  const int do_setup = h->nranks == 1;
-	  const unsigned grid = (unsigned)std::max(1, std::min<int>(TSB, h->ts_blocks)) + (scan2_tail ? 1u : 0u);
+	  const unsigned grid = (unsigned)std::max(1, std::min<int>(TSB, h->ts_blocks)) + (scan2_tail ? 7u : 0u);   // (+ one block per column of the chunk bases)
 	  if (h->sparse) hipLaunchKernelGGL(k_tscan_setup<true>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, scan2_tail);
 	  else hipLaunchKernelGGL(k_tscan_setup<false>, dim3(grid), dim3(SCHUNK), 0, st, h->ctl, sd, (int)(r & 1), trs, h->tfix.p, h->gcnt, do_setup, (int)spec, (uint32_t)r, h->pos32 ? (volatile unsigned long long*)(h->d_flag + 4) : (volatile unsigned long long*)nullptr, scan2_tail);
 	  if (do_setup) { B.setup_round = r; B.setup_sparse = h->sparse; B.setup_epoch = h->layout_epoch; }

@@ -273,7 +273,8 @@ __device__ __forceinline__ bool tile_ctx(const SegDesc &sg, uint32_t tile, TileC
 struct SplitArgs { Ctl *ctl; PoolView pool; const uint32_t *SPL; uint32_t spl_cap, epoch; volatile uint32_t *hv; uint32_t nsplitb;
 	uint32_t round1;    // the in-place round whose splits these are, + 1: reported to the host (hv[2]) -- it queues in-place rounds without waiting for them, but only a few ahead
 	SbBase *scan2; };   // scan2 != null: one more block, behind the split blocks, turns the chunk totals k_advance's scan blocks left into chunk bases (sbscan2_body; "the directory rides along", below)
-template <int NT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w /* NT / 64 words */);
+template <int NT, int CT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w /* NT / 64 words */);
+template <int NT, int CT> __device__ __forceinline__ void sbscan2_col(const Ctl *ctl, SbBase *base, uint64_t *s_w, const int col);
 __device__ __forceinline__ void split_body(Ctl *ctl, const PoolView &pool, const uint32_t *SPL, uint32_t spl_cap, uint32_t epoch, volatile uint32_t *hv,
 		const uint32_t bidx, const uint32_t nblk, uint16_t (*s_row)[7][SB], uint32_t round1);
 // Fused k_prep: in a round whose intervals are all empty (ctl->ne[par] == 0) a tile in which every string is a group of its own -- the
@@ -293,7 +294,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
 		// turns -- behind them the split blocks started when the first turn was over (16.9 us for the launch; 6.2 + 9.3 apart)
 		if (blockIdx.x < sp.nsplitb) { split_body(sp.ctl, sp.pool, sp.SPL, sp.spl_cap, sp.epoch, sp.hv, blockIdx.x, sp.nsplitb, s_row, sp.round1); return; }
-		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256>(ctl, sp.scan2, s_w2); return; }
+		if (sp.scan2 && blockIdx.x == sp.nsplitb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256, 2>(ctl, sp.scan2, s_w2); return; }
 	}
 	const bool ae = ctl->ne[par] == 0;
 	const P *U = ae ? L : UU;
@@ -650,7 +651,10 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	__shared__ uint64_t s_g[NR * 6];
 	// behind an in-place round: one more block turns the chunk totals the k_advance launch left into the directory's chunk bases ("the directory rides
 	// along", k_advance) -- here and not in the k_sym launch in front of this one, whose two thousand tile blocks its registers would hold back
-	if (scan2 && blockIdx.x + 1 == gridDim.x) { sbscan2_lean<SCHUNK>(ctl, scan2, (uint64_t*)s_out); return; }
+	// (seven blocks, one column each -- the six symbols' counts and the positions, whose chunk totals k_sbscan3 leaves side by side --, 1024 threads x 5 chunks: one pass up to
+	// 5120 chunks = 94 G symbols of the in-place layout.  One block that took the columns in turn needed a round trip to the freshly written totals and two barriers per
+	// column and pass: 27-32 us of this launch at 90 G symbols)
+	if (scan2 && blockIdx.x + 7 >= gridDim.x) { sbscan2_col<SCHUNK, 5>(ctl, scan2, (uint64_t*)s_out, (int)(blockIdx.x + 7 - gridDim.x)); return; }   // the last seven blocks: one column each
 	if (spec && ctl->overflow) return;
 	const SegDesc &sg = ctl->seg[side];
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -711,7 +715,7 @@ template <bool SPARSE> __global__ __launch_bounds__(SCHUNK) void k_tscan_setup(C
 	constexpr int NWV = SCHUNK / 64;
 	const int tw0 = (do_setup ? NWV - 1 : NWV);                 // waves of block 0 that write tile records
 	if (lead && do_setup && wv == NWV - 1) { setup_body<SPARSE>(ctl, side, s_g, par, round, hmax); return; }
-	const uint32_t nscanb = gridDim.x - (scan2 ? 1u : 0u);      // (a launch of one block: everything here)
+	const uint32_t nscanb = gridDim.x - (scan2 ? 7u : 0u);      // (a launch of one block: everything here)
 	const uint32_t wid = lead ? (uint32_t)wv : (uint32_t)tw0 + (blockIdx.x - 1u) * NWV + (uint32_t)wv, tw = (uint32_t)tw0 + (nscanb - 1u) * NWV;   // my number among the writing waves / how many there are
 	uint32_t *so = s_out[wv];
 	for (uint32_t tb = wid * 64; tb < nt; tb += tw * 64) {      // k_tfix: a wave takes 64 consecutive tiles
@@ -1529,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_split(Ctl *ctl, PoolView pool, const ui
 {
 	__shared__ uint16_t s_row[MW][7][SB];
 	const uint32_t nb = gridDim.x - (scan2 ? 1u : 0u);         // (the last block: the chunk bases of the directory, see SplitArgs::scan2)
-	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256>(ctl, scan2, s_w2); return; }
+	if (scan2 && blockIdx.x == nb) { __shared__ uint64_t s_w2[4]; sbscan2_lean<256, 2>(ctl, scan2, s_w2); return; }
 	split_body(ctl, pool, SPL, spl_cap, epoch, hv, blockIdx.x, nb, s_row, round1);
 }
 
@@ -1603,10 +1607,9 @@ constexpr int SBT = 4;                      // superblocks per thread in k_sbsca
 // exclusive prefix over the chunk totals, in place (one block): a thread takes eight consecutive chunks, the wave and block levels are
 // shuffles and one LDS exchange -- one pass for up to 8192 chunks (270 G symbols); more: with a running total
 constexpr int SB2T = 512;                   // threads of k_sbscan2 (its one block)
-template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64])
+template <int NT, int CT = 8> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, SbBase *base, uint64_t (*s_w)[NT / 64])
 {
-	constexpr int SB2T = NT;
-	constexpr int CT = 8;                                       // chunks per thread: 4096 per pass (512 threads), all six columns in flight at once
+	constexpr int SB2T = NT;                                    // CT: chunks per thread -- 4096 per pass of k_sbscan2's 512 threads, all six columns in flight at once
 	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	uint64_t run[6] = {0, 0, 0, 0, 0, 0};
@@ -1654,37 +1657,40 @@ template <int NT> __device__ __forceinline__ void sbscan2_body(const Ctl *ctl, S
 // the same, for a block that rides in another kernel's launch ("the directory rides along", k_advance): one column at a time, two chunks per thread -- two dozen
 // registers instead of a hundred (all six columns of eight chunks in flight, 64-bit values: what the riding block needs, its host kernel is compiled for);
 // the chunk totals are a few thousand records, cache-resident, and nothing waits for this block but the launch it rides in
-template <int NT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w)
+// one column of the chunk bases (0-5: a symbol's counts, 6: the positions) by one block: exclusive prefix in place, the total one entry past the last chunk
+template <int NT, int CT> __device__ __forceinline__ void sbscan2_col(const Ctl *ctl, SbBase *base, uint64_t *s_w, const int col)
 {
 	const uint64_t nc = (ctl->nsb_total + SCHUNK - 1) / SCHUNK;
 	const int ln = lane_id(), wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint64_t *colp = col < 6 ? &base[0].cum[col] : &base[0].pos;  // (records of eight 64-bit words)
+	uint64_t run = 0;
 #pragma unroll 1
-	for (int s = 0; s < 6; ++s) {
-		uint64_t run = 0;
-#pragma unroll 1
-		for (uint64_t i0 = 0; i0 < nc; i0 += 2 * NT) {
-			const uint64_t j0 = i0 + (uint64_t)threadIdx.x * 2;
-			const uint64_t v0 = j0 < nc ? base[j0].cum[s] : 0ull, v1 = j0 + 1 < nc ? base[j0 + 1].cum[s] : 0ull;
-			const uint64_t inc = dpp_incl_add64(v0 + v1);
-			if (ln == 63) s_w[wv] = inc;
-			__syncthreads();
-			uint64_t off = 0, all = 0;
-			for (int w = 0; w < NT / 64; ++w) { const uint64_t x = s_w[w]; if (w < wv) off += x; all += x; }
-			const uint64_t b0 = run + off + inc - (v0 + v1);
-			if (j0 < nc) base[j0].cum[s] = b0;
-			if (j0 + 1 < nc) base[j0 + 1].cum[s] = b0 + v0;
-			run += all;
-			__syncthreads();
-		}
-		if (threadIdx.x == 0) base[nc].cum[s] = run;                // one entry past the last chunk: the pool's totals
-	}
-	__syncthreads();                                            // (each thread reads back what it wrote itself -- but for entry nc, thread 0's)
-	for (uint64_t j = threadIdx.x; j <= nc; j += NT) {
-		uint64_t p = 0;
+	for (uint64_t i0 = 0; i0 < nc; i0 += (uint64_t)CT * NT) {       // CT consecutive chunks per thread and pass
+		const uint64_t j0 = i0 + (uint64_t)threadIdx.x * CT;
+		uint64_t v[CT], tot = 0;
 #pragma unroll
-		for (int s = 0; s < 6; ++s) p += base[j].cum[s];
-		base[j].pos = p; base[j].pad = 0;
+		for (int k = 0; k < CT; ++k) v[k] = j0 + k < nc ? colp[(j0 + k) * 8] : 0ull;
+#pragma unroll
+		for (int k = 0; k < CT; ++k) { const uint64_t x = v[k]; v[k] = tot; tot += x; }
+		const uint64_t inc = dpp_incl_add64(tot);
+		if (ln == 63) s_w[wv] = inc;
+		__syncthreads();
+		uint64_t off = 0, all = 0;
+		for (int w = 0; w < NT / 64; ++w) { const uint64_t x = s_w[w]; if (w < wv) off += x; all += x; }
+		const uint64_t b0 = run + off + inc - tot;
+#pragma unroll
+		for (int k = 0; k < CT; ++k) if (j0 + k < nc) colp[(j0 + k) * 8] = b0 + v[k];
+		run += all;
+		__syncthreads();
 	}
+	if (threadIdx.x == 0) { colp[nc * 8] = run; if (col == 6) base[nc].pad = 0; }   // one entry past the last chunk: the pool's totals
+}
+static_assert(sizeof(SbBase) == 64, "sbscan2_col strides over the records in 64-bit words");
+// all seven, one after the other (a 256-thread block that rides in k_sym<SPLIT> / k_split)
+template <int NT, int CT> __device__ __forceinline__ void sbscan2_lean(const Ctl *ctl, SbBase *base, uint64_t *s_w)
+{
+#pragma unroll 1
+	for (int col = 0; col < 7; ++col) sbscan2_col<NT, CT>(ctl, base, s_w, col);
 }
 __global__ __launch_bounds__(SB2T) void k_sbscan2(const Ctl *ctl, SbBase *base)
 {
@@ -1721,6 +1727,12 @@ __device__ __forceinline__ void sbscan3_body(const Ctl *ctl, const SbTot *sbtot,
 	}
 	// the chunk's totals, for k_sbscan2 behind this kernel (a kernel of its own read every total a second time for them)
 	if (threadIdx.x < 6) newp.sbbase[blk].cum[threadIdx.x] = (uint64_t)s_p[threadIdx.x][0] + s_p[threadIdx.x][1] + s_p[threadIdx.x][2] + s_p[threadIdx.x][3];
+	if (threadIdx.x == 6) {                                      // ... and its symbols: the position column is scanned like the six others (sbscan2_col), by whoever gets to it
+		uint64_t p = 0;
+#pragma unroll
+		for (int s = 0; s < 6; ++s) p += (uint64_t)s_p[s][0] + s_p[s][1] + s_p[s][2] + s_p[s][3];
+		newp.sbbase[blk].pos = p;
+	}
 #pragma unroll
 	for (int k = 0; k < SBT; ++k) if (i0 + k < n) {             // one 32-byte record per superblock: 128 contiguous bytes per lane
 		uint32_t o[6];
