@@ -470,9 +470,7 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, RB2_LEAF_WAVE
 #pragma unroll
 				for (int s = 0; s < 6; ++s) cs[s] = (uint32_t)__popc((uint32_t)(__ballot(mine && aj == (uint32_t)s) >> rsh) & 0xffffu);
 				const bool first_x = !p2 && (cs[0] | cs[5]) != 0;       // the leaf's first `$` / `N`: it has a plane-2 line from here on
-#ifndef RB2_EXP_NOATOM
 				dir_add_packed(pool, sbtot, oo.gl, nic ? g : 16, cs[0] | cs[1] << 16, cs[2] | cs[3] << 16, cs[4] | cs[5] << 16, first_x ? FILL_P2 : 0u);
-#endif
 				p2 = p2 || first_x;
 			}
 			// RKREL = the rank of the symbol inside the leaf AS IT WAS before the round (what rope_insert_run's descent ends with: rle_insert_cached's
@@ -524,12 +522,8 @@ template <typename P = uint64_t> __global__ __launch_bounds__(256, RB2_LEAF_WAVE
 		// on one box.  Each half alone is no gain: whole lines with plain accesses 3.09, nontemporal accesses with partial lines 3.31-3.39.)
 		if (oni) {
 			uint64_t *lw = (uint64_t*)pool.data + (uint64_t)oo.gl * LEAFW + g;
-#ifndef RB2_EXP_NOSTORE
 			RB2_STNT(w0, &lw[0]); RB2_STNT(w1, &lw[LEAFG]);
 			if (p2) RB2_STNT(w2, &lw[2 * LEAFG]);
-#else
-			if (w0 == 0x123456789ull) RB2_STNT(w0, &lw[0]);
-#endif
 		}
 		}
 		if (!more) return;
