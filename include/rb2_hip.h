@@ -28,7 +28,7 @@
  *     (checked per round, with a message); larger indexes are what the sharded build is for;
  *   - in-place (sparse) rounds are used for batches of fewer than 2^27 strings (one wave per four touched leaves in one launch);
  *     larger batches simply stay on the dense path -- a performance boundary, not an error;
- *   - leaf slots of one pool are addressed with 32 bits in the sparse layout (RKLEAF, the split list): 2^32 slots = 4.3 T symbols;
+ *   - leaf slots of one pool are addressed with 32 bits in the sparse layout (the work orders, the split list): 2^32 slots = 4.3 T symbols;
  *   - symbols must be nt6 codes 0..5, the buffer must end with a sentinel (mrope.c:268);
  *   - the index lives in HBM: 2 x 0.38 B per symbol (dense layout) plus ~100 B per string of the batch; running out of device
  *     memory reports the size that was needed.

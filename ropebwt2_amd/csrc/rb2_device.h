@@ -163,7 +163,7 @@ struct LeafDesc {           // work order of one output window (WPL leaves), wri
 };
 
 struct SpOrd {              // work order of one touched leaf in a sparse round, written by k_part_sparse, read by k_merge_leaf (16 B, in the LD buffer)
-	uint32_t gl;            // leaf slot (32 bits in the sparse layout, like RKLEAF)
+	uint32_t gl;            // leaf slot (32 bits in the sparse layout)
 	uint32_t ins0;          // index of its first new symbol in INS_E / INS_A / RKREL (a batch has < 2^32 strings)
 	uint32_t i0;            // piece position of the leaf's first symbol, low half (positions inside a leaf need no more); ni == 1: the insert itself -- its place inside the leaf (bits 0-11) and its symbol (12-14)
 	uint16_t ni, nvalid;    // new symbols / symbols in the leaf after the round (bits 0-10); bit 15 of nvalid: the leaf has a plane-2 line (FILL_P2)

@@ -1426,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_relayout(const Ctl *ctl, int side, Pool
 // ---------------------------------------------------------------------------------------------
 // k_split: the leaf split of a B+ tree (split_node, rope.c:78-112: "move the upper half of a full leaf to a new sibling, shift the
 // parent's entries"), for the sparse layout.  Runs as the LAST kernel of an in-place round -- nothing else touches the pool then,
-// and every number the round handed out (RKLEAF, RKREL, the work orders) has been consumed.  k_part_sparse listed the leaves
+// and every number the round handed out (RKOLD, RKREL, the work orders) has been consumed.  k_part_sparse listed the leaves
 // whose fill exceeds LEAF - SP_MARGIN; one wave per listed leaf, but only the first wave to CLAIM the leaf's superblock acts (an
 // atomic exchange of this round's epoch into the spare directory row 7), and does all of that superblock's splits: slots behind a split leaf move up by one (from the last one down), the split leaf
 // keeps its first h symbols (h = a whole number of words, about half) and hands the rest to the slot behind it, and the directory
