@@ -50,14 +50,23 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { st
 // open a one-bit gap at every set bit of f (ascending), in all three planes: the low bits of x[] move up past the gaps (a software bit
 // deposit; f has few bits in steady state -- one new symbol per ~170 old ones at configs[1]).  Per gap: the bits below the lowest set bit
 // of f are lm = (f - 1) & ~f -- all ones when f is empty, which makes the step a no-op for a lane that is done, no branch --, and moving
-// the part of x above them up by one is an ADD: x + (x & ~lm).  14 VALU per trip for the three planes (r04: masks from a count of
-// trailing zeros, shift and two ORs per plane: 28).  The trip count is the largest number of new symbols in one group of the window.
+// the part of x above them up by one is an ADD: x + (x & ~lm).  13 VALU per trip for the three planes (r04: masks from a count of
+// trailing zeros, shift and two ORs per plane: 28; r05: 17, the mask built first).  The trip count is the largest number of new symbols in one group of the window.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// a value that is only looked at under the condition it was loaded under starts out as whatever its register holds -- a zero is an instruction
+// (__builtin_nondeterministic_value becomes a zero as well)
+#define RB2_UNDEF(x) asm volatile("" : "=v"(x))             // (volatile: identical statements are not merged into one register that is then copied)
 __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 {
 	do {
-		const uint64_t t = f - 1ull, lm = t & ~f;
+		const uint64_t t = f - 1ull;
+		const uint32_t fl = (uint32_t)f, fh = (uint32_t)(f >> 32), tl = (uint32_t)t, th = (uint32_t)(t >> 32);
 #pragma unroll
-		for (int pl = 0; pl < 3; ++pl) x[pl] += x[pl] & ~lm;
+		for (int pl = 0; pl < 3; ++pl)                              // x & ~lm = x & (f | ~t): one v_bitop3_b32 per half, no mask to build (left to itself the compiler builds f | -f first: 4 more)
+		{
+			const u32x2 m = { (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)x[pl], fl, tl, 0xd0), (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(x[pl] >> 32), fh, th, 0xd0) };
+			x[pl] += __builtin_bit_cast(uint64_t, m);               // (a register pair as it stands: written as hi << 32 | lo it became two 64-bit additions)
+		}
 		f &= t;
 	} while (__any(f != 0));
 }
@@ -127,37 +136,40 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 	const uint32_t sh0 = (uint32_t)d.i0 & 63u;                  // the first of them: bit sh0 of old group G0 = i0 >> 6 ...
 	const uint32_t g0 = (uint32_t)(d.i0 >> 6) & 63u;            // ... which is group g0 of old window ow (of the piece)
 	const uint64_t ow = d.i0 >> 12;
-	const uint32_t nwg = (sh0 + nold + 63) >> 6;                // old groups they live in (<= WG + 1)
+	const uint32_t nwg = nold ? (sh0 + nold + 63) >> 6 : 0u;    // old groups they live in (<= WG + 1); nothing old (the first rounds on an empty index): nothing is staged and the stage reads zeros
 	const uint64_t *obw = (const uint64_t*)oldp.data + ((uint64_t)d.oleaf0 + ow * WPL) * LEAFW;   // window ow; staged group k is its group g0 + k
 	const uint32_t ln32 = (uint32_t)ln;
 
 	// ---- 1. new symbols of this window, by output position (planes and "new here" flag); the old groups it draws from
 	LF[ln] = 0; LX[ln] = 0; LX[WG + ln] = 0; LX[2 * WG + ln] = 0;
-	LO2[ln] = 0;                                                // plane 2' of the old groups of compact windows is OR-ed together from their exception lists
-	if (ln == 0) LO2[WG] = 0;
+	LO2[ln] = 0; LO2[ln + 1] = 0;                               // plane 2' of the old groups of compact windows is OR-ed together from their exception lists (WG + 1 words: one two-word store, no lane picked out)
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
 	// Loads in the order their values are needed (the wave waits for its loads in issue order): my first new symbol, the exception
 	// entries, then the plane words -- the LDS atomics of the first two run while the planes are still on their way.
 	const P *E0 = INS_E + d.ins0; const uint8_t *A0 = INS_A + d.ins0;
 	const uint32_t i0lo = (uint32_t)d.i0;
-	uint32_t e_first = 0, a_first = 0;
+	uint32_t e_first, a_first; RB2_UNDEF(e_first); RB2_UNDEF(a_first);
 	if (ln32 < ni) { e_first = (uint32_t)E0[ln32]; a_first = A0[ln32]; }   // (positions inside a window: the low half decides)
 	// the exception lists of the old windows: lane ln reads entry ln of a line (entry 0 of the first line = the number of exceptions)
 	const bool two = g0 + nwg > 64u;                            // some staged group lies in window ow + 1
-	const bool xa = nwg > 0 && h0 >= WF_C1, xb = two && h1 >= WF_C1;
-	uint32_t xe[4] = {0, 0, 0, 0};
+	const uint32_t hx0 = nwg > 0 ? h0 : 0u, hx1 = two ? h1 : 0u; // the formats as far as their lists are read (numbers, compared where they are used: a flag kept across the branches below is rebuilt from a vector register)
+#define xa (hx0 >= WF_C1)
+#define xb (hx1 >= WF_C1)
+	uint32_t xe[4]; RB2_UNDEF(xe[0]); RB2_UNDEF(xe[1]); RB2_UNDEF(xe[2]); RB2_UNDEF(xe[3]);
 	{
 		const uint16_t *x0 = (const uint16_t*)(obw + 2 * LEAFG);   // plane-2 line of the first leaf of window ow
 		if (xa) xe[0] = x0[ln32];
-		if (xa && h0 == WF_C2) xe[1] = x0[LEAFW * 4 + ln32];        // ... of its second leaf
+		if (hx0 == WF_C2) xe[1] = x0[LEAFW * 4 + ln32];             // ... of its second leaf
 		if (xb) xe[2] = x0[WPL * LEAFW * 4 + ln32];
-		if (xb && h1 == WF_C2) xe[3] = x0[WPL * LEAFW * 4 + LEAFW * 4 + ln32];
+		if (hx1 == WF_C2) xe[3] = x0[WPL * LEAFW * 4 + LEAFW * 4 + ln32];
 	}
 	const uint32_t t = g0 + ln32;                               // my staged group as a group of window ow (or, from 64 on, of ow + 1)
 	const uint32_t woff = (t >> 4) * LEAFW + (t & 15u);         // its plane-0 word
 	const bool have = ln32 < nwg;
-	const bool plain_k = have && (t < 64u ? h0 : h1) == WF_PLAIN;
-	uint64_t wa0 = 0, wa1 = 0, wa2 = 0, wt0 = 0, wt1 = 0, wt2 = 0;
+	const bool pl0 = h0 == WF_PLAIN, pl1 = h1 == WF_PLAIN;
+	const bool plain_k = have && ((t < 64u && pl0) || (t >= 64u && pl1));
+	uint64_t wa0 = 0, wa1 = 0;                                  // (zero: a window with nothing old reads its stage, see nwg)
+	uint64_t wa2, wt0, wt1, wt2; RB2_UNDEF(wa2); RB2_UNDEF(wt0); RB2_UNDEF(wt1); RB2_UNDEF(wt2);   // (group 64 of the stage is only read when it was loaded: tail)
 	if (have) { wa0 = RB2_LDNT(&obw[woff]); wa1 = RB2_LDNT(&obw[woff + LEAFG]); }
 	if (plain_k) wa2 = RB2_LDNT(&obw[woff + 2 * LEAFG]);
 	const bool tail = ln == 0 && (uint32_t)WG < nwg;            // (group g0 + 64 lies in window ow + 1)
@@ -166,8 +178,7 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 		wt0 = obw[w2]; wt1 = obw[w2 + LEAFG];
 		if (h1 == WF_PLAIN) wt2 = obw[w2 + 2 * LEAFG];
 	}
-	auto put_new = [&](uint32_t p, uint32_t a) {
-		const uint32_t ix = p >> 6;
+	auto put_new = [&](uint32_t p, uint32_t ix /* p >> 6 */, uint32_t a) {
 		const unsigned long long bit = 1ull << (p & 63);
 		atomicOr((unsigned long long*)&LF[ix], bit);
 		if (a & 1u) atomicOr((unsigned long long*)&LX[ix], bit);
@@ -175,8 +186,11 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 		if ((0x21u >> a) & 1u) atomicOr((unsigned long long*)&LX[2 * WG + ix], bit);   // plane 2': $ and N
 	};
 	const uint32_t p_first = e_first - i0lo + ln32;             // final position E[q] + q, relative to the window (kept for step 5)
-	if (ln32 < ni) put_new(p_first, a_first);
-	for (uint32_t jj = ln32 + 64; jj < ni; jj += 64) put_new((uint32_t)E0[jj] - i0lo + jj, A0[jj]);   // (more than 64 new symbols: rare in steady state)
+	uint32_t g_first = p_first >> 6;                            // its group (kept as well; opaque, or the index below becomes (p >> 3) & ~7: three instructions for two)
+	asm volatile("" : "+v"(g_first));
+	if (ln32 < ni) put_new(p_first, g_first, a_first);
+	if (ni > 64u)                                               // (more than 64 new symbols: rare in steady state -- a scalar test in front of the loop's vector one)
+		for (uint32_t jj = ln32 + 64; jj < ni; jj += 64) { const uint32_t p = (uint32_t)E0[jj] - i0lo + jj; put_new(p, p >> 6, A0[jj]); }
 	{	// exceptions -> plane 2' bits of the staged groups: entry e of window ow + wi is bit e & 63 of its group e >> 6 = staged group (e >> 6) + 64 wi - g0
 		auto x_in = [&](uint32_t e, uint32_t idx_m1 /* entry number - 1 */, uint32_t cnt, uint32_t delta) {
 			const uint32_t k = (e >> 6) + delta;
@@ -185,14 +199,16 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 		if (xa) {
 			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)xe[0]);
 			x_in(xe[0], ln32 - 1u, cnt, 0u - g0);
-			if (h0 == WF_C2) x_in(xe[1], ln32 + 63u, cnt, 0u - g0);
+			if (hx0 == WF_C2) x_in(xe[1], ln32 + 63u, cnt, 0u - g0);
 		}
 		if (xb) {
 			const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)xe[2]);
 			x_in(xe[2], ln32 - 1u, cnt, 64u - g0);
-			if (h1 == WF_C2) x_in(xe[3], ln32 + 63u, cnt, 64u - g0);
+			if (hx1 == WF_C2) x_in(xe[3], ln32 + 63u, cnt, 64u - g0);
 		}
 	}
+#undef xa
+#undef xb
 	asm volatile("" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wt0), "+v"(wt1), "+v"(wt2));   // nothing of the plane words is looked at before this point (the first look waits for them)
 	LO[ln] = wa0; LO[(WG + 2) + ln] = wa1;
 	if (plain_k) LO2[ln] = wa2 ^ ~(wa0 | wa1);                  // plain window: to the swapped coding (a word no exception list writes to)
@@ -217,8 +233,7 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 	}
 
 	// ---- 3. deal the old symbols to the not-new positions, add the new ones
-	if (nold == 0) { out[0] = out[1] = out[2] = 0; }            // nothing old (the first rounds on an empty index)
-	else if (ni) open_gaps(out, F);
+	if (nold != 0 && ni != 0) open_gaps(out, F);                // (nothing old: out[] is zero, see nwg -- and every position is a gap)
 	out[0] = (out[0] & VM) | LX[ln]; out[1] = (out[1] & VM) | LX[WG + ln]; out[2] = (out[2] & VM) | LX[2 * WG + ln];   // (the gaps hold zeros)
 
 	// ---- 4. counts per lane -> prefix inside the leaf (= DPP row) -> LeafMeta of the leaves, rank bases of the new symbols
@@ -233,22 +248,21 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 	const uint32_t s01 = row_incl_add(e01), s23 = row_incl_add(e23), s45 = row_incl_add(e45);
 	// the format of the new window: its exceptions are its $ and N symbols, already counted and scanned
 	const uint32_t nx = c[0] + c[5], xs = (s01 & 0xffffu) + (s45 >> 16);   // mine / inclusive prefix inside my row
-	uint32_t fmt = WF_PLAIN, xr0 = 0, xr1 = 0, xr2 = 0, xt = 0;
+	uint32_t fmt = WF_PLAIN, xw = xs, xt = 0;
 	if (compact_out & 1) {
-		xr0 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 15); xr1 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 31);
-		xr2 = (uint32_t)__builtin_amdgcn_readlane((int)xs, 47); xt = xr0 + xr1 + xr2 + (uint32_t)__builtin_amdgcn_readlane((int)xs, 63);
+		xw += dpp0<0x142, 0xa>(xw); xw += dpp0<0x143, 0xc>(xw);  // the row prefixes carried over the wave (row_bcast 15 / 31): two instructions, and the list below starts where it ends
+		xt = lane63(xw);
 		fmt = xt == 0 ? WF_C0 : (xt <= XCAP1 ? WF_C1 : (xt <= XCAP2 ? WF_C2 : WF_PLAIN));
 	}
 	if ((compact_out & 2) && ln == 0) atomicAdd(wfmt + fmt, 1ull);   // statistics for the tests (RB2_COMPACT_STATS=1)
 	// publish my group and my exclusive prefixes inside the leaf (the old-group stage is dead by now)
-	uint32_t *LP = (uint32_t*)LO;
+	uint16_t *LP = (uint16_t*)LO;                               // LP[8 * lane + symbol]: sixteen bytes per lane, so that a new symbol finds its entry with two instructions and reads it as it is
 	LX[ln] = out[0]; LX[WG + ln] = out[1]; LX[2 * WG + ln] = out[2];
-	LP[ln] = s01 - e01; LP[64 + ln] = s23 - e23; LP[128 + ln] = s45 - e45;   // LP[q * 64 + lane]
+	{ const u32x2 w = { s01 - e01, s23 - e23 }; *(u32x2*)(LP + 8 * ln) = w; *(uint32_t*)(LP + 8 * ln + 4) = s45 - e45; }
 	uint16_t *XL = (uint16_t*)LF;                               // the exception list on its way out (the flags are dead)
 	if (fmt >= WF_C1) {                                          // (wave-uniform)
 		uint64_t x = out[2];
-		const uint32_t row = ln32 >> 4;
-		uint32_t at = 1u + xs - nx + (row > 0 ? xr0 : 0u) + (row > 1 ? xr1 : 0u) + (row > 2 ? xr2 : 0u);
+		uint32_t at = 1u + xw - nx;
 		if (ln == 0) XL[0] = (uint16_t)xt;
 		while (x) { XL[at++] = (uint16_t)((ln32 << 6) + (uint32_t)__builtin_ctzll(x)); x &= x - 1; }
 	}
@@ -257,17 +271,20 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 	// ---- 5. leaf-relative rank of every new symbol, one per lane
 	uint16_t *RK0 = RKREL + d.ins0;
 	for (uint32_t jj = ln32; jj < ni; jj += 64) {
-		uint32_t p = p_first, a = a_first;
-		if (jj != ln32) { a = A0[jj]; p = (uint32_t)E0[jj] - i0lo + jj; }   // more than 64 new symbols in the window: read them again
-		const uint32_t lo = p >> 6;
-		uint32_t r = (LP[64 * (a >> 1) + lo] >> ((a & 1u) * 16u)) & 0xffffu;   // equal symbols in the groups of its leaf in front of its group
-		const uint32_t ai = (a & 3u) ? a : a ^ 4u;               // its code in the planes: $ <-> T
-		// the planes of its group XORed with all-ones where the bit of the code is clear (the mask is 32 bits wide: both halves use it)
-		const uint32_t m0 = (ai & 1u) - 1u, m1 = ((ai >> 1) & 1u) - 1u, m2 = (ai >> 2) - 1u;
+		uint32_t p = p_first, a = a_first, lo = g_first;
+		if (jj != ln32) { a = A0[jj]; p = (uint32_t)E0[jj] - i0lo + jj; lo = p >> 6; }   // more than 64 new symbols in the window: read them again
+		uint32_t r = LP[8 * lo + a];                               // equal symbols in the groups of its leaf in front of its group
+		// all-ones where its code in the planes ($ <-> T) has the bit set: bit a of the set of symbols whose code has it (plane 0: A T N, plane 1: C T... as
+		// numbers: 1 3 5 / 2 3 / 0 5) -- one signed bit-field extract per plane; then, per half, three three-input bit operations (v_bitop3_b32)
+		// AND together "plane bit equals code bit" and "below my position": 18 VALU per new symbol (r05: 34)
+		const uint32_t n0 = (uint32_t)__builtin_amdgcn_sbfe(0x2a, a, 1), n1 = (uint32_t)__builtin_amdgcn_sbfe(0x0c, a, 1), n2 = (uint32_t)__builtin_amdgcn_sbfe(0x21, a, 1);
 		const uint64_t q0 = LX[lo], q1 = LX[WG + lo], q2 = LX[2 * WG + lo];
-		const uint32_t el = ((uint32_t)q0 ^ m0) & ((uint32_t)q1 ^ m1) & ((uint32_t)q2 ^ m2), eh = ((uint32_t)(q0 >> 32) ^ m0) & ((uint32_t)(q1 >> 32) ^ m1) & ((uint32_t)(q2 >> 32) ^ m2);
-		const uint64_t below = (1ull << (p & 63)) - 1ull;
-		r += (uint32_t)__popc(el & (uint32_t)below) + (uint32_t)__popc(eh & (uint32_t)(below >> 32));
+		const uint64_t nb = ~0ull << (p & 63);                     // my position and above
+		uint32_t el = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)q0, n0, (uint32_t)nb, 0x41);            // ~(q ^ n) & ~nb
+		uint32_t eh = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(q0 >> 32), n0, (uint32_t)(nb >> 32), 0x41);
+		el = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)q1, n1, el, 0x82); eh = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(q1 >> 32), n1, eh, 0x82);   // ~(q ^ n) & e
+		el = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)q2, n2, el, 0x82); eh = (uint32_t)__builtin_amdgcn_bitop3_b32((uint32_t)(q2 >> 32), n2, eh, 0x82);
+		r += (uint32_t)__popc(el) + (uint32_t)__popc(eh);
 		RK0[jj] = (uint16_t)r;
 	}
 	const uint32_t lf = ln32 >> 4;                              // my leaf of the window
