@@ -553,6 +553,13 @@ __device__ __forceinline__ uint32_t dpp_incl_max(uint32_t v)     // unsigned max
 	v = max(v, dpp0<0x142, 0xa>(v)); v = max(v, dpp0<0x143, 0xc>(v));
 	return v;
 }
+// a wave-uniform 64-bit value, in scalar registers from here on
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32 | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v); }
+// a value that is only looked at under the condition it was loaded under starts out as whatever its register holds: a zero is an instruction
+// (__builtin_nondeterministic_value becomes a zero as well.  Each statement carries a number of its own: identical ones are merged into one register
+// that is then copied.  Not volatile: a volatile statement counts as a write to memory, and uniform loads behind it turn into vector loads.)
+#define RB2_UNDEFV(x) asm("" : "=v"(x) : "n"(__COUNTER__))
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }   // (__ballot takes an int: a flag kept in scalar registers is written to a vector register and compared again)
 __device__ __forceinline__ uint32_t dpp_prev_lane(uint32_t v) { return dpp0<0x138, 0xf>(v); }   // wave_shr:1, lane 0 reads 0
 __device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v) { return dpp0<0x130, 0xf>(v); }   // wave_shl:1, lane 63 reads 0
 __device__ __forceinline__ uint32_t lane63(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }

@@ -784,6 +784,7 @@ struct GroupLds {
 	uint32_t cpre[9][6];
 	TileFix fix;                                // tpre, popen, pnext, fopen of this tile (k_tfix)
 	uint32_t allsingle;                         // every string of the tile is a group of its own (the rule once intervals are narrow): group_member takes the short way
+	uint32_t okc[8];                            // ... per wave-chunk: every valid lane is a head (a scalar comparison of two ballots, by the wave that has them)
 };
 
 // fills G for the string tile of this block; sym2[h] = symbol of string t.base + h*256 + threadIdx.x (7: none).
@@ -802,10 +803,16 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 		if ((uint32_t)(h * 256) + threadIdx.x < nv) { const uint32_t a = araw[h]; sym = (int)(a & 7u); head = (a & 0x80u) != 0; fl = (int)(a & 0x40u); }
 		sym2[h] = sym; flag2[h] = fl;
 		const int c = h * 4 + w;
+		// all ballots first, then ONE lane-0 block that stores them (a store per ballot was a branch per ballot: seven exec round trips)
+		uint64_t bm[6];
 #pragma unroll
-		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) G.bal[c][s] = bm; }
-		uint64_t hm = __ballot(head);
-		if (ln == 0) G.head[c] = hm;
+		for (int s = 0; s < 6; ++s) bm[s] = ballot64(sym == s);
+		const uint64_t hm = ballot64(head), vm = ballot64((uint32_t)(h * 256) + threadIdx.x < nv);
+		if (ln == 0) {
+#pragma unroll
+			for (int s = 0; s < 6; ++s) G.bal[c][s] = bm[s];
+			G.head[c] = hm; G.okc[c] = hm == vm ? 1u : 0u;
+		}
 	}
 	__syncthreads();
 	if (threadIdx.x < 6) {
@@ -815,13 +822,10 @@ __device__ __forceinline__ void group_setup(GroupLds &G, const TileCtx &t, const
 		G.cpre[8][s] = run;
 	}
 	if (threadIdx.x == 6) {                                     // all heads, and the string behind the tile starts a group too?
-		const uint64_t nval = min((uint64_t)STILE, t.segend - t.base);
-		bool all = (G.fix.nexthead & 1u) != 0;
-		for (int c = 0; c < 8; ++c) {
-			const uint64_t vm = nval >= (uint64_t)(64 * (c + 1)) ? ~0ull : (nval > (uint64_t)(64 * c) ? lt_mask((int)(nval - 64 * c)) : 0ull);
-			all = all && G.head[c] == vm;
-		}
-		G.allsingle = all ? 1u : 0u;
+		uint32_t all = G.fix.nexthead & 1u;
+#pragma unroll
+		for (int c = 0; c < 8; ++c) all &= G.okc[c];
+		G.allsingle = all;
 	}
 	__syncthreads();
 }
@@ -841,6 +845,13 @@ struct Member { uint32_t pa, pga, slot, F; int lead; };   // lead: first member 
 __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx &t, int x, int a, const int orda[6])
 {
 	const int c = x >> 6, l6 = x & 63;
+	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
+	Member m;
+	if (G.allsingle) {                                         // (block-uniform) a tile of one-member groups -- asked FIRST: behind the search for the group's ends below, every string of such a tile (the rule from round ~14 on) still searched
+		m.pa = G.fix.tpre[a] + before(x, a);
+		m.pga = m.pa; m.F = (uint32_t)t.lt * STILE + (uint32_t)x; m.slot = m.F; m.lead = x;
+		return m;
+	}
 	const uint64_t le = lt_mask(l6) | (1ull << l6);
 	int hpos = -1, npos = -1;
 	{
@@ -850,13 +861,6 @@ __device__ __forceinline__ Member group_member(const GroupLds &G, const TileCtx 
 		uint64_t nm = G.head[c] & ~le;
 		if (nm) npos = c * 64 + __builtin_ctzll(nm);
 		else for (int cc = c + 1; cc < 8; ++cc) if (G.head[cc]) { npos = cc * 64 + __builtin_ctzll(G.head[cc]); break; }
-	}
-	auto before = [&](int y, int s) -> uint32_t { return G.cpre[y >> 6][s] + __popcll(G.bal[y >> 6][s] & lt_mask(y & 63)); };
-	Member m;
-	if (G.allsingle) {                                         // (block-uniform) a tile of one-member groups
-		m.pa = G.fix.tpre[a] + before(x, a);
-		m.pga = m.pa; m.F = (uint32_t)t.lt * STILE + (uint32_t)x; m.slot = m.F; m.lead = x;
-		return m;
 	}
 	m.pa = G.fix.tpre[a] + before(x, a);
 	if (hpos == x && npos == x + 1) {                      // a group of one (the common case once intervals are narrow)
@@ -1838,7 +1842,10 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	bool act0[2];
 	// the four (dense layout) loads of one rank, issued together and only added up when their sum is needed
 	struct RankRaw { P sbb; uint32_t sbr, meta, rkrel; };
-	const LeafMeta *metab = newp.meta + nrp.leaf0; const SbRec *sbrb = newp.sbrec + nrp.sb0;   // the piece's first leaf / superblock (a piece starts on a superblock boundary)
+	// the piece's first leaf / superblock (a piece starts on a superblock boundary) -- as scalars whatever branch the compiler first loads them in (a value merged behind a divergent branch
+	// lives in vector registers, and so does every address built on it: seven 64-bit vector additions per string)
+	const uint64_t sb0u = uniform64(nrp.sb0), leaf0u = uniform64(nrp.leaf0);
+	const LeafMeta *metab = newp.meta + leaf0u; const SbRec *sbrb = newp.sbrec + sb0u;
 	const uint16_t *RKb = RKREL + t.segstart; const P *Eb = INS_E + t.segstart; const P *ROb = SPARSE ? RKOLD + t.segstart : nullptr;
 	auto rank_issue = [&](int h, int a, uint32_t slot, P F, bool flag, RankRaw &q) {
 		if (SPARSE) {                                          // in-place rounds: the rank on the rope as it was BEFORE the round, taken on the way down: in front of the leaf (k_part_sparse) + inside it (k_merge_leaf)
@@ -1846,7 +1853,15 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 			return;
 		}
 		const P f = (P)(((!AE && flag) ? Eb[slot] : (P)(l2[h] - F)) + (P)slot);   // where my symbol went: e + slot; empty interval: e = l - F (k_prep)
-		const uint32_t lf = (uint32_t)(f >> LEAF_SH), sbq = (uint32_t)nrp.sb0 + lf / SB;      // its leaf of the piece (a piece has < 2^32 leaves), its superblock of the pool
+		const uint32_t lf = (uint32_t)(f >> LEAF_SH), sbq = (uint32_t)sb0u + lf / SB;         // its leaf of the piece (a piece has < 2^32 leaves), its superblock of the pool
+		if (sizeof(P) == 4) {                                  // positions fit 32 bits: so does every byte offset below (< 2^22 leaves) -- a scalar base + one 32-bit vector offset per gather
+			const uint32_t ua = (uint32_t)a;
+			q.sbb = *(const P*)((const char*)newp.sbbase + ((sbq >> SCHUNK_SH) * (uint32_t)sizeof(SbBase) + ua * 8u));   // (little endian: the low half of the 64-bit sum)
+			q.sbr = *(const uint32_t*)((const char*)sbrb + ((lf / SB) * (uint32_t)sizeof(SbRec) + ua * 4u));
+			q.meta = *(const uint16_t*)((const char*)metab + (lf * (uint32_t)sizeof(LeafMeta) + ua * 2u));
+			q.rkrel = *(const uint16_t*)((const char*)RKb + slot * 2u);
+			return;
+		}
 		const P *bb = (const P*)&newp.sbbase[sbq >> SCHUNK_SH].cum[a];                       // (little endian: the low half when positions are stored in 32 bits)
 		q.sbb = *bb; q.sbr = sbrb[lf / SB].cum[a]; q.meta = metab[lf].c[a]; q.rkrel = RKb[slot];
 	};
@@ -1857,8 +1872,8 @@ template <bool AE, bool SPARSE, typename P> __device__ __forceinline__ bool adva
 	for (int h = 0; h < 2; ++h) {                              // speculative: slot = F = my index in the bucket
 		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
 		const int a = (int)(araw[h] & 7u);
-		act0[h] = x < nval && a != 0 && a != 7;
-		rq[h].sbb = 0; rq[h].sbr = rq[h].meta = rq[h].rkrel = 0;
+		act0[h] = (uint32_t)(a - 1) < 6u;                        // a symbol, not the sentinel (0), not "no string here" (7: araw of x >= nval) -- one comparison, one branch
+		RB2_UNDEFV(rq[h].sbb); RB2_UNDEFV(rq[h].sbr); RB2_UNDEFV(rq[h].meta); RB2_UNDEFV(rq[h].rkrel);   // (only looked at by strings that asked: no zeros to write)
 		const uint32_t slot = (uint32_t)t.lt * STILE + x;
 		if (spec && act0[h]) rank_issue(h, a, slot, (P)slot, (araw[h] & 0x40u) != 0, rq[h]);
 	}

@@ -53,9 +53,7 @@ template <int N, class F> __device__ __forceinline__ void static_for(F &&f) { st
 // the part of x above them up by one is an ADD: x + (x & ~lm).  13 VALU per trip for the three planes (r04: masks from a count of
 // trailing zeros, shift and two ORs per plane: 28; r05: 17, the mask built first).  The trip count is the largest number of new symbols in one group of the window.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-// a value that is only looked at under the condition it was loaded under starts out as whatever its register holds -- a zero is an instruction
-// (__builtin_nondeterministic_value becomes a zero as well)
-#define RB2_UNDEF(x) asm volatile("" : "=v"(x))             // (volatile: identical statements are not merged into one register that is then copied)
+#define RB2_UNDEF(x) RB2_UNDEFV(x)                            // (rb2_device.h)
 __device__ __forceinline__ void open_gaps(uint64_t x[3], uint64_t f)
 {
 	do {
