@@ -289,6 +289,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		P *INS_E, uint8_t *INS_A)
 {
 	__shared__ uint64_t s_bal[8][6], s_head[8];
+	__shared__ __align__(16) uint32_t s_ok[4];                 // per wave: every string of the wave is a group of its own
 	if (SPLIT) {
 		__shared__ uint16_t s_row[MW][7][SB];
 		// the FIRST blocks of the grid: the splits' registers (99 VGPRs) cap the launch at five workgroups per CU, the tile blocks take two
@@ -314,7 +315,7 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 #pragma unroll
 	for (int h = 0; h < 2; ++h) {
 		const uint32_t x = (uint32_t)(h * 256) + threadIdx.x;
-		av[h] = 7; uv[h] = 0; up[h] = 0;
+		RB2_UNDEFV(av[h]); RB2_UNDEFV(uv[h]); RB2_UNDEFV(up[h]);   // (only looked at where x < nval)
 		if (x < nval) { av[h] = Ab[x]; uv[h] = Ub[x]; up[h] = (x > 0 || !first_tile) ? Ub[(int32_t)x - 1] : (P)0; }
 	}
 	const bool last_thread = threadIdx.x == 255;
@@ -335,13 +336,23 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 		}
 		sym2[h] = sym;
 		const int c = h * 4 + w;
+		uint64_t bm[6];                                             // all ballots, then one lane-0 block that stores them (group_setup)
 #pragma unroll
-		for (int s = 0; s < 6; ++s) { uint64_t bm = __ballot(sym == s); if (ln == 0) s_bal[c][s] = bm; }
-		uint64_t hm = __ballot(head);
-		if (ln == 0) s_head[c] = hm;
+		for (int s = 0; s < 6; ++s) bm[s] = ballot64(sym == s);
+		const uint64_t hm = ballot64(head);
+		if (ln == 0) {
+#pragma unroll
+			for (int s = 0; s < 6; ++s) s_bal[c][s] = bm[s];
+			s_head[c] = hm;
+		}
 	}
 	if (has_next) single = single && un != uv[1];
-	const bool allsingle = __syncthreads_and((int)single) != 0;   // (the barrier the tile summaries need anyway)
+	// "every string of the tile is a group of its own": a scalar comparison per wave, a flag per wave, ONE barrier (the one the tile summaries need
+	// anyway) -- __syncthreads_and was a DPP reduction, an LDS atomic and three barriers
+	{ const uint64_t sm = ballot64(single); if (ln == 0) s_ok[w] = sm == ~0ull ? 1u : 0u; }
+	__syncthreads();
+	const uint4 okv = *(const uint4*)s_ok;
+	const bool allsingle = (okv.x & okv.y & okv.z & okv.w) != 0;
 	const bool fused = ae && allsingle;
 	if (fused) {
 		P *Eb = INS_E + t.base; uint8_t *Ib = INS_A + t.base;     // slot + segstart = t.base + x
@@ -357,6 +368,11 @@ template <bool STRIDE, typename P = uint64_t, bool SPLIT = false> __global__ __l
 	if (threadIdx.x < 6) {
 		const int s = threadIdx.x;
 		uint32_t run = 0, fhpre = 0, lhpre = 0; int fh = -1, lh = -1;
+		if (allsingle) {                                        // (block-uniform; the rule from round ~14 on) every string is a head: the first one is string 0, the last one string nval - 1
+#pragma unroll
+			for (int c = 0; c < 8; ++c) run += __popcll(s_bal[c][s]);
+			if (nval) { fh = 0; lh = (int)nval - 1; lhpre = run - (uint32_t)((s_bal[lh >> 6][s] >> (lh & 63)) & 1ull); }
+		} else
 		for (int c = 0; c < 8; ++c) {
 			const uint64_t hm = s_head[c], bm = s_bal[c][s];
 			if (hm) {
