@@ -527,7 +527,11 @@ def main():
     # ---- the job: its -m batches (sharded: the same batches on every rank, one index; independent: this rank's own
     # ---- slice of the read stream, its own index).  Step k = batch k % nb of job k // nb; a job starts on an empty index.
     bwt = make(so, dev)
-    bwt.eng.profile(True)
+    # hipEvents inside the timed region: around the k_merge launches only (level 2: the roofline's `achieved` needs their duration, measured live);
+    # the other kernel groups are timed in a pass of their own behind the clock (sixteen events per round cost the timed job 1-2 %).
+    # RB2_BENCH_FULLPROF=1: every group inside the timed region, as in rounds 1-5.
+    full_prof = os.environ.get("RB2_BENCH_FULLPROF", "0") == "1"
+    bwt.eng.profile(1 if full_prof else 2)
     first = 0 if sharded or world == 1 else rank * args.reads
     job, done = [], 0
     while done < args.reads:
@@ -566,6 +570,15 @@ def main():
     prof = bwt.eng.profile_get()
     counts = bwt.counts()
     ok_counts = int(counts.sum()) == sum(sizes[:last]) and int(counts[:, 0].sum()) == sum(n for _, n in job[:last])
+    prof_all, prof_all_steps = prof, args.steps
+    if not full_prof:                                          # the per-group breakdown: one more job, every group timed, behind the clock
+        bwt.eng.profile(1)
+        bwt.eng.profile_get(reset=True)
+        bwt.reset()
+        for j in range(nb):
+            bwt.insert(bufs[j], sizes[j])
+        bwt.sync()
+        prof_all, prof_all_steps = bwt.eng.profile_get(), nb
     mstats = bwt.stats() if isinstance(bwt, Multi) else None
     host_api = host_api_pinned = None
     if rank == 0 and n_ranks == 1 and not args.no_extras:
@@ -622,7 +635,11 @@ def main():
                      "algorithmic_bytes_per_symbol": ALG_BYTES_PER_SYMBOL,
                      "algorithmic_bytes_per_launch": ALG_BYTES_PER_SYMBOL * units / max(1, mk["launches"]),
                      "note": None if not sharded else "rank 0 only; units per launch approximated by strings / active ranks"},
-        "kernels_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+        "kernels_ms": {k: round(v["ms"], 3) for k, v in prof_all.items()},
+        "kernels_ms_steps": prof_all_steps,
+        "kernels_ms_note": ("hipEvent scopes of every kernel group over the timed steps" if full_prof else
+                            "hipEvent scopes of every kernel group over ONE more job (%d steps) run behind the clock; inside the timed region only the k_merge launches carry events "
+                            "(roofline.avg_launch_ms)" % nb),
     }
     # HBM bytes per k_merge launch: measured now (two PMC passes of one configs[1] job -- the per-launch average does not depend on
     # K because every job is the same job); else the committed summary of the same command, but only if it was taken from the
@@ -655,12 +672,12 @@ def main():
         per = {}
         for g, ks in groups.items():
             gb = sum(tgr.get(k, 0.0) for k in ks)
-            ms = prof[g]["ms"] / mk["launches"] if g in prof else 0.0
+            ms = prof_all[g]["ms"] / max(1, prof_all["k_merge"]["launches"]) if g in prof_all else 0.0
             if gb > 0 and ms > 0:
                 per[g] = {"GB_per_round": round(gb, 4), "ms_per_round": round(ms, 4), "TB_per_s": round(gb / ms, 3), "frac_of_peak": round(gb / ms / (HBM_PEAK_GBS / 1e3), 3)}
         out["roofline"]["per_kernel"] = per
         out["roofline"]["per_kernel_note"] = ("GB_per_round: FETCH x2 + WRITE of the PMC passes (the x2 is calibrated for wide streaming reads, MI355X_MICROARCH.md: it overstates kernels "
-                                              "that gather 2-16 byte items); ms_per_round: hipEvent scopes of the timed run, launch gaps inside a scope included")
+                                              "that gather 2-16 byte items); ms_per_round: hipEvent scopes (kernels_ms_note), launch gaps inside a scope included")
     if host_api is not None:
         out["value_host_api"] = host_api
     if host_api_pinned is not None:

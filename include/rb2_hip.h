@@ -279,7 +279,7 @@ void rb2_hip_window_stats(rb2_hip_t *h, int64_t out[6]);
 #define RB2_K_RELAYOUT 8   /* change between the dense and the sparse (slack) leaf layout */
 #define RB2_K_SPLIT    9   /* leaf splits at the end of an in-place round */
 #define RB2_K_COUNT    10
-void rb2_hip_profile(rb2_hip_t *h, int enable);
+void rb2_hip_profile(rb2_hip_t *h, int enable);   /* 0: off; 1: every kernel group of a round (sixteen events per round); 2: the merge launches only (two) */
 /* launches[k], ms[k] (summed), units[k] (strings processed, summed) since the last reset */
 void rb2_hip_profile_get(rb2_hip_t *h, int64_t launches[RB2_K_COUNT], double ms[RB2_K_COUNT],
                          int64_t units[RB2_K_COUNT], int reset);

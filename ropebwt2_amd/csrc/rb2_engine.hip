@@ -278,15 +278,16 @@ hipEvent_t get_event(rb2_hip_t *h)
 }
 
 struct Scope {          // times everything enqueued between construction and destruction
-	rb2_hip_t *h; int k; ProfRec r;
+	rb2_hip_t *h; int k; ProfRec r; bool on;
 	Scope(rb2_hip_t *h_, int k_, int64_t units) : h(h_), k(k_) {
-		if (!h->prof) return;
+		on = h->prof == 1 || (h->prof == 2 && k == RB2_K_MERGE);   // (2: the merge launches only -- two events per round instead of sixteen; rb2_hip_profile)
+		if (!on) return;
 		r.k = k; r.units = units; r.round = h->cur_round; r.a = get_event(h); r.b = get_event(h);
 		HIPCHK(hipEventRecord(r.a, h->st));
 	}
 	~Scope() {
 		if (h->debug) { hipError_t e = hipStreamSynchronize(h->st); if (e != hipSuccess) { rb2_fatal("[rb2_hip] kernel group %s failed: %s\n", rb2_hip_kernel_name(k), hipGetErrorString(e)); } }
-		if (!h->prof) return;
+		if (!on) return;
 		HIPCHK(hipEventRecord(r.b, h->st));
 		h->recs.push_back(r);
 	}

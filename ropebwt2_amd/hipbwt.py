@@ -274,7 +274,8 @@ class HipBwt:
         return {"plain": int(a[0]), "compact0": int(a[1]), "compact1": int(a[2]), "compact2": int(a[3]), "compact_rounds": int(a[4]), "counted": bool(a[5])}
 
     def profile(self, on=True):
-        self.L.rb2_hip_profile(self.h, 1 if on else 0)
+        """False / 0: off; True / 1: every kernel group of a round; 2: the merge launches only (two events per round instead of sixteen)"""
+        self.L.rb2_hip_profile(self.h, int(on))
 
     def profile_get(self, reset=False):
         n = len(K_NAMES)

@@ -5,6 +5,6 @@ TAG=$1; STEPS=${2:-9}; REP=${3:-2}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 one() { python bench.py --steps $STEPS --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); n=d['steps']
+d=json.loads(sys.stdin.readline()); n=d.get('kernels_ms_steps', d['steps'])
 print('$1', round(d['value'],2), {k: round(v/n,2) for k,v in d['kernels_ms'].items() if v})"; }
 for i in $(seq $REP); do RB2_HIP_LIB=$PWD/ropebwt2_amd/lib/librb2hip_$TAG.so one $TAG; one tree; done
