@@ -579,7 +579,7 @@ void round_merge(rb2_hip_t *h, BatchState &B, uint64_t r, ShardRec *send, bool c
 	  RB2_LAUNCH_STRIDE(h, (k_part<true, P>), (k_part<false, P>), dim3(cdiv(wg + NR, 255)), dim3(256), 0, st, h->ctl, sd, RB2_P(h->INS_E.p), h->LD.p, h->pool_compact ? (const uint8_t*)oldp.xh : (const uint8_t*)nullptr); }   // (the formats of the old windows: only a pool side the compact-capable merge wrote has any but plain)
 	tl_slow(h, "k_part");
 	{ Scope sc(h, RB2_K_MERGE, units);
-	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(grid8(cdiv(wg, MW))), dim3(256), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0), (int)(r & 1)); }
+	  RB2_LAUNCH_STRIDE(h, (k_merge<true, P>), (k_merge<false, P>), dim3(grid8(cdiv(wg, MMW))), dim3(64 * MMW), 0, st, h->ctl, h->LD.p, oldp, newp, RB2_P(h->INS_E.p), h->INS_A.p, h->RKREL.p, (int)compact_out | (h->compact_stats ? 2 : 0), (int)(r & 1)); }
 	});
 	tl_slow(h, "k_merge");
 	{ Scope sc(h, RB2_K_META, units);

@@ -302,10 +302,14 @@ template <bool FULL, int GPL_, typename P> __device__ __forceinline__ void merge
 	else if (fmt >= WF_C1 && ln32 < (fmt == WF_C2 ? 32u : 16u)) RB2_STNT(((const uint64_t*)XL)[ln], &dstw[doff + 2 * LEAFG]);   // one or two whole lines of 64 entries
 }
 
-template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
+#ifndef RB2_MMW
+#define RB2_MMW 4                            // waves (= windows) per block of k_merge
+#endif
+constexpr int MMW = RB2_MMW;
+template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(64 * MMW) void k_merge(const Ctl *ctl, const LeafDesc *__restrict__ LD, PoolView oldp, PoolView newp,
 		const P *__restrict__ INS_E, const uint8_t *__restrict__ INS_A, uint16_t *RKREL, int compact_out, int par)
 {
-	__shared__ __align__(16) uint64_t lds[MW][MergeLds<GPL>::WORDS];
+	__shared__ __align__(16) uint64_t lds[MMW][MergeLds<GPL>::WORDS];
 	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const int ln = lane_id();
 	// Compact windows only when the device itself knows that no string has a non-empty interval any more (ctl->ne of this round: once zero
@@ -316,14 +320,14 @@ template <bool STRIDE, typename P = uint64_t> __global__ __launch_bounds__(256) 
 	// one window per wave; a rank of a sharded index launches fewer waves than the upper bound of its windows (the host does not
 	// know the rank's share of the batch) and a wave then takes more than one: grid stride over the windows.  The first window's
 	// work order is loaded together with the window count (LD holds an entry for every window a grid can name).
-	uint64_t gw = (uint64_t)(STRIDE ? blockIdx.x : xcd_item()) * MW + wv;
+	uint64_t gw = (uint64_t)(STRIDE ? blockIdx.x : xcd_item()) * MMW + wv;
 	LeafDesc d = LD[gw];
 	const uint64_t nwin = ctl->wf0[NR];
-	for (; gw < nwin; gw += (uint64_t)gridDim.x * MW, d = LD[gw < nwin ? gw : 0]) {
+	for (; gw < nwin; gw += (uint64_t)gridDim.x * MMW, d = LD[gw < nwin ? gw : 0]) {
 		if ((d.nvalid & 0x3fffu) == WIN) merge_window<true, GPL, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, compact_out, (unsigned long long*)ctl->wfmt);
 		else merge_window<false, GPL, P>(d, lds[wv], ln, oldp, newp, INS_E, INS_A, RKREL, compact_out, (unsigned long long*)ctl->wfmt);
 		if (!STRIDE) return;                                    // (one GPU: the grid covers every window; no loop, no extra registers)
-		if (gw + (uint64_t)gridDim.x * MW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
+		if (gw + (uint64_t)gridDim.x * MMW < nwin) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // the wave's LDS arrays are reused
 	}
 }
 
