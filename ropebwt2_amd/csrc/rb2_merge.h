@@ -21,14 +21,16 @@
 //      exception positions ("window formats" below)
 //   2. one wave prefix sum of the not-new counts -> first old symbol each lane consumes; the old bits of its group are an
 //      unaligned 64-bit window of each staged plane (three dword reads, two funnel shifts)
-//   3. expand: open one 1-bit gap per new symbol in each plane (open_gaps: an addition per plane and gap; 1-2 trips in steady
-//      state); the new symbols are already in place
+//   3. expand: open one 1-bit gap per new symbol in each plane (open_gaps: a three-input bit operation per half and an addition per
+//      plane and gap; 2-3 trips in steady state -- as many as the fullest group of the window takes new symbols); the new symbols are
+//      already in place
 //   4. symbol counts per lane: five popcounts of dense words, three packed scans inside the DPP row (= leaf) -> LeafMeta of each
 //      leaf, the format of the new window (its $ + N counts are its exceptions) and, for a compact one, its list
 //   5. RKREL: every new symbol gets the number of equal symbols before it INSIDE its leaf, one new symbol per lane (row prefix of
 //      the owning lane + a masked plane compare of its group, both read back from LDS); k_advance adds the directory prefix of the
 //      new sub-rope to obtain the reference's return value of rope_insert_run.
-// The kernel is bound by VALU issue as much as by HBM bytes: every step above is written for instruction count.
+// The kernel is bound by VALU issue, by the length of a wave's own chain at eight waves per SIMD and by HBM bytes, in that order of what was
+// found (DESIGN.md sections 6 and 10): every step above is written for instruction count -- 216 vector instructions per window as executed.
 #pragma once
 #include <type_traits>
 #include <utility>
